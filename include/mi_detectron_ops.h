@@ -1,0 +1,137 @@
+/*
+ * mi_detectron_ops.h -- C-ABI of the MI355X (gfx950) RoI-transform / NMS hot path.
+ *
+ * One shared library (libmi_detectron_ops.so, built by `hipcc --offload-arch=gfx950`)
+ * exports exactly the symbols declared here.  Signatures carry plain device pointers,
+ * sizes and an opaque stream handle (a hipStream_t passed as void*); there are no torch,
+ * THC or C++ types on the boundary.
+ *
+ * Conventions (they restate the reference's C boundary):
+ *   - every pointer except `mi_*_host` arguments is a DEVICE pointer on the caller's
+ *     current device; the library never allocates, never frees and never synchronises;
+ *   - the caller owns every buffer; backward entry points ACCUMULATE into `bottom_grad`
+ *     (the reference caller zero-fills it first: roi_xfrom/roi_align/functions/roi_align.py:39-40);
+ *   - work is enqueued on `stream` (reference: THCState_getCurrentStream, roi_align_cuda.c:31);
+ *     calls are re-entrant and hold no global mutable state besides the last-error string;
+ *   - return value: MI_OK (0) on success, a positive MI_ERR_* code otherwise.  The
+ *     reference printed to stderr and called exit(-1) on a launch failure
+ *     (roi_align_kernel.cu:135-139) and returned 0 for a malformed rois tensor
+ *     (roi_align_cuda.c:19-22); here both become error codes and the Python shim raises.
+ *   - rois are [R,5] float32 rows (batch_index, x1, y1, x2, y2) in input-image pixels.
+ *   - `layout` selects the memory order of the 4-D feature / gradient tensor:
+ *     MI_LAYOUT_NCHW (the reference's only layout) or MI_LAYOUT_NHWC (torch
+ *     channels_last storage of the same logical [N,C,H,W] tensor).  Outputs of the
+ *     forward ops are always dense [R,C,PH,PW].
+ */
+#ifndef MI_DETECTRON_OPS_H_
+#define MI_DETECTRON_OPS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+typedef void* mi_stream_t; /* hipStream_t */
+
+enum mi_status {
+  MI_OK = 0,
+  MI_ERR_BAD_ARGUMENT = 1,  /* null pointer, negative size, unknown enum value          */
+  MI_ERR_LAUNCH = 2,        /* hipGetLastError() != hipSuccess after the launch        */
+  MI_ERR_WORKSPACE = 3,     /* workspace smaller than mi_*_workspace_bytes()            */
+  MI_ERR_UNSUPPORTED = 4    /* shape outside what the kernels implement (see message)  */
+};
+
+enum mi_layout { MI_LAYOUT_NCHW = 0, MI_LAYOUT_NHWC = 1 };
+
+/* Which RoIAlign arithmetic:
+ *   CAFFE2 = lib/modeling/roi_xfrom/roi_align/src/roi_align_kernel.cu:16-121,150-270 (the one the model uses)
+ *   LEGACY = lib/model/roi_align/src/roi_align_kernel.cu:15-70,94-143 (1 sample on an (aligned-1) grid;
+ *            `sampling_ratio` is ignored) */
+enum mi_roi_align_variant { MI_ROI_ALIGN_CAFFE2 = 0, MI_ROI_ALIGN_LEGACY = 1 };
+
+/* NMS result conventions:
+ *   GE_ORIG_ASC   = lib/utils/cython_nms.pyx:37-87: dets may be unsorted, sorted internally by
+ *                   descending score (ties: higher original index first == np.argsort(kind='stable')[::-1]),
+ *                   suppress when IoU >= thresh, keep[] = int64 ORIGINAL indices in ascending order.
+ *   GT_SORTED_POS = lib/model/nms/src/nms_cuda_kernel.cu:41-161 + nms_gpu.py:7-12: dets must already be
+ *                   sorted by descending score, suppress when IoU > thresh, keep[] = int32 positions
+ *                   in the input, in kept (= ascending position) order. */
+enum mi_nms_mode { MI_NMS_GE_ORIG_ASC = 0, MI_NMS_GT_SORTED_POS = 1 };
+
+int mi_abi_version(void);
+/* Message of the most recent failing call on this host thread ("" if none). */
+const char* mi_last_error(void);
+
+/* ---- RoIAlign -------------------------------------------------------------------------
+ * replaces ROIAlignForwardLaucher / ROIAlignBackwardLaucher
+ *   (lib/modeling/roi_xfrom/roi_align/src/roi_align_kernel.h:13-30; legacy lib/model/roi_align/src/roi_align_kernel.h:13-30)
+ * and the cffi glue roi_align_forward_cuda / roi_align_backward_cuda (roi_align_cuda.c:7-76). */
+int mi_roi_align_forward(const float* features, const float* rois, float* output,
+                         int batch, int channels, int height, int width, int num_rois,
+                         int aligned_height, int aligned_width, float spatial_scale,
+                         int sampling_ratio, int variant, int layout, mi_stream_t stream);
+
+int mi_roi_align_backward(const float* top_grad, const float* rois, float* bottom_grad,
+                          int batch, int channels, int height, int width, int num_rois,
+                          int aligned_height, int aligned_width, float spatial_scale,
+                          int sampling_ratio, int variant, int layout, mi_stream_t stream);
+
+/* ---- RoIPool --------------------------------------------------------------------------
+ * replaces ROIPoolForwardLaucher / ROIPoolBackwardLaucher (lib/model/roi_pooling/src/roi_pooling_kernel.h:8-20)
+ * and roi_pooling_forward_cuda / roi_pooling_backward_cuda (roi_pooling_cuda.c:7,49).
+ * argmax[R,C,PH,PW] int32 = flat index into the whole NCHW feature tensor, -1 for an empty bin
+ * (roi_pooling_kernel.cu:75-91).  NCHW only, like the reference. */
+int mi_roi_pool_forward(const float* features, const float* rois, float* output, int32_t* argmax,
+                        int batch, int channels, int height, int width, int num_rois,
+                        int pooled_height, int pooled_width, float spatial_scale,
+                        mi_stream_t stream);
+
+int mi_roi_pool_backward(const float* top_grad, const float* rois, const int32_t* argmax,
+                         float* bottom_grad,
+                         int batch, int channels, int height, int width, int num_rois,
+                         int pooled_height, int pooled_width, float spatial_scale,
+                         mi_stream_t stream);
+
+/* ---- RoICrop (bilinear grid sampler) ---------------------------------------------------
+ * replaces BilinearSamplerBHWD_updateOutput_cuda_kernel / _updateGradInput_cuda_kernel
+ *   (lib/model/roi_crop/src/roi_crop_cuda_kernel.h:6-37) and the glue in roi_crop_cuda.c:15,54.
+ * input [N,C,H,W] dense NCHW; grid_yx [R,GH,GW,2] with (y,x) in [-1,1]; output [R,C,GH,GW].
+ * RoI r samples image r / (R / N) (roi_crop_cuda_kernel.cu:64,217).  Output elements whose four
+ * neighbours all fall outside the image are left untouched (the reference `continue`s, :92-93),
+ * so the caller zero-fills `output`.  The backward accumulates into grad_input and, like the
+ * reference (:111-194), never writes the grid gradient. */
+int mi_roi_crop_forward(const float* input, const float* grid_yx, float* output,
+                        int batch, int channels, int height, int width,
+                        int num_rois, int grid_height, int grid_width, mi_stream_t stream);
+
+int mi_roi_crop_backward(const float* input, const float* grid_yx, const float* grad_output,
+                         float* grad_input,
+                         int batch, int channels, int height, int width,
+                         int num_rois, int grid_height, int grid_width, mi_stream_t stream);
+
+/* ---- NMS -------------------------------------------------------------------------------
+ * replaces nms_cuda_compute (lib/model/nms/src/nms_cuda_kernel.h:5-6) / nms_cuda (nms_cuda.c:8-19) in
+ * mode GT_SORTED_POS and reproduces utils.cython_nms.nms (cython_nms.pyx:37-87) in mode GE_ORIG_ASC.
+ * dets [n,5] float32 (x1,y1,x2,y2,score), "+1" box-size convention.  Fully on-device and
+ * asynchronous: keep and num_keep are device buffers (keep: n elements of int64 for GE_ORIG_ASC,
+ * of int32 for GT_SORTED_POS; only the first *num_keep are written), workspace is a device
+ * scratch of at least mi_nms_workspace_bytes(n) bytes, 16-byte aligned.  n == 0 writes
+ * *num_keep = 0. */
+size_t mi_nms_workspace_bytes(int n);
+int mi_nms(const float* dets, int n, float thresh, int mode, void* keep, int32_t* num_keep,
+           void* workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* ---- IoU matrix --------------------------------------------------------------------------
+ * reproduces utils.cython_bbox.bbox_overlaps (lib/utils/cython_bbox.pyx:32-73):
+ * boxes [N,4], query [K,4] -> overlaps [N,K] float32, "+1" convention, 0 where iw<=0 or ih<=0. */
+int mi_bbox_overlaps(const float* boxes, int num_boxes, const float* query, int num_query,
+                     float* overlaps, mi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_DETECTRON_OPS_H_ */
