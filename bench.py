@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""bench.py -- the measurement contract of this repository (see DESIGN.md section "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W          (N=1 default)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One JSON line on rank 0.  A *step* is one pass of the hot path over one rank's batch of synthetic
+input, inputs resident in HBM before the timed region.  `roofline` is measured live with HIP events
+on the launch stream for the dominant kernel (RoIAlign forward, BASELINE configs[1] shape);
+`cpu_baseline` times the CPU oracle (oracle/, test infrastructure) on the host cores of the same box
+on a bounded sample.  The oracle is never on the measured GPU path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from detectron_pytorch_amd import synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="hot_path", choices=["hot_path", "e2e"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=200, help="back-to-back launches per roofline timing")
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    return rank, world, local_rank
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+# Hot-path workload: what one image of e2e_mask_rcnn_R-50-FPN asks of the RoI/NMS operators
+# (SURVEY.md section 8a/8d): box-head RoIAlign 512 RoIs x 256 x 7x7 fwd+bwd on P2, mask-head RoIAlign
+# 128 RoIs x 256 x 14x14 fwd+bwd, and the 5 per-level RPN NMS calls (n = 2000 pre-NMS, thresh 0.7).
+# ------------------------------------------------------------------------------------------------
+class HotPath:
+    def __init__(self, device, images_per_rank=2, seed=0):
+        from detectron_pytorch_amd import nms as mi_nms
+        from detectron_pytorch_amd.roi_align import roi_align_backward, roi_align_forward
+
+        self.device = device
+        self.images = images_per_rank
+        self.fwd, self.bwd, self.nms = roi_align_forward, roi_align_backward, mi_nms.nms_device
+        h, w, scale = syn.FPN_LEVELS[2]
+        self.scale = scale
+        n = images_per_rank
+        self.feat_np = syn.feature_map(n, syn.FPN_DIM, h, w, seed=seed)
+        self.feat = torch.from_numpy(self.feat_np).to(device)
+        self.box_rois_np = syn.rois_canonical(512 * n, n, seed=seed)
+        self.box_rois = torch.from_numpy(self.box_rois_np).to(device)
+        self.mask_rois_np = syn.rois_canonical(128 * n, n, seed=seed + 1)
+        self.mask_rois = torch.from_numpy(self.mask_rois_np).to(device)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.box_gtop = torch.randn(512 * n, syn.FPN_DIM, 7, 7, generator=g).to(device)
+        self.mask_gtop = torch.randn(128 * n, syn.FPN_DIM, 14, 14, generator=g).to(device)
+        self.dets = [torch.from_numpy(syn.sort_by_score(syn.boxes_clustered(2000, seed=seed + 10 + i))[0]).to(device)
+                     for i in range(5 * n)]
+
+    def step(self):
+        fs = tuple(self.feat.shape)
+        out = self.fwd(self.feat, self.box_rois, 7, 7, self.scale, 2)
+        gin = self.bwd(self.box_gtop, self.box_rois, fs, 7, 7, self.scale, 2)
+        out2 = self.fwd(self.feat, self.mask_rois, 14, 14, self.scale, 2)
+        gin2 = self.bwd(self.mask_gtop, self.mask_rois, fs, 14, 14, self.scale, 2)
+        keeps = [self.nms(d, 0.7) for d in self.dets]
+        return out, gin, out2, gin2, keeps
+
+
+def time_kernel(fn, iters, warmup=10):
+    """Average duration (s) of one call of `fn` over `iters` back-to-back launches, HIP events recorded
+    on the stream the kernels are launched on (torch's current stream)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e-3 / iters
+
+
+def roofline_roi_align_forward(device, iters):
+    """BASELINE configs[1]: RoIAlign forward, 512 RoIs x 256 ch x 7x7, sampling_ratio 2, P2 map of one image.
+    Algorithmic bytes: 4*R*C*PH*PW (write) + 4*C*U (read, U distinct pixels) + 20*R."""
+    from detectron_pytorch_amd import _lib
+
+    h, w, scale = syn.FPN_LEVELS[2]
+    c, r, res, sr = syn.FPN_DIM, 512, 7, 2
+    feat = torch.from_numpy(syn.feature_map(1, c, h, w, seed=0)).to(device)
+    rois_np = syn.rois_canonical(r, 1, seed=0)
+    rois = torch.from_numpy(rois_np).to(device)
+    out = torch.empty((r, c, res, res), device=device)
+    lib = _lib.lib()
+    stream = _lib.current_stream_handle(device)
+
+    def launch():
+        rc = lib.mi_roi_align_forward(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res,
+                                      scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, stream)
+        assert rc == 0
+
+    seconds = time_kernel(launch, iters)
+    touched = touched_pixels(rois_np, 1, h, w, res, res, scale, sr)
+    alg_bytes = 4 * r * c * res * res + 4 * c * touched + 20 * r
+    achieved = alg_bytes / seconds / 1e9
+    info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "roi_align_forward",
+            "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
+            "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
+    # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
+    gtop = torch.randn(r, c, res, res, device=device)
+    gin = torch.zeros(1, c, h, w, device=device)
+
+    def launch_bwd():
+        gin.zero_()
+        rc = lib.mi_roi_align_backward(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
+                                       scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, stream)
+        assert rc == 0
+
+    sec_bwd = time_kernel(launch_bwd, max(iters // 4, 10))
+    bwd_bytes = 4 * r * c * res * res + 4 * c * h * w + 20 * r
+    info["backward"] = {"avg_us_incl_zero_fill": round(sec_bwd * 1e6, 2),
+                        "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
+                        "algorithmic_bytes": int(bwd_bytes)}
+    return info
+
+
+def touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr):
+    """U of the algorithmic-bytes formula, counted by the oracle (a checker-side computation, not timed)."""
+    import oracle
+
+    return oracle.roi_align_touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr)
+
+
+def nms_latency(device, iters):
+    from detectron_pytorch_amd import _lib
+
+    out = {}
+    lib = _lib.lib()
+    stream = _lib.current_stream_handle(device)
+    for name, dets_np, thresh in [("cfg1_uniform_n1000_t0.5", syn.boxes_uniform(1000, seed=0), 0.5),
+                                  ("rpn_clustered_n2000_t0.7", syn.boxes_clustered(2000, seed=0), 0.7)]:
+        dets = torch.from_numpy(dets_np).to(device)
+        n = dets.shape[0]
+        keep = torch.empty(n, dtype=torch.int64, device=device)
+        num = torch.empty(1, dtype=torch.int32, device=device)
+        ws_bytes = lib.mi_nms_workspace_bytes(n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+
+        def launch():
+            rc = lib.mi_nms(dets.data_ptr(), n, thresh, _lib.NMS_GE_ORIG_ASC, keep.data_ptr(), num.data_ptr(),
+                            ws.data_ptr(), ws_bytes, stream)
+            assert rc == 0
+
+        sec = time_kernel(launch, max(iters // 4, 10))
+        out[name] = {"us_per_call": round(sec * 1e6, 1), "kept": int(num.item()),
+                     "pair_tests_per_s": round(n * (n - 1) / 2 / sec, 0)}
+    return out
+
+
+def cpu_baseline(images_per_rank):
+    """The oracle (a C port of the reference kernels, kind="port") on the host cores of this box, on a
+    bounded sample: ONE image's worth of the hot-path step (512-RoI 7x7 and 128-RoI 14x14 RoIAlign fwd+bwd on
+    a 1x256x200x336 map + 5 NMS calls of 2000 boxes), all OpenMP threads for RoIAlign, NMS single-threaded
+    (the reference's cython_nms is serial)."""
+    import oracle
+
+    threads = oracle.num_threads_available()
+    h, w, scale = syn.FPN_LEVELS[2]
+    feat = syn.feature_map(1, syn.FPN_DIM, h, w, seed=0)
+    box_rois, mask_rois = syn.rois_canonical(512, 1, seed=0), syn.rois_canonical(128, 1, seed=1)
+    box_g = np.random.RandomState(0).randn(512, syn.FPN_DIM, 7, 7).astype(np.float32)
+    mask_g = np.random.RandomState(1).randn(128, syn.FPN_DIM, 14, 14).astype(np.float32)
+    dets = [syn.boxes_clustered(2000, seed=10 + i) for i in range(5)]
+    t0 = time.perf_counter()
+    oracle.roi_align_forward(feat, box_rois, 7, 7, scale, 2, threads=threads)
+    t_fwd = time.perf_counter() - t0
+    oracle.roi_align_backward(box_g, box_rois, feat.shape, scale, 2, threads=threads)
+    oracle.roi_align_forward(feat, mask_rois, 14, 14, scale, 2, threads=threads)
+    oracle.roi_align_backward(mask_g, mask_rois, feat.shape, scale, 2, threads=threads)
+    t1 = time.perf_counter()
+    for d in dets:
+        oracle.nms_cython(d, 0.7)
+    t2 = time.perf_counter()
+    total = t2 - t0
+    extra = {"roi_align_fwd_cfg2_ms": round(t_fwd * 1e3, 2), "roi_align_all_ms": round((t1 - t0) * 1e3, 2),
+             "nms_5x2000_ms": round((t2 - t1) * 1e3, 2)}
+    try:  # the reference's own cython_nms (kind "reference") when the prebuilt module travelled with the snapshot
+        from oracle import ref
+
+        if ref.available():
+            d1000 = syn.boxes_uniform(1000, seed=0)
+            ref.cython_nms(d1000, 0.5)
+            ts = []
+            for _ in range(20):
+                t = time.perf_counter()
+                ref.cython_nms(d1000, 0.5)
+                ts.append(time.perf_counter() - t)
+            extra["reference_cython_nms_cfg1_n1000_t0.5_ms"] = round(float(np.median(ts)) * 1e3, 3)
+    except Exception as e:  # pragma: no cover
+        extra["reference_cython_nms_error"] = str(e)
+    return {"value": round(1.0 / total, 3), "unit": "images/s (hot path only)", "cores": threads, "kind": "port",
+            "sample": "one image of the hot-path step: RoIAlign fwd+bwd 512x256x7x7 and 128x256x14x14 on 1x256x200x336 "
+                      "(OpenMP, %d threads) + 5 x cython-semantics NMS n=2000 thr=0.7 (1 thread); %.2f s of CPU work"
+                      % (threads, total),
+            **extra}
+
+
+def main():
+    args = parse_args()
+    rank, world, local_rank = init_dist(args)
+    device = torch.device("cuda", local_rank)
+    images_per_rank = 2
+    work = HotPath(device, images_per_rank=images_per_rank, seed=rank)
+    for _ in range(args.warmup):
+        work.step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        work.step()
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = images_per_rank * world * args.steps / elapsed
+
+    line = None
+    if rank == 0:
+        roof = roofline_roi_align_forward(device, args.kernel_iters)
+        nms_info = nms_latency(device, args.kernel_iters)
+        line = {
+            "metric": "images/sec, RoIAlign+NMS hot path of e2e_mask_rcnn_R-50-FPN (1333x800, 512 RoIs/image)",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "hot_path: per image RoIAlign fwd+bwd 512x256x7x7 + 128x256x14x14 on P2 200x336, "
+                                   "5 RPN NMS n=2000 thr=0.7; %d images/rank" % images_per_rank,
+                       "images_per_rank": images_per_rank, "parallelism": "dp%d (independent shards)" % world},
+            "roofline": roof,
+            "nms": nms_info,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(images_per_rank)
+        print(json.dumps(line), flush=True)
+    barrier(world)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""ctypes binding of libmi_detectron_ops.so -- the only way this package reaches the GPU.
+
+No torch C++ headers are involved: tensors cross the boundary as `data_ptr()` integers and the
+current HIP stream as `torch.cuda.current_stream().cuda_stream`, exactly the information the
+reference's C glue pulled out of THCudaTensor / THCState (roi_align_cuda.c:10-31).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_detectron_ops.so")
+
+MI_OK = 0
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+ROI_ALIGN_CAFFE2, ROI_ALIGN_LEGACY = 0, 1
+NMS_GE_ORIG_ASC, NMS_GT_SORTED_POS = 0, 1
+
+_c_int, _c_float, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mi_detectron_ops.h declaration by declaration
+SIGNATURES = {
+    "mi_abi_version": (_c_int, []),
+    "mi_last_error": (ctypes.c_char_p, []),
+    "mi_roi_align_forward": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_float] + [_c_int] * 3 + [_c_void_p]),
+    "mi_roi_align_backward": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_float] + [_c_int] * 3 + [_c_void_p]),
+    "mi_roi_pool_forward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_float, _c_void_p]),
+    "mi_roi_pool_backward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_float, _c_void_p]),
+    "mi_roi_crop_forward": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p]),
+    "mi_roi_crop_backward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_void_p]),
+    "mi_nms_workspace_bytes": (_c_size_t, [_c_int]),
+    "mi_nms": (_c_int, [_c_void_p, _c_int, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "mi_bbox_overlaps": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
+}
+
+_lib = None
+
+
+class MiOpsError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library; raise (never fall back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiOpsError(
+                "%s not found: build it with `python -m detectron_pytorch_amd.build` "
+                "(or __graft_entry__.build()); there is no CPU fallback for these ops" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.mi_abi_version() != 1:
+            raise MiOpsError("ABI version mismatch: library %d, binding 1" % handle.mi_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != MI_OK:
+        msg = lib().mi_last_error().decode(errors="replace")
+        raise MiOpsError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def current_stream_handle(device):
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(t, name):
+    """The reference raises NotImplementedError for CPU features (functions/roi_align.py:29-30)."""
+    if not t.is_cuda:
+        raise NotImplementedError("%s must be a GPU tensor: this op has no CPU implementation" % name)

@@ -1,0 +1,51 @@
+// common.h -- shared host-side helpers of libmi_detectron_ops.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "mi_detectron_ops.h"
+
+namespace mi {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// Per-host-thread last-error text behind mi_last_error().
+void set_error(const char* fmt, ...);
+void clear_error();
+
+inline hipStream_t as_stream(mi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Reports a failed launch as MI_ERR_LAUNCH (the reference printed and exit(-1)'d,
+// roi_align_kernel.cu:135-139).
+inline int check_launch(const char* what) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(err));
+    return MI_ERR_LAUNCH;
+  }
+  return MI_OK;
+}
+
+inline int ceil_div(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
+
+// Grid size of a grid-stride element-wise kernel: enough workgroups to fill 256 CUs x 8.
+inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
+  long long g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return static_cast<int>(g);
+}
+
+#define MI_REQUIRE(cond, ...)          \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::mi::set_error(__VA_ARGS__);    \
+      return MI_ERR_BAD_ARGUMENT;      \
+    }                                  \
+  } while (0)
+
+}  // namespace mi

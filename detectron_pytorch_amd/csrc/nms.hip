@@ -1,0 +1,386 @@
+// nms.hip -- greedy NMS and IoU matrix for gfx950, fully on-device, C-ABI mi_nms / mi_bbox_overlaps.
+//
+// Arithmetic contract (fp32, IEEE divide, no FMA contraction: decisions at IoU == thresh must not
+// flip):
+//   MI_NMS_GE_ORIG_ASC   lib/utils/cython_nms.pyx:37-87  (areas :44, order :45, IoU :76-83, >= :84,
+//                        ascending original indices :87)
+//   MI_NMS_GT_SORTED_POS lib/model/nms/src/nms_cuda_kernel.cu:31-39 (devIoU), :41-85 (64x64 bitmask
+//                        tiles, strict >), :132-144 (greedy OR-reduce), nms_gpu.py:7-12
+//   mi_bbox_overlaps     lib/utils/cython_bbox.pyx:32-73 (fp64 intermediates, see oracle.c)
+//
+// Pipeline (no host synchronisation, no allocation; the reference does 2 cudaMalloc, 4 blocking
+// copies and the greedy reduce on the host, nms_cuda_kernel.cu:87-161):
+//   1. nms_prepare     rank-sort by score (descending, ties -> higher index first; n^2/256 LDS-staged
+//                      comparisons per workgroup) and gather boxes into sorted float4 + area arrays
+//                      (GT mode: input is already sorted, plain gather).
+//   2. nms_mask        one wavefront per 64x64 tile of the upper triangle: lane = row box, the 64
+//                      column boxes sit in LDS; bit j of the lane's 64-bit word = IoU(row, col_j)
+//                      over the threshold.  64 = wave64: one word per lane, no cross-lane traffic.
+//   3. nms_reduce      a single wavefront walks the 64-box chunks in order.  Lane w owns the
+//                      "removed" word(s) w, w+64, ...; the in-chunk greedy decision runs on the
+//                      scalar unit over the chunk's diagonal words (v_readlane), then the kept
+//                      rows are OR-ed into the owned words with coalesced, batched row loads.
+//                      Output positions come from popcount prefix sums -- no atomics, no sort.
+//   4. nms_compact     (GE mode) flags by original index -> ascending int64 indices via a
+//                      workgroup-wide exclusive scan.
+#include "common.h"
+
+namespace {
+
+constexpr int kTile = 64;             // boxes per mask word == wavefront size
+constexpr int kMaxWordsPerLane = 4;   // nms_reduce keeps ceil(n/64)/64 words per lane in registers
+constexpr int kMaxBoxes = kTile * kTile * kMaxWordsPerLane;  // 16384
+constexpr int kCompactThreads = 1024;
+
+struct Workspace {
+  float4* boxes;     // [n_pad] sorted (x1,y1,x2,y2)
+  float* areas;      // [n_pad]
+  int32_t* order;    // [n_pad] sorted position -> original index
+  int32_t* flags;    // [n_pad] kept flag per ORIGINAL index (GE mode)
+  uint64_t* mask;    // [n, col_blocks]
+  size_t bytes;
+};
+
+inline size_t align16(size_t b) { return (b + 15) & ~size_t(15); }
+
+Workspace carve(void* base, int n) {
+  Workspace w;
+  const int col_blocks = (n + kTile - 1) / kTile;
+  const size_t n_pad = (size_t)col_blocks * kTile;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  w.boxes = reinterpret_cast<float4*>(p + off);
+  off += align16(n_pad * sizeof(float4));
+  w.areas = reinterpret_cast<float*>(p + off);
+  off += align16(n_pad * sizeof(float));
+  w.order = reinterpret_cast<int32_t*>(p + off);
+  off += align16(n_pad * sizeof(int32_t));
+  w.flags = reinterpret_cast<int32_t*>(p + off);
+  off += align16(n_pad * sizeof(int32_t));
+  w.mask = reinterpret_cast<uint64_t*>(p + off);
+  off += align16((size_t)n * col_blocks * sizeof(uint64_t));
+  w.bytes = off;
+  return w;
+}
+
+// ---- 1. sort + gather -------------------------------------------------------------------
+template <bool kSort>
+__global__ void __launch_bounds__(256)
+nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
+            float* __restrict__ areas, int32_t* __restrict__ order, int32_t* __restrict__ flags) {
+  __shared__ float s_scores[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n;
+  float x1 = 0, y1 = 0, x2 = 0, y2 = 0, score = 0;
+  if (live) {
+    const float* d = dets + (long long)i * 5;
+    x1 = d[0];
+    y1 = d[1];
+    x2 = d[2];
+    y2 = d[3];
+    score = d[4];
+  }
+  int rank = i;
+  if (kSort) {
+    rank = 0;
+    for (int base = 0; base < n; base += 256) {
+      const int j = base + threadIdx.x;
+      __syncthreads();
+      s_scores[threadIdx.x] = (j < n) ? dets[(long long)j * 5 + 4] : 0.f;
+      __syncthreads();
+      const int lim = min(256, n - base);
+      if (live) {
+        for (int t = 0; t < lim; t++) {
+          const float sj = s_scores[t];
+          const int jj = base + t;
+          // descending score; equal scores: higher original index first
+          // (== np.argsort(scores, kind='stable')[::-1], the tie rule fixed in oracle.c)
+          rank += (sj > score) || (sj == score && jj > i);
+        }
+      }
+    }
+  }
+  if (live) {
+    boxes[rank] = make_float4(x1, y1, x2, y2);
+    areas[rank] = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);  // cython_nms.pyx:44 / nms_cuda_kernel.cu:36-37
+    order[rank] = i;
+    flags[i] = 0;
+  }
+}
+
+// ---- 2. IoU bitmask tiles ---------------------------------------------------------------
+template <bool kGE>
+__device__ __forceinline__ bool overlaps(const float4 a, const float area_a, const float4 b,
+                                         const float area_b, const float thresh) {
+  float xx1, yy1, xx2, yy2;
+  if (kGE) {  // cython_nms.pyx:28-32 inline max/min
+    xx1 = a.x >= b.x ? a.x : b.x;
+    yy1 = a.y >= b.y ? a.y : b.y;
+    xx2 = a.z <= b.z ? a.z : b.z;
+    yy2 = a.w <= b.w ? a.w : b.w;
+  } else {  // nms_cuda_kernel.cu:32-33
+    xx1 = fmaxf(a.x, b.x);
+    yy1 = fmaxf(a.y, b.y);
+    xx2 = fminf(a.z, b.z);
+    yy2 = fminf(a.w, b.w);
+  }
+  float w = (xx2 - xx1) + 1.f;  // pyx:80-81 / cu:34
+  float h = (yy2 - yy1) + 1.f;
+  w = w >= 0.f ? w : 0.f;
+  h = h >= 0.f ? h : 0.f;
+  const float inter = w * h;                              // pyx:82
+  const float ovr = inter / ((area_a + area_b) - inter);  // pyx:83 / cu:38, IEEE divide
+  return kGE ? (ovr >= thresh) : (ovr > thresh);          // pyx:84 / cu:78
+}
+
+template <bool kGE>
+__global__ void __launch_bounds__(kTile)
+nms_mask(const float4* __restrict__ boxes, const float* __restrict__ areas, int n, float thresh,
+         uint64_t* __restrict__ mask) {
+  const int col_start = blockIdx.x;
+  const int row_start = blockIdx.y;
+  if (col_start < row_start) return;  // lower triangle is never read by the reduce (cu:139 starts at nblock)
+  const int col_blocks = gridDim.x;
+  __shared__ float4 s_box[kTile];
+  __shared__ float s_area[kTile];
+  const int lane = threadIdx.x;
+  const int col_size = min(n - col_start * kTile, kTile);
+  const int row_size = min(n - row_start * kTile, kTile);
+  if (lane < col_size) {
+    s_box[lane] = boxes[col_start * kTile + lane];
+    s_area[lane] = areas[col_start * kTile + lane];
+  }
+  __syncthreads();
+  if (lane < row_size) {
+    const int cur = row_start * kTile + lane;
+    const float4 a = boxes[cur];
+    const float area_a = areas[cur];
+    uint64_t t = 0;
+    const int start = (row_start == col_start) ? lane + 1 : 0;  // cu:73-76
+    for (int j = start; j < col_size; j++)
+      if (overlaps<kGE>(a, area_a, s_box[j], s_area[j], thresh)) t |= 1ULL << j;
+    mask[(long long)cur * col_blocks + col_start] = t;
+  }
+}
+
+// ---- 3. greedy reduce in one wavefront ----------------------------------------------------
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane);
+  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+template <int kWords, bool kGE>
+__global__ void __launch_bounds__(kTile)
+nms_reduce(const uint64_t* __restrict__ mask, int n, const int32_t* __restrict__ order,
+           int32_t* __restrict__ flags, int32_t* __restrict__ keep32,
+           int32_t* __restrict__ num_keep) {
+  const int lane = threadIdx.x;
+  const int col_blocks = (n + kTile - 1) / kTile;
+  uint64_t remv[kWords];
+#pragma unroll
+  for (int s = 0; s < kWords; s++) remv[s] = 0;
+  int count = 0;
+  for (int k = 0; k < col_blocks; k++) {
+    // removed-word of this chunk: owned by lane k % 64, slot k / 64
+    uint64_t owned = remv[0];
+#pragma unroll
+    for (int s = 1; s < kWords; s++)
+      if (s == k / kTile) owned = remv[s];
+    uint64_t cur = readlane64(owned, k % kTile);
+    const int row = k * kTile + lane;
+    const uint64_t diag = (row < n) ? mask[(long long)row * col_blocks + k] : 0ULL;
+    const int live = n - k * kTile;
+    const uint64_t valid = live >= kTile ? ~0ULL : ((1ULL << live) - 1ULL);
+    // in-chunk greedy pass (cu:132-144 restricted to word k), wave-uniform -> scalar unit
+    uint64_t keepbits = 0;
+    uint64_t cand = ~cur & valid;
+    while (cand) {
+      const int i = __builtin_ctzll(cand);
+      keepbits |= 1ULL << i;
+      cur |= readlane64(diag, i);
+      const uint64_t upto = (i == 63) ? ~0ULL : ((2ULL << i) - 1ULL);
+      cand = ~cur & valid & ~upto;
+    }
+    // OR the kept rows into the words this lane owns (only words > k matter from here on)
+    uint64_t todo = keepbits;
+    while (todo) {
+      int idx[4];
+      bool on[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        on[u] = todo != 0;
+        idx[u] = on[u] ? __builtin_ctzll(todo) : 0;
+        if (on[u]) todo &= todo - 1;
+      }
+#pragma unroll
+      for (int s = 0; s < kWords; s++) {
+        const int w = s * kTile + lane;
+        if (w > k && w < col_blocks) {
+          uint64_t m[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            m[u] = on[u] ? mask[(long long)(k * kTile + idx[u]) * col_blocks + w] : 0ULL;
+          remv[s] |= (m[0] | m[1]) | (m[2] | m[3]);
+        }
+      }
+    }
+    // emit
+    const bool mine = (keepbits >> lane) & 1ULL;
+    if (mine) {
+      if (kGE) {
+        flags[order[row]] = 1;
+      } else {
+        const int pos = count + __popcll(keepbits & ((1ULL << lane) - 1ULL));
+        keep32[pos] = row;
+      }
+    }
+    count += __popcll(keepbits);
+  }
+  if (!kGE && lane == 0) *num_keep = count;
+}
+
+// ---- 4. flags -> ascending original indices -------------------------------------------------
+__global__ void __launch_bounds__(kCompactThreads)
+nms_compact(const int32_t* __restrict__ flags, int n, int64_t* __restrict__ keep64,
+            int32_t* __restrict__ num_keep) {
+  __shared__ int s_wave[kCompactThreads / kTile];
+  const int tid = threadIdx.x;
+  const int per = (n + kCompactThreads - 1) / kCompactThreads;
+  const int begin = min(tid * per, n), end = min(begin + per, n);
+  int local = 0;
+  for (int i = begin; i < end; i++) local += flags[i] != 0;
+  // inclusive scan inside the wavefront
+  int incl = local;
+#pragma unroll
+  for (int d = 1; d < kTile; d <<= 1) {
+    const int up = __shfl_up(incl, d, kTile);
+    if ((tid & (kTile - 1)) >= d) incl += up;
+  }
+  if ((tid & (kTile - 1)) == kTile - 1) s_wave[tid / kTile] = incl;
+  __syncthreads();
+  int wave_base = 0, total = 0;
+  for (int w = 0; w < kCompactThreads / kTile; w++) {
+    const int v = s_wave[w];
+    if (w < tid / kTile) wave_base += v;
+    total += v;
+  }
+  int pos = wave_base + incl - local;
+  for (int i = begin; i < end; i++)
+    if (flags[i] != 0) keep64[pos++] = i;
+  if (tid == 0) *num_keep = total;
+}
+
+__global__ void nms_write_zero(int32_t* num_keep) { *num_keep = 0; }
+
+// ---- IoU matrix -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+bbox_overlaps_kernel(const float* __restrict__ boxes, int N, const float* __restrict__ query, int K,
+                     float* __restrict__ overlaps) {
+  const long long total = (long long)N * K;
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(index % K);
+    const int n = (int)(index / K);
+    const float* q = query + (long long)k * 4;
+    const float* b = boxes + (long long)n * 4;
+    // cython_bbox.pyx:52-72 with the fp64 intermediates of the Cython-generated C (oracle.c)
+    const float box_area = (float)(((double)(q[2] - q[0]) + 1.0) * ((double)(q[3] - q[1]) + 1.0));
+    float result = 0.f;
+    const float iw =
+        (float)((double)((b[2] <= q[2] ? b[2] : q[2]) - (b[0] >= q[0] ? b[0] : q[0])) + 1.0);
+    if (iw > 0) {
+      const float ih =
+          (float)((double)((b[3] <= q[3] ? b[3] : q[3]) - (b[1] >= q[1] ? b[1] : q[1])) + 1.0);
+      if (ih > 0) {
+        const float ua =
+            (float)(((((double)(b[2] - b[0]) + 1.0) * ((double)(b[3] - b[1]) + 1.0)) + (double)box_area) -
+                    (double)(iw * ih));
+        result = iw * ih / ua;
+      }
+    }
+    overlaps[index] = result;
+  }
+}
+
+template <bool kGE>
+int launch_reduce(int words, const Workspace& ws, int n, int32_t* keep32, int32_t* num_keep,
+                  hipStream_t s) {
+  switch (words) {
+    case 1:
+      nms_reduce<1, kGE><<<1, kTile, 0, s>>>(ws.mask, n, ws.order, ws.flags, keep32, num_keep);
+      break;
+    case 2:
+      nms_reduce<2, kGE><<<1, kTile, 0, s>>>(ws.mask, n, ws.order, ws.flags, keep32, num_keep);
+      break;
+    default:
+      nms_reduce<kMaxWordsPerLane, kGE><<<1, kTile, 0, s>>>(ws.mask, n, ws.order, ws.flags, keep32,
+                                                            num_keep);
+      break;
+  }
+  return mi::check_launch("nms_reduce");
+}
+
+}  // namespace
+
+extern "C" size_t mi_nms_workspace_bytes(int n) {
+  if (n <= 0) return 16;
+  return carve(nullptr, n).bytes;
+}
+
+extern "C" int mi_nms(const float* dets, int n, float thresh, int mode, void* keep,
+                      int32_t* num_keep, void* workspace, size_t workspace_bytes,
+                      mi_stream_t stream) {
+  MI_REQUIRE(n >= 0, "nms: negative box count");
+  MI_REQUIRE(mode == MI_NMS_GE_ORIG_ASC || mode == MI_NMS_GT_SORTED_POS, "nms: unknown mode %d", mode);
+  MI_REQUIRE(num_keep != nullptr, "nms: null num_keep");
+  hipStream_t s = mi::as_stream(stream);
+  if (n == 0) {
+    nms_write_zero<<<1, 1, 0, s>>>(num_keep);
+    return mi::check_launch("nms_write_zero");
+  }
+  MI_REQUIRE(dets != nullptr && keep != nullptr && workspace != nullptr, "nms: null pointer");
+  if (n > kMaxBoxes) {
+    mi::set_error("nms: n = %d exceeds the %d boxes the single-wavefront reduce supports", n, kMaxBoxes);
+    return MI_ERR_UNSUPPORTED;
+  }
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "nms: workspace must be 16-byte aligned");
+  Workspace ws = carve(workspace, n);
+  if (workspace_bytes < ws.bytes) {
+    mi::set_error("nms: workspace %zu bytes < required %zu", workspace_bytes, ws.bytes);
+    return MI_ERR_WORKSPACE;
+  }
+  const int col_blocks = (n + kTile - 1) / kTile;
+  const int words = (col_blocks + kTile - 1) / kTile;
+  const bool ge = mode == MI_NMS_GE_ORIG_ASC;
+  int rc;
+  if (ge)
+    nms_prepare<true><<<(n + 255) / 256, 256, 0, s>>>(dets, n, ws.boxes, ws.areas, ws.order, ws.flags);
+  else
+    nms_prepare<false><<<(n + 255) / 256, 256, 0, s>>>(dets, n, ws.boxes, ws.areas, ws.order, ws.flags);
+  if ((rc = mi::check_launch("nms_prepare")) != MI_OK) return rc;
+  dim3 grid(col_blocks, col_blocks);
+  if (ge)
+    nms_mask<true><<<grid, kTile, 0, s>>>(ws.boxes, ws.areas, n, thresh, ws.mask);
+  else
+    nms_mask<false><<<grid, kTile, 0, s>>>(ws.boxes, ws.areas, n, thresh, ws.mask);
+  if ((rc = mi::check_launch("nms_mask")) != MI_OK) return rc;
+  if (ge) {
+    if ((rc = launch_reduce<true>(words, ws, n, nullptr, num_keep, s)) != MI_OK) return rc;
+    nms_compact<<<1, kCompactThreads, 0, s>>>(ws.flags, n, static_cast<int64_t*>(keep), num_keep);
+    return mi::check_launch("nms_compact");
+  }
+  return launch_reduce<false>(words, ws, n, static_cast<int32_t*>(keep), num_keep, s);
+}
+
+extern "C" int mi_bbox_overlaps(const float* boxes, int num_boxes, const float* query, int num_query,
+                                float* overlaps, mi_stream_t stream) {
+  MI_REQUIRE(num_boxes >= 0 && num_query >= 0, "bbox_overlaps: negative size");
+  const long long total = (long long)num_boxes * num_query;
+  if (total == 0) return MI_OK;
+  MI_REQUIRE(boxes != nullptr && query != nullptr && overlaps != nullptr, "bbox_overlaps: null pointer");
+  const int block = 256;
+  bbox_overlaps_kernel<<<mi::grid_for(total, block), block, 0, mi::as_stream(stream)>>>(
+      boxes, num_boxes, query, num_query, overlaps);
+  return mi::check_launch("bbox_overlaps");
+}

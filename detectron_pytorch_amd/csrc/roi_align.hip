@@ -1,0 +1,350 @@
+// roi_align.hip -- RoIAlign forward / backward for gfx950 (MI355X), C-ABI mi_roi_align_*.
+//
+// Arithmetic contract (kept operation for operation, fp32, compiled with -ffp-contract=off so the
+// results equal the CPU oracle bit for bit in the forward pass):
+//   CAFFE2 variant: lib/modeling/roi_xfrom/roi_align/src/roi_align_kernel.cu:16-121 (fwd), :150-270 (bwd)
+//   LEGACY variant: lib/model/roi_align/src/roi_align_kernel.cu:15-70 (fwd), :94-143 (bwd)
+//
+// Kernels in this file:
+//   roi_align_fwd_direct / roi_align_bwd_direct   one lane per output element, any layout
+//       (generic path: NHWC storage, legacy variant, windows that do not fit the LDS tile).
+//   roi_align_fwd_tile   NCHW fast path: one workgroup per (RoI, 64-channel tile); the RoI's
+//       feature window is staged in LDS with coalesced row loads, lanes own channels so every
+//       LDS read is bank-conflict-free and all sampling geometry is wave-uniform (SALU);
+//       results are transposed through LDS and stored as contiguous rows.
+//   roi_align_bwd_tile   mirror image: per-(RoI, channel tile) gradient window accumulated in
+//       LDS without atomics (a lane owns its channel plane), flushed with one coalesced
+//       atomic add per window pixel instead of 4*samples per output element.
+#include "common.h"
+
+namespace {
+
+using mi::kWave;
+
+struct FeatStrides {
+  long long n, c, h, w;  // element strides of the logical [N,C,H,W] tensor
+};
+
+__host__ FeatStrides make_strides(int layout, int C, int H, int W) {
+  if (layout == MI_LAYOUT_NHWC) return {(long long)H * W * C, 1, (long long)W * C, C};
+  return {(long long)C * H * W, (long long)H * W, W, 1};
+}
+
+// Geometry of one RoI, exactly as roi_align_kernel.cu:74-101 computes it.
+struct RoiGeom {
+  int batch_ind;
+  float start_w, start_h, bin_h, bin_w;
+  int grid_h, grid_w;
+  float count;
+};
+
+__device__ __forceinline__ RoiGeom roi_geometry(const float* __restrict__ roi, float spatial_scale,
+                                                int aligned_height, int aligned_width,
+                                                int sampling_ratio) {
+  RoiGeom g;
+  g.batch_ind = (int)roi[0];  // :76 float -> int truncation
+  g.start_w = roi[1] * spatial_scale;  // :79-82, no rounding
+  g.start_h = roi[2] * spatial_scale;
+  float end_w = roi[3] * spatial_scale;
+  float end_h = roi[4] * spatial_scale;
+  float roi_width = fmaxf(end_w - g.start_w, 1.f);  // :85-86
+  float roi_height = fmaxf(end_h - g.start_h, 1.f);
+  g.bin_h = roi_height / (float)aligned_height;  // :87-88
+  g.bin_w = roi_width / (float)aligned_width;
+  g.grid_h = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_height / (float)aligned_height);
+  g.grid_w = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_width / (float)aligned_width);
+  g.count = (float)(g.grid_h * g.grid_w);  // :101
+  return g;
+}
+
+// One bilinear sample: taps and weights of roi_align_kernel.cu:16-58 / :150-190.
+struct Taps {
+  int y_low, y_high, x_low, x_high;  // -1 when the sample is outside the [-1, H] x [-1, W] band
+  float w1, w2, w3, w4;
+};
+
+__device__ __forceinline__ Taps sample_taps(int height, int width, float y, float x) {
+  Taps t;
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
+    t.y_low = t.y_high = t.x_low = t.x_high = -1;
+    t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
+    return t;
+  }
+  if (y <= 0) y = 0;
+  if (x <= 0) x = 0;
+  t.y_low = (int)y;
+  t.x_low = (int)x;
+  if (t.y_low >= height - 1) {
+    t.y_high = t.y_low = height - 1;
+    y = (float)t.y_low;
+  } else {
+    t.y_high = t.y_low + 1;
+  }
+  if (t.x_low >= width - 1) {
+    t.x_high = t.x_low = width - 1;
+    x = (float)t.x_low;
+  } else {
+    t.x_high = t.x_low + 1;
+  }
+  float ly = y - (float)t.y_low;
+  float lx = x - (float)t.x_low;
+  float hy = 1.f - ly, hx = 1.f - lx;
+  t.w1 = hy * hx;
+  t.w2 = hy * lx;
+  t.w3 = ly * hx;
+  t.w4 = ly * lx;
+  return t;
+}
+
+__device__ __forceinline__ float sample_y(const RoiGeom& g, int ph, int iy) {
+  return g.start_h + (float)ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;  // :106-107
+}
+__device__ __forceinline__ float sample_x(const RoiGeom& g, int pw, int ix) {
+  return g.start_w + (float)pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;  // :109-110
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic direct kernels (one lane per output element; reference thread mapping)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+roi_align_fwd_direct(long long total, const float* __restrict__ feat, const float* __restrict__ rois,
+                     float* __restrict__ out, int batch, int channels, int height, int width,
+                     int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
+                     FeatStrides st) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long long)gridDim.x * blockDim.x) {
+    int pw = (int)(index % aligned_width);
+    int ph = (int)((index / aligned_width) % aligned_height);
+    int c = (int)((index / aligned_width / aligned_height) % channels);
+    int n = (int)(index / aligned_width / aligned_height / channels);
+    RoiGeom g = roi_geometry(rois + (long long)n * 5, spatial_scale, aligned_height, aligned_width,
+                             sampling_ratio);
+    if (g.batch_ind < 0 || g.batch_ind >= batch) {  // the reference would read out of bounds
+      out[index] = 0.f;
+      continue;
+    }
+    const float* plane = feat + g.batch_ind * st.n + c * st.c;
+    float output_val = 0.f;
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const float y = sample_y(g, ph, iy);
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const float x = sample_x(g, pw, ix);
+        Taps t = sample_taps(height, width, y, x);
+        float val = 0.f;
+        if (t.y_low >= 0) {
+          float v1 = plane[t.y_low * st.h + t.x_low * st.w];
+          float v2 = plane[t.y_low * st.h + t.x_high * st.w];
+          float v3 = plane[t.y_high * st.h + t.x_low * st.w];
+          float v4 = plane[t.y_high * st.h + t.x_high * st.w];
+          val = (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);  // :60
+        }
+        output_val += val;
+      }
+    }
+    output_val /= g.count;  // :117
+    out[index] = output_val;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+roi_align_bwd_direct(long long total, const float* __restrict__ top_diff,
+                     const float* __restrict__ rois, float* __restrict__ bottom_diff, int batch,
+                     int channels, int height, int width, int aligned_height, int aligned_width,
+                     float spatial_scale, int sampling_ratio, FeatStrides st) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long long)gridDim.x * blockDim.x) {
+    int pw = (int)(index % aligned_width);
+    int ph = (int)((index / aligned_width) % aligned_height);
+    int c = (int)((index / aligned_width / aligned_height) % channels);
+    int n = (int)(index / aligned_width / aligned_height / channels);
+    RoiGeom g = roi_geometry(rois + (long long)n * 5, spatial_scale, aligned_height, aligned_width,
+                             sampling_ratio);
+    if (g.batch_ind < 0 || g.batch_ind >= batch) continue;
+    float* plane = bottom_diff + g.batch_ind * st.n + c * st.c;
+    const float top_diff_this_bin = top_diff[index];
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const float y = sample_y(g, ph, iy);
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const float x = sample_x(g, pw, ix);
+        Taps t = sample_taps(height, width, y, x);
+        float g1 = top_diff_this_bin * t.w1 / g.count;  // :252-255
+        float g2 = top_diff_this_bin * t.w2 / g.count;
+        float g3 = top_diff_this_bin * t.w3 / g.count;
+        float g4 = top_diff_this_bin * t.w4 / g.count;
+        if (t.x_low >= 0 && t.x_high >= 0 && t.y_low >= 0 && t.y_high >= 0) {
+          atomicAdd(plane + t.y_low * st.h + t.x_low * st.w, g1);
+          atomicAdd(plane + t.y_low * st.h + t.x_high * st.w, g2);
+          atomicAdd(plane + t.y_high * st.h + t.x_low * st.w, g3);
+          atomicAdd(plane + t.y_high * st.h + t.x_high * st.w, g4);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Legacy variant (lib/model/roi_align/src/roi_align_kernel.cu).  The reference mixes double
+// literals into the expressions, so parts of the arithmetic are fp64; reproduced as written.
+// ------------------------------------------------------------------------------------------
+struct LegacyPoint {
+  bool inside;
+  int hstart, wstart;
+  float h_ratio, w_ratio;
+  int img;
+};
+
+__device__ __forceinline__ LegacyPoint legacy_point(const float* __restrict__ roi, int ph, int pw,
+                                                    float spatial_scale, int channels, int height,
+                                                    int width, int aligned_height,
+                                                    int aligned_width) {
+  LegacyPoint p;
+  float roi_batch_ind = roi[0];
+  float roi_start_w = roi[1] * spatial_scale;
+  float roi_start_h = roi[2] * spatial_scale;
+  float roi_end_w = roi[3] * spatial_scale;
+  float roi_end_h = roi[4] * spatial_scale;
+  float roi_width = fmaxf((float)((double)(roi_end_w - roi_start_w) + 1.), 0.f);  // :39-40
+  float roi_height = fmaxf((float)((double)(roi_end_h - roi_start_h) + 1.), 0.f);
+  float bin_size_h = (float)((double)roi_height / ((double)aligned_height - 1.));  // :41-42
+  float bin_size_w = (float)((double)roi_width / ((double)aligned_width - 1.));
+  float h = (float)(ph)*bin_size_h + roi_start_h;  // :44-45
+  float w = (float)(pw)*bin_size_w + roi_start_w;
+  p.hstart = (int)fminf(floorf(h), (float)(height - 2));  // :47-48
+  p.wstart = (int)fminf(floorf(w), (float)(width - 2));
+  // :50 `int img_start = roi_batch_ind * channels * height * width` is a float product
+  p.img = (int)(roi_batch_ind * (float)channels * (float)height * (float)width);
+  p.inside = !(h < 0 || h >= (float)height || w < 0 || w >= (float)width);  // :53
+  p.h_ratio = h - (float)p.hstart;
+  p.w_ratio = w - (float)p.wstart;
+  return p;
+}
+
+__global__ void __launch_bounds__(256)
+roi_align_legacy_fwd(long long total, const float* __restrict__ bottom_data,
+                     const float* __restrict__ rois, float* __restrict__ top_data, int batch,
+                     int channels, int height, int width, int aligned_height, int aligned_width,
+                     float spatial_scale) {
+  const long long limit = (long long)batch * channels * height * width;
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long long)gridDim.x * blockDim.x) {
+    int pw = (int)(index % aligned_width);
+    int ph = (int)((index / aligned_width) % aligned_height);
+    int c = (int)((index / aligned_width / aligned_height) % channels);
+    int n = (int)(index / aligned_width / aligned_height / channels);
+    LegacyPoint p = legacy_point(rois + (long long)n * 5, ph, pw, spatial_scale, channels, height,
+                                 width, aligned_height, aligned_width);
+    float result = 0.f;
+    if (p.inside) {
+      long long upleft = (long long)p.img + ((long long)c * height + p.hstart) * width + p.wstart;
+      long long upright = upleft + 1, downleft = upleft + width, downright = downleft + 1;
+      if (upleft >= 0 && downright < limit) {  // guard; the reference reads unchecked
+        // C++ promotion rules identical to the reference expression (:63-66): float*double terms are
+        // evaluated in fp64, the float*float*float term in fp32, the sum in fp64.
+        const float h_ratio = p.h_ratio, w_ratio = p.w_ratio;
+        result = bottom_data[upleft] * (1. - h_ratio) * (1. - w_ratio) +
+                 bottom_data[upright] * (1. - h_ratio) * w_ratio +
+                 bottom_data[downleft] * h_ratio * (1. - w_ratio) +
+                 bottom_data[downright] * h_ratio * w_ratio;
+      }
+    }
+    top_data[index] = result;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+roi_align_legacy_bwd(long long total, const float* __restrict__ top_diff,
+                     const float* __restrict__ rois, float* __restrict__ bottom_diff, int batch,
+                     int channels, int height, int width, int aligned_height, int aligned_width,
+                     float spatial_scale) {
+  const long long limit = (long long)batch * channels * height * width;
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long long)gridDim.x * blockDim.x) {
+    int pw = (int)(index % aligned_width);
+    int ph = (int)((index / aligned_width) % aligned_height);
+    int c = (int)((index / aligned_width / aligned_height) % channels);
+    int n = (int)(index / aligned_width / aligned_height / channels);
+    LegacyPoint p = legacy_point(rois + (long long)n * 5, ph, pw, spatial_scale, channels, height,
+                                 width, aligned_height, aligned_width);
+    if (!p.inside) continue;
+    long long upleft = (long long)p.img + ((long long)c * height + p.hstart) * width + p.wstart;
+    long long upright = upleft + 1, downleft = upleft + width, downright = downleft + 1;
+    if (upleft < 0 || downright >= limit) continue;
+    // same literal types as the reference (:135-138): `1.` is double, `1` is int
+    const float h_ratio = p.h_ratio, w_ratio = p.w_ratio, g = top_diff[index];
+    atomicAdd(bottom_diff + upleft, (float)(g * (1. - h_ratio) * (1 - w_ratio)));
+    atomicAdd(bottom_diff + upright, (float)(g * (1. - h_ratio) * w_ratio));
+    atomicAdd(bottom_diff + downleft, (float)(g * h_ratio * (1 - w_ratio)));
+    atomicAdd(bottom_diff + downright, (float)(g * h_ratio * w_ratio));
+  }
+}
+
+int check_common(const void* a, const void* rois, const void* b, int batch, int channels,
+                 int height, int width, int num_rois, int ah, int aw, int variant, int layout) {
+  MI_REQUIRE(batch >= 0 && channels >= 0 && height >= 0 && width >= 0 && num_rois >= 0,
+             "roi_align: negative size");
+  MI_REQUIRE(ah > 0 && aw > 0, "roi_align: aligned size must be positive");
+  MI_REQUIRE(variant == MI_ROI_ALIGN_CAFFE2 || variant == MI_ROI_ALIGN_LEGACY,
+             "roi_align: unknown variant %d", variant);
+  MI_REQUIRE(layout == MI_LAYOUT_NCHW || layout == MI_LAYOUT_NHWC, "roi_align: unknown layout %d",
+             layout);
+  MI_REQUIRE(!(variant == MI_ROI_ALIGN_LEGACY && layout != MI_LAYOUT_NCHW),
+             "roi_align: the legacy variant is NCHW only");
+  long long out_elems = (long long)num_rois * channels * ah * aw;
+  long long in_elems = (long long)batch * channels * height * width;
+  if (out_elems > 0)
+    MI_REQUIRE(a != nullptr && rois != nullptr && b != nullptr && in_elems > 0,
+               "roi_align: null pointer or empty feature map");
+  return MI_OK;
+}
+
+}  // namespace
+
+extern "C" int mi_roi_align_forward(const float* features, const float* rois, float* output,
+                                    int batch, int channels, int height, int width, int num_rois,
+                                    int aligned_height, int aligned_width, float spatial_scale,
+                                    int sampling_ratio, int variant, int layout,
+                                    mi_stream_t stream) {
+  int rc = check_common(features, rois, output, batch, channels, height, width, num_rois,
+                        aligned_height, aligned_width, variant, layout);
+  if (rc != MI_OK) return rc;
+  const long long total = (long long)num_rois * channels * aligned_height * aligned_width;
+  if (total == 0) return MI_OK;
+  hipStream_t s = mi::as_stream(stream);
+  const int block = 256;
+  if (variant == MI_ROI_ALIGN_LEGACY) {
+    roi_align_legacy_fwd<<<mi::grid_for(total, block), block, 0, s>>>(
+        total, features, rois, output, batch, channels, height, width, aligned_height,
+        aligned_width, spatial_scale);
+    return mi::check_launch("roi_align_legacy_fwd");
+  }
+  FeatStrides st = make_strides(layout, channels, height, width);
+  roi_align_fwd_direct<<<mi::grid_for(total, block), block, 0, s>>>(
+      total, features, rois, output, batch, channels, height, width, aligned_height, aligned_width,
+      spatial_scale, sampling_ratio, st);
+  return mi::check_launch("roi_align_fwd_direct");
+}
+
+extern "C" int mi_roi_align_backward(const float* top_grad, const float* rois, float* bottom_grad,
+                                     int batch, int channels, int height, int width, int num_rois,
+                                     int aligned_height, int aligned_width, float spatial_scale,
+                                     int sampling_ratio, int variant, int layout,
+                                     mi_stream_t stream) {
+  int rc = check_common(top_grad, rois, bottom_grad, batch, channels, height, width, num_rois,
+                        aligned_height, aligned_width, variant, layout);
+  if (rc != MI_OK) return rc;
+  const long long total = (long long)num_rois * channels * aligned_height * aligned_width;
+  if (total == 0) return MI_OK;
+  hipStream_t s = mi::as_stream(stream);
+  const int block = 256;
+  if (variant == MI_ROI_ALIGN_LEGACY) {
+    roi_align_legacy_bwd<<<mi::grid_for(total, block), block, 0, s>>>(
+        total, top_grad, rois, bottom_grad, batch, channels, height, width, aligned_height,
+        aligned_width, spatial_scale);
+    return mi::check_launch("roi_align_legacy_bwd");
+  }
+  FeatStrides st = make_strides(layout, channels, height, width);
+  roi_align_bwd_direct<<<mi::grid_for(total, block), block, 0, s>>>(
+      total, top_grad, rois, bottom_grad, batch, channels, height, width, aligned_height,
+      aligned_width, spatial_scale, sampling_ratio, st);
+  return mi::check_launch("roi_align_bwd_direct");
+}

@@ -1,0 +1,92 @@
+"""NMS / IoU -- host-side mirror of the reference's NMS entry points, backed by mi_nms / mi_bbox_overlaps.
+
+Reference interfaces kept:
+  * utils.cython_nms.nms(dets f32[n,5] numpy, thresh) -> int64 ascending ORIGINAL indices
+        (lib/utils/cython_nms.pyx:37-87; the NMS the model really runs, via utils/boxes.py:320-324)
+  * model.nms.nms_gpu.nms_gpu(dets cuda[n,5] sorted, thresh) -> int32 [k,1] positions
+        (lib/model/nms/nms_gpu.py:7-12) and model.nms.nms_wrapper.nms (nms_wrapper.py:11-18)
+  * utils.cython_bbox.bbox_overlaps(boxes f32[N,4], query f32[K,4]) -> f32[N,K]
+        (lib/utils/cython_bbox.pyx:32-73)
+New, device-native: `nms_device(dets_cuda, thresh, mode)` returns (keep, num_keep) as device tensors
+without any host synchronisation, for callers that stay on the GPU (proposal generation).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def nms_device(dets, thresh, mode=_lib.NMS_GE_ORIG_ASC):
+    """dets: cuda float32 [n,5].  Returns (keep, num_keep): keep is int64[n] (GE_ORIG_ASC) or int32[n]
+    (GT_SORTED_POS) with only the first num_keep[0] entries defined; num_keep is int32[1] on device."""
+    _lib.require_cuda(dets, "dets")
+    if dets.dtype != torch.float32 or dets.dim() != 2 or dets.size(1) != 5:
+        raise ValueError("dets must be float32 [n, 5] (x1, y1, x2, y2, score)")
+    dets = dets.contiguous()
+    n = dets.size(0)
+    dev = dets.device
+    keep_dtype = torch.int64 if mode == _lib.NMS_GE_ORIG_ASC else torch.int32
+    keep = torch.empty((max(n, 1),), dtype=keep_dtype, device=dev)
+    num_keep = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws_bytes = _lib.lib().mi_nms_workspace_bytes(n)
+    workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mi_nms(dets.data_ptr(), n, float(thresh), int(mode), keep.data_ptr(), num_keep.data_ptr(),
+                               workspace.data_ptr(), ws_bytes, _lib.current_stream_handle(dev))
+    _lib.check(rc, "mi_nms")
+    return keep, num_keep
+
+
+def nms_gpu(dets, thresh):
+    """model.nms.nms_gpu.nms_gpu: dets pre-sorted by descending score; returns int32 [k, 1] (one host
+    sync to slice, exactly where the reference has `keep[:num_out[0]]`, nms_gpu.py:11)."""
+    keep, num_keep = nms_device(dets, thresh, _lib.NMS_GT_SORTED_POS)
+    return keep[:int(num_keep.item())].view(-1, 1)
+
+
+def nms(dets, thresh, force_cpu=False):
+    """model.nms.nms_wrapper.nms (nms_wrapper.py:11-18).  `force_cpu` is accepted and ignored, as there."""
+    if dets.shape[0] == 0:
+        return []
+    return nms_gpu(dets, thresh)
+
+
+def cython_nms(dets, thresh, device=None):
+    """utils.cython_nms.nms replacement: numpy (or tensor) in, numpy int64 ascending original indices out.
+    Bit-exact with the reference for inputs without tied scores (tie rule: higher index first)."""
+    if isinstance(dets, np.ndarray):
+        if dets.shape[0] == 0:
+            return np.zeros((0,), dtype=np.int64)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        t = torch.from_numpy(np.ascontiguousarray(dets, dtype=np.float32)).to(dev)
+        keep, num_keep = nms_device(t, thresh, _lib.NMS_GE_ORIG_ASC)
+        return keep[:int(num_keep.item())].cpu().numpy()
+    keep, num_keep = nms_device(dets, thresh, _lib.NMS_GE_ORIG_ASC)
+    return keep[:int(num_keep.item())]
+
+
+def bbox_overlaps(boxes, query_boxes, device=None):
+    """utils.cython_bbox.bbox_overlaps replacement (numpy in -> numpy out; tensors in -> tensor out)."""
+    as_numpy = isinstance(boxes, np.ndarray)
+    if as_numpy:
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        boxes = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.float32)).to(dev)
+        query_boxes = torch.from_numpy(np.ascontiguousarray(query_boxes, dtype=np.float32)).to(dev)
+    _lib.require_cuda(boxes, "boxes")
+    boxes = boxes.contiguous()
+    query_boxes = query_boxes.contiguous()
+    if boxes.dtype != torch.float32 or query_boxes.dtype != torch.float32:
+        raise TypeError("bbox_overlaps supports float32 only")
+    n, k = boxes.size(0), query_boxes.size(0)
+    out = torch.empty((n, k), dtype=torch.float32, device=boxes.device)
+    with torch.cuda.device(boxes.device):
+        rc = _lib.lib().mi_bbox_overlaps(boxes.data_ptr(), n, query_boxes.data_ptr(), k, out.data_ptr(),
+                                         _lib.current_stream_handle(boxes.device))
+    _lib.check(rc, "mi_bbox_overlaps")
+    return out.cpu().numpy() if as_numpy else out
+
+
+def soft_nms(boxes_in, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """utils.cython_nms.soft_nms (lib/utils/cython_nms.pyx:98-203) -- off by default in the reference
+    (TEST.SOFT_NMS.ENABLED False, core/config.py:362).  Not yet on the HIP path: SURVEY.md section 8f row 3."""
+    raise NotImplementedError("soft_nms has no HIP implementation yet (reference default: disabled)")

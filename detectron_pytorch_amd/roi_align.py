@@ -1,0 +1,193 @@
+"""RoIAlign -- host-side mirror of the reference's autograd Functions, backed by mi_roi_align_*.
+
+Reference interface kept (same names, argument order and behaviour):
+  * lib/modeling/roi_xfrom/roi_align/functions/roi_align.py:7-48
+        RoIAlignFunction(aligned_height, aligned_width, spatial_scale, sampling_ratio)(features, rois)
+  * lib/model/roi_align/functions/roi_align.py:7-47   (legacy jwyang arithmetic, no sampling_ratio)
+        RoIAlignFunction(aligned_height, aligned_width, spatial_scale)(features, rois)
+  * modules RoIAlign / RoIAlignAvg / RoIAlignMax: roi_xfrom/roi_align/modules/roi_align.py:6-45 and
+    model/roi_align/modules/roi_align.py:6-42
+
+The reference uses legacy instance-style autograd Functions (config in __init__, tensors in
+__call__), which PyTorch >= 1.3 rejects.  Each public name here is a small callable whose
+__call__ invokes the modern static `_RoIAlign.apply(features, rois, ah, aw, scale, sr, variant)`;
+that `.apply` signature is the frozen one.
+
+Behaviour preserved: CPU `features` -> NotImplementedError (:29-30); no gradient w.r.t. rois
+(backward returns (grad_input, None), :48); fp32 only; output [R, C, ah, aw] in the features' dtype.
+New: features stored channels_last are consumed in place (layout flag of the C-ABI) instead of
+being copied to NCHW.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn.modules.module import Module
+from torch.nn.functional import avg_pool2d, max_pool2d
+
+from . import _lib
+
+
+def _layout_of(features):
+    """Return (tensor usable by the kernels, layout flag)."""
+    if features.is_contiguous():
+        return features, _lib.LAYOUT_NCHW
+    if features.dim() == 4 and features.is_contiguous(memory_format=torch.channels_last):
+        return features, _lib.LAYOUT_NHWC
+    return features.contiguous(), _lib.LAYOUT_NCHW
+
+
+def _check_inputs(features, rois):
+    _lib.require_cuda(features, "features")
+    if features.dtype != torch.float32 or rois.dtype != torch.float32:
+        raise TypeError("RoIAlign supports float32 features and rois only (as the reference)")
+    if features.dim() != 4:
+        raise ValueError("features must be [N, C, H, W]")
+    if rois.dim() != 2 or rois.size(1) != 5:
+        # the reference C glue returns 0 here and Python ignores it (roi_align_cuda.c:19-22)
+        raise ValueError("rois must be [R, 5] (batch_index, x1, y1, x2, y2)")
+    if rois.device != features.device:
+        raise ValueError("rois and features must be on the same device")
+
+
+def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_scale, sampling_ratio,
+                      variant=_lib.ROI_ALIGN_CAFFE2):
+    """Raw forward (no autograd): returns a new [R, C, ah, aw] tensor."""
+    _check_inputs(features, rois)
+    features, layout = _layout_of(features)
+    if variant == _lib.ROI_ALIGN_LEGACY and layout != _lib.LAYOUT_NCHW:
+        features, layout = features.contiguous(), _lib.LAYOUT_NCHW
+    rois = rois.contiguous()
+    n, c, h, w = features.shape
+    r = rois.size(0)
+    # every element is written by the kernel: no zero fill (the reference's .zero_() at :23 is redundant)
+    output = torch.empty((r, c, aligned_height, aligned_width), dtype=features.dtype, device=features.device)
+    with torch.cuda.device(features.device):
+        rc = _lib.lib().mi_roi_align_forward(
+            features.data_ptr(), rois.data_ptr(), output.data_ptr(), n, c, h, w, r,
+            int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
+            int(variant), layout, _lib.current_stream_handle(features.device))
+    _lib.check(rc, "mi_roi_align_forward")
+    return output
+
+
+def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_width, spatial_scale,
+                       sampling_ratio, variant=_lib.ROI_ALIGN_CAFFE2, channels_last=False):
+    """Raw backward: returns grad w.r.t. features, shape `feature_size` (zero-filled then accumulated,
+    functions/roi_align.py:39-44)."""
+    _lib.require_cuda(grad_output, "grad_output")
+    grad_output = grad_output.contiguous()
+    rois = rois.contiguous()
+    n, c, h, w = feature_size
+    fmt = torch.channels_last if (channels_last and variant == _lib.ROI_ALIGN_CAFFE2) else torch.contiguous_format
+    grad_input = torch.zeros((n, c, h, w), dtype=grad_output.dtype, device=grad_output.device, memory_format=fmt)
+    layout = _lib.LAYOUT_NHWC if fmt is torch.channels_last else _lib.LAYOUT_NCHW
+    with torch.cuda.device(grad_output.device):
+        rc = _lib.lib().mi_roi_align_backward(
+            grad_output.data_ptr(), rois.data_ptr(), grad_input.data_ptr(), n, c, h, w, rois.size(0),
+            int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
+            int(variant), layout, _lib.current_stream_handle(grad_output.device))
+    _lib.check(rc, "mi_roi_align_backward")
+    return grad_input
+
+
+class _RoIAlign(Function):
+    """Modern static autograd Function; `.apply(features, rois, ah, aw, scale, sampling_ratio, variant)`."""
+
+    @staticmethod
+    def forward(ctx, features, rois, aligned_height, aligned_width, spatial_scale, sampling_ratio, variant):
+        ctx.save_for_backward(rois)
+        ctx.cfg = (int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio), int(variant))
+        ctx.feature_size = tuple(features.shape)
+        ctx.channels_last = (features.dim() == 4 and not features.is_contiguous()
+                             and features.is_contiguous(memory_format=torch.channels_last))
+        return roi_align_forward(features, rois, *ctx.cfg)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        ah, aw, scale, sr, variant = ctx.cfg
+        grad_input = roi_align_backward(grad_output, rois, ctx.feature_size, ah, aw, scale, sr, variant,
+                                        channels_last=ctx.channels_last)
+        return grad_input, None, None, None, None, None, None
+
+
+class RoIAlignFunction(object):
+    """Drop-in for modeling.roi_xfrom.roi_align.functions.roi_align.RoIAlignFunction (Caffe2 semantics).
+
+    Call site kept verbatim: `RoIAlignFunction(resolution, resolution, sc, sampling_ratio)(bl_in, rois)`
+    (lib/modeling/model_builder.py:290-291, 321-322).
+    """
+
+    def __init__(self, aligned_height, aligned_width, spatial_scale, sampling_ratio):
+        self.aligned_width = int(aligned_width)
+        self.aligned_height = int(aligned_height)
+        self.spatial_scale = float(spatial_scale)
+        self.sampling_ratio = int(sampling_ratio)
+
+    def __call__(self, features, rois):
+        return _RoIAlign.apply(features, rois, self.aligned_height, self.aligned_width, self.spatial_scale,
+                               self.sampling_ratio, _lib.ROI_ALIGN_CAFFE2)
+
+
+class LegacyRoIAlignFunction(object):
+    """Drop-in for model.roi_align.functions.roi_align.RoIAlignFunction (legacy jwyang semantics)."""
+
+    def __init__(self, aligned_height, aligned_width, spatial_scale):
+        self.aligned_width = int(aligned_width)
+        self.aligned_height = int(aligned_height)
+        self.spatial_scale = float(spatial_scale)
+
+    def __call__(self, features, rois):
+        return _RoIAlign.apply(features, rois, self.aligned_height, self.aligned_width, self.spatial_scale, 0,
+                               _lib.ROI_ALIGN_LEGACY)
+
+
+# ---- modules: roi_xfrom/roi_align/modules/roi_align.py:6-45 ---------------------------------
+class RoIAlign(Module):
+    def __init__(self, aligned_height, aligned_width, spatial_scale, sampling_ratio):
+        super(RoIAlign, self).__init__()
+        self.aligned_width = int(aligned_width)
+        self.aligned_height = int(aligned_height)
+        self.spatial_scale = float(spatial_scale)
+        self.sampling_ratio = int(sampling_ratio)
+
+    def forward(self, features, rois):
+        return RoIAlignFunction(self.aligned_height, self.aligned_width, self.spatial_scale,
+                                self.sampling_ratio)(features, rois)
+
+
+class RoIAlignAvg(RoIAlign):
+    def forward(self, features, rois):
+        x = RoIAlignFunction(self.aligned_height + 1, self.aligned_width + 1, self.spatial_scale,
+                             self.sampling_ratio)(features, rois)
+        return avg_pool2d(x, kernel_size=2, stride=1)
+
+
+class RoIAlignMax(RoIAlign):
+    def forward(self, features, rois):
+        x = RoIAlignFunction(self.aligned_height + 1, self.aligned_width + 1, self.spatial_scale,
+                             self.sampling_ratio)(features, rois)
+        return max_pool2d(x, kernel_size=2, stride=1)
+
+
+# ---- legacy modules: model/roi_align/modules/roi_align.py:6-42 -------------------------------
+class LegacyRoIAlign(Module):
+    def __init__(self, aligned_height, aligned_width, spatial_scale):
+        super(LegacyRoIAlign, self).__init__()
+        self.aligned_width = int(aligned_width)
+        self.aligned_height = int(aligned_height)
+        self.spatial_scale = float(spatial_scale)
+
+    def forward(self, features, rois):
+        return LegacyRoIAlignFunction(self.aligned_height, self.aligned_width, self.spatial_scale)(features, rois)
+
+
+class LegacyRoIAlignAvg(LegacyRoIAlign):
+    def forward(self, features, rois):
+        x = LegacyRoIAlignFunction(self.aligned_height + 1, self.aligned_width + 1, self.spatial_scale)(features, rois)
+        return avg_pool2d(x, kernel_size=2, stride=1)
+
+
+class LegacyRoIAlignMax(LegacyRoIAlign):
+    def forward(self, features, rois):
+        x = LegacyRoIAlignFunction(self.aligned_height + 1, self.aligned_width + 1, self.spatial_scale)(features, rois)
+        return max_pool2d(x, kernel_size=2, stride=1)

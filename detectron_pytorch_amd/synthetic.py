@@ -1,0 +1,136 @@
+"""Seeded synthetic workloads of SURVEY.md section 8(d) (numpy only; shared by tests/ and bench.py).
+
+Shapes follow the padded blob of a 1333x800 image: [N,3,800,1344]; FPN maps with C=256:
+P2 200x336 (scale 1/4), P3 100x168, P4 50x84, P5 25x42 (lib/utils/blob.py:97-100, lib/core/config.py:686,693).
+"""
+import numpy as np
+
+IM_H, IM_W = 800, 1344
+FPN_LEVELS = {2: (200, 336, 1.0 / 4), 3: (100, 168, 1.0 / 8), 4: (50, 84, 1.0 / 16), 5: (25, 42, 1.0 / 32)}
+FPN_DIM = 256
+
+
+def boxes_uniform(n, seed=0):
+    """Config-1 'uniform' set: x1~U(0,1332), y1~U(0,799), w,h~U(8,512), clipped; unique scores."""
+    rng = np.random.RandomState(seed)
+    x1 = rng.uniform(0, 1332, n)
+    y1 = rng.uniform(0, 799, n)
+    w = rng.uniform(8, 512, n)
+    h = rng.uniform(8, 512, n)
+    x2 = np.minimum(x1 + w, 1332)
+    y2 = np.minimum(y1 + h, 799)
+    scores = rng.permutation(n) / float(max(n, 1))
+    return np.stack([x1, y1, x2, y2, scores], axis=1).astype(np.float32)
+
+
+def boxes_clustered(n, seed=0, centres=50, jitter=0.08):
+    """Config-1 'clustered' set (RPN-like, heavy suppression): boxes = centre box * (1 + N(0, jitter))."""
+    rng = np.random.RandomState(seed)
+    cx1 = rng.uniform(0, 1100, centres)
+    cy1 = rng.uniform(0, 600, centres)
+    cw = rng.uniform(32, 400, centres)
+    ch = rng.uniform(32, 400, centres)
+    base = np.stack([cx1, cy1, cx1 + cw, cy1 + ch], axis=1)
+    pick = rng.randint(0, centres, n)
+    b = base[pick] * (1.0 + rng.normal(0, jitter, (n, 4)))
+    x1 = np.clip(np.minimum(b[:, 0], b[:, 2]), 0, 1332)
+    x2 = np.clip(np.maximum(b[:, 0], b[:, 2]), 0, 1332)
+    y1 = np.clip(np.minimum(b[:, 1], b[:, 3]), 0, 799)
+    y2 = np.clip(np.maximum(b[:, 1], b[:, 3]), 0, 799)
+    scores = rng.permutation(n) / float(max(n, 1))
+    return np.stack([x1, y1, x2, y2, scores], axis=1).astype(np.float32)
+
+
+def sort_by_score(dets):
+    """Descending score, ties -> higher index first (the tie rule of oracle.c / nms.hip)."""
+    order = np.argsort(dets[:, 4], kind="stable")[::-1]
+    return np.ascontiguousarray(dets[order]), order
+
+
+def rois_canonical(num_rois=512, batch=1, seed=0, side=(16.0, 112.0), im_h=IM_H, im_w=IM_W):
+    """Config-2 RoIs: centre uniform in the image, side ~U(16,112) px (FPN level-2 sized boxes,
+    lib/utils/fpn.py:23), clipped to the image; batch index round-robin over `batch` images."""
+    rng = np.random.RandomState(seed)
+    cx = rng.uniform(0, im_w - 1, num_rois)
+    cy = rng.uniform(0, im_h - 1, num_rois)
+    w = rng.uniform(side[0], side[1], num_rois)
+    h = rng.uniform(side[0], side[1], num_rois)
+    x1 = np.clip(cx - w / 2, 0, im_w - 1)
+    x2 = np.clip(cx + w / 2, 0, im_w - 1)
+    y1 = np.clip(cy - h / 2, 0, im_h - 1)
+    y2 = np.clip(cy + h / 2, 0, im_h - 1)
+    b = (np.arange(num_rois) % batch).astype(np.float64)
+    return np.stack([b, x1, y1, x2, y2], axis=1).astype(np.float32)
+
+
+def rois_adversarial(num_rois, batch, height, width, spatial_scale, seed=0):
+    """Random RoIs that exercise every branch of the kernels: out-of-image, malformed (x2<x1),
+    sub-pixel, whole-image, and boxes hugging each border."""
+    rng = np.random.RandomState(seed)
+    im_w, im_h = width / spatial_scale, height / spatial_scale
+    x1 = rng.uniform(-0.3 * im_w, 1.2 * im_w, num_rois)
+    y1 = rng.uniform(-0.3 * im_h, 1.2 * im_h, num_rois)
+    w = rng.uniform(-0.1 * im_w, 0.8 * im_w, num_rois)
+    h = rng.uniform(-0.1 * im_h, 0.8 * im_h, num_rois)
+    r = np.stack([rng.randint(0, batch, num_rois).astype(np.float64), x1, y1, x1 + w, y1 + h], axis=1)
+    special = [
+        [0, 0, 0, im_w - 1, im_h - 1],                 # whole image
+        [0, -50, -50, im_w + 50, im_h + 50],           # larger than the image
+        [0, 10.3, 10.7, 10.9, 11.1],                   # sub-pixel
+        [0, im_w - 2, im_h - 2, im_w + 30, im_h + 30],  # bottom-right corner
+        [0, -40, -40, 1.5, 1.5],                       # top-left corner
+        [0, 50, 50, 40, 40],                           # malformed
+        [0, -3 * im_w, -3 * im_h, -2 * im_w, -2 * im_h],  # completely outside
+        [0, 5, 5, 5, 5],                               # zero size
+    ]
+    for i, s in enumerate(special[:num_rois]):
+        r[i] = s
+        r[i, 0] = i % batch
+    return r.astype(np.float32)
+
+
+def map_rois_to_fpn_levels(rois_xyxy, k_min=2, k_max=5, s0=224.0, lvl0=4):
+    """lib/utils/fpn.py:11-28: lvl = clip(floor(lvl0 + log2(sqrt(area)/s0 + 1e-6)), k_min, k_max), area with +1."""
+    w = rois_xyxy[:, 2] - rois_xyxy[:, 0] + 1
+    h = rois_xyxy[:, 3] - rois_xyxy[:, 1] + 1
+    areas = np.maximum(w * h, 0)
+    s = np.sqrt(areas)
+    lvls = np.floor(lvl0 + np.log2(s / s0 + 1e-6))
+    return np.clip(lvls, k_min, k_max).astype(np.int64)
+
+
+def rois_fpn_distributed(num_rois=1000, batch=1, seed=0, im_h=IM_H, im_w=IM_W):
+    """Config-2 variant (ii): RoIs with log-uniform sizes 16..700 px spread over FPN levels 2..5.
+    Returns (rois [R,5], levels [R])."""
+    rng = np.random.RandomState(seed)
+    side = np.exp(rng.uniform(np.log(16.0), np.log(700.0), num_rois))
+    aspect = np.exp(rng.uniform(np.log(0.5), np.log(2.0), num_rois))
+    w = side * np.sqrt(aspect)
+    h = side / np.sqrt(aspect)
+    cx = rng.uniform(0, im_w - 1, num_rois)
+    cy = rng.uniform(0, im_h - 1, num_rois)
+    x1 = np.clip(cx - w / 2, 0, im_w - 1)
+    x2 = np.clip(cx + w / 2, 0, im_w - 1)
+    y1 = np.clip(cy - h / 2, 0, im_h - 1)
+    y2 = np.clip(cy + h / 2, 0, im_h - 1)
+    b = (np.arange(num_rois) % batch).astype(np.float64)
+    rois = np.stack([b, x1, y1, x2, y2], axis=1).astype(np.float32)
+    return rois, map_rois_to_fpn_levels(rois[:, 1:5])
+
+
+def feature_map(batch, channels, height, width, seed=0):
+    return np.random.RandomState(seed).randn(batch, channels, height, width).astype(np.float32)
+
+
+def crop_grid(num_rois, gh, gw, seed=0, span=1.25):
+    """[R,gh,gw,2] (y,x) grids: affine boxes in normalised coordinates, a few reaching outside [-1,1]."""
+    rng = np.random.RandomState(seed)
+    cy = rng.uniform(-span, span, (num_rois, 1, 1))
+    cx = rng.uniform(-span, span, (num_rois, 1, 1))
+    sy = rng.uniform(0.05, 0.6, (num_rois, 1, 1))
+    sx = rng.uniform(0.05, 0.6, (num_rois, 1, 1))
+    ly = np.linspace(-1, 1, gh).reshape(1, gh, 1)
+    lx = np.linspace(-1, 1, gw).reshape(1, 1, gw)
+    y = cy + sy * ly + 0 * lx
+    x = cx + sx * lx + 0 * ly
+    return np.stack([y, x], axis=3).astype(np.float32)

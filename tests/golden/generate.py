@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz FROM THE REFERENCE ITSELF.
+
+Runs only in the build container: it needs oracle/_ref (the reference's .cu kernels compiled for
+the host and its Cython NMS/IoU modules, built by oracle/build_ref.py from /root/reference).
+The committed .npz files let the GPU box -- where /root/reference does not exist -- check both the
+oracle and the HIP kernels against outputs of the reference's own code.
+
+    python tests/golden/generate.py        # rewrites every fixture deterministically
+
+Each fixture stores inputs and reference outputs; sizes are kept small (total < 2 MB).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from detectron_pytorch_amd import synthetic as syn  # noqa: E402
+from oracle import ref  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024.0))
+
+
+def gen_roi_align():
+    n, c, h, w = 2, 6, 25, 42
+    scale = 1.0 / 32
+    feat = syn.feature_map(n, c, h, w, seed=11)
+    rois = syn.rois_adversarial(24, n, h, w, scale, seed=12)
+    out = {}
+    for sr in (2, 0, 3):
+        for res in (7, 14):
+            if res == 14 and sr != 2:
+                continue
+            key = "sr%d_r%d" % (sr, res)
+            top = ref.roi_align_forward(feat, rois, res, res, scale, sr)
+            gtop = np.random.RandomState(13 + sr + res).randn(*top.shape).astype(np.float32)
+            out["fwd_" + key] = top
+            out["gtop_" + key] = gtop
+            out["bwd_" + key] = ref.roi_align_backward(gtop, rois, feat.shape, scale, sr)
+    save("roi_align.npz", feat=feat, rois=rois, scale=np.float32(scale), **out)
+
+
+def gen_roi_align_legacy():
+    n, c, h, w = 2, 5, 20, 30
+    scale = 1.0 / 16
+    feat = syn.feature_map(n, c, h, w, seed=21)
+    rois = syn.rois_adversarial(20, n, h, w, scale, seed=22)
+    rois[:, 0] = np.clip(rois[:, 0], 0, n - 1)
+    top = ref.roi_align_legacy_forward(feat, rois, 7, 7, scale)
+    gtop = np.random.RandomState(23).randn(*top.shape).astype(np.float32)
+    bwd = ref.roi_align_legacy_backward(gtop, rois, feat.shape, scale)
+    save("roi_align_legacy.npz", feat=feat, rois=rois, scale=np.float32(scale), fwd=top, gtop=gtop, bwd=bwd)
+
+
+def gen_roi_pool():
+    n, c, h, w = 2, 6, 25, 42
+    scale = 1.0 / 16
+    feat = syn.feature_map(n, c, h, w, seed=31)
+    # plant exact ties so the first-max-wins rule (roi_pooling_kernel.cu:83) is exercised
+    feat[:, :, ::3, ::4] = np.float32(2.5)
+    rois = syn.rois_adversarial(24, n, h, w, scale, seed=32)
+    top, argmax = ref.roi_pool_forward(feat, rois, 7, 7, scale)
+    gtop = np.random.RandomState(33).randn(*top.shape).astype(np.float32)
+    bwd = ref.roi_pool_backward(gtop, rois, argmax, feat.shape, scale)
+    save("roi_pool.npz", feat=feat, rois=rois, scale=np.float32(scale), fwd=top, argmax=argmax, gtop=gtop, bwd=bwd)
+
+
+def gen_roi_crop():
+    n, c, h, w = 2, 5, 18, 27
+    feat = syn.feature_map(n, c, h, w, seed=41)
+    grid = syn.crop_grid(8, 7, 7, seed=42)
+    top = ref.roi_crop_forward(feat, grid)
+    gtop = np.random.RandomState(43).randn(*top.shape).astype(np.float32)
+    bwd, ggrid = ref.roi_crop_backward(feat, grid, gtop)
+    assert not ggrid.any()
+    save("roi_crop.npz", feat=feat, grid=grid, fwd=top, gtop=gtop, bwd=bwd)
+
+
+def gen_nms():
+    out = {}
+    cases = [("uniform1000", syn.boxes_uniform(1000, seed=0), (0.5, 0.7)),
+             ("clustered1000", syn.boxes_clustered(1000, seed=0), (0.5, 0.7)),
+             ("uniform2000", syn.boxes_uniform(2000, seed=1), (0.7,)),
+             ("clustered300", syn.boxes_clustered(300, seed=2, centres=12), (0.3, 0.5)),
+             ("uniform65", syn.boxes_uniform(65, seed=3), (0.5,)),
+             ("single", syn.boxes_uniform(1, seed=4), (0.5,))]
+    for name, dets, threshes in cases:
+        out["dets_" + name] = dets
+        sorted_dets, _ = syn.sort_by_score(dets)
+        for t in threshes:
+            tag = "%s_t%02d" % (name, int(round(t * 100)))
+            out["cython_" + tag] = np.asarray(ref.cython_nms(dets, t), dtype=np.int64)
+            out["gpu_" + tag] = ref.nms_gpu(sorted_dets, t)
+    save("nms.npz", **out)
+    boxes = syn.boxes_uniform(300, seed=5)[:, :4]
+    query = syn.boxes_clustered(40, seed=6)[:, :4]
+    save("bbox_overlaps.npz", boxes=boxes, query=query, overlaps=ref.cython_bbox_overlaps(boxes, query))
+
+
+def main():
+    if not ref.available():
+        sys.exit("oracle/_ref is not built: run `python oracle/build_ref.py` in the build container first")
+    gen_roi_align()
+    gen_roi_align_legacy()
+    gen_roi_pool()
+    gen_roi_crop()
+    gen_nms()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,280 @@
+"""GPU parity tests (-m gpu): the HIP kernels, called through the C-ABI via the host-side mirror of the
+reference's Functions, against the CPU oracle and the committed golden vectors.
+
+Bars (BASELINE.json north_star): NMS kept indices bit-exact; RoIAlign features / gradients within 1e-4.
+Integer / index outputs (argmax, kept indices) bit-exact.  Forward ops follow the reference's fp32
+operation order with FMA contraction off, so they are checked bit-exactly too where the summation
+order is deterministic; backward ops use fp32 atomics (order unspecified in the reference as well)
+and are checked to 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from detectron_pytorch_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4  # north_star tolerance for RoIAlign features / gradients
+RTOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def assert_close(actual, expected, what):
+    actual = actual.detach().cpu().numpy() if isinstance(actual, torch.Tensor) else actual
+    err = np.abs(actual.astype(np.float64) - expected.astype(np.float64))
+    tol = ATOL + RTOL * np.abs(expected)
+    assert (err <= tol).all(), "%s: max abs err %.3e (tol %.1e)" % (what, err.max(), ATOL)
+
+
+def test_extension_is_loaded_not_a_fallback(hip_lib_path):
+    from detectron_pytorch_amd import _lib
+
+    assert _lib.lib().mi_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libmi_detectron_ops.so" in maps
+
+
+# ---- RoIAlign (Caffe2 semantics) ---------------------------------------------------------------
+def _roi_align_gpu(feat, rois, res, scale, sr, gtop=None, channels_last=False):
+    from detectron_pytorch_amd.roi_align import RoIAlignFunction
+
+    f = to_dev(feat).requires_grad_(True)
+    if channels_last:
+        f = f.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = RoIAlignFunction(res, res, scale, sr)(f, to_dev(rois))
+    grad = None
+    if gtop is not None:
+        out.backward(to_dev(gtop))
+        grad = f.grad
+    return out, grad
+
+
+def test_roi_align_golden():
+    g = load_golden("roi_align.npz")
+    feat, rois, scale = g["feat"], g["rois"], float(g["scale"])
+    for key in [k[4:] for k in g.files if k.startswith("fwd_")]:
+        sr, res = int(key.split("_")[0][2:]), int(key.split("_")[1][1:])
+        out, grad = _roi_align_gpu(feat, rois, res, scale, sr, g["gtop_" + key])
+        assert np.array_equal(out.detach().cpu().numpy(), g["fwd_" + key]), "fwd " + key
+        assert_close(grad, g["bwd_" + key], "bwd " + key)
+
+
+@pytest.mark.parametrize("shape,res,sr,nrois", [((2, 8, 25, 42), 7, 2, 64), ((1, 16, 50, 84), 14, 2, 40),
+                                                ((3, 5, 13, 21), 7, 0, 50), ((1, 3, 7, 9), 3, 3, 33),
+                                                ((2, 64, 100, 168), 7, 2, 128), ((1, 70, 30, 40), 7, 1, 20)])
+def test_roi_align_vs_oracle_adversarial_rois(oracle_mod, shape, res, sr, nrois):
+    n, c, h, w = shape
+    scale = 1.0 / 16
+    feat = syn.feature_map(n, c, h, w, seed=res + sr)
+    rois = syn.rois_adversarial(nrois, n, h, w, scale, seed=nrois)
+    gtop = np.random.RandomState(7).randn(nrois, c, res, res).astype(np.float32)
+    out, grad = _roi_align_gpu(feat, rois, res, scale, sr, gtop)
+    ref_out = oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=8)
+    assert_close(out, ref_out, "fwd")
+    assert np.array_equal(out.detach().cpu().numpy(), ref_out), "forward is expected to be bit-exact"
+    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, sr, threads=8), "bwd")
+
+
+def test_roi_align_channels_last_storage(oracle_mod):
+    n, c, h, w, scale = 2, 32, 25, 42, 1.0 / 32
+    feat = syn.feature_map(n, c, h, w, seed=1)
+    rois = syn.rois_adversarial(48, n, h, w, scale, seed=2)
+    gtop = np.random.RandomState(3).randn(48, c, 7, 7).astype(np.float32)
+    out, grad = _roi_align_gpu(feat, rois, 7, scale, 2, gtop, channels_last=True)
+    assert np.array_equal(out.detach().cpu().numpy(), oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2))
+    assert grad.is_contiguous(memory_format=torch.channels_last)
+    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2), "bwd nhwc")
+
+
+def test_roi_align_config2_full_shape(oracle_mod):
+    """BASELINE configs[1]: 512 RoIs x 256 ch x 7x7 on P2 (200x336), sampling_ratio 2, fwd + bwd."""
+    feat = syn.feature_map(1, 256, 200, 336, seed=0)
+    rois = syn.rois_canonical(512, 1, seed=0)
+    gtop = np.random.RandomState(1).randn(512, 256, 7, 7).astype(np.float32)
+    out, grad = _roi_align_gpu(feat, rois, 7, 0.25, 2, gtop)
+    ref_out = oracle_mod.roi_align_forward(feat, rois, 7, 7, 0.25, 2, threads=oracle_mod.num_threads_available())
+    assert_close(out, ref_out, "config-2 fwd")
+    ref_grad = oracle_mod.roi_align_backward(gtop, rois, feat.shape, 0.25, 2,
+                                             threads=oracle_mod.num_threads_available())
+    assert_close(grad, ref_grad, "config-2 bwd")
+    # size-independent properties: mass conservation (all canonical RoIs are interior) and linearity
+    assert abs(float(grad.sum()) - float(gtop.astype(np.float64).sum())) < 1e-2 * np.abs(gtop).sum() ** 0.5
+    out2, _ = _roi_align_gpu(2.0 * feat, rois, 7, 0.25, 2)
+    assert torch.equal(out2, 2.0 * out.detach())
+
+
+def test_roi_align_mask_head_shape_and_multi_image(oracle_mod):
+    """config-2 variant (i)/(iii): 14x14 mask resolution, two images per rank."""
+    feat = syn.feature_map(2, 256, 100, 168, seed=4)
+    rois = syn.rois_canonical(128, 2, seed=5, side=(32.0, 300.0))
+    gtop = np.random.RandomState(6).randn(128, 256, 14, 14).astype(np.float32)
+    out, grad = _roi_align_gpu(feat, rois, 14, 0.125, 2, gtop)
+    assert_close(out, oracle_mod.roi_align_forward(feat, rois, 14, 14, 0.125, 2, threads=8), "mask fwd")
+    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, 0.125, 2, threads=8), "mask bwd")
+
+
+def test_roi_align_empty_and_autograd_contract():
+    from detectron_pytorch_amd.roi_align import RoIAlignFunction
+
+    f = torch.randn(1, 4, 10, 10, device=dev(), requires_grad=True)
+    out = RoIAlignFunction(7, 7, 0.25, 2)(f, torch.zeros(0, 5, device=dev()))
+    assert out.shape == (0, 4, 7, 7)
+    rois = torch.tensor([[0, 4, 4, 30, 30]], device=dev(), dtype=torch.float32, requires_grad=True)
+    out = RoIAlignFunction(7, 7, 0.25, 2)(f, rois)
+    out.sum().backward()
+    assert rois.grad is None and f.grad is not None  # backward returns (grad_input, None)
+    with pytest.raises(ValueError):
+        RoIAlignFunction(7, 7, 0.25, 2)(f, torch.zeros(3, 4, device=dev()))
+
+
+# ---- RoIAlign (legacy) ----------------------------------------------------------------------------
+def test_roi_align_legacy_golden_and_oracle(oracle_mod):
+    from detectron_pytorch_amd.roi_align import LegacyRoIAlignFunction
+
+    g = load_golden("roi_align_legacy.npz")
+    f = to_dev(g["feat"]).requires_grad_(True)
+    out = LegacyRoIAlignFunction(7, 7, float(g["scale"]))(f, to_dev(g["rois"]))
+    assert np.array_equal(out.detach().cpu().numpy(), g["fwd"])
+    out.backward(to_dev(g["gtop"]))
+    assert_close(f.grad, g["bwd"], "legacy bwd")
+    feat = syn.feature_map(2, 12, 30, 44, seed=9)
+    rois = syn.rois_canonical(40, 2, seed=10, im_h=30 * 16, im_w=44 * 16)
+    out = LegacyRoIAlignFunction(8, 8, 1.0 / 16)(to_dev(feat), to_dev(rois))
+    assert np.array_equal(out.cpu().numpy(), oracle_mod.roi_align_legacy_forward(feat, rois, 8, 8, 1.0 / 16))
+
+
+# ---- RoIPool ---------------------------------------------------------------------------------------
+def test_roi_pool_golden_and_oracle(oracle_mod):
+    from detectron_pytorch_amd.roi_pool import RoIPoolFunction, roi_pool_forward
+
+    g = load_golden("roi_pool.npz")
+    scale = float(g["scale"])
+    f = to_dev(g["feat"]).requires_grad_(True)
+    out = RoIPoolFunction(7, 7, scale)(f, to_dev(g["rois"]))
+    assert np.array_equal(out.detach().cpu().numpy(), g["fwd"])
+    _, argmax = roi_pool_forward(to_dev(g["feat"]), to_dev(g["rois"]), 7, 7, scale)
+    assert np.array_equal(argmax.cpu().numpy(), g["argmax"])
+    out.backward(to_dev(g["gtop"]))
+    assert_close(f.grad, g["bwd"], "roi_pool bwd")
+    feat = syn.feature_map(2, 40, 38, 50, seed=12)
+    rois = syn.rois_adversarial(100, 2, 38, 50, 1.0 / 16, seed=13)
+    gtop = np.random.RandomState(14).randn(100, 40, 7, 7).astype(np.float32)
+    f = to_dev(feat).requires_grad_(True)
+    out = RoIPoolFunction(7, 7, 1.0 / 16)(f, to_dev(rois))
+    ref_out, ref_arg = oracle_mod.roi_pool_forward(feat, rois, 7, 7, 1.0 / 16, threads=8)
+    assert np.array_equal(out.detach().cpu().numpy(), ref_out)
+    out.backward(to_dev(gtop))
+    assert_close(f.grad, oracle_mod.roi_pool_backward(gtop, rois, ref_arg, feat.shape, 1.0 / 16, threads=8), "bwd")
+
+
+# ---- RoICrop ---------------------------------------------------------------------------------------
+def test_roi_crop_golden_and_oracle(oracle_mod):
+    from detectron_pytorch_amd.roi_crop import RoICropFunction
+
+    g = load_golden("roi_crop.npz")
+    f = to_dev(g["feat"]).requires_grad_(True)
+    grid = to_dev(g["grid"]).requires_grad_(True)
+    out = RoICropFunction()(f, grid)
+    assert np.array_equal(out.detach().cpu().numpy(), g["fwd"])
+    out.backward(to_dev(g["gtop"]))
+    assert_close(f.grad, g["bwd"], "roi_crop bwd")
+    assert grid.grad is not None and not grid.grad.any()  # the reference never writes the grid gradient
+    feat = syn.feature_map(3, 20, 33, 47, seed=15)
+    grid_np = syn.crop_grid(12, 7, 7, seed=16)
+    gtop = np.random.RandomState(17).randn(12, 20, 7, 7).astype(np.float32)
+    f = to_dev(feat).requires_grad_(True)
+    out = RoICropFunction()(f, to_dev(grid_np))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle_mod.roi_crop_forward(feat, grid_np))
+    out.backward(to_dev(gtop))
+    assert_close(f.grad, oracle_mod.roi_crop_backward(feat, grid_np, gtop), "roi_crop bwd oracle")
+
+
+# ---- NMS: bit-exact kept indices ------------------------------------------------------------------------
+def test_nms_golden_bit_exact():
+    from detectron_pytorch_amd import nms as mi_nms
+
+    g = load_golden("nms.npz")
+    checked = 0
+    for key in g.files:
+        if not key.startswith("cython_"):
+            continue
+        name, t = key[len("cython_"):].rsplit("_t", 1)
+        dets, thresh = g["dets_" + name], int(t) / 100.0
+        keep = mi_nms.cython_nms(dets, thresh)
+        assert keep.dtype == np.int64 and np.array_equal(keep, g[key]), key
+        sorted_dets, _ = syn.sort_by_score(dets)
+        keep_gpu = mi_nms.nms_gpu(to_dev(sorted_dets), thresh)
+        assert keep_gpu.dtype == torch.int32 and keep_gpu.shape[1] == 1
+        assert np.array_equal(keep_gpu.view(-1).cpu().numpy(), g["gpu_" + name + "_t" + t]), key
+        checked += 1
+    assert checked >= 8
+
+
+@pytest.mark.parametrize("gen", [syn.boxes_uniform, syn.boxes_clustered])
+@pytest.mark.parametrize("n,thresh", [(1, 0.5), (2, 0.5), (63, 0.5), (64, 0.7), (65, 0.3), (1000, 0.5), (1000, 0.7),
+                                      (2000, 0.7), (4096, 0.7), (4097, 0.5), (6000, 0.7), (12000, 0.7)])
+def test_nms_vs_oracle_bit_exact(oracle_mod, gen, n, thresh):
+    from detectron_pytorch_amd import nms as mi_nms
+
+    dets = gen(n, seed=n + 1)
+    keep = mi_nms.cython_nms(dets, thresh)
+    ref_keep = oracle_mod.nms_cython(dets, thresh)
+    assert np.array_equal(keep, ref_keep), "GE_ORIG_ASC n=%d" % n
+    if n <= 6000:
+        sorted_dets, _ = syn.sort_by_score(dets)
+        keep_gpu = mi_nms.nms_gpu(to_dev(sorted_dets), thresh).view(-1).cpu().numpy()
+        assert np.array_equal(keep_gpu, oracle_mod.nms_gpu_semantics(sorted_dets, thresh)), "GT_SORTED_POS n=%d" % n
+    # size-independent properties: ascending output, idempotence (NMS of the kept set keeps everything)
+    assert (np.diff(keep) > 0).all()
+    again = mi_nms.cython_nms(dets[keep], thresh)
+    assert np.array_equal(again, np.arange(len(keep)))
+
+
+def test_nms_hand_cases_and_threshold_equality():
+    from detectron_pytorch_amd import nms as mi_nms
+
+    d = np.array([[0, 0, 9, 9, 0.9], [9, 0, 18, 9, 0.8]], np.float32)
+    iou = float(np.float32(10.0) / np.float32(190.0))
+    assert mi_nms.cython_nms(d, iou).tolist() == [0]  # >= at equality (cython_nms.pyx:84)
+    assert mi_nms.nms_gpu(to_dev(d), iou).view(-1).tolist() == [0, 1]  # strict > (nms_cuda_kernel.cu:78)
+    d = np.array([[100, 100, 120, 120, 0.1], [0, 0, 9, 9, 0.5], [0, 0, 9, 9, 0.9]], np.float32)
+    assert mi_nms.cython_nms(d, 0.5).tolist() == [0, 2]
+    assert mi_nms.cython_nms(np.zeros((0, 5), np.float32), 0.5).tolist() == []
+    assert mi_nms.nms(torch.zeros(0, 5, device=dev()), 0.5) == []  # nms_wrapper.py:13-14
+    # tied scores: documented rule = higher original index first
+    d = np.array([[0, 0, 9, 9, 0.5], [0, 0, 9, 9, 0.5], [50, 50, 60, 60, 0.5]], np.float32)
+    assert mi_nms.cython_nms(d, 0.5).tolist() == [1, 2]
+    keep, num = mi_nms.nms_device(to_dev(d), 0.5)
+    assert keep.is_cuda and num.is_cuda and int(num) == 2
+
+
+def test_nms_is_asynchronous_on_the_current_stream():
+    from detectron_pytorch_amd import nms as mi_nms
+
+    dets = to_dev(syn.boxes_clustered(2000, seed=3))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        keep, num = mi_nms.nms_device(dets, 0.7)
+    s.synchronize()
+    ref, refnum = mi_nms.nms_device(dets, 0.7)
+    torch.cuda.synchronize()
+    assert int(num) == int(refnum) and torch.equal(keep[:int(num)], ref[:int(refnum)])
+
+
+def test_bbox_overlaps_bit_exact(oracle_mod):
+    from detectron_pytorch_amd import nms as mi_nms
+
+    g = load_golden("bbox_overlaps.npz")
+    assert np.array_equal(mi_nms.bbox_overlaps(g["boxes"], g["query"]), g["overlaps"])
+    boxes = syn.boxes_uniform(2000, seed=8)[:, :4]
+    query = syn.boxes_clustered(8, seed=9)[:, :4]
+    assert np.array_equal(mi_nms.bbox_overlaps(boxes, query), oracle_mod.bbox_overlaps(boxes, query))

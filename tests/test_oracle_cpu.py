@@ -1,0 +1,180 @@
+"""CPU tests (no GPU): the oracle against (a) the golden vectors produced by the reference's own code,
+(b) the reference-on-host libraries when they are present, (c) analytic known answers.
+
+These pin the oracle; the -m gpu tests then compare the HIP kernels with the oracle.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from detectron_pytorch_amd import synthetic as syn
+
+
+# ---- (a) golden vectors -------------------------------------------------------------------------
+def test_roi_align_matches_golden(oracle_mod):
+    g = load_golden("roi_align.npz")
+    feat, rois, scale = g["feat"], g["rois"], float(g["scale"])
+    for key in [k[4:] for k in g.files if k.startswith("fwd_")]:
+        sr, res = int(key.split("_")[0][2:]), int(key.split("_")[1][1:])
+        out = oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr)
+        assert np.array_equal(out, g["fwd_" + key]), key
+        grad = oracle_mod.roi_align_backward(g["gtop_" + key], rois, feat.shape, scale, sr)
+        assert np.array_equal(grad, g["bwd_" + key]), key
+
+
+def test_roi_align_legacy_matches_golden(oracle_mod):
+    g = load_golden("roi_align_legacy.npz")
+    out = oracle_mod.roi_align_legacy_forward(g["feat"], g["rois"], 7, 7, float(g["scale"]))
+    assert np.array_equal(out, g["fwd"])
+    grad = oracle_mod.roi_align_legacy_backward(g["gtop"], g["rois"], g["feat"].shape, float(g["scale"]))
+    assert np.array_equal(grad, g["bwd"])
+
+
+def test_roi_pool_matches_golden(oracle_mod):
+    g = load_golden("roi_pool.npz")
+    out, argmax = oracle_mod.roi_pool_forward(g["feat"], g["rois"], 7, 7, float(g["scale"]))
+    assert np.array_equal(out, g["fwd"])
+    assert np.array_equal(argmax, g["argmax"])
+    grad = oracle_mod.roi_pool_backward(g["gtop"], g["rois"], argmax, g["feat"].shape, float(g["scale"]))
+    assert np.array_equal(grad, g["bwd"])
+
+
+def test_roi_crop_matches_golden(oracle_mod):
+    g = load_golden("roi_crop.npz")
+    assert np.array_equal(oracle_mod.roi_crop_forward(g["feat"], g["grid"]), g["fwd"])
+    assert np.array_equal(oracle_mod.roi_crop_backward(g["feat"], g["grid"], g["gtop"]), g["bwd"])
+
+
+def test_nms_matches_golden(oracle_mod):
+    g = load_golden("nms.npz")
+    n_checked = 0
+    for key in g.files:
+        if not key.startswith("cython_"):
+            continue
+        name, t = key[len("cython_"):].rsplit("_t", 1)
+        dets, thresh = g["dets_" + name], int(t) / 100.0
+        assert np.array_equal(oracle_mod.nms_cython(dets, thresh), g[key]), key
+        sorted_dets, _ = syn.sort_by_score(dets)
+        assert np.array_equal(oracle_mod.nms_gpu_semantics(sorted_dets, thresh), g["gpu_" + name + "_t" + t]), key
+        n_checked += 1
+    assert n_checked >= 8
+
+
+def test_bbox_overlaps_matches_golden(oracle_mod):
+    g = load_golden("bbox_overlaps.npz")
+    assert np.array_equal(oracle_mod.bbox_overlaps(g["boxes"], g["query"]), g["overlaps"])
+
+
+# ---- (b) reference-on-host, fresh random inputs ------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_oracle_equals_reference_on_host(oracle_mod, ref_mod, seed):
+    n, c, h, w, scale = 2, 4, 19, 23, 1.0 / 8
+    feat = syn.feature_map(n, c, h, w, seed=100 + seed)
+    rois = syn.rois_adversarial(30, n, h, w, scale, seed=200 + seed)
+    rng = np.random.RandomState(300 + seed)
+    for sr in (2, 0, 1):
+        a = oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, sr)
+        assert np.array_equal(a, ref_mod.roi_align_forward(feat, rois, 7, 7, scale, sr))
+        gt = rng.randn(*a.shape).astype(np.float32)
+        assert np.array_equal(oracle_mod.roi_align_backward(gt, rois, feat.shape, scale, sr),
+                              ref_mod.roi_align_backward(gt, rois, feat.shape, scale, sr))
+    a = oracle_mod.roi_align_legacy_forward(feat, rois, 5, 6, scale)
+    assert np.array_equal(a, ref_mod.roi_align_legacy_forward(feat, rois, 5, 6, scale))
+    gt = rng.randn(*a.shape).astype(np.float32)
+    assert np.array_equal(oracle_mod.roi_align_legacy_backward(gt, rois, feat.shape, scale),
+                          ref_mod.roi_align_legacy_backward(gt, rois, feat.shape, scale))
+    a, am = oracle_mod.roi_pool_forward(feat, rois, 6, 5, scale)
+    b, bm = ref_mod.roi_pool_forward(feat, rois, 6, 5, scale)
+    assert np.array_equal(a, b) and np.array_equal(am, bm)
+    gt = rng.randn(*a.shape).astype(np.float32)
+    assert np.array_equal(oracle_mod.roi_pool_backward(gt, rois, am, feat.shape, scale),
+                          ref_mod.roi_pool_backward(gt, rois, bm, feat.shape, scale))
+    grid = syn.crop_grid(6, 5, 4, seed=400 + seed)
+    a = oracle_mod.roi_crop_forward(feat, grid)
+    assert np.array_equal(a, ref_mod.roi_crop_forward(feat, grid))
+    gt = rng.randn(*a.shape).astype(np.float32)
+    assert np.array_equal(oracle_mod.roi_crop_backward(feat, grid, gt), ref_mod.roi_crop_backward(feat, grid, gt)[0])
+
+
+@pytest.mark.parametrize("gen,n,thresh", [(syn.boxes_uniform, 777, 0.5), (syn.boxes_clustered, 1500, 0.7),
+                                          (syn.boxes_clustered, 129, 0.3), (syn.boxes_uniform, 64, 0.5)])
+def test_oracle_nms_equals_reference_cython(oracle_mod, ref_mod, gen, n, thresh):
+    dets = gen(n, seed=n)
+    assert np.array_equal(oracle_mod.nms_cython(dets, thresh), ref_mod.cython_nms(dets, thresh))
+    sorted_dets, _ = syn.sort_by_score(dets)
+    assert np.array_equal(oracle_mod.nms_gpu_semantics(sorted_dets, thresh), ref_mod.nms_gpu(sorted_dets, thresh))
+
+
+# ---- (c) analytic known answers --------------------------------------------
+def test_roi_align_constant_map(oracle_mod):
+    feat = np.full((1, 3, 20, 30), 1.75, np.float32)
+    rois = np.array([[0, 8, 8, 72, 56], [0, 0, 0, 40, 40]], np.float32)
+    out = oracle_mod.roi_align_forward(feat, rois, 7, 7, 0.25, 2)
+    assert np.allclose(out, 1.75, atol=1e-6)
+
+
+def test_roi_align_affine_field_is_exact_at_bin_centres(oracle_mod):
+    h, w = 40, 50
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    feat = (0.5 * yy - 0.25 * xx + 3.0).astype(np.float32)[None, None]
+    rois = np.array([[0, 16, 24, 80, 88]], np.float32)  # interior: 4..20 x 6..22 at scale 1/4
+    out = oracle_mod.roi_align_forward(feat, rois, 4, 4, 0.25, 2)[0, 0]
+    x1, y1, bw, bh = 4.0, 6.0, 16.0 / 4, 16.0 / 4
+    for ph in range(4):
+        for pw in range(4):
+            cy, cx = y1 + (ph + 0.5) * bh, x1 + (pw + 0.5) * bw
+            assert abs(out[ph, pw] - (0.5 * cy - 0.25 * cx + 3.0)) < 1e-4
+
+
+def test_roi_align_backward_conserves_gradient_mass_for_interior_rois(oracle_mod):
+    rois = np.array([[0, 20, 20, 100, 90], [1, 8, 8, 60, 60]], np.float32)
+    gtop = np.random.RandomState(5).randn(2, 3, 7, 7).astype(np.float32)
+    grad = oracle_mod.roi_align_backward(gtop, rois, (2, 3, 40, 50), 0.25, 2)
+    assert np.allclose(grad.sum(), gtop.sum(), rtol=1e-4, atol=1e-3)
+    # finite-difference check of one input element against the forward
+    feat = np.random.RandomState(6).randn(2, 3, 40, 50).astype(np.float32)
+    base = (oracle_mod.roi_align_forward(feat, rois, 7, 7, 0.25, 2) * gtop).sum()
+    feat2 = feat.copy()
+    feat2[0, 1, 10, 12] += 0.5
+    fd = ((oracle_mod.roi_align_forward(feat2, rois, 7, 7, 0.25, 2) * gtop).sum() - base) / 0.5
+    assert abs(fd - grad[0, 1, 10, 12]) < 1e-2
+
+
+def test_roi_align_adaptive_grid_and_malformed_roi(oracle_mod):
+    feat = syn.feature_map(1, 1, 16, 16, seed=3)
+    # malformed RoI (x2 < x1): forced to 1x1 in feature units (roi_align_kernel.cu:85-86)
+    bad = np.array([[0, 40, 40, 8, 8]], np.float32)
+    good = np.array([[0, 40, 40, 44, 44]], np.float32)  # 10..11 at scale 1/4 -> exactly 1x1
+    a = oracle_mod.roi_align_forward(feat, bad, 2, 2, 0.25, 0)
+    b = oracle_mod.roi_align_forward(feat, good, 2, 2, 0.25, 0)
+    assert np.array_equal(a, b)
+    assert oracle_mod.roi_align_touched_pixels(good, 1, 16, 16, 2, 2, 0.25, 0) == 4
+
+
+def test_nms_hand_cases(oracle_mod):
+    # identical boxes: only the higher score survives
+    d = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 9, 0.8]], np.float32)
+    assert oracle_mod.nms_cython(d, 0.5).tolist() == [0]
+    # touching boxes overlap by one pixel column under the +1 convention: IoU = 10/190
+    d = np.array([[0, 0, 9, 9, 0.9], [9, 0, 18, 9, 0.8]], np.float32)
+    iou = np.float32(10.0) / np.float32(190.0)
+    assert oracle_mod.nms_cython(d, float(iou)).tolist() == [0]        # >= suppresses at equality
+    s, _ = syn.sort_by_score(d)
+    assert oracle_mod.nms_gpu_semantics(s, float(iou)).tolist() == [0, 1]  # strict > keeps both
+    # unsorted input: result is ascending ORIGINAL indices
+    d = np.array([[100, 100, 120, 120, 0.1], [0, 0, 9, 9, 0.5], [0, 0, 9, 9, 0.9]], np.float32)
+    assert oracle_mod.nms_cython(d, 0.5).tolist() == [0, 2]
+    # empty
+    assert oracle_mod.nms_cython(np.zeros((0, 5), np.float32), 0.5).tolist() == []
+
+
+def test_roi_pool_first_max_wins(oracle_mod):
+    feat = np.zeros((1, 1, 8, 8), np.float32)
+    feat[0, 0, 2, 3] = 5.0
+    feat[0, 0, 2, 5] = 5.0  # tie later in the row-major scan
+    rois = np.array([[0, 0, 0, 7, 7]], np.float32)
+    out, argmax = oracle_mod.roi_pool_forward(feat, rois, 1, 1, 1.0)
+    assert out[0, 0, 0, 0] == 5.0 and argmax[0, 0, 0, 0] == 2 * 8 + 3
+    # RoI entirely outside: empty bins -> 0 / -1
+    out, argmax = oracle_mod.roi_pool_forward(feat, np.array([[0, 20, 20, 30, 30]], np.float32), 2, 2, 1.0)
+    assert not out.any() and (argmax == -1).all()
