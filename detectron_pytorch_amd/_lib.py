@@ -43,6 +43,13 @@ def lib():
     """Load the HIP library; raise (never fall back) when it has not been built."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).
+        # It must be in the process BEFORE our library is dlopen()ed, so that our NEEDED
+        # libamdhip64.so.7 binds to the same runtime instance that owns torch's allocations and
+        # streams; loading ours first would pull in /opt/rocm's copy as a second runtime (observed:
+        # "no ROCm-capable device is detected" from our launches).
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise MiOpsError(
                 "%s not found: build it with `python -m detectron_pytorch_amd.build` "

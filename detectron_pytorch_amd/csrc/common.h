@@ -30,6 +30,11 @@ inline int check_launch(const char* what) {
   return MI_OK;
 }
 
+// Every launching entry point calls this first: hipGetLastError() is sticky per host thread, so an
+// error left behind by an unrelated earlier runtime call (PyTorch does not clear it) would
+// otherwise be misreported as a failure of our launch.
+inline void begin_call() { (void)hipGetLastError(); }
+
 inline int ceil_div(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
 
 // Grid size of a grid-stride element-wise kernel: enough workgroups to fill 256 CUs x 8.

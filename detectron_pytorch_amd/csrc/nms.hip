@@ -331,6 +331,7 @@ extern "C" size_t mi_nms_workspace_bytes(int n) {
 extern "C" int mi_nms(const float* dets, int n, float thresh, int mode, void* keep,
                       int32_t* num_keep, void* workspace, size_t workspace_bytes,
                       mi_stream_t stream) {
+  mi::begin_call();
   MI_REQUIRE(n >= 0, "nms: negative box count");
   MI_REQUIRE(mode == MI_NMS_GE_ORIG_ASC || mode == MI_NMS_GT_SORTED_POS, "nms: unknown mode %d", mode);
   MI_REQUIRE(num_keep != nullptr, "nms: null num_keep");
@@ -375,6 +376,7 @@ extern "C" int mi_nms(const float* dets, int n, float thresh, int mode, void* ke
 
 extern "C" int mi_bbox_overlaps(const float* boxes, int num_boxes, const float* query, int num_query,
                                 float* overlaps, mi_stream_t stream) {
+  mi::begin_call();
   MI_REQUIRE(num_boxes >= 0 && num_query >= 0, "bbox_overlaps: negative size");
   const long long total = (long long)num_boxes * num_query;
   if (total == 0) return MI_OK;

@@ -304,6 +304,7 @@ extern "C" int mi_roi_align_forward(const float* features, const float* rois, fl
                                     int aligned_height, int aligned_width, float spatial_scale,
                                     int sampling_ratio, int variant, int layout,
                                     mi_stream_t stream) {
+  mi::begin_call();
   int rc = check_common(features, rois, output, batch, channels, height, width, num_rois,
                         aligned_height, aligned_width, variant, layout);
   if (rc != MI_OK) return rc;
@@ -329,6 +330,7 @@ extern "C" int mi_roi_align_backward(const float* top_grad, const float* rois, f
                                      int aligned_height, int aligned_width, float spatial_scale,
                                      int sampling_ratio, int variant, int layout,
                                      mi_stream_t stream) {
+  mi::begin_call();
   int rc = check_common(top_grad, rois, bottom_grad, batch, channels, height, width, num_rois,
                         aligned_height, aligned_width, variant, layout);
   if (rc != MI_OK) return rc;

@@ -108,6 +108,7 @@ int check_crop(const void* a, const void* grid, const void* b, int batch, int ch
 extern "C" int mi_roi_crop_forward(const float* input, const float* grid_yx, float* output,
                                    int batch, int channels, int height, int width, int num_rois,
                                    int grid_height, int grid_width, mi_stream_t stream) {
+  mi::begin_call();
   int rc = check_crop(input, grid_yx, output, batch, channels, height, width, num_rois, grid_height,
                       grid_width);
   if (rc != MI_OK) return rc;
@@ -124,6 +125,7 @@ extern "C" int mi_roi_crop_backward(const float* input, const float* grid_yx,
                                     const float* grad_output, float* grad_input, int batch,
                                     int channels, int height, int width, int num_rois,
                                     int grid_height, int grid_width, mi_stream_t stream) {
+  mi::begin_call();
   (void)input;  // the reference reads it only for the grid gradient it then discards (:166-190)
   int rc = check_crop(grad_output, grid_yx, grad_input, batch, channels, height, width, num_rois,
                       grid_height, grid_width);

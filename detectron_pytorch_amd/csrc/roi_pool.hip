@@ -114,6 +114,7 @@ extern "C" int mi_roi_pool_forward(const float* features, const float* rois, flo
                                    int32_t* argmax, int batch, int channels, int height, int width,
                                    int num_rois, int pooled_height, int pooled_width,
                                    float spatial_scale, mi_stream_t stream) {
+  mi::begin_call();
   int rc = check_pool(features, rois, output, batch, channels, height, width, num_rois,
                       pooled_height, pooled_width);
   if (rc != MI_OK) return rc;
@@ -131,6 +132,7 @@ extern "C" int mi_roi_pool_backward(const float* top_grad, const float* rois,
                                     int channels, int height, int width, int num_rois,
                                     int pooled_height, int pooled_width, float spatial_scale,
                                     mi_stream_t stream) {
+  mi::begin_call();
   int rc = check_pool(top_grad, rois, bottom_grad, batch, channels, height, width, num_rois,
                       pooled_height, pooled_width);
   if (rc != MI_OK) return rc;

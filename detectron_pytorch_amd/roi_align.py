@@ -78,7 +78,8 @@ def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_
     rois = rois.contiguous()
     n, c, h, w = feature_size
     fmt = torch.channels_last if (channels_last and variant == _lib.ROI_ALIGN_CAFFE2) else torch.contiguous_format
-    grad_input = torch.zeros((n, c, h, w), dtype=grad_output.dtype, device=grad_output.device, memory_format=fmt)
+    grad_input = torch.empty((n, c, h, w), dtype=grad_output.dtype, device=grad_output.device,
+                             memory_format=fmt).zero_()
     layout = _lib.LAYOUT_NHWC if fmt is torch.channels_last else _lib.LAYOUT_NCHW
     with torch.cuda.device(grad_output.device):
         rc = _lib.lib().mi_roi_align_backward(

@@ -6,7 +6,7 @@ mkdir -p $R/gpurun_out
 rocminfo | grep -E "Marketing Name|Compute Unit|gfx" | head -8 > $R/gpurun_out/a_rocminfo.txt 2>&1
 nproc >> $R/gpurun_out/a_rocminfo.txt; grep -m1 "model name" /proc/cpuinfo >> $R/gpurun_out/a_rocminfo.txt
 cd $R
-timeout 900 python -m pytest tests -m gpu -x -q > $R/gpurun_out/a_pytest.log 2>&1; echo "pytest exit $?" >> $R/gpurun_out/a_pytest.log
+timeout 900 python -m pytest tests -m gpu -q > $R/gpurun_out/a_pytest.log 2>&1; echo "pytest exit $?" >> $R/gpurun_out/a_pytest.log
 timeout 300 python __graft_entry__.py --smoke > $R/gpurun_out/a_smoke.log 2>&1; echo "smoke exit $?" >> $R/gpurun_out/a_smoke.log
 timeout 600 python bench.py > $R/gpurun_out/a_bench.log 2>&1; echo "bench exit $?" >> $R/gpurun_out/a_bench.log
 cd /tmp && export TMPDIR=/tmp
