@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--workload", default="hot_path", choices=["hot_path", "e2e"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=200, help="back-to-back launches per roofline timing")
+    ap.add_argument("--only-roofline", action="store_true", help="tuning aid: print only the roofline object")
     return ap.parse_args()
 
 
@@ -247,6 +248,10 @@ def main():
     args = parse_args()
     rank, world, local_rank = init_dist(args)
     device = torch.device("cuda", local_rank)
+    if args.only_roofline:
+        print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("MI_")},
+                          "roofline": roofline_roi_align_forward(device, args.kernel_iters)}), flush=True)
+        return
     images_per_rank = 2
     work = HotPath(device, images_per_rank=images_per_rank, seed=rank)
     for _ in range(args.warmup):

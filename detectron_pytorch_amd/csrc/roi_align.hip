@@ -16,10 +16,14 @@
 //       LDS without atomics (a lane owns its channel plane), flushed with one coalesced
 //       atomic add per window pixel instead of 4*samples per output element.
 #include "common.h"
+#include "roi_align_device.h"
+
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
-using mi::kWave;
+using namespace mi;
 
 struct FeatStrides {
   long long n, c, h, w;  // element strides of the logical [N,C,H,W] tensor
@@ -28,79 +32,6 @@ struct FeatStrides {
 __host__ FeatStrides make_strides(int layout, int C, int H, int W) {
   if (layout == MI_LAYOUT_NHWC) return {(long long)H * W * C, 1, (long long)W * C, C};
   return {(long long)C * H * W, (long long)H * W, W, 1};
-}
-
-// Geometry of one RoI, exactly as roi_align_kernel.cu:74-101 computes it.
-struct RoiGeom {
-  int batch_ind;
-  float start_w, start_h, bin_h, bin_w;
-  int grid_h, grid_w;
-  float count;
-};
-
-__device__ __forceinline__ RoiGeom roi_geometry(const float* __restrict__ roi, float spatial_scale,
-                                                int aligned_height, int aligned_width,
-                                                int sampling_ratio) {
-  RoiGeom g;
-  g.batch_ind = (int)roi[0];  // :76 float -> int truncation
-  g.start_w = roi[1] * spatial_scale;  // :79-82, no rounding
-  g.start_h = roi[2] * spatial_scale;
-  float end_w = roi[3] * spatial_scale;
-  float end_h = roi[4] * spatial_scale;
-  float roi_width = fmaxf(end_w - g.start_w, 1.f);  // :85-86
-  float roi_height = fmaxf(end_h - g.start_h, 1.f);
-  g.bin_h = roi_height / (float)aligned_height;  // :87-88
-  g.bin_w = roi_width / (float)aligned_width;
-  g.grid_h = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_height / (float)aligned_height);
-  g.grid_w = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_width / (float)aligned_width);
-  g.count = (float)(g.grid_h * g.grid_w);  // :101
-  return g;
-}
-
-// One bilinear sample: taps and weights of roi_align_kernel.cu:16-58 / :150-190.
-struct Taps {
-  int y_low, y_high, x_low, x_high;  // -1 when the sample is outside the [-1, H] x [-1, W] band
-  float w1, w2, w3, w4;
-};
-
-__device__ __forceinline__ Taps sample_taps(int height, int width, float y, float x) {
-  Taps t;
-  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
-    t.y_low = t.y_high = t.x_low = t.x_high = -1;
-    t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
-    return t;
-  }
-  if (y <= 0) y = 0;
-  if (x <= 0) x = 0;
-  t.y_low = (int)y;
-  t.x_low = (int)x;
-  if (t.y_low >= height - 1) {
-    t.y_high = t.y_low = height - 1;
-    y = (float)t.y_low;
-  } else {
-    t.y_high = t.y_low + 1;
-  }
-  if (t.x_low >= width - 1) {
-    t.x_high = t.x_low = width - 1;
-    x = (float)t.x_low;
-  } else {
-    t.x_high = t.x_low + 1;
-  }
-  float ly = y - (float)t.y_low;
-  float lx = x - (float)t.x_low;
-  float hy = 1.f - ly, hx = 1.f - lx;
-  t.w1 = hy * hx;
-  t.w2 = hy * lx;
-  t.w3 = ly * hx;
-  t.w4 = ly * lx;
-  return t;
-}
-
-__device__ __forceinline__ float sample_y(const RoiGeom& g, int ph, int iy) {
-  return g.start_h + (float)ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;  // :106-107
-}
-__device__ __forceinline__ float sample_x(const RoiGeom& g, int pw, int ix) {
-  return g.start_w + (float)pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;  // :109-110
 }
 
 // ------------------------------------------------------------------------------------------
@@ -278,6 +209,20 @@ roi_align_legacy_bwd(long long total, const float* __restrict__ top_diff,
   }
 }
 
+// MI_ROI_ALIGN_IMPL=direct forces the generic kernels (A/B measurements and tests of the generic path).
+bool force_direct() {
+  const char* impl = std::getenv("MI_ROI_ALIGN_IMPL");
+  return impl != nullptr && std::strcmp(impl, "direct") == 0;
+}
+bool use_stream_path(int channels, int aligned_height, int aligned_width) {
+  return !force_direct() && mi::roi_align_stream_supported(channels, aligned_height, aligned_width);
+}
+// MI_ROI_ALIGN_RING=192|256|320: words per channel of the forward LDS ring (tuning knob; default 256)
+int ring_words() {
+  const char* v = std::getenv("MI_ROI_ALIGN_RING");
+  return v != nullptr ? std::atoi(v) : 256;
+}
+
 int check_common(const void* a, const void* rois, const void* b, int batch, int channels,
                  int height, int width, int num_rois, int ah, int aw, int variant, int layout) {
   MI_REQUIRE(batch >= 0 && channels >= 0 && height >= 0 && width >= 0 && num_rois >= 0,
@@ -318,6 +263,11 @@ extern "C" int mi_roi_align_forward(const float* features, const float* rois, fl
         aligned_width, spatial_scale);
     return mi::check_launch("roi_align_legacy_fwd");
   }
+  if (layout == MI_LAYOUT_NCHW && !force_direct() &&
+      mi::roi_align_fwd_tile_supported(channels, height, width, aligned_height, aligned_width))
+    return mi::launch_roi_align_fwd_tile(features, rois, output, batch, channels, height, width, num_rois,
+                                         aligned_height, aligned_width, spatial_scale, sampling_ratio,
+                                         ring_words(), s);
   FeatStrides st = make_strides(layout, channels, height, width);
   roi_align_fwd_direct<<<mi::grid_for(total, block), block, 0, s>>>(
       total, features, rois, output, batch, channels, height, width, aligned_height, aligned_width,
@@ -344,6 +294,10 @@ extern "C" int mi_roi_align_backward(const float* top_grad, const float* rois, f
         aligned_width, spatial_scale);
     return mi::check_launch("roi_align_legacy_bwd");
   }
+  if (layout == MI_LAYOUT_NCHW && use_stream_path(channels, aligned_height, aligned_width))
+    return mi::launch_roi_align_bwd_stream(top_grad, rois, bottom_grad, batch, channels, height, width,
+                                           num_rois, aligned_height, aligned_width, spatial_scale,
+                                           sampling_ratio, s);
   FeatStrides st = make_strides(layout, channels, height, width);
   roi_align_bwd_direct<<<mi::grid_for(total, block), block, 0, s>>>(
       total, top_grad, rois, bottom_grad, batch, channels, height, width, aligned_height,

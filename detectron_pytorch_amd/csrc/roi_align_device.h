@@ -1,0 +1,95 @@
+// roi_align_device.h -- device helpers shared by the RoIAlign kernels (roi_align.hip, roi_align_stream.hip).
+// Each function restates one piece of lib/modeling/roi_xfrom/roi_align/src/roi_align_kernel.cu in fp32,
+// operation for operation (the library is compiled with -ffp-contract=off).
+#pragma once
+
+#include "common.h"
+
+namespace mi {
+
+// Geometry of one RoI, exactly as roi_align_kernel.cu:74-101 computes it.
+struct RoiGeom {
+  int batch_ind;
+  float start_w, start_h, bin_h, bin_w;
+  int grid_h, grid_w;
+  float count;
+};
+
+__device__ __forceinline__ RoiGeom roi_geometry(const float* __restrict__ roi, float spatial_scale,
+                                                int aligned_height, int aligned_width,
+                                                int sampling_ratio) {
+  RoiGeom g;
+  g.batch_ind = (int)roi[0];  // :76 float -> int truncation
+  g.start_w = roi[1] * spatial_scale;  // :79-82, no rounding
+  g.start_h = roi[2] * spatial_scale;
+  float end_w = roi[3] * spatial_scale;
+  float end_h = roi[4] * spatial_scale;
+  float roi_width = fmaxf(end_w - g.start_w, 1.f);  // :85-86
+  float roi_height = fmaxf(end_h - g.start_h, 1.f);
+  g.bin_h = roi_height / (float)aligned_height;  // :87-88
+  g.bin_w = roi_width / (float)aligned_width;
+  g.grid_h = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_height / (float)aligned_height);
+  g.grid_w = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_width / (float)aligned_width);
+  g.count = (float)(g.grid_h * g.grid_w);  // :101
+  return g;
+}
+
+// One bilinear sample: taps and weights of roi_align_kernel.cu:16-58 / :150-190.
+struct Taps {
+  int y_low, y_high, x_low, x_high;  // -1 when the sample is outside the [-1, H] x [-1, W] band
+  float w1, w2, w3, w4;
+};
+
+__device__ __forceinline__ Taps sample_taps(int height, int width, float y, float x) {
+  Taps t;
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
+    t.y_low = t.y_high = t.x_low = t.x_high = -1;
+    t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
+    return t;
+  }
+  if (y <= 0) y = 0;
+  if (x <= 0) x = 0;
+  t.y_low = (int)y;
+  t.x_low = (int)x;
+  if (t.y_low >= height - 1) {
+    t.y_high = t.y_low = height - 1;
+    y = (float)t.y_low;
+  } else {
+    t.y_high = t.y_low + 1;
+  }
+  if (t.x_low >= width - 1) {
+    t.x_high = t.x_low = width - 1;
+    x = (float)t.x_low;
+  } else {
+    t.x_high = t.x_low + 1;
+  }
+  float ly = y - (float)t.y_low;
+  float lx = x - (float)t.x_low;
+  float hy = 1.f - ly, hx = 1.f - lx;
+  t.w1 = hy * hx;
+  t.w2 = hy * lx;
+  t.w3 = ly * hx;
+  t.w4 = ly * lx;
+  return t;
+}
+
+__device__ __forceinline__ float sample_y(const RoiGeom& g, int ph, int iy) {
+  return g.start_h + (float)ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;  // :106-107
+}
+__device__ __forceinline__ float sample_x(const RoiGeom& g, int pw, int ix) {
+  return g.start_w + (float)pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;  // :109-110
+}
+
+
+// host-side launchers of the NCHW fast paths (roi_align_fwd_tile.hip, roi_align_stream.hip)
+bool roi_align_fwd_tile_supported(int channels, int height, int width, int aligned_height, int aligned_width);
+int launch_roi_align_fwd_tile(const float* features, const float* rois, float* output, int batch, int channels,
+                              int height, int width, int num_rois, int aligned_height, int aligned_width,
+                              float spatial_scale, int sampling_ratio, int ring_words, hipStream_t stream);
+bool roi_align_stream_supported(int channels, int aligned_height, int aligned_width);
+int launch_roi_align_bwd_stream(const float* top_grad, const float* rois, float* bottom_grad, int batch,
+                                int channels, int height, int width, int num_rois, int aligned_height,
+                                int aligned_width, float spatial_scale, int sampling_ratio,
+                                hipStream_t stream);
+
+}  // namespace mi

@@ -35,6 +35,17 @@ def assert_close(actual, expected, what):
     assert (err <= tol).all(), "%s: max abs err %.3e (tol %.1e)" % (what, err.max(), ATOL)
 
 
+@pytest.fixture(params=["stream", "direct"])
+def roi_align_impl(request, monkeypatch):
+    """Run a test against both RoIAlign implementations behind mi_roi_align_*: the LDS-streaming NCHW fast
+    path (default when C % 32 == 0) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
+    if request.param == "direct":
+        monkeypatch.setenv("MI_ROI_ALIGN_IMPL", "direct")
+    else:
+        monkeypatch.delenv("MI_ROI_ALIGN_IMPL", raising=False)
+    return request.param
+
+
 def test_extension_is_loaded_not_a_fallback(hip_lib_path):
     from detectron_pytorch_amd import _lib
 
@@ -70,8 +81,10 @@ def test_roi_align_golden():
 
 @pytest.mark.parametrize("shape,res,sr,nrois", [((2, 8, 25, 42), 7, 2, 64), ((1, 16, 50, 84), 14, 2, 40),
                                                 ((3, 5, 13, 21), 7, 0, 50), ((1, 3, 7, 9), 3, 3, 33),
-                                                ((2, 64, 100, 168), 7, 2, 128), ((1, 70, 30, 40), 7, 1, 20)])
-def test_roi_align_vs_oracle_adversarial_rois(oracle_mod, shape, res, sr, nrois):
+                                                ((2, 64, 100, 168), 7, 2, 128), ((1, 70, 30, 40), 7, 1, 20),
+                                                ((2, 32, 50, 84), 7, 0, 96), ((1, 96, 25, 42), 14, 2, 64),
+                                                ((3, 32, 200, 336), 7, 2, 200), ((1, 32, 9, 70), 6, 3, 40)])
+def test_roi_align_vs_oracle_adversarial_rois(oracle_mod, roi_align_impl, shape, res, sr, nrois):
     n, c, h, w = shape
     scale = 1.0 / 16
     feat = syn.feature_map(n, c, h, w, seed=res + sr)
@@ -95,7 +108,7 @@ def test_roi_align_channels_last_storage(oracle_mod):
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2), "bwd nhwc")
 
 
-def test_roi_align_config2_full_shape(oracle_mod):
+def test_roi_align_config2_full_shape(oracle_mod, roi_align_impl):
     """BASELINE configs[1]: 512 RoIs x 256 ch x 7x7 on P2 (200x336), sampling_ratio 2, fwd + bwd."""
     feat = syn.feature_map(1, 256, 200, 336, seed=0)
     rois = syn.rois_canonical(512, 1, seed=0)
@@ -112,7 +125,7 @@ def test_roi_align_config2_full_shape(oracle_mod):
     assert torch.equal(out2, 2.0 * out.detach())
 
 
-def test_roi_align_mask_head_shape_and_multi_image(oracle_mod):
+def test_roi_align_mask_head_shape_and_multi_image(oracle_mod, roi_align_impl):
     """config-2 variant (i)/(iii): 14x14 mask resolution, two images per rank."""
     feat = syn.feature_map(2, 256, 100, 168, seed=4)
     rois = syn.rois_canonical(128, 2, seed=5, side=(32.0, 300.0))
@@ -120,6 +133,19 @@ def test_roi_align_mask_head_shape_and_multi_image(oracle_mod):
     out, grad = _roi_align_gpu(feat, rois, 14, 0.125, 2, gtop)
     assert_close(out, oracle_mod.roi_align_forward(feat, rois, 14, 14, 0.125, 2, threads=8), "mask fwd")
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, 0.125, 2, threads=8), "mask bwd")
+
+
+def test_roi_align_stream_path_small_and_fpn_sized_rois(oracle_mod):
+    """RoIs the LDS ring serves directly (FPN-assigned sizes on every level) plus degenerate ones."""
+    rois_all, lvls = syn.rois_fpn_distributed(400, batch=2, seed=3)
+    for lvl, (h, w, scale) in syn.FPN_LEVELS.items():
+        rois = rois_all[lvls == lvl]
+        feat = syn.feature_map(2, 64, h, w, seed=lvl)
+        gtop = np.random.RandomState(lvl).randn(len(rois), 64, 7, 7).astype(np.float32)
+        out, grad = _roi_align_gpu(feat, rois, 7, scale, 2, gtop)
+        assert np.array_equal(out.detach().cpu().numpy(),
+                              oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2, threads=8)), "lvl %d" % lvl
+        assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2, threads=8), "lvl %d" % lvl)
 
 
 def test_roi_align_empty_and_autograd_contract():

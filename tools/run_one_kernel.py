@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Profiling aid: launch ONE hot-path kernel a few times (config-2 shape) so that a rocprofv3 --pmc pass
+sees only it.  usage: python tools/run_one_kernel.py {roi_align_fwd|roi_align_bwd|nms} [iters]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from detectron_pytorch_amd import _lib, synthetic as syn  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "roi_align_fwd"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dev = torch.device("cuda", 0)
+lib = _lib.lib()
+stream = _lib.current_stream_handle(dev)
+h, w, scale = syn.FPN_LEVELS[2]
+c, r, res, sr = syn.FPN_DIM, 512, 7, 2
+feat = torch.from_numpy(syn.feature_map(1, c, h, w, seed=0)).to(dev)
+rois = torch.from_numpy(syn.rois_canonical(r, 1, seed=0)).to(dev)
+out = torch.empty((r, c, res, res), device=dev)
+gtop = torch.randn(r, c, res, res, device=dev)
+gin = torch.zeros(1, c, h, w, device=dev)
+dets = torch.from_numpy(syn.boxes_clustered(2000, seed=0)).to(dev)
+keep = torch.empty(2000, dtype=torch.int64, device=dev)
+num = torch.empty(1, dtype=torch.int32, device=dev)
+wsb = lib.mi_nms_workspace_bytes(2000)
+ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+torch.cuda.synchronize()
+for _ in range(iters):
+    if which == "roi_align_fwd":
+        rc = lib.mi_roi_align_forward(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, scale,
+                                      sr, 0, 0, stream)
+    elif which == "roi_align_bwd":
+        rc = lib.mi_roi_align_backward(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
+                                       scale, sr, 0, 0, stream)
+    else:
+        rc = lib.mi_nms(dets.data_ptr(), 2000, 0.7, 0, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), wsb, stream)
+    assert rc == 0
+torch.cuda.synchronize()
+print("done", which, iters)
