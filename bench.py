@@ -127,6 +127,9 @@ def roofline_roi_align_forward(device, iters):
     c, r, res, sr = syn.FPN_DIM, 512, 7, 2
     feat = torch.from_numpy(syn.feature_map(1, c, h, w, seed=0)).to(device)
     rois_np = syn.rois_canonical(r, 1, seed=0)
+    if os.environ.get("MI_BENCH_SORT_ROIS"):  # tuning experiment only: spatially sorted RoI order
+        key = (rois_np[:, 2] + rois_np[:, 4]) // (2 * 64) * 4096 + (rois_np[:, 1] + rois_np[:, 3]) / 2
+        rois_np = np.ascontiguousarray(rois_np[np.argsort(key, kind="stable")])
     rois = torch.from_numpy(rois_np).to(device)
     out = torch.empty((r, c, res, res), device=device)
     lib = _lib.lib()

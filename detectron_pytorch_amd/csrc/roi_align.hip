@@ -217,10 +217,10 @@ bool force_direct() {
 bool use_stream_path(int channels, int aligned_height, int aligned_width) {
   return !force_direct() && mi::roi_align_stream_supported(channels, aligned_height, aligned_width);
 }
-// MI_ROI_ALIGN_RING=192|256|320: words per channel of the forward LDS ring (tuning knob; default 256)
+// MI_ROI_ALIGN_CAP=192|256|320|384: window pixels per channel of the forward LDS image (tuning knob)
 int ring_words() {
-  const char* v = std::getenv("MI_ROI_ALIGN_RING");
-  return v != nullptr ? std::atoi(v) : 256;
+  const char* v = std::getenv("MI_ROI_ALIGN_CAP");
+  return v != nullptr ? std::atoi(v) : 320;
 }
 
 int check_common(const void* a, const void* rois, const void* b, int batch, int channels,

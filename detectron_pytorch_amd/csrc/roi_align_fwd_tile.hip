@@ -1,175 +1,107 @@
 // roi_align_fwd_tile.hip -- the NCHW fast path of RoIAlign forward (Caffe2 semantics) for gfx950.
 //
-// Arithmetic: identical, operation for operation, to roi_align_fwd_direct in roi_align.hip
-// (reference: lib/modeling/roi_xfrom/roi_align/src/roi_align_kernel.cu:16-121); outputs are bit-equal.
-// What changes is where the data moves and how many instructions a tap costs.
+// Arithmetic: the products and sums of roi_align_fwd_direct in roi_align.hip (reference:
+// lib/modeling/roi_xfrom/roi_align/src/roi_align_kernel.cu:16-121), in the same order, so outputs are equal to
+// the CPU oracle (-ffp-contract=off).  What changes is where the data moves and what a tap costs.
 //
-// The reference mapping (one lane per output element) issues 4*samples scattered 4-byte loads per
-// output on a channel-planar tensor -- neighbouring lanes hit different rows/columns, nothing
-// coalesces -- and recomputes the tap geometry (float->int, clamps, 4 weight products) for every
-// one of them.  rocprofv3 PMC on MI355X shows both this mapping and a naive LDS version VALU-bound
-// (SQ_ACTIVE_INST_VALU ~ half of the kernel time), so the design below minimises vector
-// instructions per tap as much as bytes per tap.
+// Why not the reference mapping: one lane per output element issues 4*samples scattered 4-byte loads per
+// output on a channel-planar tensor.  Neighbouring lanes hit different rows and columns, a wave-load touches
+// ~14 cache lines, the texture-address unit serialises them (rocprofv3: 103 us at 512x256x7x7 on a 200x336
+// map) and every lane recomputes the tap geometry that is identical for all 256 channels of a RoI.
 //
-// One 256-lane workgroup owns (RoI, 32-channel tile) and moves the RoI's feature window through LDS
-// exactly once:
-//   * the window [wy0..wy1] x [wx0..wx1] lives in an LDS ring of `nr = kCap / ww` rows per channel
-//     (ww = window width <= 32).  Small windows are resident after one prologue fill; taller ones
-//     stream top to bottom: each bin-row iteration first ISSUES the global loads of the rows the
-//     ring can take next (32-bit offsets off one scalar base, no 64-bit vector address math), then
-//     computes one row of output bins from rows that are already resident, and only then parks
-//     the loaded registers in LDS, so HBM/L2 latency hides under the arithmetic; one workgroup
-//     barrier per bin row while streaming, none once the window is resident;
-//   * row segments are loaded 32 lanes wide (coalesced 128-byte runs);
-//   * a lane owns one channel (lane & 31); the two 32-lane halves of each wavefront take different
-//     output columns.  The per-channel plane stride (kCap + 1 words) is odd, so the 32 lanes of a
-//     half always hit 32 distinct LDS banks: every bilinear tap is a conflict-free ds_read_b32 at
-//     lane_base + row_bytes + col_bytes (one v_add per tap);
-//   * tap rows/columns (as LDS byte offsets) and weights are computed once per workgroup into
-//     small LDS tables instead of 4*samples times per output element;
-//   * results are staged in LDS as [channel][bin] (odd stride) and leave as one contiguous run.
-// RoIs the ring cannot serve (window wider than 32 columns, a bin row taller than the ring, more
-// than 64 samples per axis) take the in-kernel direct path; results are identical.
+// One 256-lane workgroup owns (RoI, 32-channel tile):
+//   * window = the feature rows/columns any sample of the RoI touches.  It is copied HBM/L2 -> LDS once, by
+//     LDS-DMA (buffer_load_dword ... lds): no VGPR staging, no ds_write pass, and the WHOLE window of the
+//     tile is in flight at once (8 channels x ~5 pieces of 256 B per wave) instead of register-sized batches;
+//     a lane's piece index is flattened over (row, column) so that the LDS image is compact ([row][ww]) and
+//     every piece moves 64 useful pixels whatever the window width;
+//   * LDS image: one plane per channel with an ODD plane stride, lane & 31 = channel: the 32 lanes of a
+//     half-wave read the same (row, column) of 32 different planes -> 32 distinct banks, every bilinear tap
+//     is a conflict-free ds_read (two taps of a row with one ds_read2_b32), and all sampling geometry is
+//     identical across the half-wave;
+//   * the 8 half-waves take different output columns pw; tap rows/columns (as LDS byte offsets) and the two
+//     weights per axis sample are computed once per workgroup into two small LDS tables;
+//   * clamped border samples are expressed as the pixel pair (size-2, size-1) with weights (0, 1) instead of
+//     the reference's (size-1, size-1) with (1, 0): the same value for finite features, and "high = low + 1"
+//     holds for every sample, which is what makes the fixed +4 / +pitch tap addressing possible;
+//   * results are staged in LDS as [channel][bin] and leave as contiguous 16-byte stores.
+// Windows larger than the LDS image are processed in groups of bin rows (each group: DMA, barrier, compute);
+// output tiles larger than the LDS staging area likewise.  RoIs the scheme cannot serve (a sample outside the
+// [-1, size] band, one bin row larger than the LDS image, > 64 samples per axis, H or W < 2) take the in-kernel
+// direct path with identical results.
 #include "common.h"
 #include "roi_align_device.h"
 
 namespace mi {
 namespace {
 
-constexpr int kCT = 32;          // channels per workgroup
-constexpr int kMaxWW = 32;       // widest window on the ring path (one 32-lane segment per row)
-constexpr int kMaxS = 64;        // samples per axis the tables hold
+constexpr int kCT = 32;                    // channels per workgroup
 constexpr int kThreads = 256;
-constexpr int kSlots = kThreads / 32;   // half-waves
-constexpr int kChPerSlot = kCT / kSlots;
-constexpr int kPF = 8;           // max rows fetched per lane and channel in one batch
+constexpr int kSlots = kThreads / 32;      // half-waves; each owns output columns pw = slot, slot + 8, ...
+constexpr int kWaves = kThreads / 64;
+constexpr int kChPerWave = kCT / kWaves;   // planes a wave fills
+constexpr int kMaxS = 64;                  // samples per axis the tables hold
+constexpr int kTileBins = 64;              // output bins per channel staged in LDS between two stores
 
 struct AxisEntry {
-  int lo, hi;    // BYTE offsets: y table -> ring row start inside a channel plane, x table -> column inside a row
-  float hw, lw;  // weight of lo (1 - frac) and of hi (frac); hw < 0 marks a sample outside the [-1, size] band
+  int off;       // y table: (row_lo - wy0) * ww * 4 ; x table: (col_lo - wx0) * 4   (LDS byte offsets)
+  float hw, lw;  // weight of lo and of lo + 1
+  int lo;        // absolute row / column of the lower tap
 };
 
-struct AxisRaw {
-  int lo, hi;  // absolute row / column, -1 when the sample is outside the band
-  float hw, lw;
-};
-
-// One axis of roi_align_kernel.cu:16-52 (the y and x halves of bilinear_interpolate are independent).
-__device__ __forceinline__ AxisRaw axis_raw(float v, int size) {
-  AxisRaw e;
-  if (v < -1.0f || v > (float)size) {
-    e.lo = e.hi = -1;
-    e.hw = e.lw = 0.f;
-    return e;
-  }
+// One axis of roi_align_kernel.cu:16-52 for a sample already known to lie inside the [-1, size] band.
+// Returns the lower tap and the weights of (lo, lo + 1); see the header comment for the border case.
+__device__ __forceinline__ void axis_taps(float v, int size, int& lo, float& hw, float& lw) {
   if (v <= 0) v = 0;
-  int low = (int)v, high;
+  int low = (int)v;
   if (low >= size - 1) {
-    high = low = size - 1;
-    v = (float)low;
+    lo = size - 2;
+    hw = 0.f;  // reference: low = high = size - 1, l = 0, h = 1
+    lw = 1.f;
   } else {
-    high = low + 1;
+    lo = low;
+    lw = v - (float)low;
+    hw = 1.f - lw;
   }
-  const float l = v - (float)low;
-  e.lo = low;
-  e.hi = high;
-  e.lw = l;
-  e.hw = 1.f - l;
-  return e;
 }
 
 template <int kCap>
 struct Lds {
-  static constexpr int kPlane = kCap + 1;  // odd
-  float* ring;    // [kCT][kPlane]
-  float* tile;    // [kCT][os]
+  static constexpr int kPlane = kCap + 1;              // odd plane stride (words); kCap is a multiple of 64
+  static constexpr int kTileWords = kCT * (kTileBins + 1);
+  float* img;     // [kCT][kPlane]
+  float* tile;    // [kCT][ts]
   AxisEntry* ty;  // [kMaxS]
   AxisEntry* tx;  // [kMaxS]
-  int* band_lo;   // [kMaxS] first / last absolute feature row each output-bin row reads (hi = -1: none)
-  int* band_hi;
-  int* misc;      // wx0, wx1, wy0, wy1, invalid-sample count
-  __device__ __forceinline__ Lds(float* smem, int os) {
-    ring = smem;
-    tile = ring + kCT * kPlane;
-    float* p = tile + kCT * os;
-    p += (4 - ((kCT * kPlane + kCT * os) & 3)) & 3;  // 16-byte align the tables
-    ty = reinterpret_cast<AxisEntry*>(p);
+  __device__ __forceinline__ explicit Lds(float* smem) {
+    ty = reinterpret_cast<AxisEntry*>(smem);
     tx = ty + kMaxS;
-    band_lo = reinterpret_cast<int*>(tx + kMaxS);
-    band_hi = band_lo + kMaxS;
-    misc = band_hi + kMaxS;
+    tile = reinterpret_cast<float*>(tx + kMaxS);
+    img = tile + kTileWords;
   }
-  static size_t bytes(int bins) {
-    size_t words = (size_t)kCT * kPlane + (size_t)kCT * (bins | 1);
-    words = (words + 3) & ~size_t(3);
-    return words * 4 + 2 * kMaxS * sizeof(AxisEntry) + 2 * kMaxS * 4 + 32;
-  }
+  static constexpr size_t bytes() { return 2 * kMaxS * sizeof(AxisEntry) + (size_t)(kTileWords + kCT * kPlane) * 4; }
 };
 
 __device__ __forceinline__ void store_zero_tile(float* dst, int n, int tid) {
   for (int i = tid; i < n; i += kThreads) dst[i] = 0.f;
 }
 
-__device__ __forceinline__ float lds_at(const float* base, int byte_off) {
+__device__ __forceinline__ float lds_f(const float* base, int byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-// N row loads per channel of this lane through a raw buffer descriptor: the per-lane part of the address
-// (column, channel slot) is one 32-bit voffset computed once per workgroup, the per-row / per-channel part is
-// a scalar soffset -- no vector address arithmetic per load.
-template <int N>
-__device__ __forceinline__ void issue_rows(float (&pf)[kChPerSlot][kPF], __amdgpu_buffer_rsrc_t rsrc,
-                                           unsigned voff_bytes, unsigned row0_bytes, unsigned plane_step_bytes,
-                                           unsigned width_bytes) {
-#pragma unroll
-  for (int cc = 0; cc < kChPerSlot; cc++) {
-#pragma unroll
-    for (int k = 0; k < N; k++)
-      pf[cc][k] = __builtin_bit_cast(
-          float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes,
-                                                      row0_bytes + cc * plane_step_bytes + k * width_bytes, 0));
-  }
-}
+using lds_ptr_t = __attribute__((address_space(3))) void*;
 
-template <int kPlane, int N>
-__device__ __forceinline__ void park_rows(const float (&pf)[kChPerSlot][kPF], float* lrow, int next_slot, int nr,
-                                          int ww, bool loader) {
-  if (!loader) return;  // only the stores are predicated
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    int rr = next_slot + k;
-    if (rr >= nr) rr -= nr;
-    float* p = lrow + rr * ww;
-#pragma unroll
-    for (int cc = 0; cc < kChPerSlot; cc++) p[cc * kSlots * kPlane] = pf[cc][k];
-  }
-}
-
-#define MI_SWITCH_N(n, STMT)                      \
-  switch (n) {                                    \
-    case 1: { constexpr int N = 1; STMT; } break; \
-    case 2: { constexpr int N = 2; STMT; } break; \
-    case 3: { constexpr int N = 3; STMT; } break; \
-    case 4: { constexpr int N = 4; STMT; } break; \
-    case 5: { constexpr int N = 5; STMT; } break; \
-    case 6: { constexpr int N = 6; STMT; } break; \
-    case 7: { constexpr int N = 7; STMT; } break; \
-    case 8: { constexpr int N = 8; STMT; } break; \
-    default: break;                               \
-  }
-
-// kSR > 0: sampling_ratio == kSR at compile time (sample loops unrolled; all 4*kSR*kSR tap reads of a bin
-// are in flight before the first use).  kSR == 0: run-time grid (adaptive ratio, or any other value).
+// kSR > 0: sampling_ratio == kSR at compile time.  kSR == 0: run-time grid (adaptive ratio, or any other value).
 template <int kSR, int kCap>
 __global__ void __launch_bounds__(kThreads)
 roi_align_fwd_tile(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
                    int batch, int channels, int height, int width, int aligned_height, int aligned_width,
-                   float spatial_scale, int sampling_ratio, unsigned bins_magic) {
+                   float spatial_scale, int sampling_ratio) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int bins = aligned_height * aligned_width;
-  const int os = bins | 1;
-  const Lds<kCap> s(smem, os);
+  const Lds<kCap> s(smem);
   constexpr int kPlane = Lds<kCap>::kPlane;
+  const int bins = aligned_height * aligned_width;
   const int tid = threadIdx.x;
   const int tiles = channels / kCT;
   const int r = blockIdx.x / tiles;
@@ -181,74 +113,88 @@ roi_align_fwd_tile(const float* __restrict__ feat, const float* __restrict__ roi
     store_zero_tile(dst, kCT * bins, tid);
     return;
   }
-  // wave-uniform values that the compiler cannot prove uniform go through readfirstlane (scalar control flow,
-  // SGPR buffer descriptor: cdna_hip_programming.md T20)
   const int batch_ind = __builtin_amdgcn_readfirstlane(g.batch_ind);
   const float* __restrict__ src = feat + ((long long)batch_ind * channels + c0) * height * width;
   const int gh = kSR > 0 ? kSR : g.grid_h, gw = kSR > 0 ? kSR : g.grid_w;
   const int nsy = aligned_height * gh, nsx = aligned_width * gw;
 
-  // ---- tables, pass 1: raw taps, window and per-bin-row extents ------------------------------------
-  bool fast = nsy <= kMaxS && nsx <= kMaxS;  // uniform
-  AxisRaw raw;
-  raw.lo = raw.hi = -1;
-  raw.hw = raw.lw = 0.f;
+  // ---- window: first and last sample of each axis (sample coordinates are monotonic in the sample index) ----
+  const float yf = sample_y(g, 0, 0), yl = sample_y(g, aligned_height - 1, gh - 1);
+  const float xf = sample_x(g, 0, 0), xl = sample_x(g, aligned_width - 1, gw - 1);
+  bool fast = nsy <= kMaxS && nsx <= kMaxS && height >= 2 && width >= 2 &&
+              !(yf < -1.0f || yl > (float)height || xf < -1.0f || xl > (float)width) && yl >= yf && xl >= xf;
+  int wy0 = 0, wy1 = 0, wx0 = 0, wx1 = 0;
+  {
+    float hw, lw;
+    axis_taps(yf, height, wy0, hw, lw);
+    axis_taps(yl, height, wy1, hw, lw);
+    axis_taps(xf, width, wx0, hw, lw);
+    axis_taps(xl, width, wx1, hw, lw);
+    wy0 = __builtin_amdgcn_readfirstlane(wy0);
+    wy1 = __builtin_amdgcn_readfirstlane(wy1) + 1;
+    wx0 = __builtin_amdgcn_readfirstlane(wx0);
+    wx1 = __builtin_amdgcn_readfirstlane(wx1) + 1;
+  }
+  fast = __builtin_amdgcn_readfirstlane(fast);
+  const int ww = wx1 - wx0 + 1, nrows = wy1 - wy0 + 1;
+  const int pitch = ww * 4;                                  // bytes between two window rows in a plane
+  const bool single = fast && nrows * ww <= kCap;            // the whole window fits the LDS image
+
+  // ---- LDS-DMA of window rows [row0, row0 + nr) -> img[channel][(row - row0) * ww + col] ----
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src + (long long)wave * kChPerWave * height * width), /*stride*/ 0,
+      (int)((unsigned)kChPerWave * plane_bytes), 0x00020000);
+  const unsigned magic = fast ? ((1u << 20) / (unsigned)ww + 1u) : 0u;  // p / ww == (p * magic) >> 20 for p*ww < 2^20
+  auto issue_dma = [&](int row0, int nr) {
+    const int npx = nr * ww;
+    float* plane0 = s.img + wave * kChPerWave * kPlane;
+    for (int k = 0; k * 64 < npx; k++) {
+      const unsigned p = (unsigned)(k * 64 + lane);
+      const unsigned q = (p * magic) >> 20;
+      const unsigned col = p - q * (unsigned)ww;
+      // lanes past the window carry an out-of-range offset: the buffer bounds check answers 0 without a memory access
+      const unsigned voff = p < (unsigned)npx ? (((unsigned)row0 + q) * (unsigned)width + (unsigned)wx0 + col) * 4u
+                                              : 0xffffff00u;
+#pragma unroll
+      for (int c = 0; c < kChPerWave; c++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(plane0 + c * kPlane + k * 64), 4, voff,
+                                                 c * plane_bytes, 0, 0);
+    }
+  };
+  if (single) issue_dma(wy0, nrows);
+
+  // ---- tables (threads 0.. : y samples, threads 64.. : x samples) ----
   if (fast) {
-    if (tid < kMaxS) {
-      s.band_lo[tid] = 0x7fffffff;
-      s.band_hi[tid] = -1;
-    }
-    if (tid == 0) {
-      s.misc[0] = 0x7fffffff;
-      s.misc[1] = -1;
-      s.misc[2] = 0x7fffffff;
-      s.misc[3] = -1;
-      s.misc[4] = 0;
-    }
-    __syncthreads();
     if (tid < nsy) {
-      raw = axis_raw(sample_y(g, tid / gh, tid % gh), height);
-      if (raw.lo >= 0) {
-        atomicMin(&s.band_lo[tid / gh], raw.lo);
-        atomicMax(&s.band_hi[tid / gh], raw.hi);
-        atomicMin(&s.misc[2], raw.lo);
-        atomicMax(&s.misc[3], raw.hi);
-      } else {
-        atomicAdd(&s.misc[4], 1);
-      }
+      AxisEntry e;
+      axis_taps(sample_y(g, tid / gh, tid % gh), height, e.lo, e.hw, e.lw);
+      e.lo = min(max(e.lo, wy0), wy1 - 1);
+      e.off = (e.lo - wy0) * pitch;
+      s.ty[tid] = e;
     } else if (tid >= 64 && tid - 64 < nsx) {
       const int k = tid - 64;
-      raw = axis_raw(sample_x(g, k / gw, k % gw), width);
-      if (raw.lo >= 0) {
-        atomicMin(&s.misc[0], raw.lo);
-        atomicMax(&s.misc[1], raw.hi);
-      } else {
-        atomicAdd(&s.misc[4], 1);
-      }
+      AxisEntry e;
+      axis_taps(sample_x(g, k / gw, k % gw), width, e.lo, e.hw, e.lw);
+      e.lo = min(max(e.lo, wx0), wx1 - 1);
+      e.off = (e.lo - wx0) * 4;
+      s.tx[k] = e;
     }
-    __syncthreads();
-  }
-  const int wx0 = fast ? __builtin_amdgcn_readfirstlane(s.misc[0]) : 0;
-  const int wx1 = fast ? __builtin_amdgcn_readfirstlane(s.misc[1]) : -1;
-  const int wy0 = fast ? __builtin_amdgcn_readfirstlane(s.misc[2]) : 0;
-  const int wy1 = fast ? __builtin_amdgcn_readfirstlane(s.misc[3]) : -1;
-  // no sample of this RoI is outside the band
-  const bool all_valid = fast && __builtin_amdgcn_readfirstlane(s.misc[4]) == 0;
-  const int ww = wx1 - wx0 + 1;
-  const bool any = wx1 >= 0 && wy1 >= 0;               // some sample lands inside the band
-  const int nr = any && ww <= kMaxWW ? kCap / ww : 0;  // ring rows
-  if (fast && any) {
-    fast = ww <= kMaxWW;
-    for (int ph = 0; fast && ph < aligned_height; ph++) {
-      const int lo = __builtin_amdgcn_readfirstlane(s.band_lo[ph]), hi = __builtin_amdgcn_readfirstlane(s.band_hi[ph]);
-      if (hi >= 0 && hi - lo + 1 > nr) fast = false;
+    __syncthreads();  // tables visible; the DMA of a single-pass window has landed (vmcnt(0) precedes the barrier)
+    if (!single) {    // every bin row must fit the LDS image on its own
+      for (int ph = 0; fast && ph < aligned_height; ph++) {
+        const int lo = s.ty[ph * gh].lo, hi = s.ty[ph * gh + gh - 1].lo + 1;
+        if ((hi - lo + 1) * ww > kCap) fast = false;
+      }
+      fast = __builtin_amdgcn_readfirstlane(fast);
     }
   }
 
   if (!fast) {
     // direct path for this (RoI, channel tile): reference mapping, coalesced stores
     for (int i = tid; i < kCT * bins; i += kThreads) {
-      const int c = (int)__umulhi((unsigned)i, bins_magic), bin = i - c * bins;
+      const int c = i / bins, bin = i - c * bins;
       const int ph = bin / aligned_width, pw = bin - ph * aligned_width;
       const float* plane = src + (long long)c * height * width;
       float output_val = 0.f;
@@ -270,175 +216,111 @@ roi_align_fwd_tile(const float* __restrict__ feat, const float* __restrict__ roi
     }
     return;
   }
-  if (!any) {  // every sample outside the band: all outputs are 0 / count = 0
-    store_zero_tile(dst, kCT * bins, tid);
-    return;
-  }
 
-  // ---- tables, pass 2: LDS byte offsets (invalid samples point at word 0 and carry hw = -1) -------
-  if (tid < nsy) {
-    AxisEntry e;
-    const bool ok = raw.lo >= 0;
-    const int slot_lo = ok ? (raw.lo - wy0) % nr : 0;
-    int slot_hi = slot_lo + (raw.hi - raw.lo);  // hi is lo or lo + 1
-    if (slot_hi >= nr) slot_hi -= nr;
-    e.lo = slot_lo * ww * 4;
-    e.hi = ok ? slot_hi * ww * 4 : 0;
-    e.hw = ok ? raw.hw : -1.f;
-    e.lw = raw.lw;
-    s.ty[tid] = e;
-  } else if (tid >= 64 && tid - 64 < nsx) {
-    AxisEntry e;
-    const bool ok = raw.lo >= 0;
-    e.lo = ok ? (raw.lo - wx0) * 4 : 0;
-    e.hi = ok ? (raw.hi - wx0) * 4 : 0;
-    e.hw = ok ? raw.hw : -1.f;
-    e.lw = raw.lw;
-    s.tx[tid - 64] = e;
-  }
-  // (visibility of the tables is covered by the barrier after the prologue fill)
+  const int cl = tid & 31, slot = tid >> 5;
+  const float* img_c = s.img + cl * kPlane;
+  const int max_rows_tile = max(kTileBins / aligned_width, 1);  // bin rows per output staging pass
 
-  const int lx = tid & 31, slot = tid >> 5;
-  const int cl = tid & 31;  // channel of this lane in the compute phase
-  const float* ring_c = s.ring + cl * kPlane;
-  const bool loader = lx < ww;
-  const unsigned width_bytes = (unsigned)width * 4u;
-  const unsigned plane_step_bytes = (unsigned)kSlots * (unsigned)height * width_bytes;
-  const unsigned voff_bytes =
-      loader ? (unsigned)slot * (unsigned)height * width_bytes + (unsigned)(wx0 + lx) * 4u : 0xffffff00u;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(src), /*stride*/ 0, (int)((unsigned)kCT * (unsigned)height * width_bytes), 0x00020000);
-  float* lrow = s.ring + slot * kPlane + lx;  // + cc*kSlots*kPlane, + ringrow*ww
-
-  int resident_hi = wy0 - 1;  // rows <= resident_hi are in the ring (after the next barrier)
-  int next_slot = 0;          // ring row that row resident_hi + 1 goes to
-  float pf[kChPerSlot][kPF];
-
-  // Control flow around the loads is wave-uniform (scalar branches, no per-lane predication): lanes right of the
-  // window carry an out-of-range voffset, which the buffer bounds check answers with 0 without touching memory.
-  auto issue = [&](int n) {  // loads of rows (resident_hi, resident_hi + n] -> pf
-    const unsigned row0_bytes = (unsigned)(resident_hi + 1) * width_bytes;
-    MI_SWITCH_N(n, (issue_rows<N>(pf, rsrc, voff_bytes, row0_bytes, plane_step_bytes, width_bytes)))
-  };
-  auto park = [&](int n) {  // pf -> ring; advance resident_hi / next_slot
-    MI_SWITCH_N(n, (park_rows<kPlane, N>(pf, lrow, next_slot, nr, ww, loader)))
-    resident_hi += n;
-    next_slot += n;
-    if (next_slot >= nr) next_slot -= nr;
-  };
-
-  // one row of output bins (all of whose feature rows are resident) -> s.tile
-  auto compute_bin_row = [&](int ph) {
-    for (int pw = slot; pw < aligned_width; pw += kSlots) {
-      float output_val = 0.f;
-      if (kSR > 0) {
-        constexpr int kS = kSR > 0 ? kSR : 1;
-        AxisEntry ey[kS], ex[kS];
-#pragma unroll
-        for (int i = 0; i < kS; i++) {
-          ey[i] = s.ty[ph * kS + i];
-          ex[i] = s.tx[pw * kS + i];
-        }
-        float v[kS][kS][4];
-#pragma unroll
-        for (int iy = 0; iy < kS; iy++) {
-          const float* ra = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ring_c) + ey[iy].lo);
-          const float* rb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ring_c) + ey[iy].hi);
-#pragma unroll
-          for (int ix = 0; ix < kS; ix++) {
-            v[iy][ix][0] = lds_at(ra, ex[ix].lo);
-            v[iy][ix][1] = lds_at(ra, ex[ix].hi);
-            v[iy][ix][2] = lds_at(rb, ex[ix].lo);
-            v[iy][ix][3] = lds_at(rb, ex[ix].hi);
-          }
-        }
-#pragma unroll
-        for (int iy = 0; iy < kS; iy++) {
-#pragma unroll
-          for (int ix = 0; ix < kS; ix++) {
-            const float w1 = ey[iy].hw * ex[ix].hw, w2 = ey[iy].hw * ex[ix].lw;
-            const float w3 = ey[iy].lw * ex[ix].hw, w4 = ey[iy].lw * ex[ix].lw;
-            float val = (w1 * v[iy][ix][0] + w2 * v[iy][ix][1] + w3 * v[iy][ix][2] + w4 * v[iy][ix][3]);
-            if (!all_valid)  // uniform branch; roi_align_kernel.cu:19-22: outside the band -> 0
-              val = (ey[iy].hw >= 0.f && ex[ix].hw >= 0.f) ? val : 0.f;
-            output_val += val;
-          }
-        }
-        constexpr float kInvCount = 1.f / (float)(kS * kS);
-        // count = kSR^2: for a power of two the reciprocal multiply is exact and equals the division bit for bit
-        output_val = ((kS & (kS - 1)) == 0) ? output_val * kInvCount : output_val / g.count;
-      } else {
-        for (int iy = 0; iy < gh; iy++) {
-          const AxisEntry ey = s.ty[ph * gh + iy];
-          for (int ix = 0; ix < gw; ix++) {
-            const AxisEntry ex = s.tx[pw * gw + ix];
-            float val = 0.f;
-            if (ey.hw >= 0.f && ex.hw >= 0.f) {
-              const float* ra = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ring_c) + ey.lo);
-              const float* rb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ring_c) + ey.hi);
-              const float v1 = lds_at(ra, ex.lo), v2 = lds_at(ra, ex.hi);
-              const float v3 = lds_at(rb, ex.lo), v4 = lds_at(rb, ex.hi);
-              const float w1 = ey.hw * ex.hw, w2 = ey.hw * ex.lw, w3 = ey.lw * ex.hw, w4 = ey.lw * ex.lw;
-              val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);  // roi_align_kernel.cu:58-60
-            }
-            output_val += val;  // :113
-          }
-        }
-        output_val = output_val / g.count;  // :117
-      }
-      s.tile[cl * os + ph * aligned_width + pw] = output_val;
-    }
-  };
-
-  // ---- prologue: fill the ring (the whole window when it fits) ---------------------------------
-  {
-    const int target = min(wy1, wy0 + nr - 1);
-    while (resident_hi < target) {
-      const int n = min(kPF, target - resident_hi);
-      issue(n);
-      park(n);
-    }
-  }
-  __syncthreads();
-
-  for (int ph = 0; ph < aligned_height; ph++) {
-    const int ya = __builtin_amdgcn_readfirstlane(s.band_lo[ph]);
-    const int yb = __builtin_amdgcn_readfirstlane(s.band_hi[ph]);
-    const bool more = resident_hi < wy1;  // uniform: the window is still streaming
-    int n = 0;
-    if (yb >= 0) {
-      if (yb > resident_hi) {
-        // rare: this bin row and the previous one do not fit the ring together -> synchronous refill
-        // (every wave is past the barrier that ended the previous iteration, so its reads are done)
-        if (resident_hi < ya - 1) {  // rows between two bin rows that nobody reads are skipped
-          resident_hi = ya - 1;
-          next_slot = (ya - wy0) % nr;
-        }
-        while (resident_hi < yb) {
-          const int m = min(kPF, yb - resident_hi);
-          issue(m);
-          park(m);
-        }
-        __syncthreads();
-      }
-      if (more) {
-        // rows the ring can take without touching a row >= ya; at most kPF per iteration
-        n = __builtin_amdgcn_readfirstlane(max(min(min(wy1, ya + nr - 1) - resident_hi, kPF), 0));
-        issue(n);
-      }
-      compute_bin_row(ph);
-    } else {
-      for (int pw = slot; pw < aligned_width; pw += kSlots) s.tile[cl * os + ph * aligned_width + pw] = 0.f;
-    }
-    if (more) {
-      park(n);
+  for (int ph0 = 0; ph0 < aligned_height;) {
+    // ---- group of bin rows [ph0, ph1): fits the output staging tile and (when streaming) the LDS image ----
+    int ph1 = min(aligned_height, ph0 + max_rows_tile);
+    int row0 = wy0;
+    if (!single) {
+      row0 = s.ty[ph0 * gh].lo;
+      int e = ph0 + 1;
+      while (e < ph1 && (s.ty[e * gh + gh - 1].lo + 1 - row0 + 1) * ww <= kCap) e++;
+      ph1 = e;
+      const int row1 = s.ty[(ph1 - 1) * gh + gh - 1].lo + 1;
+      row0 = __builtin_amdgcn_readfirstlane(row0);
+      ph1 = __builtin_amdgcn_readfirstlane(ph1);
+      issue_dma(row0, __builtin_amdgcn_readfirstlane(row1) - row0 + 1);
       __syncthreads();
     }
-  }
-  __syncthreads();
-  for (int i = tid; i < kCT * bins; i += kThreads) {
-    const int c = (int)__umulhi((unsigned)i, bins_magic), bin = i - c * bins;
-    dst[i] = s.tile[c * os + bin];
+    const int base_off = (row0 - wy0) * pitch;  // table offsets are relative to wy0
+    const int nb = (ph1 - ph0) * aligned_width;
+    const int ts = nb | 1;
+
+    for (int pw = slot; pw < aligned_width; pw += kSlots) {
+      if (kSR > 0) {
+        constexpr int kS = kSR > 0 ? kSR : 1;
+        AxisEntry ex[kS];
+        const float* xa[kS];
+#pragma unroll
+        for (int i = 0; i < kS; i++) {
+          ex[i] = s.tx[pw * kS + i];
+          xa[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(img_c) + (ex[i].off - base_off));
+        }
+        for (int ph = ph0; ph < ph1; ph++) {
+          AxisEntry ey[kS];
+#pragma unroll
+          for (int i = 0; i < kS; i++) ey[i] = s.ty[ph * kS + i];
+          float v[kS][kS][4];
+#pragma unroll
+          for (int iy = 0; iy < kS; iy++) {
+#pragma unroll
+            for (int ix = 0; ix < kS; ix++) {
+              const float* a = reinterpret_cast<const float*>(reinterpret_cast<const char*>(xa[ix]) + ey[iy].off);
+              const float* b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a) + pitch);
+              v[iy][ix][0] = a[0];
+              v[iy][ix][1] = a[1];
+              v[iy][ix][2] = b[0];
+              v[iy][ix][3] = b[1];
+            }
+          }
+          float output_val = 0.f;
+#pragma unroll
+          for (int iy = 0; iy < kS; iy++) {
+#pragma unroll
+            for (int ix = 0; ix < kS; ix++) {
+              const float w1 = ey[iy].hw * ex[ix].hw, w2 = ey[iy].hw * ex[ix].lw;
+              const float w3 = ey[iy].lw * ex[ix].hw, w4 = ey[iy].lw * ex[ix].lw;
+              const float val = (w1 * v[iy][ix][0] + w2 * v[iy][ix][1] + w3 * v[iy][ix][2] + w4 * v[iy][ix][3]);
+              output_val += val;
+            }
+          }
+          constexpr float kInvCount = 1.f / (float)(kS * kS);
+          // count = kSR^2: for a power of two the reciprocal multiply is exact and equals the division bit for bit
+          output_val = ((kS & (kS - 1)) == 0) ? output_val * kInvCount : output_val / g.count;
+          s.tile[cl * ts + (ph - ph0) * aligned_width + pw] = output_val;
+        }
+      } else {
+        for (int ph = ph0; ph < ph1; ph++) {
+          float output_val = 0.f;
+          for (int iy = 0; iy < gh; iy++) {
+            const AxisEntry ey = s.ty[ph * gh + iy];
+            for (int ix = 0; ix < gw; ix++) {
+              const AxisEntry ex = s.tx[pw * gw + ix];
+              const int o = ey.off + ex.off - base_off;
+              const float v1 = lds_f(img_c, o), v2 = lds_f(img_c, o + 4);
+              const float v3 = lds_f(img_c, o + pitch), v4 = lds_f(img_c, o + pitch + 4);
+              const float w1 = ey.hw * ex.hw, w2 = ey.hw * ex.lw, w3 = ey.lw * ex.hw, w4 = ey.lw * ex.lw;
+              const float val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);  // roi_align_kernel.cu:58-60
+              output_val += val;                                          // :113
+            }
+          }
+          output_val = output_val / g.count;  // :117
+          s.tile[cl * ts + (ph - ph0) * aligned_width + pw] = output_val;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- staged outputs -> HBM ----
+    float* gdst = dst + ph0 * aligned_width;
+    if (nb == bins && ts == nb && ((kCT * nb) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+      // the whole [kCT][bins] block is one contiguous run and the LDS tile has the same layout
+      const float4* t4 = reinterpret_cast<const float4*>(s.tile);
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      for (int i = tid; i < kCT * nb / 4; i += kThreads) d4[i] = t4[i];
+    } else {
+      const unsigned nb_magic = (1u << 20) / (unsigned)nb + 1u;
+      for (int i = tid; i < kCT * nb; i += kThreads) {
+        const int c = (int)(((unsigned)i * nb_magic) >> 20), b = i - c * nb;
+        gdst[(long long)c * bins + b] = s.tile[c * ts + b];
+      }
+    }
+    ph0 = ph1;
+    if (ph0 < aligned_height) __syncthreads();  // the tile (and, when streaming, the image) is reused
   }
 }
 
@@ -446,39 +328,37 @@ template <int kCap>
 int launch_cap(const float* features, const float* rois, float* output, int batch, int channels, int height,
                int width, int num_rois, int aligned_height, int aligned_width, float spatial_scale,
                int sampling_ratio, hipStream_t stream) {
-  const int bins = aligned_height * aligned_width;
   const int grid = num_rois * (channels / kCT);
-  const size_t lds = Lds<kCap>::bytes(bins);
-  // c = floor(i / bins) for 0 <= i < kCT * bins via one mul-hi: magic = ceil(2^32 / bins)
-  const unsigned magic = (unsigned)(((1ULL << 32) + bins - 1) / bins);
+  const size_t lds = Lds<kCap>::bytes();
   if (sampling_ratio == 2)
     roi_align_fwd_tile<2, kCap><<<grid, kThreads, lds, stream>>>(features, rois, output, batch, channels, height,
                                                                  width, aligned_height, aligned_width,
-                                                                 spatial_scale, sampling_ratio, magic);
+                                                                 spatial_scale, sampling_ratio);
   else
     roi_align_fwd_tile<0, kCap><<<grid, kThreads, lds, stream>>>(features, rois, output, batch, channels, height,
                                                                  width, aligned_height, aligned_width,
-                                                                 spatial_scale, sampling_ratio, magic);
+                                                                 spatial_scale, sampling_ratio);
   return check_launch("roi_align_fwd_tile");
 }
 
 }  // namespace
 
 bool roi_align_fwd_tile_supported(int channels, int height, int width, int aligned_height, int aligned_width) {
-  const int bins = aligned_height * aligned_width;
-  // 32-bit element offsets inside one (image, 32-channel) slab; LDS budget of the smallest ring
-  return channels > 0 && channels % kCT == 0 && bins <= 2048 && (long long)kCT * height * width < (1LL << 31) &&
-         Lds<192>::bytes(bins) <= 64 * 1024;
+  // 32-bit byte offsets inside one (image, channel tile) slab of the DMA descriptor; a bin row fits the staging tile
+  return channels > 0 && channels % kCT == 0 && aligned_width <= kTileBins && aligned_height > 0 &&
+         (long long)kCT * height * width * 4 < (1LL << 31);
 }
 
 int launch_roi_align_fwd_tile(const float* features, const float* rois, float* output, int batch, int channels,
                               int height, int width, int num_rois, int aligned_height, int aligned_width,
-                              float spatial_scale, int sampling_ratio, int ring_words, hipStream_t stream) {
-  const int bins = aligned_height * aligned_width;
-  if (ring_words >= 320 && Lds<320>::bytes(bins) <= 64 * 1024)
+                              float spatial_scale, int sampling_ratio, int cap_px, hipStream_t stream) {
+  if (cap_px >= 384)
+    return launch_cap<384>(features, rois, output, batch, channels, height, width, num_rois, aligned_height,
+                           aligned_width, spatial_scale, sampling_ratio, stream);
+  if (cap_px >= 320)
     return launch_cap<320>(features, rois, output, batch, channels, height, width, num_rois, aligned_height,
                            aligned_width, spatial_scale, sampling_ratio, stream);
-  if (ring_words >= 256 && Lds<256>::bytes(bins) <= 64 * 1024)
+  if (cap_px >= 256)
     return launch_cap<256>(features, rois, output, batch, channels, height, width, num_rois, aligned_height,
                            aligned_width, spatial_scale, sampling_ratio, stream);
   return launch_cap<192>(features, rois, output, batch, channels, height, width, num_rois, aligned_height,
