@@ -135,9 +135,17 @@ def roofline_roi_align_forward(device, iters):
     lib = _lib.lib()
     stream = _lib.current_stream_handle(device)
 
-    def launch():
-        rc = lib.mi_roi_align_forward(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res,
-                                      scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, stream)
+    layout = _lib.LAYOUT_NCHW
+    if os.environ.get("MI_BENCH_NHWC"):  # tuning experiment only: channels_last storage of the same logical tensor
+        feat = feat.permute(0, 2, 3, 1).contiguous()
+        layout = _lib.LAYOUT_NHWC
+
+    ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+
+    def launch():  # one call of the C-ABI = both launches of the fast path (RoI records, then the gather)
+        rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res,
+                                         scale, sr, _lib.ROI_ALIGN_CAFFE2, layout, ws.data_ptr(), ws_bytes, stream)
         assert rc == 0
 
     seconds = time_kernel(launch, iters)

@@ -22,6 +22,9 @@ SIGNATURES = {
     "mi_abi_version": (_c_int, []),
     "mi_last_error": (ctypes.c_char_p, []),
     "mi_roi_align_forward": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_float] + [_c_int] * 3 + [_c_void_p]),
+    "mi_roi_align_forward_workspace_bytes": (_c_size_t, [_c_int]),
+    "mi_roi_align_forward_ws": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_float] + [_c_int] * 3
+                                + [_c_void_p, _c_size_t, _c_void_p]),
     "mi_roi_align_backward": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_float] + [_c_int] * 3 + [_c_void_p]),
     "mi_roi_pool_forward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_float, _c_void_p]),
     "mi_roi_pool_backward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_float, _c_void_p]),
@@ -30,6 +33,7 @@ SIGNATURES = {
     "mi_nms_workspace_bytes": (_c_size_t, [_c_int]),
     "mi_nms": (_c_int, [_c_void_p, _c_int, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "mi_bbox_overlaps": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "mi_dbg_roi_align_timeline": (None, [_c_void_p]),
 }
 
 _lib = None

@@ -219,8 +219,12 @@ bool use_stream_path(int channels, int aligned_height, int aligned_width) {
 }
 // MI_ROI_ALIGN_CAP=192|256|320|384: window pixels per channel of the forward LDS image (tuning knob)
 int ring_words() {
+  const char* ab = std::getenv("MI_ROI_ALIGN_ABLATE");
+  mi::roi_align_fwd_tile_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
+  mi::roi_align_fwd_persist_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
+  mi::roi_align_fwd_persist_set_mode(std::getenv("MI_ROI_ALIGN_PERSIST") != nullptr);
   const char* v = std::getenv("MI_ROI_ALIGN_CAP");
-  return v != nullptr ? std::atoi(v) : 320;
+  return v != nullptr ? std::atoi(v) : 336;
 }
 
 int check_common(const void* a, const void* rois, const void* b, int batch, int channels,
@@ -244,11 +248,18 @@ int check_common(const void* a, const void* rois, const void* b, int batch, int 
 
 }  // namespace
 
-extern "C" int mi_roi_align_forward(const float* features, const float* rois, float* output,
-                                    int batch, int channels, int height, int width, int num_rois,
-                                    int aligned_height, int aligned_width, float spatial_scale,
-                                    int sampling_ratio, int variant, int layout,
-                                    mi_stream_t stream) {
+// Tuning aid, not part of include/mi_detectron_ops.h: device buffer of 8 int64 stamps per forward workgroup
+// (tools/timeline.py); nullptr switches the stamps off.
+extern "C" void mi_dbg_roi_align_timeline(long long* device_buffer) {
+  mi::roi_align_fwd_tile_set_timeline(device_buffer);
+  mi::roi_align_fwd_persist_set_timeline(device_buffer);
+}
+
+namespace {
+int roi_align_forward_impl(const float* features, const float* rois, float* output, int batch, int channels,
+                           int height, int width, int num_rois, int aligned_height, int aligned_width,
+                           float spatial_scale, int sampling_ratio, int variant, int layout, void* workspace,
+                           size_t workspace_bytes, mi_stream_t stream) {
   mi::begin_call();
   int rc = check_common(features, rois, output, batch, channels, height, width, num_rois,
                         aligned_height, aligned_width, variant, layout);
@@ -263,16 +274,51 @@ extern "C" int mi_roi_align_forward(const float* features, const float* rois, fl
         aligned_width, spatial_scale);
     return mi::check_launch("roi_align_legacy_fwd");
   }
+  const int cap = ring_words();
+  if (workspace != nullptr) {
+    MI_REQUIRE(workspace_bytes >= mi::roi_align_fwd_persist_workspace_bytes(num_rois),
+               "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
+               mi::roi_align_fwd_persist_workspace_bytes(num_rois));
+    MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
+    if (layout == MI_LAYOUT_NCHW && !force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
+        mi::roi_align_fwd_persist_supported(channels, height, width, num_rois, aligned_height, aligned_width))
+      return mi::launch_roi_align_fwd_persist(features, rois, output, workspace, batch, channels, height, width,
+                                              num_rois, aligned_height, aligned_width, spatial_scale,
+                                              sampling_ratio, cap, s);
+  }
   if (layout == MI_LAYOUT_NCHW && !force_direct() &&
       mi::roi_align_fwd_tile_supported(channels, height, width, aligned_height, aligned_width))
     return mi::launch_roi_align_fwd_tile(features, rois, output, batch, channels, height, width, num_rois,
-                                         aligned_height, aligned_width, spatial_scale, sampling_ratio,
-                                         ring_words(), s);
+                                         aligned_height, aligned_width, spatial_scale, sampling_ratio, cap, s);
   FeatStrides st = make_strides(layout, channels, height, width);
   roi_align_fwd_direct<<<mi::grid_for(total, block), block, 0, s>>>(
       total, features, rois, output, batch, channels, height, width, aligned_height, aligned_width,
       spatial_scale, sampling_ratio, st);
   return mi::check_launch("roi_align_fwd_direct");
+}
+}  // namespace
+
+extern "C" int mi_roi_align_forward(const float* features, const float* rois, float* output,
+                                    int batch, int channels, int height, int width, int num_rois,
+                                    int aligned_height, int aligned_width, float spatial_scale,
+                                    int sampling_ratio, int variant, int layout,
+                                    mi_stream_t stream) {
+  return roi_align_forward_impl(features, rois, output, batch, channels, height, width, num_rois, aligned_height,
+                                aligned_width, spatial_scale, sampling_ratio, variant, layout, nullptr, 0, stream);
+}
+
+extern "C" size_t mi_roi_align_forward_workspace_bytes(int num_rois) {
+  return mi::roi_align_fwd_persist_workspace_bytes(num_rois);
+}
+
+extern "C" int mi_roi_align_forward_ws(const float* features, const float* rois, float* output,
+                                       int batch, int channels, int height, int width, int num_rois,
+                                       int aligned_height, int aligned_width, float spatial_scale,
+                                       int sampling_ratio, int variant, int layout,
+                                       void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+  return roi_align_forward_impl(features, rois, output, batch, channels, height, width, num_rois, aligned_height,
+                                aligned_width, spatial_scale, sampling_ratio, variant, layout, workspace,
+                                workspace_bytes, stream);
 }
 
 extern "C" int mi_roi_align_backward(const float* top_grad, const float* rois, float* bottom_grad,

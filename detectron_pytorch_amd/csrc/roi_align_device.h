@@ -86,6 +86,19 @@ bool roi_align_fwd_tile_supported(int channels, int height, int width, int align
 int launch_roi_align_fwd_tile(const float* features, const float* rois, float* output, int batch, int channels,
                               int height, int width, int num_rois, int aligned_height, int aligned_width,
                               float spatial_scale, int sampling_ratio, int ring_words, hipStream_t stream);
+void roi_align_fwd_tile_set_timeline(long long* device_buffer);
+void roi_align_fwd_tile_set_ablate(int mask);
+// two-launch forward fast path with caller scratch (roi_align_fwd_persist.hip)
+void roi_align_fwd_persist_set_ablate(int mask);
+void roi_align_fwd_persist_set_mode(bool persistent);
+void roi_align_fwd_persist_set_timeline(long long* device_buffer);
+size_t roi_align_fwd_persist_workspace_bytes(int num_rois);
+bool roi_align_fwd_persist_supported(int channels, int height, int width, int num_rois, int aligned_height,
+                                     int aligned_width);
+int launch_roi_align_fwd_persist(const float* features, const float* rois, float* output, void* workspace, int batch,
+                                 int channels, int height, int width, int num_rois, int aligned_height,
+                                 int aligned_width, float spatial_scale, int sampling_ratio, int cap_px,
+                                 hipStream_t stream);
 bool roi_align_stream_supported(int channels, int aligned_height, int aligned_width);
 int launch_roi_align_bwd_stream(const float* top_grad, const float* rois, float* bottom_grad, int batch,
                                 int channels, int height, int width, int num_rois, int aligned_height,

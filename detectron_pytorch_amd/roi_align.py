@@ -60,12 +60,16 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
     r = rois.size(0)
     # every element is written by the kernel: no zero fill (the reference's .zero_() at :23 is redundant)
     output = torch.empty((r, c, aligned_height, aligned_width), dtype=features.dtype, device=features.device)
+    lib = _lib.lib()
+    # device scratch of the two-launch fast path (per-RoI records); the caching allocator makes this a free-list pop
+    ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=features.device)
     with torch.cuda.device(features.device):
-        rc = _lib.lib().mi_roi_align_forward(
+        rc = lib.mi_roi_align_forward_ws(
             features.data_ptr(), rois.data_ptr(), output.data_ptr(), n, c, h, w, r,
             int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
-            int(variant), layout, _lib.current_stream_handle(features.device))
-    _lib.check(rc, "mi_roi_align_forward")
+            int(variant), layout, workspace.data_ptr(), ws_bytes, _lib.current_stream_handle(features.device))
+    _lib.check(rc, "mi_roi_align_forward_ws")
     return output
 
 

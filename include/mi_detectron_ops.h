@@ -75,6 +75,18 @@ int mi_roi_align_forward(const float* features, const float* rois, float* output
                          int aligned_height, int aligned_width, float spatial_scale,
                          int sampling_ratio, int variant, int layout, mi_stream_t stream);
 
+/* Same operation with caller-provided device scratch (the fast path on NCHW features): a first launch condenses each
+ * RoI into a record in `workspace` (window, tap tables, LDS stages), persistent workgroups then consume the records.
+ * `workspace` must hold mi_roi_align_forward_workspace_bytes(num_rois) bytes, 16-byte aligned; its contents are
+ * scratch (no initialisation needed, overwritten by every call; two calls that may run concurrently on different
+ * streams need distinct workspaces).  workspace == NULL behaves exactly like mi_roi_align_forward. */
+size_t mi_roi_align_forward_workspace_bytes(int num_rois);
+int mi_roi_align_forward_ws(const float* features, const float* rois, float* output,
+                            int batch, int channels, int height, int width, int num_rois,
+                            int aligned_height, int aligned_width, float spatial_scale,
+                            int sampling_ratio, int variant, int layout,
+                            void* workspace, size_t workspace_bytes, mi_stream_t stream);
+
 int mi_roi_align_backward(const float* top_grad, const float* rois, float* bottom_grad,
                           int batch, int channels, int height, int width, int num_rois,
                           int aligned_height, int aligned_width, float spatial_scale,
@@ -130,6 +142,11 @@ int mi_nms(const float* dets, int n, float thresh, int mode, void* keep, int32_t
  * boxes [N,4], query [K,4] -> overlaps [N,K] float32, "+1" convention, 0 where iw<=0 or ih<=0. */
 int mi_bbox_overlaps(const float* boxes, int num_boxes, const float* query, int num_query,
                      float* overlaps, mi_stream_t stream);
+
+/* ---- diagnostics (no reference counterpart) ---------------------------------------------------
+ * Tuning aid used by tools/timeline.py: while a non-NULL device buffer of 8 int64 per forward workgroup is set,
+ * the self-contained RoIAlign forward kernel stamps s_memtime at its phase boundaries into it. */
+void mi_dbg_roi_align_timeline(long long* device_buffer);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,10 @@ pytestmark = pytest.mark.gpu
 
 ATOL = 1e-4  # north_star tolerance for RoIAlign features / gradients
 RTOL = 1e-4
+# The NCHW fast path of RoIAlign forward reads the reference's taps with the reference's weights but sums them
+# separably with FMAs (roi_align_fwd_tile.hip): fp32 rounding differences only.  Bar used below: 1e-5 (10x inside
+# the contract); the generic direct kernel keeps the reference operation order and is checked bit-exactly.
+FAST_ATOL = 1e-5
 
 
 def dev():
@@ -28,11 +32,20 @@ def to_dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
 
 
-def assert_close(actual, expected, what):
+def assert_close(actual, expected, what, atol=ATOL, rtol=RTOL):
     actual = actual.detach().cpu().numpy() if isinstance(actual, torch.Tensor) else actual
     err = np.abs(actual.astype(np.float64) - expected.astype(np.float64))
-    tol = ATOL + RTOL * np.abs(expected)
-    assert (err <= tol).all(), "%s: max abs err %.3e (tol %.1e)" % (what, err.max(), ATOL)
+    tol = atol + rtol * np.abs(expected)
+    assert (err <= tol).all(), "%s: max abs err %.3e (tol %.1e)" % (what, err.max(), atol)
+
+
+def assert_fwd(actual, expected, what, exact):
+    """exact: the direct kernel (reference operation order); otherwise the separable-FMA fast path."""
+    actual = actual.detach().cpu().numpy() if isinstance(actual, torch.Tensor) else actual
+    if exact:
+        assert np.array_equal(actual, expected), "%s: forward of the direct kernel is expected to be bit-exact" % what
+    else:
+        assert_close(actual, expected, what, atol=FAST_ATOL, rtol=FAST_ATOL)
 
 
 @pytest.fixture(params=["stream", "direct"])
@@ -75,7 +88,7 @@ def test_roi_align_golden():
     for key in [k[4:] for k in g.files if k.startswith("fwd_")]:
         sr, res = int(key.split("_")[0][2:]), int(key.split("_")[1][1:])
         out, grad = _roi_align_gpu(feat, rois, res, scale, sr, g["gtop_" + key])
-        assert np.array_equal(out.detach().cpu().numpy(), g["fwd_" + key]), "fwd " + key
+        assert_fwd(out, g["fwd_" + key], "fwd " + key, exact=False)
         assert_close(grad, g["bwd_" + key], "bwd " + key)
 
 
@@ -92,8 +105,7 @@ def test_roi_align_vs_oracle_adversarial_rois(oracle_mod, roi_align_impl, shape,
     gtop = np.random.RandomState(7).randn(nrois, c, res, res).astype(np.float32)
     out, grad = _roi_align_gpu(feat, rois, res, scale, sr, gtop)
     ref_out = oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=8)
-    assert_close(out, ref_out, "fwd")
-    assert np.array_equal(out.detach().cpu().numpy(), ref_out), "forward is expected to be bit-exact"
+    assert_fwd(out, ref_out, "fwd", exact=(roi_align_impl == "direct" or c % 32 != 0))
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, sr, threads=8), "bwd")
 
 
@@ -103,7 +115,7 @@ def test_roi_align_channels_last_storage(oracle_mod):
     rois = syn.rois_adversarial(48, n, h, w, scale, seed=2)
     gtop = np.random.RandomState(3).randn(48, c, 7, 7).astype(np.float32)
     out, grad = _roi_align_gpu(feat, rois, 7, scale, 2, gtop, channels_last=True)
-    assert np.array_equal(out.detach().cpu().numpy(), oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2))
+    assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2), "fwd nhwc", exact=True)
     assert grad.is_contiguous(memory_format=torch.channels_last)
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2), "bwd nhwc")
 
@@ -115,7 +127,7 @@ def test_roi_align_config2_full_shape(oracle_mod, roi_align_impl):
     gtop = np.random.RandomState(1).randn(512, 256, 7, 7).astype(np.float32)
     out, grad = _roi_align_gpu(feat, rois, 7, 0.25, 2, gtop)
     ref_out = oracle_mod.roi_align_forward(feat, rois, 7, 7, 0.25, 2, threads=oracle_mod.num_threads_available())
-    assert_close(out, ref_out, "config-2 fwd")
+    assert_fwd(out, ref_out, "config-2 fwd", exact=(roi_align_impl == "direct"))
     ref_grad = oracle_mod.roi_align_backward(gtop, rois, feat.shape, 0.25, 2,
                                              threads=oracle_mod.num_threads_available())
     assert_close(grad, ref_grad, "config-2 bwd")
@@ -131,7 +143,8 @@ def test_roi_align_mask_head_shape_and_multi_image(oracle_mod, roi_align_impl):
     rois = syn.rois_canonical(128, 2, seed=5, side=(32.0, 300.0))
     gtop = np.random.RandomState(6).randn(128, 256, 14, 14).astype(np.float32)
     out, grad = _roi_align_gpu(feat, rois, 14, 0.125, 2, gtop)
-    assert_close(out, oracle_mod.roi_align_forward(feat, rois, 14, 14, 0.125, 2, threads=8), "mask fwd")
+    assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, 14, 14, 0.125, 2, threads=8), "mask fwd",
+               exact=(roi_align_impl == "direct"))
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, 0.125, 2, threads=8), "mask bwd")
 
 
@@ -143,8 +156,8 @@ def test_roi_align_stream_path_small_and_fpn_sized_rois(oracle_mod):
         feat = syn.feature_map(2, 64, h, w, seed=lvl)
         gtop = np.random.RandomState(lvl).randn(len(rois), 64, 7, 7).astype(np.float32)
         out, grad = _roi_align_gpu(feat, rois, 7, scale, 2, gtop)
-        assert np.array_equal(out.detach().cpu().numpy(),
-                              oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2, threads=8)), "lvl %d" % lvl
+        assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2, threads=8), "lvl %d" % lvl,
+                   exact=False)
         assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2, threads=8), "lvl %d" % lvl)
 
 

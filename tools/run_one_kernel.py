@@ -18,7 +18,12 @@ stream = _lib.current_stream_handle(dev)
 h, w, scale = syn.FPN_LEVELS[2]
 c, r, res, sr = syn.FPN_DIM, 512, 7, 2
 feat = torch.from_numpy(syn.feature_map(1, c, h, w, seed=0)).to(dev)
-rois = torch.from_numpy(syn.rois_canonical(r, 1, seed=0)).to(dev)
+rois_np = syn.rois_canonical(r, 1, seed=0)
+if os.environ.get("MI_BENCH_SORT_ROIS"):
+    import numpy as np
+    key = (rois_np[:, 2] + rois_np[:, 4]) // (2 * 64) * 4096 + (rois_np[:, 1] + rois_np[:, 3]) / 2
+    rois_np = np.ascontiguousarray(rois_np[np.argsort(key, kind="stable")])
+rois = torch.from_numpy(rois_np).to(dev)
 out = torch.empty((r, c, res, res), device=dev)
 gtop = torch.randn(r, c, res, res, device=dev)
 gin = torch.zeros(1, c, h, w, device=dev)
@@ -27,11 +32,12 @@ keep = torch.empty(2000, dtype=torch.int64, device=dev)
 num = torch.empty(1, dtype=torch.int32, device=dev)
 wsb = lib.mi_nms_workspace_bytes(2000)
 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+fws = torch.empty(lib.mi_roi_align_forward_workspace_bytes(r), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
 for _ in range(iters):
     if which == "roi_align_fwd":
-        rc = lib.mi_roi_align_forward(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, scale,
-                                      sr, 0, 0, stream)
+        rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, scale,
+                                         sr, 0, 0, fws.data_ptr(), fws.numel(), stream)
     elif which == "roi_align_bwd":
         rc = lib.mi_roi_align_backward(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
                                        scale, sr, 0, 0, stream)
