@@ -222,7 +222,8 @@ int ring_words() {
   const char* ab = std::getenv("MI_ROI_ALIGN_ABLATE");
   mi::roi_align_fwd_tile_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
   mi::roi_align_fwd_persist_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
-  mi::roi_align_fwd_persist_set_mode(std::getenv("MI_ROI_ALIGN_PERSIST") != nullptr);
+  const char* ct = std::getenv("MI_ROI_ALIGN_CT");
+  mi::roi_align_fwd_persist_set_mode(std::getenv("MI_ROI_ALIGN_PERSIST") != nullptr, ct != nullptr ? std::atoi(ct) : 32);
   const char* v = std::getenv("MI_ROI_ALIGN_CAP");
   return v != nullptr ? std::atoi(v) : 336;
 }

@@ -107,7 +107,9 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
     for (int d = 32; d >= 1; d >>= 1) rank += __shfl_xor(rank, d);
   }
   int* __restrict__ rec = ws + kCounterDwords + (long long)rank * kRecDwords;
-  const float* __restrict__ roi = rois + (long long)r * 5;
+  // the RoI's five floats: wave-uniform address -> scalar loads
+  using const_float_ptr = const __attribute__((address_space(4))) float*;
+  const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)__builtin_amdgcn_readfirstlane(r) * 5);
   const int batch_ind = (int)roi[0];
   const float start_w = roi[1] * spatial_scale, start_h = roi[2] * spatial_scale;
   const float roi_width = fmaxf(roi[3] * spatial_scale - start_w, 1.f);
@@ -169,11 +171,11 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
     const int half = stage_px;
     int ph0 = 0;
     while (ph0 < aligned_height) {
-      const int row0 = __shfl(ylo, ph0 * gh);
+      const int row0 = __builtin_amdgcn_readlane(ylo, ph0 * gh);
       int e = ph0;
       int row1 = row0;
       while (e < aligned_height && e < ph0 + max_rows_tile) {
-        const int hi = __shfl(ylo, e * gh + gh - 1) + 1;
+        const int hi = __builtin_amdgcn_readlane(ylo, e * gh + gh - 1) + 1;
         const int px = (hi - row0 + 1) * ww;
         if (px > (e == ph0 ? cap_px : half)) break;
         row1 = hi;
@@ -190,6 +192,7 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
         st.z = row1 - row0 + 1;
         st.w = 0;
         reinterpret_cast<int4*>(rec + kRecStages)[nstages] = st;
+        if (nstages == 0) reinterpret_cast<int4*>(rec)[3] = st;  // stage 0 rides in the header (one scalar load)
       }
       nstages++;
       ph0 = e;
@@ -667,21 +670,33 @@ roi_align_fwd_persist(const float* __restrict__ feat, const float* __restrict__ 
 // arithmetic; the per-RoI prologue of roi_align_fwd_tile.hip (geometry, tables, window) is replaced by one scalar
 // load of the record, and workgroups are dispatched in sweep order.
 // -------------------------------------------------------------------------------------------------------------------
-template <int kSR, int kCap>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+template <int kSR, int kCap, int kCTt>
+__global__ void __launch_bounds__(kCTt * 8)
 roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
                       const int* __restrict__ ws, int num_rois, int batch, int channels, int height, int width,
                       int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio, int ablate) {
+  // kCTt channels per workgroup (32: half-waves own output columns; 16: quarter-waves do, twice as many workgroups
+  // fit a CU -- the per-workgroup chain record load -> DMA -> landing -> arithmetic -> store drain is latency, and
+  // what hides it is the number of workgroups in flight)
+  constexpr int kCT = kCTt, kThreads = kCTt * 8, kChPerWave = 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Lds<kCap> s(smem);
-  constexpr int kPlane = Lds<kCap>::kPlane;
+  constexpr int kPlane = kCap | 1;
+  constexpr int kTileWords = kCT * (kTileBins + 1);
+  struct {
+    TabEntry* tab;
+    float* tile;
+    float* img;
+  } s;
+  s.tab = reinterpret_cast<TabEntry*>(smem);
+  s.tile = reinterpret_cast<float*>(s.tab + 2 * kMaxS);
+  s.img = s.tile + kTileWords;
   const int tid = threadIdx.x;
   const int bins = aligned_height * aligned_width;
   const int tiles = channels / kCT;
   const int pos = blockIdx.x / tiles;
   const int c0 = (blockIdx.x - pos * tiles) * kCT;
   const int wave = uniform(tid >> 6), lane = tid & 63;
-  const int cl = tid & 31, slot = tid >> 5;
+  const int cl = tid % kCT, slot = tid / kCT;
   const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
   const float* img_c = s.img + cl * kPlane;
   const int* __restrict__ records = ws + kCounterDwords;
@@ -731,7 +746,7 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
   const TabEntry* tx = s.tab + kMaxS;
 
   for (int k = 0; k < nstages; k++) {
-    const const_int_ptr st = rec + kRecStages + 4 * k;
+    const const_int_ptr st = k == 0 ? rec + 12 : rec + kRecStages + 4 * k;
     const int pp = st[0], row0 = st[1], nrows = st[2];
     const int ph0 = pp & 0xffff, ph1 = pp >> 16;
     if (k > 0) __syncthreads();  // image and tile are reused
@@ -864,7 +879,11 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
 
 int g_ablate_p = 0;
 long long* g_timeline_p = nullptr;
-bool g_persistent = false;  // MI_ROI_ALIGN_PERSIST=1: persistent consumer (tuning aid)
+bool g_persistent = false;
+int g_ct = 32;  // MI_ROI_ALIGN_CT=16|32: channels per workgroup of the record consumer
+size_t records_lds_bytes(int cap, int ct) {
+  return 2 * kMaxS * sizeof(TabEntry) + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4;
+}  // MI_ROI_ALIGN_PERSIST=1: persistent consumer (tuning aid)
 
 template <int kCap>
 int launch_cap(const float* features, const float* rois, float* output, int* ws, int batch, int channels, int height,
@@ -884,14 +903,19 @@ int launch_cap(const float* features, const float* rois, float* output, int* ws,
   if (grid < tiles) grid = tiles;
   const size_t lds = Lds<kCap>::bytes();
   if (!g_persistent) {
-    if (sampling_ratio == 2)
-      roi_align_fwd_records<2, kCap><<<(int)items, kThreads, lds, stream>>>(
-          features, rois, output, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width,
-          spatial_scale, sampling_ratio, g_ablate_p);
+#define MI_LAUNCH_REC(SR, CT)                                                                                         \
+  roi_align_fwd_records<SR, kCap, CT><<<num_rois * (channels / CT), CT * 8, records_lds_bytes(kCap, CT), stream>>>(    \
+      features, rois, output, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width,           \
+      spatial_scale, sampling_ratio, g_ablate_p)
+    if (g_ct == 16 && sampling_ratio == 2)
+      MI_LAUNCH_REC(2, 16);
+    else if (g_ct == 16)
+      MI_LAUNCH_REC(0, 16);
+    else if (sampling_ratio == 2)
+      MI_LAUNCH_REC(2, 32);
     else
-      roi_align_fwd_records<0, kCap><<<(int)items, kThreads, lds, stream>>>(
-          features, rois, output, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width,
-          spatial_scale, sampling_ratio, g_ablate_p);
+      MI_LAUNCH_REC(0, 32);
+#undef MI_LAUNCH_REC
     return check_launch("roi_align_fwd_records");
   }
   if (sampling_ratio == 2)
@@ -908,7 +932,10 @@ int launch_cap(const float* features, const float* rois, float* output, int* ws,
 }  // namespace
 
 void roi_align_fwd_persist_set_ablate(int mask) { g_ablate_p = mask; }
-void roi_align_fwd_persist_set_mode(bool persistent) { g_persistent = persistent; }
+void roi_align_fwd_persist_set_mode(bool persistent, int ct) {
+  g_persistent = persistent;
+  g_ct = ct == 16 ? 16 : 32;
+}
 void roi_align_fwd_persist_set_timeline(long long* device_buffer) { g_timeline_p = device_buffer; }
 
 size_t roi_align_fwd_persist_workspace_bytes(int num_rois) {
@@ -927,6 +954,12 @@ int launch_roi_align_fwd_persist(const float* features, const float* rois, float
                                  int aligned_width, float spatial_scale, int sampling_ratio, int cap_px,
                                  hipStream_t stream) {
   int* ws = static_cast<int*>(workspace);
+  if (cap_px >= 640)
+    return launch_cap<640>(features, rois, output, ws, batch, channels, height, width, num_rois, aligned_height,
+                           aligned_width, spatial_scale, sampling_ratio, stream);
+  if (cap_px >= 448)
+    return launch_cap<448>(features, rois, output, ws, batch, channels, height, width, num_rois, aligned_height,
+                           aligned_width, spatial_scale, sampling_ratio, stream);
   if (cap_px >= 336)
     return launch_cap<336>(features, rois, output, ws, batch, channels, height, width, num_rois, aligned_height,
                            aligned_width, spatial_scale, sampling_ratio, stream);
