@@ -14,6 +14,7 @@ MI_OK = 0
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 ROI_ALIGN_CAFFE2, ROI_ALIGN_LEGACY = 0, 1
 NMS_GE_ORIG_ASC, NMS_GT_SORTED_POS = 0, 1
+ROI_ALIGN_RECORDS_READY, ROI_ALIGN_OVERWRITE = 1, 2
 
 _c_int, _c_float, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
@@ -26,6 +27,9 @@ SIGNATURES = {
     "mi_roi_align_forward_ws": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_float] + [_c_int] * 3
                                 + [_c_void_p, _c_size_t, _c_void_p]),
     "mi_roi_align_backward": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_float] + [_c_int] * 3 + [_c_void_p]),
+    "mi_roi_align_backward_ws": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_float] + [_c_int] * 3
+                                 + [_c_void_p, _c_size_t, _c_int, _c_void_p]),
+    "mi_roi_align_backward_overwrites": (_c_int, [_c_int] * 8),
     "mi_roi_pool_forward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_float, _c_void_p]),
     "mi_roi_pool_backward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_float, _c_void_p]),
     "mi_roi_crop_forward": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p]),

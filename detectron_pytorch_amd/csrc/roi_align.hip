@@ -322,11 +322,11 @@ extern "C" int mi_roi_align_forward_ws(const float* features, const float* rois,
                                 workspace_bytes, stream);
 }
 
-extern "C" int mi_roi_align_backward(const float* top_grad, const float* rois, float* bottom_grad,
-                                     int batch, int channels, int height, int width, int num_rois,
-                                     int aligned_height, int aligned_width, float spatial_scale,
-                                     int sampling_ratio, int variant, int layout,
-                                     mi_stream_t stream) {
+namespace {
+int roi_align_backward_impl(const float* top_grad, const float* rois, float* bottom_grad, int batch, int channels,
+                            int height, int width, int num_rois, int aligned_height, int aligned_width,
+                            float spatial_scale, int sampling_ratio, int variant, int layout, void* workspace,
+                            size_t workspace_bytes, int records_ready /* bit0: records ready, bit1: overwrite */, mi_stream_t stream) {
   mi::begin_call();
   int rc = check_common(top_grad, rois, bottom_grad, batch, channels, height, width, num_rois,
                         aligned_height, aligned_width, variant, layout);
@@ -341,6 +341,18 @@ extern "C" int mi_roi_align_backward(const float* top_grad, const float* rois, f
         aligned_width, spatial_scale);
     return mi::check_launch("roi_align_legacy_bwd");
   }
+  if (workspace != nullptr) {
+    MI_REQUIRE(workspace_bytes >= mi::roi_align_fwd_persist_workspace_bytes(num_rois),
+               "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
+               mi::roi_align_fwd_persist_workspace_bytes(num_rois));
+    MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
+    if (layout == MI_LAYOUT_NCHW && !force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
+        mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
+      return mi::launch_roi_align_bwd_records(top_grad, rois, bottom_grad, workspace, (records_ready & 1) != 0,
+                                              (records_ready & 2) != 0, batch, channels, height, width, num_rois,
+                                              aligned_height, aligned_width, spatial_scale, sampling_ratio,
+                                              ring_words(), s);
+  }
   if (layout == MI_LAYOUT_NCHW && use_stream_path(channels, aligned_height, aligned_width))
     return mi::launch_roi_align_bwd_stream(top_grad, rois, bottom_grad, batch, channels, height, width,
                                            num_rois, aligned_height, aligned_width, spatial_scale,
@@ -350,4 +362,34 @@ extern "C" int mi_roi_align_backward(const float* top_grad, const float* rois, f
       total, top_grad, rois, bottom_grad, batch, channels, height, width, aligned_height,
       aligned_width, spatial_scale, sampling_ratio, st);
   return mi::check_launch("roi_align_bwd_direct");
+}
+}  // namespace
+
+extern "C" int mi_roi_align_backward(const float* top_grad, const float* rois, float* bottom_grad,
+                                     int batch, int channels, int height, int width, int num_rois,
+                                     int aligned_height, int aligned_width, float spatial_scale,
+                                     int sampling_ratio, int variant, int layout,
+                                     mi_stream_t stream) {
+  return roi_align_backward_impl(top_grad, rois, bottom_grad, batch, channels, height, width, num_rois,
+                                 aligned_height, aligned_width, spatial_scale, sampling_ratio, variant, layout, nullptr,
+                                 0, 0, stream);
+}
+
+extern "C" int mi_roi_align_backward_ws(const float* top_grad, const float* rois, float* bottom_grad,
+                                        int batch, int channels, int height, int width, int num_rois,
+                                        int aligned_height, int aligned_width, float spatial_scale,
+                                        int sampling_ratio, int variant, int layout, void* workspace,
+                                        size_t workspace_bytes, int flags, mi_stream_t stream) {
+  return roi_align_backward_impl(top_grad, rois, bottom_grad, batch, channels, height, width, num_rois,
+                                 aligned_height, aligned_width, spatial_scale, sampling_ratio, variant, layout,
+                                 workspace, workspace_bytes, flags, stream);
+}
+
+extern "C" int mi_roi_align_backward_overwrites(int channels, int height, int width, int num_rois, int aligned_height,
+                                                int aligned_width, int variant, int layout) {
+  return variant == MI_ROI_ALIGN_CAFFE2 && layout == MI_LAYOUT_NCHW && !force_direct() &&
+                 std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
+                 mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width)
+             ? 1
+             : 0;
 }

@@ -1,4 +1,5 @@
-// roi_align_fwd_persist.hip -- RoIAlign forward (Caffe2 semantics), NCHW, the two-launch fast path for gfx950:
+// roi_align_records.hip -- RoIAlign forward and backward (Caffe2 semantics), NCHW, the record-driven fast path for
+// gfx950 (caller workspace, two launches):
 //
 //   roi_align_prepare   one wavefront per RoI.  Computes, with exactly the reference's fp32 operations
 //       (lib/modeling/roi_xfrom/roi_align/src/roi_align_kernel.cu:74-110 and :16-52), everything that is identical
@@ -46,14 +47,20 @@ constexpr int kBandRows = 16;              // feature rows per sweep band
 
 // ---- per-RoI record (dwords), stored at the RoI's rank along the sweep ---------------------------------------------
 constexpr int kRecHeader = 16;  // [0] flags [1] batch_ind [2] wx0 [3] ww [4] magic [5] nstages [6] gh [7] gw [8] roi
+                                // [9] wy0 [10] wy1 (last window row) [12..15] stage 0
 constexpr int kRecStages = kRecHeader;                 // kMaxStages x {ph0 | ph1 << 16, row0, nrows, 0}
 constexpr int kRecY = kRecStages + 4 * kMaxStages;     // kMaxS x {row_lo * ww * 4, hw / count, lw / count, row_lo}
 constexpr int kRecX = kRecY + 4 * kMaxS;               // kMaxS x {(col_lo - wx0) * 4, hw, lw, col_lo}
-constexpr int kRecDwords = kRecX + 4 * kMaxS;          // 400 dwords = 1600 B
+constexpr int kMaxWin = 63;                            // window rows / columns the backward tables cover
+constexpr int kRecXF = kRecX + 4 * kMaxS;              // kMaxWin+1 ints: xfirst[c] = #x samples with col_lo < wx0 + c
+constexpr int kRecYF = kRecXF + kMaxWin + 1;           // kMaxWin+1 ints: yfirst[r] = #y samples with row_lo < wy0 + r
+constexpr int kRecDwords = kRecYF + kMaxWin + 1;       // 528 dwords = 2112 B
+// after the records: one int4 per rank {x0, x1, batch*H + y0, batch*H + y1} = window of a backward-capable RoI
+// ({0x3fffffff, -1, ..} otherwise), read by the backward tiles to find the RoIs that touch them
 constexpr int kCounterDwords = 64;                     // ticket counters, zeroed by prepare
 constexpr int kNoItem = 0x7fffffff;
 
-enum : int { kFlagFast = 1, kFlagZero = 2 };
+enum : int { kFlagFast = 1, kFlagZero = 2, kFlagBwd = 4 };  // forward LDS path / no such image / backward tile path
 
 __device__ __forceinline__ void axis_taps(float v, int size, int& lo, float& hw, float& lw) {
   if (v <= 0) v = 0;
@@ -164,6 +171,24 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
       reinterpret_cast<int4*>(rec + kRecX)[lane] = e;
     }
   }
+  // backward tables: number of samples whose lower tap lies left of / above each window column / row
+  const int nrows_win = wy1 - wy0 + 1;
+  const bool bwd_ok = fast && ww <= kMaxWin && nrows_win <= kMaxWin;
+  if (bwd_ok) {
+    int cx = 0, cy = 0;
+    for (int i = 0; i < nsx; i++) cx += (__builtin_amdgcn_readlane(xlo, i) < wx0 + lane) ? 1 : 0;
+    for (int i = 0; i < nsy; i++) cy += (__builtin_amdgcn_readlane(ylo, i) < wy0 + lane) ? 1 : 0;
+    rec[kRecXF + lane] = cx;
+    rec[kRecYF + lane] = cy;
+  }
+  if (lane == 0) {
+    int4 bnd;
+    bnd.x = bwd_ok ? wx0 : 0x3fffffff;  // an interval that overlaps no tile
+    bnd.y = bwd_ok ? wx1 : -1;
+    bnd.z = batch_ind * height + wy0;
+    bnd.w = batch_ind * height + wy1;
+    reinterpret_cast<int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords)[rank] = bnd;
+  }
   // stages: consecutive bin rows whose window fits half the LDS image (so that the next stage can be prefetched while
   // this one is computed), the whole image if a single bin row needs it; at most max_rows_tile output rows
   int nstages = 0;
@@ -199,6 +224,7 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
     }
   }
   if (fast) flags |= kFlagFast;
+  if (bwd_ok) flags |= kFlagBwd;
   if (lane == 0) {
     int4 h0, h1, h2;
     h0.x = flags;
@@ -210,7 +236,9 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
     h1.z = gh;
     h1.w = gw;
     h2.x = r;
-    h2.y = h2.z = h2.w = 0;
+    h2.y = wy0;
+    h2.z = wy1;
+    h2.w = 0;
     reinterpret_cast<int4*>(rec)[0] = h0;
     reinterpret_cast<int4*>(rec)[1] = h1;
     reinterpret_cast<int4*>(rec)[2] = h2;
@@ -877,6 +905,228 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// Backward (roi_align_kernel.cu:150-270) as a GATHER over tiles of the feature-map gradient -- no atomics, no
+// zero fill, deterministic.
+//
+// Measured first on MI355X (512 RoIs x 256 ch x 7x7 on 200x336): scatter formulations are bound by the atomic units,
+// not by bandwidth -- 37 M global_atomic_add_f32 (one per window pixel and channel, already coalesced) cost ~190 us,
+// and accumulating a RoI's window in LDS with ds_add_f32 is slower still (~500 us: the LDS executes float atomics
+// lane by lane).  The reference's 16 atomics per output element are worse on both counts.
+//
+// The bilinear scatter is separable:  dF[row][col] = sum_ph wy(ph,row) * ( sum_pw wx(pw,col) * g[ph][pw] ).
+// One 256-lane workgroup owns an 8-row x 32-column tile of dF for KC channels and walks the RoIs whose window touches
+// the tile (found by scanning the int4 window of every rank; kept in sweep order, so the summation order is fixed):
+//   pass 1  lanes = (channel, column): T[c][ph][col] = sum over the x samples whose taps hit `col` of w * g[c][ph][pw]
+//           (the samples are contiguous ranges given by the record's xfirst table; 7 register accumulators)
+//   pass 2  lanes = (row, column), a half-wave per row: acc[c] += sum over the y samples whose taps hit `row` of
+//           w * T[c][ph][col], for the KC channels held in registers (yfirst table)
+// g, the axis tables and xfirst/yfirst of the NEXT RoI arrive by LDS-DMA while the current one is processed.
+// At the end each lane stores its KC sums as 128-byte rows (or adds them to what the caller supplied).
+// RoIs the tables cannot describe (a sample outside the [-1, size] band, window > 63 rows or columns, > 32 samples
+// per axis) are added afterwards by roi_align_bwd_slow with the reference's arithmetic and atomics.
+// Weights: g * (hy / count) * hx instead of the reference's g * (hy * hx) / count -- fp32 rounding only (the
+// accumulation order of the reference's atomics is unspecified; contract 1e-4).
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int kTH = 8, kTW = 32;  // tile of dF owned by a workgroup
+
+template <int KC>
+struct BwdLds {
+  static constexpr int kTabDw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);  // y table, x table, xfirst, yfirst (record order)
+  static constexpr int kTStride = kMaxStages * kTW + 1;            // words per channel of T (odd): up to 32 bin rows
+  static constexpr int kGWords = KC * kTileBins * 4;               // g block: up to 224 bins per channel
+};
+
+template <int kSR, int KC>
+__global__ void __launch_bounds__(256)
+roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bottom_grad, const int* __restrict__ ws,
+                    int num_rois, int batch, int channels, int height, int width, int aligned_height,
+                    int aligned_width, int tiles_x, int tiles_y, int overwrite, int t_stride, int g_words) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kTabDw = BwdLds<KC>::kTabDw;
+  // LDS (all of it in the dynamic region, 16-byte aligned pieces):
+  //   ctl[8] | list[num_rois] | tab[2][kTabDw] | g[2][g_words] | T[KC][t_stride]
+  int* wave_count = reinterpret_cast<int*>(smem);
+  int& list_len = wave_count[4];
+  int* list = wave_count + 8;
+  const int list_words = (num_rois + 3) & ~3;
+  int* tab0 = list + list_words;
+  float* g0 = reinterpret_cast<float*>(tab0 + 2 * kTabDw);
+  float* T = g0 + 2 * g_words;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int bins = aligned_height * aligned_width;
+  const int ncg = channels / KC;
+  const int cg = blockIdx.x % ncg;
+  const int tile_lin = blockIdx.x / ncg;
+  const int n = tile_lin / (tiles_x * tiles_y);
+  const int trem = tile_lin - n * tiles_x * tiles_y;
+  const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+  const int x0 = txi * kTW, y0 = tyi * kTH;            // tile origin in the feature map
+  const int gy0 = n * height + y0;                      // in "global rows" (image index folded in)
+  const int c0 = cg * KC;
+  const int* __restrict__ records = ws + kCounterDwords;
+  const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
+
+  // ---- RoIs whose window touches this tile, in rank order ----
+  if (tid == 0) list_len = 0;
+  __syncthreads();
+  for (int base = 0; base < num_rois; base += 256) {
+    const int i = base + tid;
+    bool hit = false;
+    if (i < num_rois) {
+      const int4 b = bounds[i];
+      hit = b.y >= x0 && b.x < x0 + kTW && b.w >= gy0 && b.z < gy0 + kTH && b.z / height == n;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_count[wave] = __popcll(m);
+    __syncthreads();
+    int off = list_len;
+    for (int w = 0; w < wave; w++) off += wave_count[w];
+    if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();
+    if (tid == 0) list_len += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    __syncthreads();
+  }
+  const int nlist = uniform(list_len);
+
+  // pass-2 identity of this lane: one pixel of the tile
+  const int prow = tid >> 5, pcol = tid & 31;
+  float acc[KC];
+#pragma unroll
+  for (int c = 0; c < KC; c++) acc[c] = 0.f;
+
+  // LDS-DMA of RoI `pos`: tables + xfirst/yfirst (contiguous in the record) and the [KC][bins] block of top gradients
+  auto issue_loads = [&](int pos, int buf) {
+    const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)uniform(pos) * kRecDwords);
+    const int r = rec[8];
+    const srd_t tsrd = make_srd(records + (long long)uniform(pos) * kRecDwords + kRecY, kTabDw * 4);
+    const unsigned tdst = lds_addr_uniform(tab0 + buf * kTabDw);
+    for (int k = wave; k * 64 < kTabDw; k += 4)
+      if (k * 64 + lane < kTabDw) dma_dword(tsrd, tdst + (unsigned)k * 256u, (unsigned)(k * 64 + lane) * 4u, 0u);
+    const int gw_ = KC * bins;
+    const srd_t gsrd = make_srd(top_grad + ((long long)r * channels + c0) * bins, (unsigned)gw_ * 4u);
+    const unsigned gdst = lds_addr_uniform(g0 + buf * g_words);
+    for (int k = wave; k * 64 < gw_; k += 4)
+      if (k * 64 + lane < gw_) dma_dword(gsrd, gdst + (unsigned)k * 256u, (unsigned)(k * 64 + lane) * 4u, 0u);
+  };
+
+  if (nlist > 0) issue_loads(list[0], 0);
+  for (int li = 0; li < nlist; li++) {
+    const int buf = li & 1;
+    const int pos = uniform(list[li]);
+    const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)pos * kRecDwords);
+    const int wx0 = rec[2], ww = rec[3], rgh = rec[6], rgw = rec[7], wy0 = rec[9], wy1 = rec[10];
+    const int gh = kSR > 0 ? kSR : rgh, gw = kSR > 0 ? kSR : rgw;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // B1: buffers of this RoI have landed; everybody is done with the previous RoI (T, other buffer)
+    if (li + 1 < nlist) issue_loads(list[li + 1], buf ^ 1);
+    const TabEntry* ty = reinterpret_cast<const TabEntry*>(tab0 + buf * kTabDw);
+    const TabEntry* tx = ty + kMaxS;
+    const int* xfirst = tab0 + buf * kTabDw + 8 * kMaxS;
+    const int* yfirst = xfirst + kMaxWin + 1;
+    const float* g = g0 + buf * g_words;
+
+    // ---- pass 1: T[c][ph][col] for the tile columns inside the window ----
+    {
+      const int c = tid % KC, slot = tid / KC;
+      constexpr int kColStep = 256 / KC;
+      for (int col = slot; col < kTW; col += kColStep) {
+        const int lc = x0 + col - wx0;
+        if (lc < 0 || lc >= ww) continue;
+        const int sa = xfirst[lc], sb = xfirst[lc + 1];   // samples with col_lo == this column   (weight hw)
+        const int sp = lc > 0 ? xfirst[lc - 1] : 0;        // samples with col_lo == column - 1  : [sp, sa)  (weight lw)
+        const float* gc = g + c * bins;
+        for (int ph0 = 0; ph0 < aligned_height; ph0 += 8) {
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) t[j] = 0.f;
+          for (int sidx = sp; sidx < sb; sidx++) {
+            const TabEntry ex = tx[sidx];
+            const float wgt = sidx < sa ? ex.lw : ex.hw;
+            const int pw = kSR > 0 ? sidx / (kSR > 0 ? kSR : 1) : sidx / gw;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+              if (ph0 + j < aligned_height) t[j] = __builtin_fmaf(wgt, gc[(ph0 + j) * aligned_width + pw], t[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            if (ph0 + j < aligned_height) T[c * t_stride + (ph0 + j) * kTW + col] = t[j];
+        }
+      }
+    }
+    __syncthreads();  // B2: T complete
+
+    // ---- pass 2: this lane's pixel, all KC channels ----
+    {
+      const int lr = y0 + prow - wy0, lc = x0 + pcol - wx0;
+      if (lr >= 0 && lr <= wy1 - wy0 && lc >= 0 && lc < ww) {
+        const int sa = yfirst[lr], sb = yfirst[lr + 1];
+        const int sp = lr > 0 ? yfirst[lr - 1] : 0;
+        for (int sidx = sp; sidx < sb; sidx++) {
+          const TabEntry ey = ty[sidx];
+          const float wgt = sidx < sa ? ey.lw : ey.hw;
+          const int ph = kSR > 0 ? sidx / (kSR > 0 ? kSR : 1) : sidx / gh;
+          const float* tp = T + ph * kTW + pcol;
+#pragma unroll
+          for (int c = 0; c < KC; c++) acc[c] = __builtin_fmaf(wgt, tp[c * t_stride], acc[c]);
+        }
+      }
+    }
+  }
+
+  // ---- the tile leaves as 128-byte rows ----
+  const int row = y0 + prow, col = x0 + pcol;
+  if (row < height && col < width) {
+    float* dst = bottom_grad + (((long long)n * channels + c0) * height + row) * width + col;
+    const long long plane = (long long)height * width;
+#pragma unroll
+    for (int c = 0; c < KC; c++) {
+      if (overwrite)
+        dst[c * plane] = acc[c];
+      else
+        dst[c * plane] += acc[c];
+    }
+  }
+}
+
+// RoIs the tile kernel does not cover: reference mapping, arithmetic and atomics (roi_align_kernel.cu:195-270).
+__global__ void __launch_bounds__(256)
+roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__ rois, float* __restrict__ bottom_grad,
+                   const int* __restrict__ ws, int num_rois, int batch, int channels, int height, int width,
+                   int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio) {
+  const int tiles = channels / kCT;
+  const int pos = blockIdx.x / tiles;
+  const int c0 = (blockIdx.x - pos * tiles) * kCT;
+  const const_int_ptr rec = (const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)pos * kRecDwords);
+  const int flags = rec[0], r = rec[8];
+  if (flags & (kFlagBwd | kFlagZero)) return;
+  const int bins = aligned_height * aligned_width;
+  const int tid = threadIdx.x;
+  const float* __restrict__ gsrc = top_grad + ((long long)r * channels + c0) * bins;
+  const RoiGeom g = roi_geometry(rois + (long long)r * 5, spatial_scale, aligned_height, aligned_width, sampling_ratio);
+  float* gdst = bottom_grad + ((long long)g.batch_ind * channels + c0) * height * width;
+  for (int i = tid; i < kCT * bins; i += 256) {
+    const int c = i / bins, bin = i - c * bins;
+    const int ph = bin / aligned_width, pw = bin - ph * aligned_width;
+    float* plane = gdst + (long long)c * height * width;
+    const float top_diff_this_bin = gsrc[i];
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const float y = sample_y(g, ph, iy);
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const float x = sample_x(g, pw, ix);
+        const Taps t = sample_taps(height, width, y, x);
+        if (t.y_low < 0) continue;
+        atomicAdd(plane + t.y_low * width + t.x_low, top_diff_this_bin * t.w1 / g.count);
+        atomicAdd(plane + t.y_low * width + t.x_high, top_diff_this_bin * t.w2 / g.count);
+        atomicAdd(plane + t.y_high * width + t.x_low, top_diff_this_bin * t.w3 / g.count);
+        atomicAdd(plane + t.y_high * width + t.x_high, top_diff_this_bin * t.w4 / g.count);
+      }
+    }
+  }
+}
+
 int g_ablate_p = 0;
 long long* g_timeline_p = nullptr;
 bool g_persistent = false;
@@ -929,7 +1179,73 @@ int launch_cap(const float* features, const float* rois, float* output, int* ws,
   return check_launch("roi_align_fwd_persist");
 }
 
+template <int kCap>
+int launch_prepare_only(const float* rois, int* ws, int batch, int height, int width, int num_rois, int aligned_height,
+                        int aligned_width, float spatial_scale, int sampling_ratio, hipStream_t stream) {
+  const int max_rows_tile = kTileBins / aligned_width;
+  roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
+      rois, num_rois, batch, height, width, aligned_height, aligned_width, spatial_scale, sampling_ratio, kCap, kCap,
+      max_rows_tile, ws);
+  return check_launch("roi_align_prepare");
+}
+
 }  // namespace
+
+int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float* bottom_grad, void* workspace,
+                                 bool records_ready, bool overwrite, int batch, int channels, int height, int width,
+                                 int num_rois, int aligned_height, int aligned_width, float spatial_scale,
+                                 int sampling_ratio, int cap_px, hipStream_t stream) {
+  int* ws = static_cast<int*>(workspace);
+  if (!records_ready) {
+    // backward tables do not depend on the LDS capacity the forward stages were cut for
+    int rc = cap_px >= 336 ? launch_prepare_only<336>(rois, ws, batch, height, width, num_rois, aligned_height,
+                                                      aligned_width, spatial_scale, sampling_ratio, stream)
+                           : launch_prepare_only<192>(rois, ws, batch, height, width, num_rois, aligned_height,
+                                                      aligned_width, spatial_scale, sampling_ratio, stream);
+    if (rc != MI_OK) return rc;
+  }
+  const int bins = aligned_height * aligned_width;
+  const int tiles_x = (width + kTW - 1) / kTW, tiles_y = (height + kTH - 1) / kTH;
+  // channels per workgroup: 32 accumulators per lane while the g block and T fit LDS comfortably, else 16
+  const int kc = (bins <= 64) ? 32 : 16;
+  const int t_stride = aligned_height * kTW + 1;
+  const int g_words = (kc * bins + 3) & ~3;
+  const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
+  const size_t lds = (8 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)kc * t_stride) * 4;
+  const int grid = tiles_x * tiles_y * batch * (channels / kc);
+#define MI_LAUNCH_TILES(SR, KC)                                                                                       \
+  roi_align_bwd_tiles<SR, KC><<<grid, 256, lds, stream>>>(top_grad, bottom_grad, ws, num_rois, batch, channels,      \
+                                                          height, width, aligned_height, aligned_width, tiles_x,      \
+                                                          tiles_y, overwrite ? 1 : 0, t_stride, g_words)
+  if (g_ablate_p & 8) {
+  } else if (kc == 32 && sampling_ratio == 2)
+    MI_LAUNCH_TILES(2, 32);
+  else if (kc == 32)
+    MI_LAUNCH_TILES(0, 32);
+  else if (sampling_ratio == 2)
+    MI_LAUNCH_TILES(2, 16);
+  else
+    MI_LAUNCH_TILES(0, 16);
+#undef MI_LAUNCH_TILES
+  int rc = check_launch("roi_align_bwd_tiles");
+  if (rc != MI_OK) return rc;
+  if (!(g_ablate_p & 16))
+    roi_align_bwd_slow<<<num_rois * (channels / kCT), 256, 0, stream>>>(top_grad, rois, bottom_grad, ws, num_rois, batch,
+                                                                    channels, height, width, aligned_height,
+                                                                    aligned_width, spatial_scale, sampling_ratio);
+  return check_launch("roi_align_bwd_slow");
+}
+
+bool roi_align_bwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
+                                     int aligned_width) {
+  const int bins = aligned_height * aligned_width;
+  const int kc = (bins <= 64) ? 32 : 16;
+  const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
+  const size_t lds = (8 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * ((kc * bins + 3) & ~3) +
+                      (size_t)kc * (aligned_height * kTW + 1)) * 4;
+  return channels > 0 && channels % 32 == 0 && aligned_height > 0 && aligned_width > 0 &&
+         aligned_height <= kMaxStages && num_rois <= kMaxRois && lds <= 64 * 1024;
+}
 
 void roi_align_fwd_persist_set_ablate(int mask) { g_ablate_p = mask; }
 void roi_align_fwd_persist_set_mode(bool persistent, int ct) {
@@ -939,7 +1255,7 @@ void roi_align_fwd_persist_set_mode(bool persistent, int ct) {
 void roi_align_fwd_persist_set_timeline(long long* device_buffer) { g_timeline_p = device_buffer; }
 
 size_t roi_align_fwd_persist_workspace_bytes(int num_rois) {
-  return ((size_t)kCounterDwords + (size_t)(num_rois > 0 ? num_rois : 0) * kRecDwords) * sizeof(int);
+  return ((size_t)kCounterDwords + (size_t)(num_rois > 0 ? num_rois : 0) * (kRecDwords + 4)) * sizeof(int);
 }
 
 bool roi_align_fwd_persist_supported(int channels, int height, int width, int num_rois, int aligned_height,

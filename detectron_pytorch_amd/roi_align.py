@@ -49,8 +49,9 @@ def _check_inputs(features, rois):
 
 
 def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_scale, sampling_ratio,
-                      variant=_lib.ROI_ALIGN_CAFFE2):
-    """Raw forward (no autograd): returns a new [R, C, ah, aw] tensor."""
+                      variant=_lib.ROI_ALIGN_CAFFE2, return_workspace=False):
+    """Raw forward (no autograd): returns a new [R, C, ah, aw] tensor (and, on request, the device scratch holding
+    the per-RoI records, which a backward over the same rois can reuse)."""
     _check_inputs(features, rois)
     features, layout = _layout_of(features)
     if variant == _lib.ROI_ALIGN_LEGACY and layout != _lib.LAYOUT_NCHW:
@@ -70,11 +71,11 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
             int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
             int(variant), layout, workspace.data_ptr(), ws_bytes, _lib.current_stream_handle(features.device))
     _lib.check(rc, "mi_roi_align_forward_ws")
-    return output
+    return (output, workspace) if return_workspace else output
 
 
 def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_width, spatial_scale,
-                       sampling_ratio, variant=_lib.ROI_ALIGN_CAFFE2, channels_last=False):
+                       sampling_ratio, variant=_lib.ROI_ALIGN_CAFFE2, channels_last=False, workspace=None):
     """Raw backward: returns grad w.r.t. features, shape `feature_size` (zero-filled then accumulated,
     functions/roi_align.py:39-44)."""
     _lib.require_cuda(grad_output, "grad_output")
@@ -82,15 +83,29 @@ def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_
     rois = rois.contiguous()
     n, c, h, w = feature_size
     fmt = torch.channels_last if (channels_last and variant == _lib.ROI_ALIGN_CAFFE2) else torch.contiguous_format
-    grad_input = torch.empty((n, c, h, w), dtype=grad_output.dtype, device=grad_output.device,
-                             memory_format=fmt).zero_()
     layout = _lib.LAYOUT_NHWC if fmt is torch.channels_last else _lib.LAYOUT_NCHW
+    lib = _lib.lib()
+    r = rois.size(0)
+    # The NCHW tile path writes every element itself; everywhere else the kernels accumulate into a zero-filled
+    # buffer like the reference (functions/roi_align.py:39-44).
+    overwrite = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, int(aligned_height), int(aligned_width),
+                                                          int(variant), layout)) and r > 0
+    grad_input = torch.empty((n, c, h, w), dtype=grad_output.dtype, device=grad_output.device, memory_format=fmt)
+    if not overwrite:
+        grad_input.zero_()
+    ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+    # `workspace`: the scratch of the forward over the same rois (records are reused); else a fresh one
+    ready = workspace is not None and workspace.numel() >= ws_bytes and workspace.device == grad_output.device
+    if not ready:
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_output.device)
+    flags = (_lib.ROI_ALIGN_RECORDS_READY if ready else 0) | (_lib.ROI_ALIGN_OVERWRITE if overwrite else 0)
     with torch.cuda.device(grad_output.device):
-        rc = _lib.lib().mi_roi_align_backward(
-            grad_output.data_ptr(), rois.data_ptr(), grad_input.data_ptr(), n, c, h, w, rois.size(0),
+        rc = lib.mi_roi_align_backward_ws(
+            grad_output.data_ptr(), rois.data_ptr(), grad_input.data_ptr(), n, c, h, w, r,
             int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
-            int(variant), layout, _lib.current_stream_handle(grad_output.device))
-    _lib.check(rc, "mi_roi_align_backward")
+            int(variant), layout, workspace.data_ptr(), workspace.numel(), flags,
+            _lib.current_stream_handle(grad_output.device))
+    _lib.check(rc, "mi_roi_align_backward_ws")
     return grad_input
 
 
@@ -99,19 +114,23 @@ class _RoIAlign(Function):
 
     @staticmethod
     def forward(ctx, features, rois, aligned_height, aligned_width, spatial_scale, sampling_ratio, variant):
-        ctx.save_for_backward(rois)
         ctx.cfg = (int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio), int(variant))
         ctx.feature_size = tuple(features.shape)
         ctx.channels_last = (features.dim() == 4 and not features.is_contiguous()
                              and features.is_contiguous(memory_format=torch.channels_last))
-        return roi_align_forward(features, rois, *ctx.cfg)
+        output, workspace = roi_align_forward(features, rois, *ctx.cfg, return_workspace=True)
+        # the records are valid for the backward only if it uses the fast NCHW path on the same rois
+        nchw = features.is_contiguous() and variant == _lib.ROI_ALIGN_CAFFE2
+        ctx.save_for_backward(rois, workspace if nchw else rois.new_empty(0))
+        return output
 
     @staticmethod
     def backward(ctx, grad_output):
-        (rois,) = ctx.saved_tensors
+        rois, workspace = ctx.saved_tensors
         ah, aw, scale, sr, variant = ctx.cfg
         grad_input = roi_align_backward(grad_output, rois, ctx.feature_size, ah, aw, scale, sr, variant,
-                                        channels_last=ctx.channels_last)
+                                        channels_last=ctx.channels_last,
+                                        workspace=workspace if workspace.numel() > 0 else None)
         return grad_input, None, None, None, None, None, None
 
 

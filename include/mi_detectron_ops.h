@@ -92,6 +92,25 @@ int mi_roi_align_backward(const float* top_grad, const float* rois, float* botto
                           int aligned_height, int aligned_width, float spatial_scale,
                           int sampling_ratio, int variant, int layout, mi_stream_t stream);
 
+/* Backward with caller scratch (same workspace contract as mi_roi_align_forward_ws).  `flags`:
+ *   MI_ROI_ALIGN_RECORDS_READY  `workspace` still holds the records written by mi_roi_align_forward_ws for the SAME
+ *                               rois, feature-map size, aligned size, spatial_scale and sampling_ratio (nothing else
+ *                               touched it since): the record launch is skipped;
+ *   MI_ROI_ALIGN_OVERWRITE      bottom_grad is fully WRITTEN (no zero fill by the caller needed) instead of
+ *                               accumulated into (the reference contract, functions/roi_align.py:39-44).  Honoured on
+ *                               the NCHW tile path only; test mi_roi_align_backward_overwrites() before relying on it.
+ * On NCHW this path is a gather over tiles of bottom_grad: no atomics, deterministic summation order. */
+#define MI_ROI_ALIGN_RECORDS_READY 1
+#define MI_ROI_ALIGN_OVERWRITE 2
+int mi_roi_align_backward_ws(const float* top_grad, const float* rois, float* bottom_grad,
+                             int batch, int channels, int height, int width, int num_rois,
+                             int aligned_height, int aligned_width, float spatial_scale,
+                             int sampling_ratio, int variant, int layout,
+                             void* workspace, size_t workspace_bytes, int flags, mi_stream_t stream);
+/* 1 when mi_roi_align_backward_ws would honour MI_ROI_ALIGN_OVERWRITE for these arguments (with a workspace). */
+int mi_roi_align_backward_overwrites(int channels, int height, int width, int num_rois, int aligned_height,
+                                     int aligned_width, int variant, int layout);
+
 /* ---- RoIPool --------------------------------------------------------------------------
  * replaces ROIPoolForwardLaucher / ROIPoolBackwardLaucher (lib/model/roi_pooling/src/roi_pooling_kernel.h:8-20)
  * and roi_pooling_forward_cuda / roi_pooling_backward_cuda (roi_pooling_cuda.c:7,49).
