@@ -304,6 +304,7 @@ __device__ __forceinline__ srd_t make_srd(const void* base, unsigned num_bytes) 
   return r;
 }
 __device__ __forceinline__ void dma_dword(srd_t srd, unsigned lds_base, unsigned voff, unsigned soff) {
+  lds_base = (unsigned)uniform((int)lds_base);  // the "s" constraint alone does not move a VGPR-resident value
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds"
                :
                : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff)
@@ -941,11 +942,13 @@ template <int kSR, int KC>
 __global__ void __launch_bounds__(256)
 roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bottom_grad, const int* __restrict__ ws,
                     int num_rois, int batch, int channels, int height, int width, int aligned_height,
-                    int aligned_width, int tiles_x, int tiles_y, int overwrite, int t_stride, int g_words) {
+                    int aligned_width, int tiles_x, int tiles_y, int overwrite, int ablate, int g_words, int ah_pad,
+                    int g_cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kTabDw = BwdLds<KC>::kTabDw;
+  constexpr int kCS = KC + 4;  // words per (bin row, column) of T
   // LDS (all of it in the dynamic region, 16-byte aligned pieces):
-  //   ctl[8] | list[num_rois] | tab[2][kTabDw] | g[2][g_words] | T[KC][t_stride]
+  //   ctl[8] | list[num_rois] | tab[2][kTabDw] | g[2][g_words] | T[aligned_height][kTW][KC + 4]
   int* wave_count = reinterpret_cast<int*>(smem);
   int& list_len = wave_count[4];
   int* list = wave_count + 8;
@@ -997,6 +1000,21 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
 #pragma unroll
   for (int c = 0; c < KC; c++) acc[c] = 0.f;
 
+  // source byte offsets of this lane's pieces of the transposed g block (the same for every RoI)
+  constexpr int kGP = 16;  // pieces per wave at most: KC * g_cs <= 4 * 16 * 64 words
+  unsigned gsrc_off[kGP];
+  {
+    const int per_c = aligned_width * ah_pad;
+#pragma unroll
+    for (int kk = 0; kk < kGP; kk++) {
+      const int i = (wave + 4 * kk) * 64 + lane;  // LDS word index
+      const int c = i / g_cs, rem = i - c * g_cs;
+      const int pw = rem / ah_pad, ph = rem - pw * ah_pad;
+      gsrc_off[kk] = (c < KC && rem < per_c && ph < aligned_height) ? (unsigned)(c * bins + ph * aligned_width + pw) * 4u
+                                                                      : 0xffffffffu;
+    }
+  }
+
   // LDS-DMA of RoI `pos`: tables + xfirst/yfirst (contiguous in the record) and the [KC][bins] block of top gradients
   auto issue_loads = [&](int pos, int buf) {
     const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)uniform(pos) * kRecDwords);
@@ -1005,11 +1023,16 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
     const unsigned tdst = lds_addr_uniform(tab0 + buf * kTabDw);
     for (int k = wave; k * 64 < kTabDw; k += 4)
       if (k * 64 + lane < kTabDw) dma_dword(tsrd, tdst + (unsigned)k * 256u, (unsigned)(k * 64 + lane) * 4u, 0u);
-    const int gw_ = KC * bins;
-    const srd_t gsrd = make_srd(top_grad + ((long long)r * channels + c0) * bins, (unsigned)gw_ * 4u);
+    // top gradients: global [c][ph][pw] -> LDS [c][pw][ph] (bin rows of one column contiguous, padded to ah_pad; channel
+    // stride g_cs = 4 * odd): the DMA's per-lane source address does the transpose, pass 1 then reads a column's bin
+    // rows with ds_read_b128
+    const srd_t gsrd = make_srd(top_grad + ((long long)r * channels + c0) * bins, (unsigned)(KC * bins) * 4u);
     const unsigned gdst = lds_addr_uniform(g0 + buf * g_words);
-    for (int k = wave; k * 64 < gw_; k += 4)
-      if (k * 64 + lane < gw_) dma_dword(gsrd, gdst + (unsigned)k * 256u, (unsigned)(k * 64 + lane) * 4u, 0u);
+#pragma unroll
+    for (int kk = 0; kk < kGP; kk++) {
+      const int k = wave + 4 * kk;
+      if (k * 64 < KC * g_cs && gsrc_off[kk] != 0xffffffffu) dma_dword(gsrd, gdst + (unsigned)k * 256u, gsrc_off[kk], 0u);
+    }
   };
 
   if (nlist > 0) issue_loads(list[0], 0);
@@ -1028,8 +1051,8 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
     const int* yfirst = xfirst + kMaxWin + 1;
     const float* g = g0 + buf * g_words;
 
-    // ---- pass 1: T[c][ph][col] for the tile columns inside the window ----
-    {
+    // ---- pass 1: T[ph][col][c] for the tile columns inside the window ----
+    if (!(ablate & 1)) {
       const int c = tid % KC, slot = tid / KC;
       constexpr int kColStep = 256 / KC;
       for (int col = slot; col < kTW; col += kColStep) {
@@ -1037,29 +1060,44 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
         if (lc < 0 || lc >= ww) continue;
         const int sa = xfirst[lc], sb = xfirst[lc + 1];   // samples with col_lo == this column   (weight hw)
         const int sp = lc > 0 ? xfirst[lc - 1] : 0;        // samples with col_lo == column - 1  : [sp, sa)  (weight lw)
-        const float* gc = g + c * bins;
+        const float* gc = g + c * g_cs;
         for (int ph0 = 0; ph0 < aligned_height; ph0 += 8) {
           float t[8];
 #pragma unroll
           for (int j = 0; j < 8; j++) t[j] = 0.f;
-          for (int sidx = sp; sidx < sb; sidx++) {
-            const TabEntry ex = tx[sidx];
-            const float wgt = sidx < sa ? ex.lw : ex.hw;
-            const int pw = kSR > 0 ? sidx / (kSR > 0 ? kSR : 1) : sidx / gw;
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-              if (ph0 + j < aligned_height) t[j] = __builtin_fmaf(wgt, gc[(ph0 + j) * aligned_width + pw], t[j]);
+          const int kg = kSR > 0 ? kSR : gw;
+          for (int pw = sp / kg; pw * kg < sb; pw++) {
+            // combined weight of this output column's samples that hit `col`
+            float wgt = 0.f;
+            for (int ix = 0; ix < kg; ix++) {
+              const int sidx = pw * kg + ix;
+              if (sidx >= sp && sidx < sb) {
+                const TabEntry ex = tx[sidx];
+                wgt += sidx < sa ? ex.lw : ex.hw;
+              }
+            }
+            const float4* gp = reinterpret_cast<const float4*>(gc + pw * ah_pad + ph0);
+            const float4 ga = gp[0];
+            const float4 gb = (ph0 + 4 < ah_pad) ? gp[1] : float4{0.f, 0.f, 0.f, 0.f};
+            t[0] = __builtin_fmaf(wgt, ga.x, t[0]);
+            t[1] = __builtin_fmaf(wgt, ga.y, t[1]);
+            t[2] = __builtin_fmaf(wgt, ga.z, t[2]);
+            t[3] = __builtin_fmaf(wgt, ga.w, t[3]);
+            t[4] = __builtin_fmaf(wgt, gb.x, t[4]);
+            t[5] = __builtin_fmaf(wgt, gb.y, t[5]);
+            t[6] = __builtin_fmaf(wgt, gb.z, t[6]);
+            t[7] = __builtin_fmaf(wgt, gb.w, t[7]);
           }
 #pragma unroll
           for (int j = 0; j < 8; j++)
-            if (ph0 + j < aligned_height) T[c * t_stride + (ph0 + j) * kTW + col] = t[j];
+            if (ph0 + j < aligned_height) T[((ph0 + j) * kTW + col) * kCS + c] = t[j];
         }
       }
     }
     __syncthreads();  // B2: T complete
 
     // ---- pass 2: this lane's pixel, all KC channels ----
-    {
+    if (!(ablate & 2)) {
       const int lr = y0 + prow - wy0, lc = x0 + pcol - wx0;
       if (lr >= 0 && lr <= wy1 - wy0 && lc >= 0 && lc < ww) {
         const int sa = yfirst[lr], sb = yfirst[lr + 1];
@@ -1068,9 +1106,17 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
           const TabEntry ey = ty[sidx];
           const float wgt = sidx < sa ? ey.lw : ey.hw;
           const int ph = kSR > 0 ? sidx / (kSR > 0 ? kSR : 1) : sidx / gh;
-          const float* tp = T + ph * kTW + pcol;
+          // T is [ph][col][channel] with a column stride of KC + 4 words: the lane's KC channels are KC / 4
+          // conflict-free ds_read_b128 (16-lane groups land on 16 distinct 4-bank slots)
+          const float4* tp = reinterpret_cast<const float4*>(T + (ph * kTW + pcol) * kCS);
 #pragma unroll
-          for (int c = 0; c < KC; c++) acc[c] = __builtin_fmaf(wgt, tp[c * t_stride], acc[c]);
+          for (int c4 = 0; c4 < KC / 4; c4++) {
+            const float4 tv = tp[c4];
+            acc[4 * c4 + 0] = __builtin_fmaf(wgt, tv.x, acc[4 * c4 + 0]);
+            acc[4 * c4 + 1] = __builtin_fmaf(wgt, tv.y, acc[4 * c4 + 1]);
+            acc[4 * c4 + 2] = __builtin_fmaf(wgt, tv.z, acc[4 * c4 + 2]);
+            acc[4 * c4 + 3] = __builtin_fmaf(wgt, tv.w, acc[4 * c4 + 3]);
+          }
         }
       }
     }
@@ -1208,24 +1254,32 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
   const int tiles_x = (width + kTW - 1) / kTW, tiles_y = (height + kTH - 1) / kTH;
   // channels per workgroup: 32 accumulators per lane while the g block and T fit LDS comfortably, else 16
   const int kc = (bins <= 64) ? 32 : 16;
-  const int t_stride = aligned_height * kTW + 1;
-  const int g_words = (kc * bins + 3) & ~3;
+  const int ah_pad = (aligned_height + 3) & ~3;
+  const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);  // channel stride of the transposed g block: 4 * odd
+  const int g_words = kc * g_cs;
   const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
-  const size_t lds = (8 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)kc * t_stride) * 4;
+  const size_t lds = (8 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
   const int grid = tiles_x * tiles_y * batch * (channels / kc);
 #define MI_LAUNCH_TILES(SR, KC)                                                                                       \
-  roi_align_bwd_tiles<SR, KC><<<grid, 256, lds, stream>>>(top_grad, bottom_grad, ws, num_rois, batch, channels,      \
-                                                          height, width, aligned_height, aligned_width, tiles_x,      \
-                                                          tiles_y, overwrite ? 1 : 0, t_stride, g_words)
+  do {                                                                                                                \
+    if (lds > 64 * 1024)                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+    roi_align_bwd_tiles<SR, KC><<<grid, 256, lds, stream>>>(top_grad, bottom_grad, ws, num_rois, batch, channels,    \
+                                                            height, width, aligned_height, aligned_width, tiles_x,    \
+                                                            tiles_y, overwrite ? 1 : 0, g_ablate_p & 7, g_words,      \
+                                                            ah_pad, g_cs);                                            \
+  } while (0)
   if (g_ablate_p & 8) {
-  } else if (kc == 32 && sampling_ratio == 2)
+  } else if (kc == 32 && sampling_ratio == 2) {
     MI_LAUNCH_TILES(2, 32);
-  else if (kc == 32)
+  } else if (kc == 32) {
     MI_LAUNCH_TILES(0, 32);
-  else if (sampling_ratio == 2)
+  } else if (sampling_ratio == 2) {
     MI_LAUNCH_TILES(2, 16);
-  else
+  } else {
     MI_LAUNCH_TILES(0, 16);
+  }
 #undef MI_LAUNCH_TILES
   int rc = check_launch("roi_align_bwd_tiles");
   if (rc != MI_OK) return rc;
@@ -1241,10 +1295,13 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
   const int bins = aligned_height * aligned_width;
   const int kc = (bins <= 64) ? 32 : 16;
   const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
-  const size_t lds = (8 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * ((kc * bins + 3) & ~3) +
-                      (size_t)kc * (aligned_height * kTW + 1)) * 4;
+  const int ah_pad = (aligned_height + 3) & ~3;
+  const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);
+  const size_t lds = (8 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * (size_t)kc * g_cs +
+                      (size_t)aligned_height * kTW * (kc + 4)) * 4;
   return channels > 0 && channels % 32 == 0 && aligned_height > 0 && aligned_width > 0 &&
-         aligned_height <= kMaxStages && num_rois <= kMaxRois && lds <= 64 * 1024;
+         aligned_height <= kMaxStages && num_rois <= kMaxRois && lds <= 160 * 1024 - 4096 &&
+         kc * g_cs <= 4 * 16 * 64;
 }
 
 void roi_align_fwd_persist_set_ablate(int mask) { g_ablate_p = mask; }

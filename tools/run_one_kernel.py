@@ -39,8 +39,8 @@ for _ in range(iters):
         rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, scale,
                                          sr, 0, 0, fws.data_ptr(), fws.numel(), stream)
     elif which == "roi_align_bwd":
-        rc = lib.mi_roi_align_backward(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
-                                       scale, sr, 0, 0, stream)
+        rc = lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
+                                          scale, sr, 0, 0, fws.data_ptr(), fws.numel(), 2, stream)
     else:
         rc = lib.mi_nms(dets.data_ptr(), 2000, 0.7, 0, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), wsb, stream)
     assert rc == 0
