@@ -1,0 +1,98 @@
+"""Data-parallel plumbing of the hot path: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI
+on ROCm; "gloo" in the CPU tests).
+
+Replaces the reference's single-process DataParallel (lib/nn/parallel/data_parallel.py:74-116): no per-step
+parameter broadcast (`replicate.py:12`), no scatter/gather through GPU 0 (`_functions.py:6-86`), no Python thread per
+GPU (`parallel_apply.py:50-59`).  What remains of it on this path:
+
+  * the batch is per-image independent, so rank r of W owns images r, r+W, ...  and every
+    RoI / detection belonging to them -- no data-path collective;
+  * the one exchange step of a training iteration is the gradient reduction
+    (`Broadcast.backward -> ReduceAddCoalesced`, `_functions.py:26-39`), here an all-reduce of flat fp32 buckets.
+    The reference sums the replicas' gradients of a loss that is the MEAN over GPUs
+    (`utils/training_stats.py:84`), i.e. averaged gradients == `ReduceOp.AVG` semantics.
+"""
+import torch
+import torch.distributed as dist
+
+BUCKET_BYTES = 64 << 20  # xGMI is point-to-point (7 links x ~153 GB/s): few, large messages per link
+
+
+def world():
+    """(rank, world_size) -- (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(num_items, rank=None, world_size=None):
+    """Indices of the items (images) rank `rank` owns: rank, rank + W, rank + 2W, ...  Round-robin rather than
+    contiguous blocks so that a dataset sorted by aspect ratio / size spreads evenly."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    return list(range(rank, num_items, world_size))
+
+
+def shard_rois_by_image(rois, num_images, rank=None, world_size=None):
+    """Split a [R,5] RoI tensor (batch_index, x1, y1, x2, y2) by image ownership.  Returns (local_rois, index) where
+    local_rois carries batch indices renumbered to the rank's local image order and `index` are the rows of `rois`
+    that were kept (so per-RoI outputs can be scattered back)."""
+    mine = shard_range(num_images, rank, world_size)
+    remap = torch.full((max(num_images, 1),), -1, dtype=torch.long, device=rois.device)
+    if mine:
+        remap[torch.tensor(mine, device=rois.device)] = torch.arange(len(mine), device=rois.device)
+    local_batch = remap[rois[:, 0].long().clamp(0, max(num_images - 1, 0))]
+    valid = (rois[:, 0] >= 0) & (rois[:, 0] < num_images)
+    keep = torch.nonzero((local_batch >= 0) & valid, as_tuple=False).flatten()
+    local = rois[keep].clone()
+    local[:, 0] = local_batch[keep].to(rois.dtype)
+    return local, keep
+
+
+def allreduce_gradients(params, bucket_bytes=BUCKET_BYTES, average=True, group=None):
+    """Average (or sum) the .grad of `params` over all ranks with as few collectives as possible: gradients are packed
+    into flat fp32 buckets of up to `bucket_bytes`, each bucket is one all-reduce, then unpacked in place.
+    Parameters whose grad is None on this rank contribute zeros (every rank must call with the same list)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    params = [p for p in params if p.requires_grad]
+    n_coll = 0
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size, n_coll
+        if not bucket:
+            return
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= dist.get_world_size(group)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+        n_coll += 1
+        bucket, size = [], 0
+
+    for p in params:
+        nbytes = p.numel() * 4
+        if bucket and size + nbytes > bucket_bytes:
+            flush()
+        bucket.append(p)
+        size += nbytes
+    flush()
+    return n_coll
+
+
+def max_over_ranks(seconds, device=None):
+    """The step time the job sees: the slowest rank's (bench.py takes MAX over ranks)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
