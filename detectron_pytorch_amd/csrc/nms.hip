@@ -38,6 +38,7 @@ struct Workspace {
   int32_t* order;    // [n_pad] sorted position -> original index
   int32_t* flags;    // [n_pad] kept flag per ORIGINAL index (GE mode)
   uint64_t* mask;    // [n, col_blocks]
+  uint64_t* diag_t;  // [n_pad] transposed diagonal tiles: bit i of diag_t[j] = box i (i < j, same chunk) overlaps box j
   size_t bytes;
 };
 
@@ -59,17 +60,26 @@ Workspace carve(void* base, int n) {
   off += align16(n_pad * sizeof(int32_t));
   w.mask = reinterpret_cast<uint64_t*>(p + off);
   off += align16((size_t)n * col_blocks * sizeof(uint64_t));
+  w.diag_t = reinterpret_cast<uint64_t*>(p + off);
+  off += align16(n_pad * sizeof(uint64_t));
   w.bytes = off;
   return w;
 }
 
 // ---- 1. sort + gather -------------------------------------------------------------------
+// Rank sort by counting.  A 256-lane workgroup ranks 64 boxes: lane & 63 = box, the 4 waves each count over a
+// quarter of the comparison range (scores staged through LDS 2048 at a time, every lane of a wave reads the same
+// word -> broadcast), the partial ranks meet in LDS.  n = 2000: 32 workgroups x 500 comparisons per lane
+// (the first version ranked 256 boxes per workgroup over the whole range: 8 workgroups on a 256-CU chip, 55 us).
+constexpr int kPrepChunk = 2048;
 template <bool kSort>
 __global__ void __launch_bounds__(256)
 nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
             float* __restrict__ areas, int32_t* __restrict__ order, int32_t* __restrict__ flags) {
-  __shared__ float s_scores[256];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float s_scores[kPrepChunk];
+  __shared__ int s_rank[4][kTile];
+  const int tid = threadIdx.x, bi = tid & (kTile - 1), part = tid >> 6;
+  const int i = blockIdx.x * kTile + bi;
   const bool live = i < n;
   float x1 = 0, y1 = 0, x2 = 0, y2 = 0, score = 0;
   if (live) {
@@ -82,25 +92,29 @@ nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
   }
   int rank = i;
   if (kSort) {
-    rank = 0;
-    for (int base = 0; base < n; base += 256) {
-      const int j = base + threadIdx.x;
+    int cnt = 0;
+    for (int base = 0; base < n; base += kPrepChunk) {
+      const int lim = min(kPrepChunk, n - base);
       __syncthreads();
-      s_scores[threadIdx.x] = (j < n) ? dets[(long long)j * 5 + 4] : 0.f;
+      for (int t = tid; t < lim; t += 256) s_scores[t] = dets[(long long)(base + t) * 5 + 4];
       __syncthreads();
-      const int lim = min(256, n - base);
+      const int per = (lim + 3) / 4;
+      const int t0 = part * per, t1 = min(t0 + per, lim);
       if (live) {
-        for (int t = 0; t < lim; t++) {
+        for (int t = t0; t < t1; t++) {
           const float sj = s_scores[t];
           const int jj = base + t;
           // descending score; equal scores: higher original index first
           // (== np.argsort(scores, kind='stable')[::-1], the tie rule fixed in oracle.c)
-          rank += (sj > score) || (sj == score && jj > i);
+          cnt += (sj > score) || (sj == score && jj > i);
         }
       }
     }
+    s_rank[part][bi] = cnt;
+    __syncthreads();
+    rank = s_rank[0][bi] + s_rank[1][bi] + s_rank[2][bi] + s_rank[3][bi];
   }
-  if (live) {
+  if (live && part == 0) {
     boxes[rank] = make_float4(x1, y1, x2, y2);
     areas[rank] = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);  // cython_nms.pyx:44 / nms_cuda_kernel.cu:36-37
     order[rank] = i;
@@ -136,14 +150,38 @@ __device__ __forceinline__ bool overlaps(const float4 a, const float area_a, con
 template <bool kGE>
 __global__ void __launch_bounds__(kTile)
 nms_mask(const float4* __restrict__ boxes, const float* __restrict__ areas, int n, float thresh,
-         uint64_t* __restrict__ mask) {
+         uint64_t* __restrict__ mask, uint64_t* __restrict__ diag_t) {
   const int col_start = blockIdx.x;
   const int row_start = blockIdx.y;
-  if (col_start < row_start) return;  // lower triangle is never read by the reduce (cu:139 starts at nblock)
   const int col_blocks = gridDim.x;
   __shared__ float4 s_box[kTile];
   __shared__ float s_area[kTile];
   const int lane = threadIdx.x;
+  // The lower triangle is never read by the reduce (cu:139 starts at nblock).  Its block (row-1, row) computes the
+  // TRANSPOSED diagonal tile of chunk `row` instead (chunk 0: block (0,0) does both), which the reduce's fixpoint
+  // iteration needs: bit i of diag_t[j] = box i (i < j, same chunk) overlaps box j.  The IoU test is symmetric bit
+  // for bit (max/min and the fp32 sum of the two areas commute), so this is the transpose of the diagonal tile.
+  const bool transposed = col_start + 1 == row_start;
+  if (col_start < row_start && !transposed) return;
+  if (transposed || (col_start == 0 && row_start == 0)) {
+    const int chunk = row_start;
+    const int size = min(n - chunk * kTile, kTile);
+    if (lane < size) {
+      s_box[lane] = boxes[chunk * kTile + lane];
+      s_area[lane] = areas[chunk * kTile + lane];
+    }
+    __syncthreads();
+    if (lane < size) {
+      const float4 a = s_box[lane];
+      const float area_a = s_area[lane];
+      uint64_t tt = 0;
+      for (int j = 0; j < lane; j++)
+        if (overlaps<kGE>(s_box[j], s_area[j], a, area_a, thresh)) tt |= 1ULL << j;
+      diag_t[chunk * kTile + lane] = tt;
+    }
+    if (transposed) return;
+    __syncthreads();
+  }
   const int col_size = min(n - col_start * kTile, kTile);
   const int row_size = min(n - row_start * kTile, kTile);
   if (lane < col_size) {
@@ -240,6 +278,75 @@ nms_reduce(const uint64_t* __restrict__ mask, int n, const int32_t* __restrict__
   if (!kGE && lane == 0) *num_keep = count;
 }
 
+// Reduce for n <= 4096 (col_blocks <= 64, one removed-word per lane).  Lane w owns word w of the removed set.  For a
+// chunk, the lane's word of ALL 64 mask rows is loaded up front (64 coalesced row loads in flight at once, issued
+// one chunk ahead, 128 VGPRs each for the current and the next chunk -- a lone wavefront owns the whole register
+// file), so OR-ing the kept rows is register selects instead of a dependent trip to L2 per group of four kept rows
+// (the first version: 140 us at n = 2000).  The greedy decisions stay on the scalar unit (v_readlane).
+template <bool kGE>
+__global__ void __launch_bounds__(kTile)
+nms_reduce_regs(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ diag_t, int n,
+                const int32_t* __restrict__ order, int32_t* __restrict__ flags, int32_t* __restrict__ keep32,
+                int32_t* __restrict__ num_keep) {
+  const int lane = threadIdx.x;
+  const int col_blocks = (n + kTile - 1) / kTile;
+  const bool owner = lane < col_blocks;
+  uint64_t nxt[kTile];
+  uint64_t nxt_diag;
+  int nxt_order = 0;
+  auto fetch = [&](int k) {
+    const int nrow = n - k * kTile;
+#pragma unroll
+    for (int r = 0; r < kTile; r++)
+      nxt[r] = (owner && r < nrow) ? mask[(long long)(k * kTile + r) * col_blocks + lane] : 0ULL;
+    nxt_diag = (lane < nrow) ? diag_t[k * kTile + lane] : 0ULL;
+    if (kGE) nxt_order = (lane < nrow) ? order[k * kTile + lane] : 0;
+  };
+  uint64_t remv = 0;
+  int count = 0;
+  fetch(0);
+  for (int k = 0; k < col_blocks; k++) {
+    uint64_t v[kTile];
+#pragma unroll
+    for (int r = 0; r < kTile; r++) v[r] = nxt[r];
+    const uint64_t diag = nxt_diag;
+    const int my_order = nxt_order;
+    if (k + 1 < col_blocks) fetch(k + 1);
+    uint64_t cur = readlane64(remv, k);
+    const int row = k * kTile + lane;
+    const int live = n - k * kTile;
+    const uint64_t valid = live >= kTile ? ~0ULL : ((1ULL << live) - 1ULL);
+    // In-chunk greedy pass (cu:132-144 restricted to word k) as a fixpoint iteration instead of a walk over the kept
+    // boxes: kept[j] = cand[j] and no kept i < j overlaps j.  Lane j holds WHO overlaps it (diag, the transposed
+    // tile), so one iteration is an AND with the wave-uniform kept set and a compare whose lane mask IS the next kept
+    // set.  Box j is final after j+1 iterations whatever the start; the loop ends at the first repeat, i.e. after
+    // (longest suppression chain in the chunk) + 1 rounds -- the walk cost ~250 scalar-unit cycles per kept box.
+    const uint64_t cand = ~cur & valid;
+    uint64_t keepbits = cand;
+    for (;;) {
+      const uint64_t next = __ballot((diag & keepbits) == 0ULL) & cand;
+      if (next == keepbits) break;
+      keepbits = next;
+    }
+    // OR the kept rows into the owned word (words <= k are dead from here on; harmless)
+#pragma unroll
+    for (int r = 0; r < kTile; r++)
+      if ((keepbits >> r) & 1ULL) remv |= v[r];
+    // emit
+    const bool mine = (keepbits >> lane) & 1ULL;
+    if (mine) {
+      if (kGE) {
+        flags[my_order] = 1;
+      } else {
+        const int pos = count + __popcll(keepbits & ((1ULL << lane) - 1ULL));
+        keep32[pos] = row;
+      }
+    }
+    count += __popcll(keepbits);
+  }
+  if (!kGE && lane == 0) *num_keep = count;
+}
+
 // ---- 4. flags -> ascending original indices -------------------------------------------------
 __global__ void __launch_bounds__(kCompactThreads)
 nms_compact(const int32_t* __restrict__ flags, int n, int64_t* __restrict__ keep64,
@@ -307,9 +414,10 @@ template <bool kGE>
 int launch_reduce(int words, const Workspace& ws, int n, int32_t* keep32, int32_t* num_keep,
                   hipStream_t s) {
   switch (words) {
-    case 1:
-      nms_reduce<1, kGE><<<1, kTile, 0, s>>>(ws.mask, n, ws.order, ws.flags, keep32, num_keep);
+    case 1: {
+      nms_reduce_regs<kGE><<<1, kTile, 0, s>>>(ws.mask, ws.diag_t, n, ws.order, ws.flags, keep32, num_keep);
       break;
+    }
     case 2:
       nms_reduce<2, kGE><<<1, kTile, 0, s>>>(ws.mask, n, ws.order, ws.flags, keep32, num_keep);
       break;
@@ -356,15 +464,15 @@ extern "C" int mi_nms(const float* dets, int n, float thresh, int mode, void* ke
   const bool ge = mode == MI_NMS_GE_ORIG_ASC;
   int rc;
   if (ge)
-    nms_prepare<true><<<(n + 255) / 256, 256, 0, s>>>(dets, n, ws.boxes, ws.areas, ws.order, ws.flags);
+    nms_prepare<true><<<(n + kTile - 1) / kTile, 256, 0, s>>>(dets, n, ws.boxes, ws.areas, ws.order, ws.flags);
   else
-    nms_prepare<false><<<(n + 255) / 256, 256, 0, s>>>(dets, n, ws.boxes, ws.areas, ws.order, ws.flags);
+    nms_prepare<false><<<(n + kTile - 1) / kTile, 256, 0, s>>>(dets, n, ws.boxes, ws.areas, ws.order, ws.flags);
   if ((rc = mi::check_launch("nms_prepare")) != MI_OK) return rc;
   dim3 grid(col_blocks, col_blocks);
   if (ge)
-    nms_mask<true><<<grid, kTile, 0, s>>>(ws.boxes, ws.areas, n, thresh, ws.mask);
+    nms_mask<true><<<grid, kTile, 0, s>>>(ws.boxes, ws.areas, n, thresh, ws.mask, ws.diag_t);
   else
-    nms_mask<false><<<grid, kTile, 0, s>>>(ws.boxes, ws.areas, n, thresh, ws.mask);
+    nms_mask<false><<<grid, kTile, 0, s>>>(ws.boxes, ws.areas, n, thresh, ws.mask, ws.diag_t);
   if ((rc = mi::check_launch("nms_mask")) != MI_OK) return rc;
   if (ge) {
     if ((rc = launch_reduce<true>(words, ws, n, nullptr, num_keep, s)) != MI_OK) return rc;
