@@ -6,9 +6,12 @@
 
 One JSON line on rank 0.  A *step* is one pass of the hot path over one rank's batch of synthetic
 input, inputs resident in HBM before the timed region.  `roofline` is measured live with HIP events
-on the launch stream for the dominant kernel (RoIAlign forward, BASELINE configs[1] shape);
-`cpu_baseline` times the CPU oracle (oracle/, test infrastructure) on the host cores of the same box
-on a bounded sample.  The oracle is never on the measured GPU path.
+on the launch stream for the dominant kernel (RoIAlign forward, BASELINE configs[1] shape; one call of
+the C-ABI = the record launch + the gather launch); its `traffic` is the HBM byte count of the same call
+from the committed rocprofv3 PMC summary (profiles/*_pmc_roi_align.json: FETCH_SIZE doubled as the gfx950
+correction prescribes, + WRITE_SIZE), null when no summary is in the tree.  `cpu_baseline` times the CPU
+oracle (oracle/, test infrastructure) on the host cores of the same box on a bounded sample.  The oracle is
+never on the measured GPU path.
 """
 import argparse
 import json
@@ -154,8 +157,10 @@ def roofline_roi_align_forward(device, iters):
     touched = touched_pixels(rois_np, 1, h, w, res, res, scale, sr)
     alg_bytes = 4 * r * c * res * res + 4 * c * touched + 20 * r
     achieved = alg_bytes / seconds / 1e9
+    traffic, traffic_src = pmc_traffic("forward")
     info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "roi_align_forward",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
             "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
             "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
     # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
@@ -179,6 +184,21 @@ def roofline_roi_align_forward(device, iters):
                         "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
                         "algorithmic_bytes": int(bwd_bytes)}
     return info
+
+
+def pmc_traffic(direction):
+    """HBM bytes per call from the newest committed PMC summary (profiles/rNN_pmc_roi_align.json), or None."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_roi_align.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return int(d[direction]["hbm_bytes_per_call"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
 
 
 def touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr):
