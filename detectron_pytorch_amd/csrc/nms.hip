@@ -161,10 +161,13 @@ nms_mask(const float4* __restrict__ boxes, const float* __restrict__ areas, int 
   // TRANSPOSED diagonal tile of chunk `row` instead (chunk 0: block (0,0) does both), which the reduce's fixpoint
   // iteration needs: bit i of diag_t[j] = box i (i < j, same chunk) overlaps box j.  The IoU test is symmetric bit
   // for bit (max/min and the fp32 sum of the two areas commute), so this is the transpose of the diagonal tile.
-  const bool transposed = col_start + 1 == row_start;
+  // chunk 0 has no block to its left: block (0, 2) takes it when the grid has one, else block (0, 0) does both
+  const bool t0_idle = col_blocks >= 3 && col_start == 0 && row_start == 2;
+  const bool t0_self = col_blocks < 3 && col_start == 0 && row_start == 0;
+  const bool transposed = col_start + 1 == row_start || t0_idle;
   if (col_start < row_start && !transposed) return;
-  if (transposed || (col_start == 0 && row_start == 0)) {
-    const int chunk = row_start;
+  if (transposed || t0_self) {
+    const int chunk = t0_idle ? 0 : row_start;
     const int size = min(n - chunk * kTile, kTile);
     if (lane < size) {
       s_box[lane] = boxes[chunk * kTile + lane];
@@ -278,49 +281,57 @@ nms_reduce(const uint64_t* __restrict__ mask, int n, const int32_t* __restrict__
   if (!kGE && lane == 0) *num_keep = count;
 }
 
-// Reduce for n <= 4096 (col_blocks <= 64, one removed-word per lane).  Lane w owns word w of the removed set.  For a
-// chunk, the lane's word of ALL 64 mask rows is loaded up front (64 coalesced row loads in flight at once, issued
-// one chunk ahead, 128 VGPRs each for the current and the next chunk -- a lone wavefront owns the whole register
-// file), so OR-ing the kept rows is register selects instead of a dependent trip to L2 per group of four kept rows
-// (the first version: 140 us at n = 2000).  The greedy decisions stay on the scalar unit (v_readlane).
+// Reduce for n <= 4096 (col_blocks <= 64, one removed-word per lane), four wavefronts.
+// Lane w of every wave owns word w of the removed set; wave q accumulates the OR of the kept mask rows r = q (mod 4)
+// of each chunk, so the removed set is the OR of the four waves' partial sets.  Per chunk:
+//   1. the four partial words k meet in LDS (one barrier, double-buffered slots) -> cur, wave-uniform everywhere;
+//   2. every wave runs the in-chunk greedy decision itself, as a fixpoint iteration on the TRANSPOSED diagonal tile:
+//      kept[j] = cand[j] and no kept i < j overlaps j.  Lane j holds who overlaps it, so one round is an AND with the
+//      wave-uniform kept set and a compare whose lane mask IS the next kept set.  Box j is final after j+1 rounds
+//      whatever the start; the loop ends at the first repeat = (longest suppression chain in the chunk) + 1 rounds.
+//      (The first version walked the kept boxes on the scalar unit: ~250 cycles per kept box, 120 us at n = 2000.)
+//   3. each wave ORs its 16 rows -- loaded one chunk ahead, register selects, no dependent memory trip.
 template <bool kGE>
-__global__ void __launch_bounds__(kTile)
+__global__ void __launch_bounds__(256)
 nms_reduce_regs(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ diag_t, int n,
                 const int32_t* __restrict__ order, int32_t* __restrict__ flags, int32_t* __restrict__ keep32,
                 int32_t* __restrict__ num_keep) {
-  const int lane = threadIdx.x;
+  constexpr int kParts = 4, kRows = kTile / kParts;
+  __shared__ uint64_t s_word[2][kParts];
+  const int lane = threadIdx.x & (kTile - 1);
+  const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col_blocks = (n + kTile - 1) / kTile;
   const bool owner = lane < col_blocks;
-  uint64_t nxt[kTile];
+  uint64_t nxt[kRows];
   uint64_t nxt_diag;
   int nxt_order = 0;
   auto fetch = [&](int k) {
     const int nrow = n - k * kTile;
 #pragma unroll
-    for (int r = 0; r < kTile; r++)
-      nxt[r] = (owner && r < nrow) ? mask[(long long)(k * kTile + r) * col_blocks + lane] : 0ULL;
+    for (int i = 0; i < kRows; i++) {
+      const int r = part + kParts * i;
+      nxt[i] = (owner && r < nrow) ? mask[(long long)(k * kTile + r) * col_blocks + lane] : 0ULL;
+    }
     nxt_diag = (lane < nrow) ? diag_t[k * kTile + lane] : 0ULL;
-    if (kGE) nxt_order = (lane < nrow) ? order[k * kTile + lane] : 0;
+    if (kGE && part == 0) nxt_order = (lane < nrow) ? order[k * kTile + lane] : 0;
   };
-  uint64_t remv = 0;
+  uint64_t remv = 0;  // this wave's partial removed set, word `lane`
   int count = 0;
   fetch(0);
   for (int k = 0; k < col_blocks; k++) {
-    uint64_t v[kTile];
+    uint64_t v[kRows];
 #pragma unroll
-    for (int r = 0; r < kTile; r++) v[r] = nxt[r];
+    for (int i = 0; i < kRows; i++) v[i] = nxt[i];
     const uint64_t diag = nxt_diag;
     const int my_order = nxt_order;
     if (k + 1 < col_blocks) fetch(k + 1);
-    uint64_t cur = readlane64(remv, k);
+    const uint64_t mine_k = readlane64(remv, k);
+    if (lane == 0) s_word[k & 1][part] = mine_k;
+    __syncthreads();
+    const uint64_t cur = (s_word[k & 1][0] | s_word[k & 1][1]) | (s_word[k & 1][2] | s_word[k & 1][3]);
     const int row = k * kTile + lane;
     const int live = n - k * kTile;
     const uint64_t valid = live >= kTile ? ~0ULL : ((1ULL << live) - 1ULL);
-    // In-chunk greedy pass (cu:132-144 restricted to word k) as a fixpoint iteration instead of a walk over the kept
-    // boxes: kept[j] = cand[j] and no kept i < j overlaps j.  Lane j holds WHO overlaps it (diag, the transposed
-    // tile), so one iteration is an AND with the wave-uniform kept set and a compare whose lane mask IS the next kept
-    // set.  Box j is final after j+1 iterations whatever the start; the loop ends at the first repeat, i.e. after
-    // (longest suppression chain in the chunk) + 1 rounds -- the walk cost ~250 scalar-unit cycles per kept box.
     const uint64_t cand = ~cur & valid;
     uint64_t keepbits = cand;
     for (;;) {
@@ -328,23 +339,25 @@ nms_reduce_regs(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ 
       if (next == keepbits) break;
       keepbits = next;
     }
-    // OR the kept rows into the owned word (words <= k are dead from here on; harmless)
+    // OR this wave's kept rows into its partial set (words <= k are dead from here on; harmless)
 #pragma unroll
-    for (int r = 0; r < kTile; r++)
-      if ((keepbits >> r) & 1ULL) remv |= v[r];
-    // emit
-    const bool mine = (keepbits >> lane) & 1ULL;
-    if (mine) {
-      if (kGE) {
-        flags[my_order] = 1;
-      } else {
-        const int pos = count + __popcll(keepbits & ((1ULL << lane) - 1ULL));
-        keep32[pos] = row;
+    for (int i = 0; i < kRows; i++)
+      if ((keepbits >> (part + kParts * i)) & 1ULL) remv |= v[i];
+    // emit (wave 0)
+    if (part == 0) {
+      const bool mine = (keepbits >> lane) & 1ULL;
+      if (mine) {
+        if (kGE) {
+          flags[my_order] = 1;
+        } else {
+          const int pos = count + __popcll(keepbits & ((1ULL << lane) - 1ULL));
+          keep32[pos] = row;
+        }
       }
+      count += __popcll(keepbits);
     }
-    count += __popcll(keepbits);
   }
-  if (!kGE && lane == 0) *num_keep = count;
+  if (!kGE && threadIdx.x == 0) *num_keep = count;
 }
 
 // ---- 4. flags -> ascending original indices -------------------------------------------------
@@ -415,7 +428,7 @@ int launch_reduce(int words, const Workspace& ws, int n, int32_t* keep32, int32_
                   hipStream_t s) {
   switch (words) {
     case 1: {
-      nms_reduce_regs<kGE><<<1, kTile, 0, s>>>(ws.mask, ws.diag_t, n, ws.order, ws.flags, keep32, num_keep);
+      nms_reduce_regs<kGE><<<1, 256, 0, s>>>(ws.mask, ws.diag_t, n, ws.order, ws.flags, keep32, num_keep);
       break;
     }
     case 2:
