@@ -76,7 +76,7 @@ template <bool kSort>
 __global__ void __launch_bounds__(256)
 nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
             float* __restrict__ areas, int32_t* __restrict__ order, int32_t* __restrict__ flags) {
-  __shared__ float s_scores[kPrepChunk];
+  __shared__ __attribute__((aligned(16))) float s_scores[kPrepChunk];
   __shared__ int s_rank[4][kTile];
   const int tid = threadIdx.x, bi = tid & (kTile - 1), part = tid >> 6;
   const int i = blockIdx.x * kTile + bi;
@@ -95,18 +95,23 @@ nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
     int cnt = 0;
     for (int base = 0; base < n; base += kPrepChunk) {
       const int lim = min(kPrepChunk, n - base);
+      const int lim4 = (lim + 15) & ~15;  // padded with NaN (never greater, never equal): four scores per LDS read
       __syncthreads();
-      for (int t = tid; t < lim; t += 256) s_scores[t] = dets[(long long)(base + t) * 5 + 4];
+      for (int t = tid; t < lim4; t += 256)
+        s_scores[t] = t < lim ? dets[(long long)(base + t) * 5 + 4] : __builtin_nanf("");
       __syncthreads();
-      const int per = (lim + 3) / 4;
-      const int t0 = part * per, t1 = min(t0 + per, lim);
+      const int per = lim4 / 4;  // a multiple of 4
+      const int t0 = part * per, t1 = t0 + per;
       if (live) {
-        for (int t = t0; t < t1; t++) {
-          const float sj = s_scores[t];
+        for (int t = t0; t < t1; t += 4) {
+          const float4 s4 = *reinterpret_cast<const float4*>(&s_scores[t]);
           const int jj = base + t;
           // descending score; equal scores: higher original index first
           // (== np.argsort(scores, kind='stable')[::-1], the tie rule fixed in oracle.c)
-          cnt += (sj > score) || (sj == score && jj > i);
+          cnt += (s4.x > score) || (s4.x == score && jj > i);
+          cnt += (s4.y > score) || (s4.y == score && jj + 1 > i);
+          cnt += (s4.z > score) || (s4.z == score && jj + 2 > i);
+          cnt += (s4.w > score) || (s4.w == score && jj + 3 > i);
         }
       }
     }
