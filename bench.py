@@ -183,7 +183,41 @@ def roofline_roi_align_forward(device, iters):
     info["backward"] = {"zero_fill_needed": not overwrite, "avg_us_incl_zero_fill": round(sec_bwd * 1e6, 2),
                         "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
                         "algorithmic_bytes": int(bwd_bytes)}
+    info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
     return info
+
+
+def other_shapes(device, lib, stream, iters):
+    """Per-call times of the other RoIAlign shapes of the step (not roofline-gated): the mask head (128 x 256 x 14x14) and
+    the two-image box head (1024 RoIs, N = 2), forward and backward through the workspace entry points."""
+    from detectron_pytorch_amd import _lib
+
+    out = {}
+    h, w, scale = syn.FPN_LEVELS[2]
+    c, sr = syn.FPN_DIM, 2
+    for name, n, r, res in [("mask_128x256x14x14", 1, 128, 14), ("box_1024x256x7x7_2img", 2, 1024, 7)]:
+        feat = torch.from_numpy(syn.feature_map(n, c, h, w, seed=0)).to(device)
+        rois = torch.from_numpy(syn.rois_canonical(r, n, seed=1)).to(device)
+        o = torch.empty((r, c, res, res), device=device)
+        gtop = torch.randn(r, c, res, res, device=device)
+        gin = torch.empty(n, c, h, w, device=device)
+        ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        over = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
+        flags = _lib.ROI_ALIGN_RECORDS_READY | (_lib.ROI_ALIGN_OVERWRITE if over else 0)
+
+        def fwd():
+            assert lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), o.data_ptr(), n, c, h, w, r, res, res, scale,
+                                               sr, 0, 0, ws.data_ptr(), ws_bytes, stream) == 0
+
+        def bwd():
+            if not over:
+                gin.zero_()
+            assert lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), n, c, h, w, r, res, res,
+                                                scale, sr, 0, 0, ws.data_ptr(), ws_bytes, flags, stream) == 0
+
+        out[name] = {"fwd_us": round(time_kernel(fwd, iters) * 1e6, 1), "bwd_us": round(time_kernel(bwd, iters) * 1e6, 1)}
+    return out
 
 
 def pmc_traffic(direction):

@@ -699,15 +699,16 @@ roi_align_fwd_persist(const float* __restrict__ feat, const float* __restrict__ 
 // arithmetic; the per-RoI prologue of roi_align_fwd_tile.hip (geometry, tables, window) is replaced by one scalar
 // load of the record, and workgroups are dispatched in sweep order.
 // -------------------------------------------------------------------------------------------------------------------
-template <int kSR, int kCap, int kCTt>
-__global__ void __launch_bounds__(kCTt * 8)
+template <int kSR, int kCap, int kCTt, int kHalves>
+__global__ void __launch_bounds__(kCTt * 8 * kHalves)
 roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
                       const int* __restrict__ ws, int num_rois, int batch, int channels, int height, int width,
                       int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio, int ablate) {
   // kCTt channels per workgroup (32: half-waves own output columns; 16: quarter-waves do, twice as many workgroups
   // fit a CU -- the per-workgroup chain record load -> DMA -> landing -> arithmetic -> store drain is latency, and
   // what hides it is the number of workgroups in flight)
-  constexpr int kCT = kCTt, kThreads = kCTt * 8, kChPerWave = 8;
+  // kHalves = 2: twice the lanes per workgroup, the two halves take the upper / lower bin rows of a stage
+  constexpr int kCT = kCTt, kThreads = kCTt * 8 * kHalves, kChPerWave = kCT / (kThreads / 64);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kPlane = kCap | 1;
   constexpr int kTileWords = kCT * (kTileBins + 1);
@@ -725,7 +726,7 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
   const int pos = blockIdx.x / tiles;
   const int c0 = (blockIdx.x - pos * tiles) * kCT;
   const int wave = uniform(tid >> 6), lane = tid & 63;
-  const int cl = tid % kCT, slot = tid / kCT;
+  const int cl = tid % kCT, slot = (tid / kCT) & 7, half = tid / (kCT * 8);
   const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
   const float* img_c = s.img + cl * kPlane;
   const int* __restrict__ records = ws + kCounterDwords;
@@ -793,7 +794,7 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
         }
       }
     }
-    if (k == 0 && wave < 2) {  // axis tables: record -> LDS (wave 0: y, wave 1: x)
+    if (k == 0 && wave < 2) {  // axis tables: record -> LDS (wave 0: y, wave 1: x); every variant has >= 2 waves
       const int n = (wave == 0 ? aligned_height * gh : aligned_width * gw) * 4;
       const srd_t tsrd = make_srd(records + (long long)pos * kRecDwords + (wave == 0 ? kRecY : kRecX), 4 * kMaxS * 4);
       const unsigned dstl = lds_addr_uniform(s.tab + wave * kMaxS);
@@ -805,6 +806,9 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
     const int base_off = row0 * pitch;
     const int nb = (ph1 - ph0) * aligned_width;
     const int ts = nb | 1;
+    // this half's share of the stage's bin rows
+    const int phm = ph0 + (ph1 - ph0 + kHalves - 1) / kHalves;
+    const int pa = half == 0 ? ph0 : phm, pb = (kHalves == 1 || half == 1) ? ph1 : phm;
     if (ablate & 2) {
     } else if (kSR > 0) {
       constexpr int kS = kSR > 0 ? kSR : 1;
@@ -857,9 +861,9 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
             s.tile[cl * ts + (ph + b - ph0) * aligned_width + pw] = acc;
           }
         };
-        int ph = ph0;
-        for (; ph + 4 <= ph1; ph += 4) rows(ph, std::integral_constant<int, 4>());
-        switch (ph1 - ph) {
+        int ph = pa;
+        for (; ph + 4 <= pb; ph += 4) rows(ph, std::integral_constant<int, 4>());
+        switch (pb - ph) {
           case 3: rows(ph, std::integral_constant<int, 3>()); break;
           case 2: rows(ph, std::integral_constant<int, 2>()); break;
           case 1: rows(ph, std::integral_constant<int, 1>()); break;
@@ -868,7 +872,7 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
       }
     } else {
       for (int pw = slot; pw < aligned_width; pw += kSlots) {
-        for (int ph = ph0; ph < ph1; ph++) {
+        for (int ph = pa; ph < pb; ph++) {
           float acc = 0.f;
           for (int iy = 0; iy < gh; iy++) {
             const TabEntry ey = ty[ph * gh + iy];
@@ -1177,6 +1181,7 @@ int g_ablate_p = 0;
 long long* g_timeline_p = nullptr;
 bool g_persistent = false;
 int g_ct = 32;  // MI_ROI_ALIGN_CT=16|32: channels per workgroup of the record consumer
+int g_halves = 1;  // MI_ROI_ALIGN_HALVES=2 (with CT=16): 256 lanes per 16-channel workgroup
 size_t records_lds_bytes(int cap, int ct) {
   return 2 * kMaxS * sizeof(TabEntry) + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4;
 }  // MI_ROI_ALIGN_PERSIST=1: persistent consumer (tuning aid)
@@ -1199,18 +1204,21 @@ int launch_cap(const float* features, const float* rois, float* output, int* ws,
   if (grid < tiles) grid = tiles;
   const size_t lds = Lds<kCap>::bytes();
   if (!g_persistent) {
-#define MI_LAUNCH_REC(SR, CT)                                                                                         \
-  roi_align_fwd_records<SR, kCap, CT><<<num_rois * (channels / CT), CT * 8, records_lds_bytes(kCap, CT), stream>>>(    \
-      features, rois, output, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width,           \
-      spatial_scale, sampling_ratio, g_ablate_p)
-    if (g_ct == 16 && sampling_ratio == 2)
-      MI_LAUNCH_REC(2, 16);
+#define MI_LAUNCH_REC(SR, CT, HV)                                                                                     \
+  roi_align_fwd_records<SR, kCap, CT, HV>                                                                             \
+      <<<num_rois * (channels / CT), CT * 8 * HV, records_lds_bytes(kCap, CT), stream>>>(                             \
+          features, rois, output, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width,       \
+          spatial_scale, sampling_ratio, g_ablate_p)
+    if (g_ct == 16 && g_halves == 2 && sampling_ratio == 2)
+      MI_LAUNCH_REC(2, 16, 2);
+    else if (g_ct == 16 && sampling_ratio == 2)
+      MI_LAUNCH_REC(2, 16, 1);
     else if (g_ct == 16)
-      MI_LAUNCH_REC(0, 16);
+      MI_LAUNCH_REC(0, 16, 1);
     else if (sampling_ratio == 2)
-      MI_LAUNCH_REC(2, 32);
+      MI_LAUNCH_REC(2, 32, 1);
     else
-      MI_LAUNCH_REC(0, 32);
+      MI_LAUNCH_REC(0, 32, 1);
 #undef MI_LAUNCH_REC
     return check_launch("roi_align_fwd_records");
   }
@@ -1307,7 +1315,8 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
 void roi_align_fwd_persist_set_ablate(int mask) { g_ablate_p = mask; }
 void roi_align_fwd_persist_set_mode(bool persistent, int ct) {
   g_persistent = persistent;
-  g_ct = ct == 16 ? 16 : 32;
+  g_ct = (ct == 16 || ct == 162) ? 16 : 32;
+  g_halves = ct == 162 ? 2 : 1;
 }
 void roi_align_fwd_persist_set_timeline(long long* device_buffer) { g_timeline_p = device_buffer; }
 
