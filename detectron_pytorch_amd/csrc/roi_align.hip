@@ -222,6 +222,8 @@ int ring_words() {
   const char* ab = std::getenv("MI_ROI_ALIGN_ABLATE");
   mi::roi_align_fwd_tile_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
   mi::roi_align_fwd_persist_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
+  const char* th = std::getenv("MI_ROI_ALIGN_BWD_TH");
+  mi::roi_align_bwd_set_tile_rows(th != nullptr ? std::atoi(th) : 16);
   const char* ct = std::getenv("MI_ROI_ALIGN_CT");
   mi::roi_align_fwd_persist_set_mode(std::getenv("MI_ROI_ALIGN_PERSIST") != nullptr, ct != nullptr ? std::atoi(ct) : 32);
   const char* v = std::getenv("MI_ROI_ALIGN_CAP");

@@ -91,6 +91,7 @@ void roi_align_fwd_tile_set_ablate(int mask);
 // two-launch forward fast path with caller scratch (roi_align_fwd_persist.hip)
 void roi_align_fwd_persist_set_ablate(int mask);
 void roi_align_fwd_persist_set_mode(bool persistent, int channels_per_workgroup);
+void roi_align_bwd_set_tile_rows(int rows);
 void roi_align_fwd_persist_set_timeline(long long* device_buffer);
 size_t roi_align_fwd_persist_workspace_bytes(int num_rois);
 bool roi_align_fwd_persist_supported(int channels, int height, int width, int num_rois, int aligned_height,

@@ -933,7 +933,7 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
 // Weights: g * (hy / count) * hx instead of the reference's g * (hy * hx) / count -- fp32 rounding only (the
 // accumulation order of the reference's atomics is unspecified; contract 1e-4).
 // -------------------------------------------------------------------------------------------------------------------
-constexpr int kTH = 8, kTW = 32;  // tile of dF owned by a workgroup
+constexpr int kTW = 32;  // columns of the dF tile owned by a workgroup (rows: template parameter, 32 lanes each)
 
 template <int KC>
 struct BwdLds {
@@ -942,20 +942,21 @@ struct BwdLds {
   static constexpr int kGWords = KC * kTileBins * 4;               // g block: up to 224 bins per channel
 };
 
-template <int kSR, int KC>
-__global__ void __launch_bounds__(256)
+template <int kSR, int KC, int kTH>
+__global__ void __launch_bounds__(kTH * 32)
 roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bottom_grad, const int* __restrict__ ws,
                     int num_rois, int batch, int channels, int height, int width, int aligned_height,
                     int aligned_width, int tiles_x, int tiles_y, int overwrite, int ablate, int g_words, int ah_pad,
                     int g_cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kTabDw = BwdLds<KC>::kTabDw;
+  constexpr int kThreads = kTH * kTW, kNWaves = kThreads / 64;
   constexpr int kCS = KC + 4;  // words per (bin row, column) of T
   // LDS (all of it in the dynamic region, 16-byte aligned pieces):
-  //   ctl[8] | list[num_rois] | tab[2][kTabDw] | g[2][g_words] | T[aligned_height][kTW][KC + 4]
+  //   ctl[32] | list[num_rois] | tab[2][kTabDw] | g[2][g_words] | T[aligned_height][kTW][KC + 4]
   int* wave_count = reinterpret_cast<int*>(smem);
-  int& list_len = wave_count[4];
-  int* list = wave_count + 8;
+  int& list_len = wave_count[kNWaves];
+  int* list = wave_count + 32;
   const int list_words = (num_rois + 3) & ~3;
   int* tab0 = list + list_words;
   float* g0 = reinterpret_cast<float*>(tab0 + 2 * kTabDw);
@@ -979,7 +980,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
   // ---- RoIs whose window touches this tile, in rank order ----
   if (tid == 0) list_len = 0;
   __syncthreads();
-  for (int base = 0; base < num_rois; base += 256) {
+  for (int base = 0; base < num_rois; base += kThreads) {
     const int i = base + tid;
     bool hit = false;
     if (i < num_rois) {
@@ -993,7 +994,11 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
     for (int w = 0; w < wave; w++) off += wave_count[w];
     if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
     __syncthreads();
-    if (tid == 0) list_len += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    if (tid == 0) {
+      int add = 0;
+      for (int w = 0; w < kNWaves; w++) add += wave_count[w];
+      list_len += add;
+    }
     __syncthreads();
   }
   const int nlist = uniform(list_len);
@@ -1005,13 +1010,13 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
   for (int c = 0; c < KC; c++) acc[c] = 0.f;
 
   // source byte offsets of this lane's pieces of the transposed g block (the same for every RoI)
-  constexpr int kGP = 16;  // pieces per wave at most: KC * g_cs <= 4 * 16 * 64 words
+  constexpr int kGP = 64 / kNWaves;  // pieces per wave at most: KC * g_cs <= 64 * 64 words
   unsigned gsrc_off[kGP];
   {
     const int per_c = aligned_width * ah_pad;
 #pragma unroll
     for (int kk = 0; kk < kGP; kk++) {
-      const int i = (wave + 4 * kk) * 64 + lane;  // LDS word index
+      const int i = (wave + kNWaves * kk) * 64 + lane;  // LDS word index
       const int c = i / g_cs, rem = i - c * g_cs;
       const int pw = rem / ah_pad, ph = rem - pw * ah_pad;
       gsrc_off[kk] = (c < KC && rem < per_c && ph < aligned_height) ? (unsigned)(c * bins + ph * aligned_width + pw) * 4u
@@ -1025,7 +1030,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
     const int r = rec[8];
     const srd_t tsrd = make_srd(records + (long long)uniform(pos) * kRecDwords + kRecY, kTabDw * 4);
     const unsigned tdst = lds_addr_uniform(tab0 + buf * kTabDw);
-    for (int k = wave; k * 64 < kTabDw; k += 4)
+    for (int k = wave; k * 64 < kTabDw; k += kNWaves)
       if (k * 64 + lane < kTabDw) dma_dword(tsrd, tdst + (unsigned)k * 256u, (unsigned)(k * 64 + lane) * 4u, 0u);
     // top gradients: global [c][ph][pw] -> LDS [c][pw][ph] (bin rows of one column contiguous, padded to ah_pad; channel
     // stride g_cs = 4 * odd): the DMA's per-lane source address does the transpose, pass 1 then reads a column's bin
@@ -1034,7 +1039,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
     const unsigned gdst = lds_addr_uniform(g0 + buf * g_words);
 #pragma unroll
     for (int kk = 0; kk < kGP; kk++) {
-      const int k = wave + 4 * kk;
+      const int k = wave + kNWaves * kk;
       if (k * 64 < KC * g_cs && gsrc_off[kk] != 0xffffffffu) dma_dword(gsrd, gdst + (unsigned)k * 256u, gsrc_off[kk], 0u);
     }
   };
@@ -1058,7 +1063,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
     // ---- pass 1: T[ph][col][c] for the tile columns inside the window ----
     if (!(ablate & 1)) {
       const int c = tid % KC, slot = tid / KC;
-      constexpr int kColStep = 256 / KC;
+      constexpr int kColStep = kThreads / KC;
       for (int col = slot; col < kTW; col += kColStep) {
         const int lc = x0 + col - wx0;
         if (lc < 0 || lc >= ww) continue;
@@ -1181,6 +1186,7 @@ int g_ablate_p = 0;
 long long* g_timeline_p = nullptr;
 bool g_persistent = false;
 int g_ct = 32;  // MI_ROI_ALIGN_CT=16|32: channels per workgroup of the record consumer
+int g_bwd_th = 16;  // MI_ROI_ALIGN_BWD_TH=8|16|32: rows per backward tile (16: 100 -> 79 us at config 2; 32: 95 us)
 int g_halves = 1;  // MI_ROI_ALIGN_HALVES=2 (with CT=16): 256 lanes per 16-channel workgroup
 size_t records_lds_bytes(int cap, int ct) {
   return 2 * kMaxS * sizeof(TabEntry) + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4;
@@ -1259,24 +1265,33 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
     if (rc != MI_OK) return rc;
   }
   const int bins = aligned_height * aligned_width;
-  const int tiles_x = (width + kTW - 1) / kTW, tiles_y = (height + kTH - 1) / kTH;
+  const int th = g_bwd_th;  // rows per tile (8 or 16): 32 * th lanes per workgroup
+  const int tiles_x = (width + kTW - 1) / kTW, tiles_y = (height + th - 1) / th;
   // channels per workgroup: 32 accumulators per lane while the g block and T fit LDS comfortably, else 16
   const int kc = (bins <= 64) ? 32 : 16;
   const int ah_pad = (aligned_height + 3) & ~3;
   const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);  // channel stride of the transposed g block: 4 * odd
   const int g_words = kc * g_cs;
   const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
-  const size_t lds = (8 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
+  const size_t lds = (32 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
   const int grid = tiles_x * tiles_y * batch * (channels / kc);
-#define MI_LAUNCH_TILES(SR, KC)                                                                                       \
+#define MI_LAUNCH_TILES_TH(SR, KC, TH)                                                                                \
   do {                                                                                                                \
     if (lds > 64 * 1024)                                                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC>),                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC, TH>),                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    roi_align_bwd_tiles<SR, KC><<<grid, 256, lds, stream>>>(top_grad, bottom_grad, ws, num_rois, batch, channels,    \
-                                                            height, width, aligned_height, aligned_width, tiles_x,    \
-                                                            tiles_y, overwrite ? 1 : 0, g_ablate_p & 7, g_words,      \
-                                                            ah_pad, g_cs);                                            \
+    roi_align_bwd_tiles<SR, KC, TH><<<grid, TH * 32, lds, stream>>>(                                                 \
+        top_grad, bottom_grad, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width, tiles_x,  \
+        tiles_y, overwrite ? 1 : 0, g_ablate_p & 7, g_words, ah_pad, g_cs);                                           \
+  } while (0)
+#define MI_LAUNCH_TILES(SR, KC)                                                                                       \
+  do {                                                                                                                \
+    if (th == 32)                                                                                                     \
+      MI_LAUNCH_TILES_TH(SR, KC, 32);                                                                                 \
+    else if (th == 16)                                                                                                \
+      MI_LAUNCH_TILES_TH(SR, KC, 16);                                                                                 \
+    else                                                                                                              \
+      MI_LAUNCH_TILES_TH(SR, KC, 8);                                                                                  \
   } while (0)
   if (g_ablate_p & 8) {
   } else if (kc == 32 && sampling_ratio == 2) {
@@ -1289,6 +1304,7 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
     MI_LAUNCH_TILES(0, 16);
   }
 #undef MI_LAUNCH_TILES
+#undef MI_LAUNCH_TILES_TH
   int rc = check_launch("roi_align_bwd_tiles");
   if (rc != MI_OK) return rc;
   if (!(g_ablate_p & 16))
@@ -1305,14 +1321,15 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
   const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
   const int ah_pad = (aligned_height + 3) & ~3;
   const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);
-  const size_t lds = (8 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * (size_t)kc * g_cs +
+  const size_t lds = (32 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * (size_t)kc * g_cs +
                       (size_t)aligned_height * kTW * (kc + 4)) * 4;
   return channels > 0 && channels % 32 == 0 && aligned_height > 0 && aligned_width > 0 &&
          aligned_height <= kMaxStages && num_rois <= kMaxRois && lds <= 160 * 1024 - 4096 &&
-         kc * g_cs <= 4 * 16 * 64;
+         kc * g_cs <= 64 * 64;
 }
 
 void roi_align_fwd_persist_set_ablate(int mask) { g_ablate_p = mask; }
+void roi_align_bwd_set_tile_rows(int rows) { g_bwd_th = (rows == 8 || rows == 32) ? rows : 16; }
 void roi_align_fwd_persist_set_mode(bool persistent, int ct) {
   g_persistent = persistent;
   g_ct = (ct == 16 || ct == 162) ? 16 : 32;
