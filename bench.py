@@ -80,7 +80,7 @@ class HotPath:
 
         self.device = device
         self.images = images_per_rank
-        self.fwd, self.bwd, self.nms = roi_align_forward, roi_align_backward, mi_nms.nms_device
+        self.fwd, self.bwd, self.nms_many = roi_align_forward, roi_align_backward, mi_nms.nms_device_many
         h, w, scale = syn.FPN_LEVELS[2]
         self.scale = scale
         n = images_per_rank
@@ -104,7 +104,8 @@ class HotPath:
         gin = self.bwd(self.box_gtop, self.box_rois, fs, 7, 7, self.scale, 2, workspace=ws)
         out2, ws2 = self.fwd(self.feat, self.mask_rois, 14, 14, self.scale, 2, return_workspace=True)
         gin2 = self.bwd(self.mask_gtop, self.mask_rois, fs, 14, 14, self.scale, 2, workspace=ws2)
-        keeps = [self.nms(d, 0.7) for d in self.dets]
+        # the per-level, per-image RPN NMS problems are independent: fanned out over side streams
+        keeps = self.nms_many(self.dets, 0.7)
         return out, gin, out2, gin2, keeps
 
 

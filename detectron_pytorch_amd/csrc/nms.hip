@@ -74,13 +74,13 @@ Workspace carve(void* base, int n) {
 // (the first version ranked 256 boxes per workgroup over the whole range: 8 workgroups on a 256-CU chip, 55 us).
 constexpr int kPrepChunk = 2048;
 template <bool kSort>
-__global__ void __launch_bounds__(256)
-nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
-            float* __restrict__ areas, int32_t* __restrict__ order, int32_t* __restrict__ flags) {
+__device__ __forceinline__ void prepare_body(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
+                                             float* __restrict__ areas, int32_t* __restrict__ order,
+                                             int32_t* __restrict__ flags, int chunk) {
   __shared__ __attribute__((aligned(16))) float s_scores[kPrepChunk];
   __shared__ int s_rank[4][kTile];
   const int tid = threadIdx.x, bi = tid & (kTile - 1), part = tid >> 6;
-  const int i = blockIdx.x * kTile + bi;
+  const int i = chunk * kTile + bi;
   const bool live = i < n;
   float x1 = 0, y1 = 0, x2 = 0, y2 = 0, score = 0;
   if (live) {
@@ -128,6 +128,13 @@ nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
   }
 }
 
+template <bool kSort>
+__global__ void __launch_bounds__(256)
+nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
+            float* __restrict__ areas, int32_t* __restrict__ order, int32_t* __restrict__ flags) {
+  prepare_body<kSort>(dets, n, boxes, areas, order, flags, blockIdx.x);
+}
+
 // ---- 2. IoU bitmask tiles ---------------------------------------------------------------
 template <bool kGE>
 __device__ __forceinline__ bool overlaps(const float4 a, const float area_a, const float4 b,
@@ -154,12 +161,9 @@ __device__ __forceinline__ bool overlaps(const float4 a, const float area_a, con
 }
 
 template <bool kGE>
-__global__ void __launch_bounds__(kTile)
-nms_mask(const float4* __restrict__ boxes, const float* __restrict__ areas, int n, float thresh,
-         uint64_t* __restrict__ mask, uint64_t* __restrict__ diag_t) {
-  const int col_start = blockIdx.x;
-  const int row_start = blockIdx.y;
-  const int col_blocks = gridDim.x;
+__device__ __forceinline__ void mask_body(const float4* __restrict__ boxes, const float* __restrict__ areas, int n,
+                                          float thresh, uint64_t* __restrict__ mask, uint64_t* __restrict__ diag_t,
+                                          int col_start, int row_start, int col_blocks) {
   __shared__ float4 s_box[kTile];
   __shared__ float s_area[kTile];
   const int lane = threadIdx.x;
@@ -208,6 +212,13 @@ nms_mask(const float4* __restrict__ boxes, const float* __restrict__ areas, int 
       if (overlaps<kGE>(a, area_a, s_box[j], s_area[j], thresh)) t |= 1ULL << j;
     mask[(long long)cur * col_blocks + col_start] = t;
   }
+}
+
+template <bool kGE>
+__global__ void __launch_bounds__(kTile)
+nms_mask(const float4* __restrict__ boxes, const float* __restrict__ areas, int n, float thresh,
+         uint64_t* __restrict__ mask, uint64_t* __restrict__ diag_t) {
+  mask_body<kGE>(boxes, areas, n, thresh, mask, diag_t, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // ---- 3. greedy reduce in one wavefront ----------------------------------------------------
@@ -298,10 +309,10 @@ nms_reduce(const uint64_t* __restrict__ mask, int n, const int32_t* __restrict__
 //      (The first version walked the kept boxes on the scalar unit: ~250 cycles per kept box, 120 us at n = 2000.)
 //   3. each wave ORs its 16 rows -- loaded one chunk ahead, register selects, no dependent memory trip.
 template <bool kGE>
-__global__ void __launch_bounds__(256)
-nms_reduce_regs(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ diag_t, int n,
-                const int32_t* __restrict__ order, int32_t* __restrict__ flags, int32_t* __restrict__ keep32,
-                int64_t* __restrict__ keep64, int32_t* __restrict__ num_keep) {
+__device__ __forceinline__ void reduce_regs_body(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ diag_t,
+                                                 int n, const int32_t* __restrict__ order, int32_t* __restrict__ flags,
+                                                 int32_t* __restrict__ keep32, int64_t* __restrict__ keep64,
+                                                 int32_t* __restrict__ num_keep) {
   constexpr int kParts = 4, kRows = kTile / kParts;
   __shared__ uint64_t s_word[2][kParts];
   const int lane = threadIdx.x & (kTile - 1);
@@ -395,6 +406,57 @@ nms_reduce_regs(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ 
   for (int i = begin; i < end; i++)
     if (flags[i] != 0) keep64[pos++] = i;
   if (tid == 0) *num_keep = total;
+}
+
+template <bool kGE>
+__global__ void __launch_bounds__(256)
+nms_reduce_regs(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ diag_t, int n,
+                const int32_t* __restrict__ order, int32_t* __restrict__ flags, int32_t* __restrict__ keep32,
+                int64_t* __restrict__ keep64, int32_t* __restrict__ num_keep) {
+  reduce_regs_body<kGE>(mask, diag_t, n, order, flags, keep32, keep64, num_keep);
+}
+
+// ---- batched entry points: independent problems (the RPN runs one NMS per FPN level and image) in ONE launch of each
+// stage.  One problem's reduce occupies a single CU and its three launches are a dependent chain, so P problems issued
+// one after the other leave a 256-CU chip idle; here the P reduces run side by side. ----
+constexpr int kMaxBatch = 32;
+struct BatchTable {
+  int count;
+  int n[kMaxBatch];
+  int chunk_start[kMaxBatch + 1];  // prefix sum of ceil(n / 64)
+  const float* dets[kMaxBatch];
+  void* keep[kMaxBatch];
+  int32_t* num_keep[kMaxBatch];
+  Workspace ws[kMaxBatch];
+};
+
+template <bool kSort>
+__global__ void __launch_bounds__(256) nms_prepare_batched(const BatchTable t) {
+  int p = 0;
+  while (p + 1 < t.count && (int)blockIdx.x >= t.chunk_start[p + 1]) p++;
+  prepare_body<kSort>(t.dets[p], t.n[p], t.ws[p].boxes, t.ws[p].areas, t.ws[p].order, t.ws[p].flags,
+                      blockIdx.x - t.chunk_start[p]);
+}
+
+template <bool kGE>
+__global__ void __launch_bounds__(kTile) nms_mask_batched(const BatchTable t, float thresh) {
+  const int p = blockIdx.z;
+  const int n = t.n[p];
+  const int col_blocks = (n + kTile - 1) / kTile;
+  if ((int)blockIdx.x >= col_blocks || (int)blockIdx.y >= col_blocks) return;
+  mask_body<kGE>(t.ws[p].boxes, t.ws[p].areas, n, thresh, t.ws[p].mask, t.ws[p].diag_t, blockIdx.x, blockIdx.y,
+                 col_blocks);
+}
+
+template <bool kGE>
+__global__ void __launch_bounds__(256) nms_reduce_batched(const BatchTable t) {
+  const int p = blockIdx.x;
+  if (t.n[p] == 0) {
+    if (threadIdx.x == 0) *t.num_keep[p] = 0;
+    return;
+  }
+  reduce_regs_body<kGE>(t.ws[p].mask, t.ws[p].diag_t, t.n[p], t.ws[p].order, t.ws[p].flags,
+                        static_cast<int32_t*>(t.keep[p]), static_cast<int64_t*>(t.keep[p]), t.num_keep[p]);
 }
 
 // ---- 4. flags -> ascending original indices (n > 4096 path) -------------------------------------------------
@@ -531,6 +593,80 @@ extern "C" int mi_nms(const float* dets, int n, float thresh, int mode, void* ke
     return mi::check_launch("nms_compact");
   }
   return launch_reduce<false>(words, ws, n, static_cast<int32_t*>(keep), nullptr, num_keep, s);
+}
+
+extern "C" size_t mi_nms_batched_workspace_bytes(int num_problems, const int* n) {
+  size_t total = 0;
+  for (int p = 0; p < num_problems; p++) total += (n[p] > 0 ? carve(nullptr, n[p]).bytes : 16);
+  return total + 16;
+}
+
+extern "C" int mi_nms_batched(int num_problems, const float* const* dets, const int* n, float thresh, int mode,
+                              void* const* keep, int32_t* const* num_keep, void* workspace,
+                              size_t workspace_bytes, mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(num_problems >= 0, "nms_batched: negative problem count");
+  MI_REQUIRE(mode == MI_NMS_GE_ORIG_ASC || mode == MI_NMS_GT_SORTED_POS, "nms_batched: unknown mode %d", mode);
+  if (num_problems == 0) return MI_OK;
+  MI_REQUIRE(dets != nullptr && n != nullptr && keep != nullptr && num_keep != nullptr && workspace != nullptr,
+             "nms_batched: null pointer");
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "nms_batched: workspace must be 16-byte aligned");
+  if (workspace_bytes < mi_nms_batched_workspace_bytes(num_problems, n)) {
+    mi::set_error("nms_batched: workspace %zu bytes < required %zu", workspace_bytes,
+                  mi_nms_batched_workspace_bytes(num_problems, n));
+    return MI_ERR_WORKSPACE;
+  }
+  for (int p = 0; p < num_problems; p++) {
+    MI_REQUIRE(n[p] >= 0, "nms_batched: negative box count");
+    if (n[p] > kTile * kTile) {
+      mi::set_error("nms_batched: problem %d has %d boxes; the batched path takes at most %d (use mi_nms)", p, n[p],
+                    kTile * kTile);
+      return MI_ERR_UNSUPPORTED;
+    }
+    MI_REQUIRE(num_keep[p] != nullptr && (n[p] == 0 || (dets[p] != nullptr && keep[p] != nullptr)),
+               "nms_batched: null pointer in problem %d", p);
+  }
+  hipStream_t s = mi::as_stream(stream);
+  const bool ge = mode == MI_NMS_GE_ORIG_ASC;
+  char* base = static_cast<char*>(workspace);
+  for (int first = 0; first < num_problems; first += kMaxBatch) {
+    BatchTable t;
+    t.count = num_problems - first < kMaxBatch ? num_problems - first : kMaxBatch;
+    int max_cb = 0;
+    t.chunk_start[0] = 0;
+    for (int q = 0; q < t.count; q++) {
+      const int p = first + q;
+      t.n[q] = n[p];
+      t.dets[q] = dets[p];
+      t.keep[q] = keep[p];
+      t.num_keep[q] = num_keep[p];
+      const int cb = (n[p] + kTile - 1) / kTile;
+      t.chunk_start[q + 1] = t.chunk_start[q] + cb;
+      max_cb = cb > max_cb ? cb : max_cb;
+      t.ws[q] = carve(base, n[p] > 0 ? n[p] : 1);
+      base += n[p] > 0 ? t.ws[q].bytes : 16;
+    }
+    int rc;
+    if (t.chunk_start[t.count] > 0) {
+      if (ge)
+        nms_prepare_batched<true><<<t.chunk_start[t.count], 256, 0, s>>>(t);
+      else
+        nms_prepare_batched<false><<<t.chunk_start[t.count], 256, 0, s>>>(t);
+      if ((rc = mi::check_launch("nms_prepare_batched")) != MI_OK) return rc;
+      dim3 grid(max_cb, max_cb, t.count);
+      if (ge)
+        nms_mask_batched<true><<<grid, kTile, 0, s>>>(t, thresh);
+      else
+        nms_mask_batched<false><<<grid, kTile, 0, s>>>(t, thresh);
+      if ((rc = mi::check_launch("nms_mask_batched")) != MI_OK) return rc;
+    }
+    if (ge)
+      nms_reduce_batched<true><<<t.count, 256, 0, s>>>(t);
+    else
+      nms_reduce_batched<false><<<t.count, 256, 0, s>>>(t);
+    if ((rc = mi::check_launch("nms_reduce_batched")) != MI_OK) return rc;
+  }
+  return MI_OK;
 }
 
 extern "C" int mi_bbox_overlaps(const float* boxes, int num_boxes, const float* query, int num_query,

@@ -37,6 +37,71 @@ def nms_device(dets, thresh, mode=_lib.NMS_GE_ORIG_ASC):
     return keep, num_keep
 
 
+_STREAM_POOL = {}
+_BATCH_MAX_BOXES = 4096
+
+
+def nms_device_many(dets_list, thresh, mode=_lib.NMS_GE_ORIG_ASC, max_streams=8):
+    """Independent NMS problems (the RPN runs one per FPN level and image: modeling/generate_proposals.py:91-99,161).
+    One problem's greedy reduce occupies a single CU and its launches are a dependent chain, so ten problems issued back
+    to back leave a 256-CU chip idle.  Problems of up to 4096 boxes go through mi_nms_batched (one launch per stage for
+    all of them, one host call); anything larger is fanned out over side HIP streams through mi_nms.
+    Returns [(keep, num_keep), ...] with the nms_device() conventions, usable on the caller's current stream."""
+    import ctypes
+
+    if not dets_list:
+        return []
+    dev = dets_list[0].device
+    for d in dets_list:
+        _lib.require_cuda(d, "dets")
+        if d.dtype != torch.float32 or d.dim() != 2 or d.size(1) != 5 or d.device != dev:
+            raise ValueError("every dets must be float32 [n, 5] on the same device")
+    if all(d.size(0) <= _BATCH_MAX_BOXES for d in dets_list):
+        lib = _lib.lib()
+        p = len(dets_list)
+        dets_list = [d.contiguous() for d in dets_list]
+        ns = [int(d.size(0)) for d in dets_list]
+        keep_dtype = torch.int64 if mode == _lib.NMS_GE_ORIG_ASC else torch.int32
+        offs = [0]
+        for n in ns:
+            offs.append(offs[-1] + max(n, 1))
+        keep_all = torch.empty((offs[-1],), dtype=keep_dtype, device=dev)
+        num_all = torch.empty((p,), dtype=torch.int32, device=dev)
+        n_arr = (ctypes.c_int * p)(*ns)
+        ws_bytes = lib.mi_nms_batched_workspace_bytes(p, n_arr)
+        workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        item = keep_all.element_size()
+        dets_arr = (ctypes.c_void_p * p)(*[d.data_ptr() for d in dets_list])
+        keep_arr = (ctypes.c_void_p * p)(*[keep_all.data_ptr() + offs[i] * item for i in range(p)])
+        num_arr = (ctypes.c_void_p * p)(*[num_all.data_ptr() + 4 * i for i in range(p)])
+        with torch.cuda.device(dev):
+            rc = lib.mi_nms_batched(p, dets_arr, n_arr, float(thresh), int(mode), keep_arr, num_arr, workspace.data_ptr(),
+                                    ws_bytes, _lib.current_stream_handle(dev))
+        _lib.check(rc, "mi_nms_batched")
+        return [(keep_all[offs[i]:offs[i + 1]], num_all[i:i + 1]) for i in range(p)]
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, max_streams)
+    if key not in _STREAM_POOL:
+        _STREAM_POOL[key] = [torch.cuda.Stream(device=dev) for _ in range(max_streams)]
+    pool = _STREAM_POOL[key]
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    outs, used = [], []
+    for i, dets in enumerate(dets_list):
+        side = pool[i % len(pool)]
+        if i < len(pool):
+            side.wait_event(ready)  # inputs produced on the caller's stream
+            used.append(side)
+        with torch.cuda.stream(side):
+            keep, num_keep = nms_device(dets, thresh, mode)
+        keep.record_stream(cur)
+        num_keep.record_stream(cur)
+        outs.append((keep, num_keep))
+    for side in used:
+        cur.wait_stream(side)
+    return outs
+
+
 def nms_gpu(dets, thresh):
     """model.nms.nms_gpu.nms_gpu: dets pre-sorted by descending score; returns int32 [k, 1] (one host
     sync to slice, exactly where the reference has `keep[:num_out[0]]`, nms_gpu.py:11)."""

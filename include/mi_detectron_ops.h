@@ -156,6 +156,16 @@ size_t mi_nms_workspace_bytes(int n);
 int mi_nms(const float* dets, int n, float thresh, int mode, void* keep, int32_t* num_keep,
            void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
+/* Independent NMS problems in one call (no reference counterpart: the reference runs one cython_nms per FPN level and
+ * image on the host, modeling/generate_proposals.py:91-99,161).  `dets`, `n`, `keep`, `num_keep` are HOST arrays of
+ * `num_problems` entries (device pointers / box counts); each problem follows the mi_nms contract, with at most 4096
+ * boxes.  Every stage is one launch for all problems, so their greedy reduces run side by side.  Results are identical
+ * to num_problems calls of mi_nms. */
+size_t mi_nms_batched_workspace_bytes(int num_problems, const int* n);
+int mi_nms_batched(int num_problems, const float* const* dets, const int* n, float thresh, int mode,
+                   void* const* keep, int32_t* const* num_keep, void* workspace, size_t workspace_bytes,
+                   mi_stream_t stream);
+
 /* ---- IoU matrix --------------------------------------------------------------------------
  * reproduces utils.cython_bbox.bbox_overlaps (lib/utils/cython_bbox.pyx:32-73):
  * boxes [N,4], query [K,4] -> overlaps [N,K] float32, "+1" convention, 0 where iw<=0 or ih<=0. */

@@ -317,3 +317,29 @@ def test_bbox_overlaps_bit_exact(oracle_mod):
     boxes = syn.boxes_uniform(2000, seed=8)[:, :4]
     query = syn.boxes_clustered(8, seed=9)[:, :4]
     assert np.array_equal(mi_nms.bbox_overlaps(boxes, query), oracle_mod.bbox_overlaps(boxes, query))
+
+
+def test_nms_many_matches_serial(oracle_mod):
+    """nms_device_many (independent problems in one batched call, or fanned out over HIP streams) == serial calls."""
+    from detectron_pytorch_amd import nms as mi_nms
+
+    # batched entry point (every problem <= 4096 boxes, incl. an empty one and 40 problems > one table of 32)
+    sets = [syn.boxes_clustered(500 + 137 * i, seed=20 + i) for i in range(11)] + [np.zeros((0, 5), np.float32)]
+    sets += [syn.boxes_uniform(64 * i + 1, seed=i) for i in range(28)]
+    outs = mi_nms.nms_device_many([to_dev(d) for d in sets], 0.7)
+    torch.cuda.synchronize()
+    for d, (keep, num) in zip(sets, outs):
+        k = keep[:int(num.item())].cpu().numpy()
+        assert np.array_equal(k, oracle_mod.nms_cython(d, 0.7) if len(d) else np.zeros(0, np.int64))
+    # GT_SORTED_POS through the batched path
+    from detectron_pytorch_amd import _lib
+    srt = [syn.sort_by_score(d)[0] for d in sets[:5]]
+    outs = mi_nms.nms_device_many([to_dev(d) for d in srt], 0.7, _lib.NMS_GT_SORTED_POS)
+    for d, (keep, num) in zip(srt, outs):
+        assert np.array_equal(keep[:int(num.item())].cpu().numpy(), oracle_mod.nms_gpu_semantics(d, 0.7))
+    # stream fan-out (a problem above the batched limit forces it)
+    big = [syn.boxes_clustered(5000, seed=3), syn.boxes_clustered(700, seed=4)]
+    outs = mi_nms.nms_device_many([to_dev(d) for d in big], 0.7)
+    torch.cuda.synchronize()
+    for d, (keep, num) in zip(big, outs):
+        assert np.array_equal(keep[:int(num.item())].cpu().numpy(), oracle_mod.nms_cython(d, 0.7))
