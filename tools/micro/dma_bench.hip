@@ -14,7 +14,7 @@ using lds_ptr_t = __attribute__((address_space(3))) void*;
 
 struct Win { int x0, y0, ww, nr; };
 
-template <int MODE>
+template <int MODE, int AUX>
 __global__ void __launch_bounds__(256) k(const float* __restrict__ feat, const Win* __restrict__ wins, int nwin,
                                          float* __restrict__ sink, int items_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) k(const float* __restrict__ feat, const W
 #pragma unroll
           for (int c = 0; c < 8; c++) {
             if (MODE == 0)
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(plane0 + c * 400 + kk * 64), 4, voff, c * H * W * 4, 0, 0);
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(plane0 + c * 400 + kk * 64), 4, voff, c * H * W * 4, 0, AUX);
             else
               plane0[c * 400 + p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, c * H * W * 4, 0));
           }
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) k(const float* __restrict__ feat, const W
         if (p < (unsigned)ng) {
 #pragma unroll
           for (int c = 0; c < 8; c++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(plane0 + c * 400 + kk * 256), 16, voff, c * H * W * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(plane0 + c * 400 + kk * 256), 16, voff, c * H * W * 4, 0, AUX);
         }
       }
     } else {
@@ -103,18 +103,28 @@ int main(int argc, char** argv) {
   const int grid = 768, items = 6;  // 4608 (window, tile) items ~ config 2
   const double bytes = (double)px / nwin * grid * items * 32 * 4;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int mode = 0; mode < 4; mode++) {
+  for (int mode = 0; mode < 12; mode++) {
     for (int rep = 0; rep < 3; rep++) {
       hipEventRecord(a);
       for (int i = 0; i < 20; i++) {
-        if (mode == 0) k<0><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items);
-        if (mode == 1) k<1><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items);
-        if (mode == 2) k<2><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items);
-        if (mode == 3) k<3><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items);
+        switch (mode) {
+          case 0: k<0, 0><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 1: k<0, 1><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 2: k<0, 2><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 3: k<0, 16><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 4: k<0, 17><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 5: k<0, 18><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 6: k<1, 0><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 7: k<1, 1><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 8: k<1, 2><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 9: k<1, 16><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 10: k<1, 17><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+          case 11: k<2, 0><<<grid, 256, 32 * 400 * 4>>>(feat, dw, nwin, sink, items); break;
+        }
       }
       hipEventRecord(b); hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b);
-      if (rep == 2) printf("variant %d mode %d: %.2f us per launch, %.1f MB window bytes -> %.0f GB/s useful\n", variant, mode, ms * 1000 / 20, bytes / 1e6, bytes / (ms / 20 * 1e-3) / 1e9);
+      if (rep == 2) printf("variant %d case %d (0-5: dword aux 0,1,2,16,17,18; 6-10: dwordx4 aux 0,1,2,16,17; 11: vgpr): %.2f us per launch\n", variant, mode, ms * 1000 / 20);
     }
   }
   printf("err %s\n", hipGetErrorString(hipGetLastError()));
