@@ -90,13 +90,10 @@ def rois_adversarial(num_rois, batch, height, width, spatial_scale, seed=0):
 
 
 def map_rois_to_fpn_levels(rois_xyxy, k_min=2, k_max=5, s0=224.0, lvl0=4):
-    """lib/utils/fpn.py:11-28: lvl = clip(floor(lvl0 + log2(sqrt(area)/s0 + 1e-6)), k_min, k_max), area with +1."""
-    w = rois_xyxy[:, 2] - rois_xyxy[:, 0] + 1
-    h = rois_xyxy[:, 3] - rois_xyxy[:, 1] + 1
-    areas = np.maximum(w * h, 0)
-    s = np.sqrt(areas)
-    lvls = np.floor(lvl0 + np.log2(s / s0 + 1e-6))
-    return np.clip(lvls, k_min, k_max).astype(np.int64)
+    """lib/utils/fpn.py:11-28; the implementation lives with its caller in roi_xform.py."""
+    from .roi_xform import map_rois_to_fpn_levels as impl
+
+    return impl(rois_xyxy, k_min, k_max, s0, lvl0)
 
 
 def rois_fpn_distributed(num_rois=1000, batch=1, seed=0, im_h=IM_H, im_w=IM_W):

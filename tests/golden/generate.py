@@ -105,6 +105,57 @@ def gen_nms():
     save("bbox_overlaps.npz", boxes=boxes, query=query, overlaps=ref.cython_bbox_overlaps(boxes, query))
 
 
+def _reference_fpn_module():
+    """Import the reference's lib/utils/fpn.py as it lies under /root/reference.  Its two imports are satisfied
+    without the reference's config machinery: `core.config.cfg` by a namespace carrying the two defaults it reads
+    (lib/core/config.py: FPN.ROI_CANONICAL_SCALE=224, FPN.ROI_CANONICAL_LEVEL=4) and `utils.boxes` by the
+    reference's own boxes_area source lines, executed from the reference file."""
+    import importlib.util
+    import re
+    import types
+    import warnings
+
+    lib = "/root/reference/lib"
+    cfg = types.SimpleNamespace(FPN=types.SimpleNamespace(ROI_CANONICAL_SCALE=224, ROI_CANONICAL_LEVEL=4))
+    src = open(os.path.join(lib, "utils", "boxes.py")).read()
+    body = re.search(r"^def boxes_area\(boxes\):.*?(?=^def )", src, re.S | re.M).group(0)
+    boxes_mod = types.ModuleType("utils.boxes")
+    boxes_mod.np, boxes_mod.warnings = np, warnings
+    exec(compile(body, os.path.join(lib, "utils", "boxes.py"), "exec"), boxes_mod.__dict__)
+    utils_pkg, core_pkg = types.ModuleType("utils"), types.ModuleType("core")
+    config_mod = types.ModuleType("core.config")
+    config_mod.cfg = cfg
+    utils_pkg.boxes = boxes_mod
+    saved = {k: sys.modules.get(k) for k in ("utils", "utils.boxes", "core", "core.config")}
+    sys.modules.update({"utils": utils_pkg, "utils.boxes": boxes_mod, "core": core_pkg, "core.config": config_mod})
+    try:
+        spec = importlib.util.spec_from_file_location("reference_utils_fpn", os.path.join(lib, "utils", "fpn.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+def gen_fpn():
+    fpn = _reference_fpn_module()
+    rois, _ = syn.rois_fpn_distributed(400, batch=2, seed=31)
+    edge = np.array([[0, 0, 0, 223, 223], [1, 0, 0, 222, 222], [0, 5, 5, 4, 4], [1, 10, 10, 10, 10],
+                     [0, 0, 0, 447, 447], [1, 0, 0, 111, 111], [0, 0, 0, 1332, 799], [1, 3, 3, 1, 9]], np.float32)
+    rois = np.vstack([rois, edge]).astype(np.float32)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lvls = fpn.map_rois_to_fpn_levels(rois[:, 1:5], 2, 5)
+    blobs = {}
+    fpn.add_multilevel_roi_blobs(blobs, "rois", rois, lvls, 2, 5)
+    save("fpn.npz", rois=rois, levels=lvls, **blobs)
+
+
 def main():
     if not ref.available():
         sys.exit("oracle/_ref is not built: run `python oracle/build_ref.py` in the build container first")
@@ -113,6 +164,7 @@ def main():
     gen_roi_pool()
     gen_roi_crop()
     gen_nms()
+    gen_fpn()
 
 
 if __name__ == "__main__":

@@ -343,3 +343,57 @@ def test_nms_many_matches_serial(oracle_mod):
     torch.cuda.synchronize()
     for d, (keep, num) in zip(big, outs):
         assert np.array_equal(keep[:int(num.item())].cpu().numpy(), oracle_mod.nms_cython(d, 0.7))
+
+
+# ---- roi_feature_transform: the caller of the RoI operators (model_builder.py:252-324) ---------------------------
+def _fpn_inputs(channels=32, num_rois=300, batch=2, seed=41):
+    from detectron_pytorch_amd import roi_xform
+
+    rois, lvls = syn.rois_fpn_distributed(num_rois, batch=batch, seed=seed)
+    blobs = roi_xform.add_multilevel_roi_blobs({}, "rois", rois, lvls, 2, 5)
+    scales = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4]          # coarsest level first, as the reference orders them
+    feats = [syn.feature_map(batch, channels, int(np.ceil(syn.IM_H * s)), int(np.ceil(syn.IM_W * s)), seed=seed + i)
+             for i, s in enumerate(scales)]
+    return rois, lvls, blobs, scales, feats
+
+
+def test_roi_feature_transform_fpn_roi_align_vs_oracle(oracle_mod):
+    from detectron_pytorch_amd import roi_xform
+
+    rois, lvls, blobs, scales, feats = _fpn_inputs()
+    dev_feats = [to_dev(f).requires_grad_(True) for f in feats]
+    out = roi_xform.roi_feature_transform(dev_feats, blobs, "rois", "RoIAlign", 7, scales, 2)
+    assert out.shape == (rois.shape[0], feats[0].shape[1], 7, 7)
+    gtop = np.random.RandomState(5).randn(*out.shape).astype(np.float32)
+    out.backward(to_dev(gtop))
+    expected = np.empty(out.shape, np.float32)
+    for lvl in range(2, 6):
+        idx = np.nonzero(lvls == lvl)[0]
+        if idx.size == 0:
+            continue
+        feat, sc = feats[5 - lvl], scales[5 - lvl]
+        expected[idx] = oracle_mod.roi_align_forward(feat, rois[idx], 7, 7, sc, 2)
+        grad = oracle_mod.roi_align_backward(gtop[idx], rois[idx], feat.shape, sc, 2)
+        assert_close(dev_feats[5 - lvl].grad, grad, "fpn level %d grad" % lvl)
+    assert_fwd(out, expected, "fpn roi_feature_transform", exact=False)
+
+
+@pytest.mark.parametrize("method", ["RoIPoolF", "RoICrop", "RoIAlign"])
+def test_roi_feature_transform_single_level_methods(oracle_mod, method):
+    from detectron_pytorch_amd import roi_xform
+
+    feat = syn.feature_map(2, 16, 38, 50, seed=3)
+    rois = syn.rois_adversarial(40, 2, 38, 50, 1.0 / 16, seed=4)
+    rois[:, 0] = np.clip(rois[:, 0], 0, 1)
+    out = roi_xform.roi_feature_transform(to_dev(feat), {"rois": rois}, "rois", method, 7, 1.0 / 16, 2)
+    if method == "RoIAlign":
+        assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, 7, 7, 1.0 / 16, 2), method, exact=False)
+    elif method == "RoIPoolF":
+        assert np.array_equal(out.cpu().numpy(), oracle_mod.roi_pool_forward(feat, rois, 7, 7, 1.0 / 16)[0])
+    else:
+        grid_xy = roi_xform.affine_grid_gen(torch.from_numpy(rois), feat.shape[2:], 14)
+        grid_yx = torch.stack([grid_xy[..., 1], grid_xy[..., 0]], 3).contiguous().numpy()
+        crop = torch.from_numpy(oracle_mod.roi_crop_forward(feat, grid_yx))
+        expected = torch.nn.functional.max_pool2d(crop, 2, 2).numpy()
+        assert out.shape == (40, 16, 7, 7)
+        assert_close(out, expected, method)   # the grid itself is computed by torch on two devices

@@ -178,3 +178,31 @@ def test_roi_pool_first_max_wins(oracle_mod):
     # RoI entirely outside: empty bins -> 0 / -1
     out, argmax = oracle_mod.roi_pool_forward(feat, np.array([[0, 20, 20, 30, 30]], np.float32), 2, 2, 1.0)
     assert not out.any() and (argmax == -1).all()
+
+
+# ---- FPN level mapping / multilevel RoI blobs (host logic of roi_feature_transform) -----------------------------
+def test_fpn_level_mapping_and_restore_permutation_match_reference_fixture():
+    """tests/golden/fpn.npz was produced by importing the reference's lib/utils/fpn.py (generate.py:gen_fpn)."""
+    from detectron_pytorch_amd import roi_xform
+
+    g = load_golden("fpn.npz")
+    rois = g["rois"]
+    lvls = roi_xform.map_rois_to_fpn_levels(rois[:, 1:5], 2, 5)
+    assert np.array_equal(lvls, g["levels"].astype(np.int64))
+    blobs = roi_xform.add_multilevel_roi_blobs({}, "rois", rois, lvls, 2, 5)
+    for key in ("rois_fpn2", "rois_fpn3", "rois_fpn4", "rois_fpn5", "rois_idx_restore_int32"):
+        assert np.array_equal(blobs[key], g[key]), key
+        assert blobs[key].dtype == g[key].dtype, key
+    stacked = np.vstack([blobs["rois_fpn%d" % l] for l in range(2, 6)])
+    assert np.array_equal(stacked[blobs["rois_idx_restore_int32"]], rois)
+
+
+def test_roi_feature_transform_rejects_unknown_method_and_level_count():
+    import torch
+    from detectron_pytorch_amd import roi_xform
+
+    with pytest.raises(AssertionError):
+        roi_xform.roi_feature_transform(torch.zeros(1, 1, 2, 2), {"rois": np.zeros((0, 5), np.float32)}, method="Nope")
+    with pytest.raises(AssertionError):
+        roi_xform.roi_feature_transform([torch.zeros(1, 1, 2, 2)] * 3, {}, method="RoIAlign",
+                                        spatial_scale=[1 / 32, 1 / 16, 1 / 8])
