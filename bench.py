@@ -185,7 +185,49 @@ def roofline_roi_align_forward(device, iters):
                         "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
                         "algorithmic_bytes": int(bwd_bytes)}
     info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
+    if layout == _lib.LAYOUT_NCHW:
+        info["channels_last"] = channels_last_variant(device, lib, stream, feat, rois, out, ws, alg_bytes, gtop, iters)
+    copy_gbs = copy_ceiling(device)
+    info["copy_ceiling"] = {"measured": round(copy_gbs, 1), "unit": "GB/s", "frac_of_copy": round(achieved / copy_gbs, 4),
+                            "what": "torch device-to-device copy of 256 MiB, read + write bytes / time"}
     return info
+
+
+def channels_last_variant(device, lib, stream, feat_nchw, rois, out, ws, alg_bytes, gtop, iters):
+    """Same logical input with the features stored channels-last (what MIOpen's NHWC convolutions hand over on gfx950):
+    forward = roi_align_prepare + roi_align_fwd_nhwc, output still dense [R,C,PH,PW]; backward = the host-side path of
+    roi_align.roi_align_backward (NCHW tile kernel + one layout change).  Reported beside the NCHW headline, not as it."""
+    from detectron_pytorch_amd import _lib, roi_align as ra
+
+    n, c, h, w = feat_nchw.shape
+    r, _, res, _ = out.shape
+    feat = feat_nchw.permute(0, 2, 3, 1).contiguous()
+    scale, sr = syn.FPN_LEVELS[2][2], 2
+
+    def launch():
+        rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), n, c, h, w, r, res, res,
+                                         scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NHWC, ws.data_ptr(), ws.numel(),
+                                         stream)
+        assert rc == 0
+
+    sec = time_kernel(launch, iters)
+
+    def bwd():
+        ra.roi_align_backward(gtop, rois, (n, c, h, w), res, res, scale, sr, channels_last=True)
+
+    sec_bwd = time_kernel(bwd, max(iters // 8, 5))
+    gbs = alg_bytes / sec / 1e9
+    return {"kernel": "roi_align_prepare + roi_align_fwd_nhwc", "avg_launch_us": round(sec * 1e6, 2),
+            "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "bwd_us_incl_layout_change": round(sec_bwd * 1e6, 2)}
+
+
+def copy_ceiling(device):
+    """The box's own streaming ceiling (SURVEY.md section 8d asks for both denominators): a plain device copy."""
+    a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=device)
+    b = torch.empty_like(a)
+    sec = time_kernel(lambda: b.copy_(a), 20)
+    return 2 * a.numel() * 4 / sec / 1e9
 
 
 def other_shapes(device, lib, stream, iters):
@@ -218,7 +260,30 @@ def other_shapes(device, lib, stream, iters):
                                                 scale, sr, 0, 0, ws.data_ptr(), ws_bytes, flags, stream) == 0
 
         out[name] = {"fwd_us": round(time_kernel(fwd, iters) * 1e6, 1), "bwd_us": round(time_kernel(bwd, iters) * 1e6, 1)}
+    out["fpn_1000rois_P2-P5_7x7"] = fpn_variant(device, iters)
     return out
+
+
+def fpn_variant(device, iters):
+    """Config-2 variant (ii): 1000 RoIs distributed over P2..P5 by the FPN heuristic, pooled by
+    roi_xform.roi_feature_transform (one RoIAlign call per level + concat + restore permutation), RoIs on the device."""
+    from detectron_pytorch_amd import roi_xform
+
+    rois, lvls = syn.rois_fpn_distributed(1000, batch=1, seed=2)
+    blobs = roi_xform.add_multilevel_roi_blobs({}, "rois", rois, lvls, 2, 5)
+    blobs = {k: torch.from_numpy(v).to(device) for k, v in blobs.items()}
+    feats, scales = [], []
+    for lvl in (5, 4, 3, 2):  # coarsest first, as the reference orders blobs_in
+        h, w, scale = syn.FPN_LEVELS[lvl]
+        feats.append(torch.from_numpy(syn.feature_map(1, syn.FPN_DIM, h, w, seed=lvl)).to(device))
+        scales.append(scale)
+
+    def fwd():
+        with torch.no_grad():
+            roi_xform.roi_feature_transform(feats, blobs, "rois", "RoIAlign", 7, scales, 2)
+
+    return {"fwd_us": round(time_kernel(fwd, iters) * 1e6, 1),
+            "rois_per_level": {int(l): int((lvls == l).sum()) for l in (2, 3, 4, 5)}}
 
 
 def pmc_traffic(direction):

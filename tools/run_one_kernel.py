@@ -23,6 +23,10 @@ if os.environ.get("MI_BENCH_SORT_ROIS"):
     import numpy as np
     key = (rois_np[:, 2] + rois_np[:, 4]) // (2 * 64) * 4096 + (rois_np[:, 1] + rois_np[:, 3]) / 2
     rois_np = np.ascontiguousarray(rois_np[np.argsort(key, kind="stable")])
+layout = 0
+if os.environ.get("MI_BENCH_NHWC"):  # channels-last storage of the same logical tensor
+    feat = feat.permute(0, 2, 3, 1).contiguous()
+    layout = 1
 rois = torch.from_numpy(rois_np).to(dev)
 out = torch.empty((r, c, res, res), device=dev)
 gtop = torch.randn(r, c, res, res, device=dev)
@@ -37,7 +41,7 @@ torch.cuda.synchronize()
 for _ in range(iters):
     if which == "roi_align_fwd":
         rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, scale,
-                                         sr, 0, 0, fws.data_ptr(), fws.numel(), stream)
+                                         sr, 0, layout, fws.data_ptr(), fws.numel(), stream)
     elif which == "roi_align_bwd":
         rc = lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
                                           scale, sr, 0, 0, fws.data_ptr(), fws.numel(), 2, stream)
