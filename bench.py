@@ -331,6 +331,17 @@ def nms_latency(device, iters):
         sec = time_kernel(launch, max(iters // 4, 10))
         out[name] = {"us_per_call": round(sec * 1e6, 1), "kept": int(num.item()),
                      "pair_tests_per_s": round(n * (n - 1) / 2 / sec, 0)}
+    # Soft-NMS (off by default in the reference, core/config.py:362): one sequential pick per kept box, all in LDS
+    dets = torch.from_numpy(syn.boxes_uniform(1000, seed=0)).to(device)
+    od, oi = torch.empty((1000, 5), device=device), torch.empty(1000, dtype=torch.int64, device=device)
+    num = torch.empty(1, dtype=torch.int32, device=device)
+
+    def launch_soft():
+        assert lib.mi_soft_nms(dets.data_ptr(), 1000, 0.5, 0.3, 0.001, 1, od.data_ptr(), oi.data_ptr(), num.data_ptr(),
+                               stream) == 0
+
+    sec = time_kernel(launch_soft, 5, warmup=2)
+    out["soft_nms_linear_uniform_n1000"] = {"us_per_call": round(sec * 1e6, 1), "kept": int(num.item())}
     return out
 
 

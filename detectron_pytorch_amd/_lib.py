@@ -39,6 +39,8 @@ SIGNATURES = {
     "mi_nms_batched_workspace_bytes": (_c_size_t, [_c_int, _c_void_p]),
     "mi_nms_batched": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t,
                                _c_void_p]),
+    "mi_soft_nms": (_c_int, [_c_void_p, _c_int, _c_float, _c_float, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                            _c_void_p]),
     "mi_bbox_overlaps": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "mi_dbg_roi_align_timeline": (None, [_c_void_p]),
 }

@@ -151,7 +151,47 @@ def bbox_overlaps(boxes, query_boxes, device=None):
     return out.cpu().numpy() if as_numpy else out
 
 
-def soft_nms(boxes_in, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
-    """utils.cython_nms.soft_nms (lib/utils/cython_nms.pyx:98-203) -- off by default in the reference
-    (TEST.SOFT_NMS.ENABLED False, core/config.py:362).  Not yet on the HIP path: SURVEY.md section 8f row 3."""
-    raise NotImplementedError("soft_nms has no HIP implementation yet (reference default: disabled)")
+SOFT_NMS_METHODS = {"hard": 0, "linear": 1, "gaussian": 2}  # utils/boxes.py:334
+
+
+def soft_nms_device(dets, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method=1):
+    """On-device Soft-NMS, no host synchronisation: returns (out_dets [n,5], out_inds int64 [n], num_out int32 [1]);
+    the first num_out rows are the reference's boxes[:N] / inds[:N]."""
+    _lib.require_cuda(dets, "dets")
+    if dets.dtype != torch.float32 or dets.dim() != 2 or dets.size(1) != 5:
+        raise TypeError("soft_nms expects float32 dets [n, 5]")
+    dets = dets.contiguous()
+    n = dets.size(0)
+    out_dets = torch.empty((n, 5), dtype=torch.float32, device=dets.device)
+    out_inds = torch.empty((n,), dtype=torch.int64, device=dets.device)
+    num_out = torch.empty((1,), dtype=torch.int32, device=dets.device)
+    with torch.cuda.device(dets.device):
+        rc = _lib.lib().mi_soft_nms(dets.data_ptr(), n, float(sigma), float(overlap_thresh), float(score_thresh),
+                                    int(method), out_dets.data_ptr(), out_inds.data_ptr(), num_out.data_ptr(),
+                                    _lib.current_stream_handle(dets.device))
+    _lib.check(rc, "mi_soft_nms")
+    return out_dets, out_inds, num_out
+
+
+def soft_nms(boxes_in, sigma=0.5, Nt=0.3, threshold=0.001, method=0, device=None):
+    """utils.cython_nms.soft_nms replacement (lib/utils/cython_nms.pyx:98-203): numpy float32 [n,5] in ->
+    (boxes[:N] float32 [N,5], inds[:N] int64) out, same rows in the same order as the reference; tensors in ->
+    tensors out.  `method`: 0 hard, 1 linear, 2 gaussian (what utils/boxes.py:337-343 passes)."""
+    as_numpy = isinstance(boxes_in, np.ndarray)
+    if as_numpy:
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        boxes_in = torch.from_numpy(np.ascontiguousarray(boxes_in, dtype=np.float32)).to(dev)
+    out_dets, out_inds, num_out = soft_nms_device(boxes_in, sigma, Nt, threshold, int(method))
+    k = int(num_out.item())
+    if as_numpy:
+        return out_dets[:k].cpu().numpy(), out_inds[:k].cpu().numpy()
+    return out_dets[:k], out_inds[:k]
+
+
+def box_utils_soft_nms(dets, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method="linear"):
+    """utils.boxes.soft_nms (lib/utils/boxes.py:327-344): the named-method wrapper the test-time code calls."""
+    if dets.shape[0] == 0:
+        return dets, []
+    if method not in SOFT_NMS_METHODS:
+        raise AssertionError("Unknown soft_nms method: {}".format(method))
+    return soft_nms(dets, sigma, overlap_thresh, score_thresh, SOFT_NMS_METHODS[method])

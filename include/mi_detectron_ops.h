@@ -156,6 +156,15 @@ size_t mi_nms_workspace_bytes(int n);
 int mi_nms(const float* dets, int n, float thresh, int mode, void* keep, int32_t* num_keep,
            void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
+/* Soft-NMS: replaces utils.cython_nms.soft_nms (lib/utils/cython_nms.pyx:98-203; wrapper utils/boxes.py:327-344, call
+ * site core/test.py:753-760 when TEST.SOFT_NMS.ENABLED).  dets [n,5] float32, n <= 4096.  method: 0 hard, 1 linear,
+ * 2 gaussian (the values utils/boxes.py:334 passes).  Results as the reference returns them -- the re-scored rows
+ * boxes[:N] into out_dets ([n,5] buffer, first *num_out rows written) and their original indices inds[:N] into
+ * out_inds (int64) -- in the reference's row order (pick order, with its swap-with-last compaction).  On-device,
+ * asynchronous, no workspace (state lives in LDS).  n == 0 writes *num_out = 0. */
+int mi_soft_nms(const float* dets, int n, float sigma, float overlap_thresh, float score_thresh, int method,
+                float* out_dets, int64_t* out_inds, int32_t* num_out, mi_stream_t stream);
+
 /* Independent NMS problems in one call (no reference counterpart: the reference runs one cython_nms per FPN level and
  * image on the host, modeling/generate_proposals.py:91-99,161).  `dets`, `n`, `keep`, `num_keep` are HOST arrays of
  * `num_problems` entries (device pointers / box counts); each problem follows the mi_nms contract, with at most 4096

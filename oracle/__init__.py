@@ -157,6 +157,17 @@ def nms_cython(dets, thresh):
     return keep[:k].copy()
 
 
+def soft_nms(dets, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method=1):
+    """cython_nms.soft_nms semantics: (boxes[:N] float32 [N,5], inds[:N] int64); method 0 hard, 1 linear, 2 gaussian."""
+    dets, dp = _f32(dets)
+    n = dets.shape[0]
+    boxes = np.zeros((max(n, 1), 5), np.float32)
+    inds = np.zeros((max(n, 1),), np.int64)
+    k = lib().oracle_soft_nms(dp, n, ctypes.c_float(sigma), ctypes.c_float(overlap_thresh), ctypes.c_float(score_thresh),
+                              int(method), boxes.ctypes.data_as(_f32p), inds.ctypes.data_as(_i64p))
+    return boxes[:k].copy(), inds[:k].copy()
+
+
 def nms_gpu_semantics(dets_sorted, thresh):
     """nms_gpu semantics: positions in the (pre-sorted) input, int32."""
     dets_sorted, dp = _f32(dets_sorted)

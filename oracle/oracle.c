@@ -613,6 +613,82 @@ int oracle_nms_cython(const float* dets, int ndets, float thresh, int64_t* keep)
   return k;
 }
 
+/* utils.cython_nms.soft_nms, lib/utils/cython_nms.pyx:98-203.  boxes_in [n,5] (x1,y1,x2,y2,score);
+ * `boxes` [n,5] and `inds` [n] receive the working copies (:108,:116); the first <return value> rows
+ * are the result (boxes[:N], inds[:N], :203).  method 0 = hard, 1 = linear, 2 = gaussian (:177-190).
+ * Typing follows the Cython declarations (:110-115) AND the C that Cython generates from them: variables are C
+ * floats, but integer literals inside float expressions become double constants (see below); the gaussian
+ * weight is np.exp of a Python float, i.e. exp in double of the float argument, cast back to float. */
+int oracle_soft_nms(const float* boxes_in, int n, float sigma, float Nt, float threshold, int method,
+                    float* boxes, int64_t* inds) {
+  unsigned int N = (unsigned int)n; /* :109 */
+  memcpy(boxes, boxes_in, sizeof(float) * 5 * (size_t)n);
+  for (int i = 0; i < n; i++) inds[i] = i; /* :116 */
+  for (int i = 0; i < n; i++) {            /* :118, range(N) evaluated once */
+    float maxscore = boxes[i * 5 + 4];     /* :119-120 */
+    int maxpos = i;
+    float tx1 = boxes[i * 5 + 0], ty1 = boxes[i * 5 + 1], tx2 = boxes[i * 5 + 2], ty2 = boxes[i * 5 + 3];
+    float ts = boxes[i * 5 + 4];
+    int64_t ti = inds[i];
+    int pos = i + 1;
+    while (pos < (int)N) { /* :131-135: first maximum wins (strict <) */
+      if (maxscore < boxes[pos * 5 + 4]) {
+        maxscore = boxes[pos * 5 + 4];
+        maxpos = pos;
+      }
+      pos = pos + 1;
+    }
+    for (int k = 0; k < 5; k++) boxes[i * 5 + k] = boxes[maxpos * 5 + k]; /* :138-143 */
+    inds[i] = inds[maxpos];
+    boxes[maxpos * 5 + 0] = tx1; /* :146-151 */
+    boxes[maxpos * 5 + 1] = ty1;
+    boxes[maxpos * 5 + 2] = tx2;
+    boxes[maxpos * 5 + 3] = ty2;
+    boxes[maxpos * 5 + 4] = ts;
+    inds[maxpos] = ti;
+    tx1 = boxes[i * 5 + 0]; /* :153-157 */
+    ty1 = boxes[i * 5 + 1];
+    tx2 = boxes[i * 5 + 2];
+    ty2 = boxes[i * 5 + 3];
+    pos = i + 1;
+    while (pos < (int)N) { /* :162-201 */
+      float x1 = boxes[pos * 5 + 0], y1 = boxes[pos * 5 + 1], x2 = boxes[pos * 5 + 2], y2 = boxes[pos * 5 + 3];
+      /* Cython turns the literal 1 of these float expressions into the double constant 1.0 (both in the reference's
+       * shipped cython_nms.c:3882-3938 and in a fresh cythonization), so the sums and the products below are
+       * evaluated in double and rounded to float on assignment. */
+      float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0)); /* :169 */
+      float iw = (float)((double)(f32min(tx2, x2) - f32max(tx1, x1)) + 1.0);       /* :170 */
+      if (iw > 0) {
+        float ih = (float)((double)(f32min(ty2, y2) - f32max(ty1, y1)) + 1.0); /* :172 */
+        if (ih > 0) {
+          float ua = (float)(((((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0)) + (double)area) -
+                             (double)(iw * ih)); /* :174 */
+          float ov = iw * ih / ua;                                                          /* :175 */
+          float weight;
+          if (method == 1) { /* :177-181 */
+            if (ov > Nt) weight = (float)(1.0 - (double)ov);
+            else weight = 1;
+          } else if (method == 2) { /* :182-183 */
+            weight = (float)exp((double)(-(ov * ov) / sigma));
+          } else { /* :184-188 */
+            if (ov > Nt) weight = 0;
+            else weight = 1;
+          }
+          boxes[pos * 5 + 4] = weight * boxes[pos * 5 + 4]; /* :190 */
+          if (boxes[pos * 5 + 4] < threshold) {             /* :194-201: swap with the last box, shrink */
+            for (int k = 0; k < 5; k++) boxes[pos * 5 + k] = boxes[(N - 1) * 5 + k];
+            inds[pos] = inds[N - 1];
+            N = N - 1;
+            pos = pos - 1;
+          }
+        }
+      }
+      pos = pos + 1;
+    }
+  }
+  return (int)N;
+}
+
 /* devIoU, lib/model/nms/src/nms_cuda_kernel.cu:31-39 */
 static float nms_dev_iou(const float* a, const float* b) {
   float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);

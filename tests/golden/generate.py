@@ -105,6 +105,22 @@ def gen_nms():
     save("bbox_overlaps.npz", boxes=boxes, query=query, overlaps=ref.cython_bbox_overlaps(boxes, query))
 
 
+def gen_soft_nms():
+    """utils.cython_nms.soft_nms of the reference (oracle/_ref build of lib/utils/cython_nms.pyx)."""
+    out = {}
+    for name, dets in (("uniform250", syn.boxes_uniform(250, seed=7)), ("clustered250", syn.boxes_clustered(250, seed=8)),
+                       ("uniform70", syn.boxes_uniform(70, seed=9))):
+        out["dets_" + name] = dets
+        for method in (0, 1, 2):
+            for ci, (sigma, nt, th) in enumerate(((0.5, 0.3, 0.001), (0.5, 0.3, 0.05), (0.3, 0.5, 0.2))):
+                boxes, inds = ref.cython_soft_nms(dets, sigma, nt, th, method)
+                tag = "%s_m%d_c%d" % (name, method, ci)
+                out["boxes_" + tag] = np.asarray(boxes, dtype=np.float32)
+                out["inds_" + tag] = np.asarray(inds, dtype=np.int64)
+    out["cfgs"] = np.array([[0.5, 0.3, 0.001], [0.5, 0.3, 0.05], [0.3, 0.5, 0.2]], dtype=np.float32)
+    save("soft_nms.npz", **out)
+
+
 def _reference_fpn_module():
     """Import the reference's lib/utils/fpn.py as it lies under /root/reference.  Its two imports are satisfied
     without the reference's config machinery: `core.config.cfg` by a namespace carrying the two defaults it reads
@@ -164,6 +180,7 @@ def main():
     gen_roi_pool()
     gen_roi_crop()
     gen_nms()
+    gen_soft_nms()
     gen_fpn()
 
 

@@ -441,3 +441,60 @@ def test_roi_feature_transform_single_level_methods(oracle_mod, method):
         expected = torch.nn.functional.max_pool2d(crop, 2, 2).numpy()
         assert out.shape == (40, 16, 7, 7)
         assert_close(out, expected, method)   # the grid itself is computed by torch on two devices
+
+
+# ---- Soft-NMS (utils.cython_nms.soft_nms) -----------------------------------------------------------------------
+def test_soft_nms_golden_bit_exact():
+    """Rows, row order, re-scored scores and original indices as the reference's cython build produced them."""
+    from detectron_pytorch_amd import nms as mi_nms
+
+    g = load_golden("soft_nms.npz")
+    cfgs, checked = g["cfgs"], 0
+    for key in g.files:
+        if not key.startswith("boxes_"):
+            continue
+        tag = key[len("boxes_"):]
+        name, m, c = tag.rsplit("_", 2)
+        sigma, nt, th = (float(v) for v in cfgs[int(c[1:])])
+        boxes, inds = mi_nms.soft_nms(g["dets_" + name], sigma, nt, th, int(m[1:]))
+        assert boxes.dtype == np.float32 and inds.dtype == np.int64
+        assert np.array_equal(inds, g["inds_" + tag]), tag
+        assert np.array_equal(boxes, g[key]), tag
+        checked += 1
+    assert checked == 27
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("gen,n", [(syn.boxes_uniform, 1), (syn.boxes_uniform, 2), (syn.boxes_clustered, 64),
+                                   (syn.boxes_uniform, 65), (syn.boxes_clustered, 257), (syn.boxes_uniform, 1000),
+                                   (syn.boxes_clustered, 2000), (syn.boxes_uniform, 4096)])
+def test_soft_nms_vs_oracle_bit_exact(oracle_mod, gen, n, method):
+    from detectron_pytorch_amd import nms as mi_nms
+
+    dets = gen(n, seed=n + method)
+    for sigma, nt, th in ((0.5, 0.3, 0.001), (0.4, 0.5, 0.1)):
+        ob, oi = oracle_mod.soft_nms(dets, sigma, nt, th, method)
+        boxes, inds = mi_nms.soft_nms(dets, sigma, nt, th, method)
+        assert np.array_equal(inds, oi), "indices n=%d method=%d" % (n, method)
+        assert np.array_equal(boxes, ob), "rows n=%d method=%d" % (n, method)
+
+
+def test_soft_nms_contract_and_wrapper():
+    from detectron_pytorch_amd import nms as mi_nms
+
+    out_dets, out_inds, num = mi_nms.soft_nms_device(torch.zeros((0, 5), device=dev()))
+    assert int(num.item()) == 0
+    dets = np.array([[0, 0, 9, 9, 0.5], [0, 0, 9, 9, 0.9], [20, 20, 29, 29, 0.7]], np.float32)
+    boxes, inds = mi_nms.soft_nms(dets, 0.5, 0.3, 0.001, 0)
+    assert inds.tolist() == [1, 2]
+    boxes, keep = mi_nms.box_utils_soft_nms(dets, method="linear")            # utils/boxes.py:327-344
+    assert keep.tolist() == [1, 2] and boxes.shape == (2, 5)
+    assert mi_nms.box_utils_soft_nms(np.zeros((0, 5), np.float32))[1] == []
+    with pytest.raises(AssertionError):
+        mi_nms.box_utils_soft_nms(dets, method="nope")
+    with pytest.raises(RuntimeError):
+        mi_nms.soft_nms(syn.boxes_uniform(4097, seed=0))
+    # tensor in -> tensors out, asynchronous entry point leaves everything on the device
+    t = to_dev(syn.boxes_uniform(300, seed=3))
+    b, i = mi_nms.soft_nms(t, 0.5, 0.3, 0.001, 2)
+    assert b.is_cuda and i.is_cuda and i.dtype == torch.int64

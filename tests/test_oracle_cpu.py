@@ -206,3 +206,50 @@ def test_roi_feature_transform_rejects_unknown_method_and_level_count():
     with pytest.raises(AssertionError):
         roi_xform.roi_feature_transform([torch.zeros(1, 1, 2, 2)] * 3, {}, method="RoIAlign",
                                         spatial_scale=[1 / 32, 1 / 16, 1 / 8])
+
+
+# ---- Soft-NMS ----------------------------------------------------------------------------------------------------
+def _soft_nms_golden_cases():
+    g = load_golden("soft_nms.npz")
+    cfgs = g["cfgs"]
+    for key in g.files:
+        if not key.startswith("boxes_"):
+            continue
+        name, m, c = key[len("boxes_"):].rsplit("_", 2)
+        sigma, nt, th = (float(v) for v in cfgs[int(c[1:])])
+        yield key[len("boxes_"):], g["dets_" + name], sigma, nt, th, int(m[1:]), g[key], g["inds_" + key[len("boxes_"):]]
+
+
+def test_soft_nms_matches_golden(oracle_mod):
+    """Fixture produced by the reference's own cython_nms.soft_nms (tests/golden/generate.py:gen_soft_nms): same rows,
+    same order, same bits -- including the gaussian re-scoring (exp in double) and the swap-with-last compaction."""
+    n = 0
+    for tag, dets, sigma, nt, th, method, boxes, inds in _soft_nms_golden_cases():
+        ob, oi = oracle_mod.soft_nms(dets, sigma, nt, th, method)
+        assert np.array_equal(ob, boxes) and np.array_equal(oi, inds), tag
+        n += 1
+    assert n == 27
+
+
+def test_soft_nms_matches_reference_build(oracle_mod, ref_mod):
+    for gen, n in ((syn.boxes_uniform, 1), (syn.boxes_uniform, 400), (syn.boxes_clustered, 1000)):
+        dets = gen(n, seed=n)
+        for method in (0, 1, 2):
+            rb, ri = ref_mod.cython_soft_nms(dets, 0.5, 0.3, 0.01, method)
+            ob, oi = oracle_mod.soft_nms(dets, 0.5, 0.3, 0.01, method)
+            assert np.array_equal(rb, ob) and np.array_equal(np.asarray(ri), oi), (gen.__name__, n, method)
+
+
+def test_soft_nms_known_answers(oracle_mod):
+    # two identical boxes + one disjoint: hard mode drops the duplicate (score 0 < threshold), keeps pick order
+    dets = np.array([[0, 0, 9, 9, 0.5], [0, 0, 9, 9, 0.9], [20, 20, 29, 29, 0.7]], np.float32)
+    boxes, inds = oracle_mod.soft_nms(dets, 0.5, 0.3, 0.001, 0)
+    assert inds.tolist() == [1, 2] and boxes[:, 4].tolist() == [np.float32(0.9), np.float32(0.7)]
+    # linear: the duplicate (IoU 1) is re-scored to 0.5 * (1 - 1) = 0 and dropped; with a lower overlap it survives
+    dets = np.array([[0, 0, 9, 9, 0.9], [0, 5, 9, 14, 0.8]], np.float32)  # IoU = 50 / 150
+    boxes, inds = oracle_mod.soft_nms(dets, 0.5, 0.3, 0.001, 1)
+    assert inds.tolist() == [0, 1]
+    assert boxes[1, 4] == np.float32(np.float32(1.0 - np.float64(np.float32(50.0) / np.float32(150.0))) * np.float32(0.8))
+    # a box that does not overlap is never dropped, even below the threshold (the test sits inside `if ih > 0`)
+    dets = np.array([[0, 0, 9, 9, 0.9], [50, 50, 59, 59, 0.0001]], np.float32)
+    assert oracle_mod.soft_nms(dets, 0.5, 0.3, 0.001, 1)[1].tolist() == [0, 1]
