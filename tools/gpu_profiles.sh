@@ -1,9 +1,11 @@
 #!/bin/bash
-# Round profiles: rocprofv3 kernel-trace stats of `python bench.py` (the judged command) + PMC passes (separate runs)
-# over the roofline kernel.  Writes summaries under gpurun_out/prof_<TAG>/ ; copy what is to be judged into profiles/.
+# Round profiles: rocprofv3 kernel-trace stats of `python bench.py` (the judged command) + PMC passes (separate runs,
+# --kernel-trace only beside --pmc) over the roofline kernels.  Writes gpurun_out/prof_<TAG>/ ; copy what is to be
+# judged into profiles/ (tools/make_pmc_json.py composes the JSON bench.py reads `traffic` from).
 TAG=${1:-r01}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/bench -o b -f csv -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_stdout.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/bench -o b -f csv -- python $R/bench.py > $O/bench_stdout.log 2>&1
 cp $O/bench/*kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null
+grep '^{' $O/bench_stdout.log | tail -1 > $O/bench_line.json
 j=0
 for grp in "FETCH_SIZE" "WRITE_SIZE TCC_EA0_RDREQ_sum" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
@@ -12,6 +14,11 @@ for grp in "FETCH_SIZE" "WRITE_SIZE TCC_EA0_RDREQ_sum" "TCC_HIT_sum TCC_MISS_sum
   j=$((j+1))
   timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc$j -o p -- python $R/tools/run_one_kernel.py roi_align_fwd 5 > $O/pmc$j.log 2>&1
   timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $O/pmcb$j -o p -- python $R/tools/run_one_kernel.py roi_align_bwd 5 > $O/pmcb$j.log 2>&1
+  MI_BENCH_NHWC=1 timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $O/pmcn$j -o p -- python $R/tools/run_one_kernel.py roi_align_fwd 5 > $O/pmcn$j.log 2>&1
 done
-python $R/tools/rocpd_pmc.py $O/pmc*/*.db | grep -v "Fill\|distribution\|elementwise" > $O/pmc_summary.txt
-tail -3 $O/bench_stdout.log | cut -c1-300; head -12 $O/bench_kernel_stats.csv | cut -c1-160; grep -c . $O/pmc_summary.txt
+python $R/tools/rocpd_pmc.py --json $O/pmc_fwd.json $O/pmc[0-9]*/*.db > $O/pmc_fwd.txt
+python $R/tools/rocpd_pmc.py --json $O/pmc_bwd.json $O/pmcb[0-9]*/*.db > $O/pmc_bwd.txt
+python $R/tools/rocpd_pmc.py --json $O/pmc_nhwc.json $O/pmcn[0-9]*/*.db > $O/pmc_nhwc.txt
+python $R/tools/make_pmc_json.py $TAG $O/pmc_fwd.json $O/pmc_bwd.json $O/pmc_nhwc.json > $O/pmc_roi_align.json
+rm -rf $O/pmc[0-9]* $O/pmcb[0-9]* $O/pmcn[0-9]* $O/bench
+cut -c1-400 $O/bench_line.json; head -14 $O/bench_kernel_stats.csv | cut -c1-160; grep hbm_bytes $O/pmc_roi_align.json

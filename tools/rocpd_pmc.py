@@ -1,9 +1,27 @@
 #!/usr/bin/env python3
-"""Print per-kernel PMC counter averages from rocprofv3 rocpd databases: python tools/rocpd_pmc.py db [db ...]"""
+"""Per-kernel PMC counter averages from rocprofv3 rocpd databases.
+    python tools/rocpd_pmc.py db [db ...]                 # text lines: kernel counter n avg
+    python tools/rocpd_pmc.py --json out.json db [...]    # {kernel: {counter: avg}} as well"""
+import json
+import re
 import sqlite3
 import sys
 
-for path in sys.argv[1:]:
+
+def short(name):
+    """`void mi::(anonymous namespace)::roi_align_fwd_records<2, 336, 32, 1>(float const*, ...)` -> `roi_align_fwd_records<2,336,32,1>`"""
+    name = name or ""
+    head = name.split("(float")[0].split("(int")[0].split("(long")[0]
+    m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)(<[^()]*>)?\s*$", head.replace("(anonymous namespace)::", ""))
+    return (m.group(1) + (m.group(2) or "")).replace(" ", "") if m else name[-50:]
+
+
+args = sys.argv[1:]
+out_json = None
+if args and args[0] == "--json":
+    out_json, args = args[1], args[2:]
+table = {}
+for path in args:
     c = sqlite3.connect(path)
     try:
         cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
@@ -13,6 +31,11 @@ for path in sys.argv[1:]:
     namecol = "kernel_name" if "kernel_name" in cols else ("name" if "name" in cols else None)
     q = ("select %s, counter_name, count(*), avg(value) from counters_collection group by 1, 2 order by 1, 2" % namecol)
     for kname, cname, n, avg in c.execute(q):
-        if "at6native" in (kname or "") or "rocclr" in (kname or ""):
+        if "at6native" in (kname or "") or "rocclr" in (kname or "") or "at::native" in (kname or ""):
             continue
-        print("%-50s %-26s n=%-4d avg=%.4g" % ((kname or "")[-50:], cname, n, avg))
+        s = short(kname)
+        print("%-46s %-28s n=%-4d avg=%.4g" % (s[:46], cname, n, avg))
+        table.setdefault(s, {})[cname] = avg
+if out_json:
+    with open(out_json, "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
