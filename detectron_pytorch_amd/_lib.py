@@ -30,6 +30,7 @@ SIGNATURES = {
     "mi_roi_align_backward_ws": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_float] + [_c_int] * 3
                                  + [_c_void_p, _c_size_t, _c_int, _c_void_p]),
     "mi_roi_align_backward_overwrites": (_c_int, [_c_int] * 8),
+    "mi_roi_align_forward_writes_records": (_c_int, [_c_int] * 8),
     "mi_roi_pool_forward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_float, _c_void_p]),
     "mi_roi_pool_backward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_float, _c_void_p]),
     "mi_roi_crop_forward": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p]),

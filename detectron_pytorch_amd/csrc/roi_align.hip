@@ -363,12 +363,12 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
                mi::roi_align_fwd_persist_workspace_bytes(num_rois));
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
-    if (layout == MI_LAYOUT_NCHW && !force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
+    if (!force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
         mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
       return mi::launch_roi_align_bwd_records(top_grad, rois, bottom_grad, workspace, (records_ready & 1) != 0,
-                                              (records_ready & 2) != 0, batch, channels, height, width, num_rois,
-                                              aligned_height, aligned_width, spatial_scale, sampling_ratio,
-                                              ring_words(), s);
+                                              (records_ready & 2) != 0, layout == MI_LAYOUT_NHWC, batch, channels,
+                                              height, width, num_rois, aligned_height, aligned_width, spatial_scale,
+                                              sampling_ratio, ring_words(), s);
   }
   if (layout == MI_LAYOUT_NCHW && use_stream_path(channels, aligned_height, aligned_width))
     return mi::launch_roi_align_bwd_stream(top_grad, rois, bottom_grad, batch, channels, height, width,
@@ -402,9 +402,23 @@ extern "C" int mi_roi_align_backward_ws(const float* top_grad, const float* rois
                                  workspace, workspace_bytes, flags, stream);
 }
 
+extern "C" int mi_roi_align_forward_writes_records(int channels, int height, int width, int num_rois,
+                                                   int aligned_height, int aligned_width, int variant, int layout) {
+  if (variant != MI_ROI_ALIGN_CAFFE2 || force_direct() || std::getenv("MI_ROI_ALIGN_NO_WS") != nullptr || num_rois <= 0)
+    return 0;
+  if (layout == MI_LAYOUT_NCHW)
+    return mi::roi_align_fwd_persist_supported(channels, height, width, num_rois, aligned_height, aligned_width) ? 1 : 0;
+  if (layout == MI_LAYOUT_NHWC)
+    return num_rois <= 8192 &&
+                   mi::roi_align_fwd_nhwc_supported(channels, height, width, num_rois, aligned_height, aligned_width)
+               ? 1
+               : 0;
+  return 0;
+}
+
 extern "C" int mi_roi_align_backward_overwrites(int channels, int height, int width, int num_rois, int aligned_height,
                                                 int aligned_width, int variant, int layout) {
-  return variant == MI_ROI_ALIGN_CAFFE2 && layout == MI_LAYOUT_NCHW && !force_direct() &&
+  return variant == MI_ROI_ALIGN_CAFFE2 && (layout == MI_LAYOUT_NCHW || layout == MI_LAYOUT_NHWC) && !force_direct() &&
                  std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
                  mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width)
              ? 1

@@ -102,9 +102,10 @@ int launch_roi_align_fwd_persist(const float* features, const float* rois, float
                                  hipStream_t stream);
 // records_ready: the workspace already holds the records of THESE rois at THIS geometry (written by a forward call)
 // overwrite: every element of bottom_grad is written (no zero fill needed) instead of accumulated into
+// nhwc: bottom_grad is stored channels-last ([N][H][W][C]); top_grad is always dense [R][C][PH][PW]
 int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float* bottom_grad, void* workspace,
-                                 bool records_ready, bool overwrite, int batch, int channels, int height, int width,
-                                 int num_rois, int aligned_height, int aligned_width, float spatial_scale,
+                                 bool records_ready, bool overwrite, bool nhwc, int batch, int channels, int height,
+                                 int width, int num_rois, int aligned_height, int aligned_width, float spatial_scale,
                                  int sampling_ratio, int cap_px, hipStream_t stream);
 bool roi_align_bwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width);

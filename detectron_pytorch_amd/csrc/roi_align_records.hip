@@ -1115,17 +1115,33 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
     }
   }
 
-  // ---- the tile leaves as 128-byte rows ----
+  // ---- the tile leaves as 128-byte rows (NCHW) or as one 4*KC-byte run per pixel (channels-last) ----
   const int row = y0 + prow, col = x0 + pcol;
   if (row < height && col < width) {
-    float* dst = bottom_grad + (((long long)n * channels + c0) * height + row) * width + col;
-    const long long plane = (long long)height * width;
+    if (overwrite & 2) {
+      float4* dst = reinterpret_cast<float4*>(bottom_grad + (((long long)n * height + row) * width + col) * channels + c0);
 #pragma unroll
-    for (int c = 0; c < KC; c++) {
-      if (overwrite)
-        dst[c * plane] = acc[c];
-      else
-        dst[c * plane] += acc[c];
+      for (int c4 = 0; c4 < KC / 4; c4++) {
+        float4 v = make_float4(acc[4 * c4 + 0], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
+        if (!(overwrite & 1)) {
+          const float4 o = dst[c4];
+          v.x += o.x;
+          v.y += o.y;
+          v.z += o.z;
+          v.w += o.w;
+        }
+        dst[c4] = v;
+      }
+    } else {
+      float* dst = bottom_grad + (((long long)n * channels + c0) * height + row) * width + col;
+      const long long plane = (long long)height * width;
+#pragma unroll
+      for (int c = 0; c < KC; c++) {
+        if (overwrite & 1)
+          dst[c * plane] = acc[c];
+        else
+          dst[c * plane] += acc[c];
+      }
     }
   }
 }
@@ -1134,7 +1150,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
 __global__ void __launch_bounds__(256)
 roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__ rois, float* __restrict__ bottom_grad,
                    const int* __restrict__ ws, int num_rois, int batch, int channels, int height, int width,
-                   int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio) {
+                   int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio, int nhwc) {
   const int tiles = channels / kCT;
   const int pos = blockIdx.x / tiles;
   const int c0 = (blockIdx.x - pos * tiles) * kCT;
@@ -1145,11 +1161,13 @@ roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__
   const int tid = threadIdx.x;
   const float* __restrict__ gsrc = top_grad + ((long long)r * channels + c0) * bins;
   const RoiGeom g = roi_geometry(rois + (long long)r * 5, spatial_scale, aligned_height, aligned_width, sampling_ratio);
-  float* gdst = bottom_grad + ((long long)g.batch_ind * channels + c0) * height * width;
+  // element strides of (channel, pixel) in the gradient map: NCHW or channels-last
+  const long long cs = nhwc ? 1 : (long long)height * width, ps = nhwc ? channels : 1;
+  float* gdst = bottom_grad + (long long)g.batch_ind * channels * height * width + c0 * cs;
   for (int i = tid; i < kCT * bins; i += 256) {
     const int c = i / bins, bin = i - c * bins;
     const int ph = bin / aligned_width, pw = bin - ph * aligned_width;
-    float* plane = gdst + (long long)c * height * width;
+    float* plane = gdst + (long long)c * cs;
     const float top_diff_this_bin = gsrc[i];
     for (int iy = 0; iy < g.grid_h; iy++) {
       const float y = sample_y(g, ph, iy);
@@ -1157,10 +1175,10 @@ roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__
         const float x = sample_x(g, pw, ix);
         const Taps t = sample_taps(height, width, y, x);
         if (t.y_low < 0) continue;
-        atomicAdd(plane + t.y_low * width + t.x_low, top_diff_this_bin * t.w1 / g.count);
-        atomicAdd(plane + t.y_low * width + t.x_high, top_diff_this_bin * t.w2 / g.count);
-        atomicAdd(plane + t.y_high * width + t.x_low, top_diff_this_bin * t.w3 / g.count);
-        atomicAdd(plane + t.y_high * width + t.x_high, top_diff_this_bin * t.w4 / g.count);
+        atomicAdd(plane + (t.y_low * width + t.x_low) * ps, top_diff_this_bin * t.w1 / g.count);
+        atomicAdd(plane + (t.y_low * width + t.x_high) * ps, top_diff_this_bin * t.w2 / g.count);
+        atomicAdd(plane + (t.y_high * width + t.x_low) * ps, top_diff_this_bin * t.w3 / g.count);
+        atomicAdd(plane + (t.y_high * width + t.x_high) * ps, top_diff_this_bin * t.w4 / g.count);
       }
     }
   }
@@ -1236,8 +1254,8 @@ int launch_prepare_only(const float* rois, int* ws, int batch, int height, int w
 }  // namespace
 
 int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float* bottom_grad, void* workspace,
-                                 bool records_ready, bool overwrite, int batch, int channels, int height, int width,
-                                 int num_rois, int aligned_height, int aligned_width, float spatial_scale,
+                                 bool records_ready, bool overwrite, bool nhwc, int batch, int channels, int height,
+                                 int width, int num_rois, int aligned_height, int aligned_width, float spatial_scale,
                                  int sampling_ratio, int cap_px, hipStream_t stream) {
   int* ws = static_cast<int*>(workspace);
   if (!records_ready) {
@@ -1266,7 +1284,7 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
     roi_align_bwd_tiles<SR, KC, TH><<<grid, TH * 32, lds, stream>>>(                                                 \
         top_grad, bottom_grad, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width, tiles_x,  \
-        tiles_y, overwrite ? 1 : 0, g_ablate_p & 7, g_words, ah_pad, g_cs);                                           \
+        tiles_y, (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs);                                           \
   } while (0)
 #define MI_LAUNCH_TILES(SR, KC)                                                                                       \
   do {                                                                                                                \
@@ -1294,7 +1312,8 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
   if (!(g_ablate_p & 16))
     roi_align_bwd_slow<<<num_rois * (channels / kCT), 256, 0, stream>>>(top_grad, rois, bottom_grad, ws, num_rois, batch,
                                                                     channels, height, width, aligned_height,
-                                                                    aligned_width, spatial_scale, sampling_ratio);
+                                                                    aligned_width, spatial_scale, sampling_ratio,
+                                                                    nhwc ? 1 : 0);
   return check_launch("roi_align_bwd_slow");
 }
 

@@ -18,8 +18,6 @@ Behaviour preserved: CPU `features` -> NotImplementedError (:29-30); no gradient
 New: features stored channels_last are consumed in place (layout flag of the C-ABI) instead of
 being copied to NCHW.
 """
-import os
-
 import torch
 from torch.autograd import Function
 from torch.nn.modules.module import Module
@@ -84,12 +82,6 @@ def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_
     grad_output = grad_output.contiguous()
     rois = rois.contiguous()
     n, c, h, w = feature_size
-    if channels_last and variant == _lib.ROI_ALIGN_CAFFE2 and os.environ.get("MI_ROI_ALIGN_IMPL") != "direct":
-        # gradient for channels_last features: the atomic-free NCHW tile kernel, then one layout change (a strided
-        # copy) -- 5x faster than scattering atomics into NHWC storage, and deterministic
-        grad = roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_width, spatial_scale,
-                                  sampling_ratio, variant, channels_last=False, workspace=workspace)
-        return grad.contiguous(memory_format=torch.channels_last)
     fmt = torch.channels_last if (channels_last and variant == _lib.ROI_ALIGN_CAFFE2) else torch.contiguous_format
     layout = _lib.LAYOUT_NHWC if fmt is torch.channels_last else _lib.LAYOUT_NCHW
     lib = _lib.lib()
@@ -127,9 +119,13 @@ class _RoIAlign(Function):
         ctx.channels_last = (features.dim() == 4 and not features.is_contiguous()
                              and features.is_contiguous(memory_format=torch.channels_last))
         output, workspace = roi_align_forward(features, rois, *ctx.cfg, return_workspace=True)
-        # the records are valid for the backward only if it uses the fast NCHW path on the same rois
-        nchw = features.is_contiguous() and variant == _lib.ROI_ALIGN_CAFFE2
-        ctx.save_for_backward(rois, workspace if nchw else rois.new_empty(0))
+        # the records the forward left in the workspace serve the backward over the same rois (both layouts run
+        # roi_align_prepare); whether they were written is the library's business: the flag is only a promise that
+        # nothing else touched the buffer
+        reuse = variant == _lib.ROI_ALIGN_CAFFE2 and _lib.lib().mi_roi_align_forward_writes_records(
+            features.size(1), features.size(2), features.size(3), rois.size(0), ctx.cfg[0], ctx.cfg[1],
+            int(variant), _lib.LAYOUT_NHWC if ctx.channels_last else _lib.LAYOUT_NCHW)
+        ctx.save_for_backward(rois, workspace if reuse else rois.new_empty(0))
         return output
 
     @staticmethod

@@ -98,8 +98,9 @@ int mi_roi_align_backward(const float* top_grad, const float* rois, float* botto
  *                               touched it since): the record launch is skipped;
  *   MI_ROI_ALIGN_OVERWRITE      bottom_grad is fully WRITTEN (no zero fill by the caller needed) instead of
  *                               accumulated into (the reference contract, functions/roi_align.py:39-44).  Honoured on
- *                               the NCHW tile path only; test mi_roi_align_backward_overwrites() before relying on it.
- * On NCHW this path is a gather over tiles of bottom_grad: no atomics, deterministic summation order. */
+ *                               the tile path only (NCHW or channels-last bottom_grad); test
+ *                               mi_roi_align_backward_overwrites() before relying on it.
+ * The tile path is a gather over tiles of bottom_grad: no atomics, deterministic summation order. */
 #define MI_ROI_ALIGN_RECORDS_READY 1
 #define MI_ROI_ALIGN_OVERWRITE 2
 int mi_roi_align_backward_ws(const float* top_grad, const float* rois, float* bottom_grad,
@@ -107,6 +108,10 @@ int mi_roi_align_backward_ws(const float* top_grad, const float* rois, float* bo
                              int aligned_height, int aligned_width, float spatial_scale,
                              int sampling_ratio, int variant, int layout,
                              void* workspace, size_t workspace_bytes, int flags, mi_stream_t stream);
+/* 1 when mi_roi_align_forward_ws with these arguments leaves the records of its rois in the workspace (so that a
+ * backward over the same rois may pass MI_ROI_ALIGN_RECORDS_READY); 0 when it takes a path without records. */
+int mi_roi_align_forward_writes_records(int channels, int height, int width, int num_rois, int aligned_height,
+                                        int aligned_width, int variant, int layout);
 /* 1 when mi_roi_align_backward_ws would honour MI_ROI_ALIGN_OVERWRITE for these arguments (with a workspace). */
 int mi_roi_align_backward_overwrites(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width, int variant, int layout);
