@@ -221,11 +221,9 @@ bool use_stream_path(int channels, int aligned_height, int aligned_width) {
 int ring_words() {
   const char* ab = std::getenv("MI_ROI_ALIGN_ABLATE");
   mi::roi_align_fwd_tile_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
-  mi::roi_align_fwd_persist_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
+  mi::roi_align_records_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
   const char* th = std::getenv("MI_ROI_ALIGN_BWD_TH");
   mi::roi_align_bwd_set_tile_rows(th != nullptr ? std::atoi(th) : 16);
-  const char* ct = std::getenv("MI_ROI_ALIGN_CT");
-  mi::roi_align_fwd_persist_set_mode(std::getenv("MI_ROI_ALIGN_PERSIST") != nullptr, ct != nullptr ? std::atoi(ct) : 32);
   const char* nv = std::getenv("MI_ROI_ALIGN_NHWC_V");
   const char* npb = std::getenv("MI_ROI_ALIGN_NHWC_PB");
   const char* nom = std::getenv("MI_ROI_ALIGN_NHWC_ORDER_MUL");
@@ -260,7 +258,6 @@ int check_common(const void* a, const void* rois, const void* b, int batch, int 
 // (tools/timeline.py); nullptr switches the stamps off.
 extern "C" void mi_dbg_roi_align_timeline(long long* device_buffer) {
   mi::roi_align_fwd_tile_set_timeline(device_buffer);
-  mi::roi_align_fwd_persist_set_timeline(device_buffer);
   mi::roi_align_fwd_nhwc_set_timeline(device_buffer);
 }
 
@@ -285,13 +282,13 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
   }
   const int cap = ring_words();
   if (workspace != nullptr) {
-    MI_REQUIRE(workspace_bytes >= mi::roi_align_fwd_persist_workspace_bytes(num_rois),
+    MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
-               mi::roi_align_fwd_persist_workspace_bytes(num_rois));
+               mi::roi_align_records_workspace_bytes(num_rois));
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
     if (layout == MI_LAYOUT_NCHW && !force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
-        mi::roi_align_fwd_persist_supported(channels, height, width, num_rois, aligned_height, aligned_width))
-      return mi::launch_roi_align_fwd_persist(features, rois, output, workspace, batch, channels, height, width,
+        mi::roi_align_fwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
+      return mi::launch_roi_align_fwd_records(features, rois, output, workspace, batch, channels, height, width,
                                               num_rois, aligned_height, aligned_width, spatial_scale,
                                               sampling_ratio, cap, s);
     if (layout == MI_LAYOUT_NHWC && !force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
@@ -326,7 +323,7 @@ extern "C" int mi_roi_align_forward(const float* features, const float* rois, fl
 }
 
 extern "C" size_t mi_roi_align_forward_workspace_bytes(int num_rois) {
-  return mi::roi_align_fwd_persist_workspace_bytes(num_rois);
+  return mi::roi_align_records_workspace_bytes(num_rois);
 }
 
 extern "C" int mi_roi_align_forward_ws(const float* features, const float* rois, float* output,
@@ -359,9 +356,9 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
     return mi::check_launch("roi_align_legacy_bwd");
   }
   if (workspace != nullptr) {
-    MI_REQUIRE(workspace_bytes >= mi::roi_align_fwd_persist_workspace_bytes(num_rois),
+    MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
-               mi::roi_align_fwd_persist_workspace_bytes(num_rois));
+               mi::roi_align_records_workspace_bytes(num_rois));
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
     if (!force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
         mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
@@ -407,7 +404,7 @@ extern "C" int mi_roi_align_forward_writes_records(int channels, int height, int
   if (variant != MI_ROI_ALIGN_CAFFE2 || force_direct() || std::getenv("MI_ROI_ALIGN_NO_WS") != nullptr || num_rois <= 0)
     return 0;
   if (layout == MI_LAYOUT_NCHW)
-    return mi::roi_align_fwd_persist_supported(channels, height, width, num_rois, aligned_height, aligned_width) ? 1 : 0;
+    return mi::roi_align_fwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width) ? 1 : 0;
   if (layout == MI_LAYOUT_NHWC)
     return num_rois <= 8192 &&
                    mi::roi_align_fwd_nhwc_supported(channels, height, width, num_rois, aligned_height, aligned_width)

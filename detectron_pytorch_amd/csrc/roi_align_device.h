@@ -88,15 +88,13 @@ int launch_roi_align_fwd_tile(const float* features, const float* rois, float* o
                               float spatial_scale, int sampling_ratio, int ring_words, hipStream_t stream);
 void roi_align_fwd_tile_set_timeline(long long* device_buffer);
 void roi_align_fwd_tile_set_ablate(int mask);
-// two-launch forward fast path with caller scratch (roi_align_fwd_persist.hip)
-void roi_align_fwd_persist_set_ablate(int mask);
-void roi_align_fwd_persist_set_mode(bool persistent, int channels_per_workgroup);
+// two-launch forward fast path with caller scratch (roi_align_records.hip)
+void roi_align_records_set_ablate(int mask);
 void roi_align_bwd_set_tile_rows(int rows);
-void roi_align_fwd_persist_set_timeline(long long* device_buffer);
-size_t roi_align_fwd_persist_workspace_bytes(int num_rois);
-bool roi_align_fwd_persist_supported(int channels, int height, int width, int num_rois, int aligned_height,
+size_t roi_align_records_workspace_bytes(int num_rois);
+bool roi_align_fwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width);
-int launch_roi_align_fwd_persist(const float* features, const float* rois, float* output, void* workspace, int batch,
+int launch_roi_align_fwd_records(const float* features, const float* rois, float* output, void* workspace, int batch,
                                  int channels, int height, int width, int num_rois, int aligned_height,
                                  int aligned_width, float spatial_scale, int sampling_ratio, int cap_px,
                                  hipStream_t stream);
@@ -109,7 +107,7 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
                                  int sampling_ratio, int cap_px, hipStream_t stream);
 bool roi_align_bwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width);
-// records only (the first launch of the two-launch paths); `workspace` as roi_align_fwd_persist_workspace_bytes
+// records only (the first launch of the two-launch paths); `workspace` as roi_align_records_workspace_bytes
 int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,
                              int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
                              hipStream_t stream);

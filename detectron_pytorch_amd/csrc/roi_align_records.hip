@@ -10,15 +10,12 @@
 //       the main kernel walks the feature map coherently: rocprofv3 TCC counters on the config-2 input (512 RoIs in
 //       random order) show 235 MB of fabric reads per call in arrival order and 67 MB in sweep order, against
 //       60 MB of distinct bytes -- in arrival order the gather is bound by the Infinity-Cache -> L2 rate.
-//   roi_align_fwd_persist   persistent workgroups (3 per CU), each bound to one 32-channel tile (== one XCD when
-//       C = 256: a tile's slab of the feature map is served by one L2) and to one contiguous slice of the sweep.
-//       Per stage:   wait own DMA | B1 | issue the NEXT stage's LDS-DMA into the free part of the LDS image |
-//                    store the previous stage's outputs | bins of this stage: LDS image -> LDS tile | B2 |
-//                    tile -> registers
-//       so the landing of a window, the record fetch of the next RoI and the output stores all sit under a compute
-//       phase; what remains serial inside a workgroup is DMA issue (bound by the L2 -> L1 fill rate of the CU) and
-//       the arithmetic.  RoIs are dealt statically (round-robin inside the slice) except for the last rounds of a
-//       slice, which are drawn from a ticket counter to even out the different RoI sizes.
+//   roi_align_fwd_records   one 256-lane workgroup per (rank, 32-channel tile); tile index = blockIdx % 8, i.e. the
+//       slab of the feature map a tile reads is served by one XCD's L2.  Record by scalar load -> window by LDS-DMA ->
+//       one vmcnt(0) + barrier -> bins -> LDS tile -> contiguous 16-byte stores.  (A persistent variant that
+//       prefetched the next window under the arithmetic of the current one measured 66 us against 40 us -- per-stage
+//       overheads -- and was removed; so were 16-channel workgroups, which gained nothing.)
+//   roi_align_bwd_tiles / roi_align_bwd_slow   the backward over the same records (see below).
 //
 // Data movement and arithmetic are those of roi_align_fwd_tile.hip (see its header): LDS-DMA of the compact
 // [row][ww] window into one odd-stride plane per channel, lane & 31 = channel, conflict-free ds_read2_b32 tap pairs,
@@ -38,8 +35,6 @@ namespace {
 constexpr int kCT = 32;                    // channels per workgroup
 constexpr int kThreads = 256;
 constexpr int kSlots = kThreads / 32;      // half-waves; each owns output columns pw = slot, slot + 8, ...
-constexpr int kWaves = kThreads / 64;
-constexpr int kChPerWave = kCT / kWaves;   // planes a wave fills
 constexpr int kTileBins = 56;              // output bins per channel staged in LDS between two stores
 constexpr int kMaxRois = 8192;             // the rank pass keeps one key per RoI in LDS
 constexpr int kBandRows = 16;              // feature rows per sweep band
@@ -236,23 +231,6 @@ struct TabEntry {
   int lo;
 };
 
-template <int kCap>
-struct Lds {
-  static constexpr int kPlane = kCap | 1;  // odd plane stride (words)
-  static constexpr int kTileWords = kCT * (kTileBins + 1);
-  TabEntry* tab;  // [2 buffers][y: kMaxS | x: kMaxS]
-  int* scratch;   // [4]: positions of the workgroup's upcoming items
-  float* tile;    // [kCT][ts]
-  float* img;     // [kCT][kPlane]
-  __device__ __forceinline__ explicit Lds(float* smem) {
-    tab = reinterpret_cast<TabEntry*>(smem);
-    scratch = reinterpret_cast<int*>(tab + 4 * kMaxS);
-    tile = reinterpret_cast<float*>(scratch + 4);
-    img = tile + kTileWords;
-  }
-  static constexpr size_t bytes() { return 4 * kMaxS * sizeof(TabEntry) + 16 + (size_t)(kTileWords + kCT * kPlane) * 4; }
-};
-
 using lds_ptr_t = __attribute__((address_space(3))) void*;
 using lds_cfloat_t = __attribute__((address_space(3))) const float*;
 using const_int_ptr = const __attribute__((address_space(4))) int*;
@@ -298,390 +276,10 @@ __device__ __forceinline__ unsigned lds_addr_uniform(const void* p) {
   return (unsigned)uniform((int)(unsigned)(uintptr_t)(lds_cfloat_t)p);
 }
 
-// wave-uniform description of one stage of one RoI
-struct Desc {
-  int valid;
-  int pos;                                                   // rank == record index
-  int r, flags, batch_ind, wx0, ww, magic, nstages, gh, gw;  // record header
-  int stage_idx, ph0, ph1, row0, nrows;                      // stage
-  int tb;                                                    // table buffer of the RoI
-};
-
-// kSR > 0: sampling_ratio == kSR at compile time.
-template <int kSR, int kCap>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
-roi_align_fwd_persist(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
-                      int* __restrict__ ws, int num_rois, int batch, int channels, int height, int width,
-                      int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio, int ablate,
-                      long long* __restrict__ timeline) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Lds<kCap> s(smem);
-  constexpr int kPlane = Lds<kCap>::kPlane;
-  const int tid = threadIdx.x;
-  const int bins = aligned_height * aligned_width;
-  const int tiles = channels / kCT;
-  const int tile_id = blockIdx.x % tiles;
-  const int c0 = tile_id * kCT;
-  const int wave = uniform(tid >> 6), lane = tid & 63;
-  const int cl = tid & 31, slot = tid >> 5;
-  const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
-  const float* img_c = s.img + cl * kPlane;
-  const int* __restrict__ records = ws + kCounterDwords;
-  // tuning aid (tools/timeline_persist.py): 8 s_memtime stamps per loop iteration, first 8 iterations of a workgroup
-  int iter = 0;
-  auto stamp = [&](int k) {
-    if (timeline != nullptr && tid == 0 && iter < 8) timeline[((long long)blockIdx.x * 8 + iter) * 8 + k] = (long long)clock64();
-  };
-
-  // ---- which RoIs this workgroup handles ----
-  // The sweep is cut into `groups` contiguous slices; the workgroups of a tile are dealt round-robin to the slices.
-  // Inside a slice the first `static_rounds` rounds are dealt statically (no atomics, positions known in advance);
-  // the rest is drawn from the slice's ticket counter (few contenders per counter: a returning atomic on a word
-  // hammered by ~100 workgroups takes microseconds).
-  const int wgs_per_tile = (int)gridDim.x / tiles;
-  const int groups = max(1, min(kCounterDwords / tiles, wgs_per_tile / 8));
-  const int group = (blockIdx.x / tiles) % groups;
-  const int j = (blockIdx.x / tiles) / groups;  // index inside the group
-  const int n_wg = wgs_per_tile / groups + ((wgs_per_tile % groups) > group ? 1 : 0);
-  const int slice = (num_rois + groups - 1) / groups;
-  const int slice_begin = group * slice, slice_end = min(num_rois, slice_begin + slice);
-  const int slice_len = max(slice_end - slice_begin, 0);
-  const int static_rounds = max(0, slice_len / n_wg - 1);
-  const int dyn_begin = slice_begin + static_rounds * n_wg;
-  int* __restrict__ counter = ws + tile_id * groups + group;
-  // position (rank) of this workgroup's q-th item; thread 0 only (the dynamic part is a blocking atomic)
-  auto position = [&](int q) -> int {
-    if (q < static_rounds) return slice_begin + j + q * n_wg;
-    const int t = dyn_begin + atomicAdd(counter, 1);
-    return t < slice_end ? t : kNoItem;
-  };
-
-  auto load_header = [&](int pos, int tb) -> Desc {
-    Desc d;
-    d.valid = pos != kNoItem;
-    d.pos = pos;
-    d.tb = tb;
-    d.stage_idx = 0;
-    d.ph0 = d.ph1 = d.row0 = d.nrows = 0;
-    d.r = d.flags = d.batch_ind = d.wx0 = d.magic = d.nstages = 0;
-    d.ww = d.gh = d.gw = 1;
-    if (d.valid) {
-      // read-only, wave-uniform addresses: constant-address-space pointers make these scalar loads (SGPR results,
-      // lgkmcnt) instead of vector loads queued behind the DMA (vmcnt)
-      const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)uniform(pos) * kRecDwords);
-      d.flags = rec[0];
-      d.batch_ind = rec[1];
-      d.wx0 = rec[2];
-      d.ww = rec[3];
-      d.magic = rec[4];
-      d.nstages = rec[5];
-      d.gh = rec[6];
-      d.gw = rec[7];
-      d.r = rec[8];
-    }
-    return d;
-  };
-  auto load_stage = [&](Desc& d) {
-    const const_int_ptr st =
-        (const_int_ptr)(uintptr_t)(records + (long long)uniform(d.pos) * kRecDwords + kRecStages + 4 * uniform(d.stage_idx));
-    const int p = st[0];
-    d.ph0 = p & 0xffff;
-    d.ph1 = p >> 16;
-    d.row0 = st[1];
-    d.nrows = st[2];
-  };
-  // LDS-DMA of window rows [row0, row0 + nrows) of this wave's 8 channels -> img[channel][off + (row - row0) * ww + col]
-  auto issue_dma = [&](const Desc& d, int off) {
-    const float* src = feat + ((long long)d.batch_ind * channels + c0 + wave * kChPerWave) * height * width;
-    const srd_t srd = make_srd(src, (unsigned)kChPerWave * plane_bytes);
-    const int npx = d.nrows * d.ww;
-    const unsigned plane0 = lds_addr_uniform(s.img + wave * kChPerWave * kPlane + off);
-    for (int k = 0; k * 64 < npx; k++) {
-      const unsigned p = (unsigned)(k * 64 + lane);
-      const unsigned q = (p * (unsigned)d.magic) >> 20;  // p / ww
-      const unsigned col = p - q * (unsigned)d.ww;
-      const unsigned voff = (((unsigned)d.row0 + q) * (unsigned)width + (unsigned)d.wx0 + col) * 4u;
-      if (p < (unsigned)npx) {  // lanes past the window neither read memory nor write LDS
-#pragma unroll
-        for (int c = 0; c < kChPerWave; c++)
-          dma_dword(srd, plane0 + (unsigned)(c * kPlane + k * 64) * 4u, voff, (unsigned)c * plane_bytes);
-      }
-    }
-  };
-  // the RoI's axis tables: record -> LDS by LDS-DMA as well (wave 0: y table, wave 1: x table), so that they land
-  // under the same vmcnt(0) + barrier as the image and never force an early wait
-  auto copy_tables = [&](const Desc& d) {
-    if (wave >= 2) return;
-    const int n = (wave == 0 ? aligned_height * d.gh : aligned_width * d.gw) * 4;  // dwords
-    const int* tab = records + (long long)d.pos * kRecDwords + (wave == 0 ? kRecY : kRecX);
-    const srd_t srd = make_srd(tab, 4 * kMaxS * 4);
-    const unsigned dstl = lds_addr_uniform(s.tab + (d.tb * 2 + wave) * kMaxS);
-    for (int k = 0; k * 64 < n; k++) dma_dword(srd, dstl + (unsigned)k * 256u, (unsigned)(k * 64 + lane) * 4u, 0u);
-  };
-  auto wait_vm = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
-  // ---- item queue: scratch[q % 3] holds the position of the workgroup's q-th item ----
-  int q_next = 0;  // next item index whose position has not been consumed yet
-  bool exhausted = false;
-  // descriptor that follows `d` (next stage of the same RoI, or the first stage of the workgroup's next RoI).
-  // Crossing to a new RoI consumes scratch[q_next % 3] and lets thread 0 refill the slot two items ahead; callers
-  // guarantee a barrier between two consecutive crossings.
-  auto advance = [&](const Desc& d) -> Desc {
-    if (d.valid && (d.flags & kFlagFast) && d.stage_idx + 1 < d.nstages) {
-      Desc n = d;
-      n.stage_idx = d.stage_idx + 1;
-      load_stage(n);
-      return n;
-    }
-    const int pos = exhausted ? kNoItem : uniform(s.scratch[q_next % 3]);
-    if (pos == kNoItem) exhausted = true;  // positions are monotone: once a slice is used up it stays so
-    if (!exhausted && tid == 0) s.scratch[(q_next + 2) % 3] = position(q_next + 2);
-    q_next++;
-    Desc n = load_header(pos, d.tb ^ 1);
-    if (n.valid && (n.flags & kFlagFast)) load_stage(n);
-    return n;
-  };
-
-  if (tid == 0) {
-    const int p0 = position(0);
-    s.scratch[0] = p0;
-    s.scratch[1] = p0 != kNoItem ? position(1) : kNoItem;
-    s.scratch[2] = kNoItem;
-  }
-  __syncthreads();
-  Desc seed;
-  seed.valid = 0;
-  seed.flags = 0;
-  seed.stage_idx = seed.nstages = 0;
-  seed.tb = 1;
-  Desc cur = advance(seed);  // consumes slot 0, thread 0 fills slot 2
-  if (!cur.valid) return;
-  __syncthreads();
-  int cur_off = 0;
-  bool cur_issued = false;
-  if (cur.flags & kFlagFast) {
-    if (!(ablate & 1)) issue_dma(cur, 0);
-    copy_tables(cur);
-    cur_issued = true;
-  }
-  Desc next = advance(cur);  // next stage of cur, or consumes slot 1 (thread 0 fills slot 0)
-
-  // outputs of the previous stage, held in registers until they are stored under the next compute phase
-  float4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-  float4* pend_dst = nullptr;
-  int pend_n4 = 0;
-  auto flush_pending = [&]() {
-    if (pend_dst != nullptr) {
-      if (tid < pend_n4) pend_dst[tid] = o0;
-      if (tid + kThreads < pend_n4) pend_dst[tid + kThreads] = o1;
-      pend_dst = nullptr;
-    }
-  };
-
-  for (;;) {
-    if (!cur.valid) {
-      flush_pending();
-      return;
-    }
-    float* __restrict__ dst = out + ((long long)cur.r * channels + c0) * bins;
-    if (!(cur.flags & kFlagFast)) {
-      // ---- zero output / direct path for this (RoI, channel tile): reference mapping and operation order ----
-      flush_pending();
-      if (cur.flags & kFlagZero) {
-        for (int i = tid; i < kCT * bins; i += kThreads) dst[i] = 0.f;
-      } else {
-        const RoiGeom g = roi_geometry(rois + (long long)cur.r * 5, spatial_scale, aligned_height, aligned_width,
-                                       sampling_ratio);
-        const float* src = feat + ((long long)g.batch_ind * channels + c0) * height * width;
-        for (int i = tid; i < kCT * bins; i += kThreads) {
-          const int c = i / bins, bin = i - c * bins;
-          const int ph = bin / aligned_width, pw = bin - ph * aligned_width;
-          const float* plane = src + (long long)c * height * width;
-          float output_val = 0.f;
-          for (int iy = 0; iy < g.grid_h; iy++) {
-            const float y = sample_y(g, ph, iy);
-            for (int ix = 0; ix < g.grid_w; ix++) {
-              const float x = sample_x(g, pw, ix);
-              const Taps t = sample_taps(height, width, y, x);
-              float val = 0.f;
-              if (t.y_low >= 0) {
-                const float v1 = plane[t.y_low * width + t.x_low], v2 = plane[t.y_low * width + t.x_high];
-                const float v3 = plane[t.y_high * width + t.x_low], v4 = plane[t.y_high * width + t.x_high];
-                val = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t.w1, v1), __fmul_rn(t.w2, v2)), __fmul_rn(t.w3, v3)),
-                                __fmul_rn(t.w4, v4));
-              }
-              output_val = __fadd_rn(output_val, val);
-            }
-          }
-          dst[i] = output_val / g.count;
-        }
-      }
-      __syncthreads();  // separates two crossings of advance()
-      cur = next;
-      cur_issued = false;
-      cur_off = 0;
-      next = advance(cur);
-      continue;
-    }
-
-    // ---- B1: this stage's DMA has landed (every wave waits for its own pieces BEFORE the barrier: lanes read all
-    // 32 planes, most of them filled by other waves) and the RoI's tables are visible ----
-    stamp(0);
-    if (!cur_issued) {  // it could not be prefetched (the free part of the image was too small)
-      if (!(ablate & 1)) issue_dma(cur, cur_off);
-      if (cur.stage_idx == 0) copy_tables(cur);
-    }
-    wait_vm();
-    stamp(1);
-    __syncthreads();
-    stamp(2);
-
-    // ---- prefetch the next stage into the part of the image this stage does not occupy ----
-    const int cur_px = cur.nrows * cur.ww;
-    int next_off = 0;
-    bool next_issued = false;
-    if (next.valid && (next.flags & kFlagFast)) {
-      const int next_px = next.nrows * next.ww;
-      next_off = (cur_off + cur_px + next_px <= kCap) ? cur_off + cur_px : 0;
-      const bool disjoint = next_off >= cur_off + cur_px || next_off + next_px <= cur_off;
-      if (disjoint) {
-        if (!(ablate & 1)) issue_dma(next, next_off);
-        if (next.stage_idx == 0) copy_tables(next);
-        next_issued = true;
-      }
-    }
-    stamp(3);
-    flush_pending();  // the previous stage's outputs drain under this compute phase
-
-    const int pitch = cur.ww * 4;
-    const int base_off = cur.row0 * pitch - cur_off * 4;  // y table offsets are row_lo * pitch
-    const int nb = (cur.ph1 - cur.ph0) * aligned_width;
-    const int ts = nb | 1;
-    const int gh = kSR > 0 ? kSR : cur.gh, gw = kSR > 0 ? kSR : cur.gw;
-    const TabEntry* ty = s.tab + (cur.tb * 2 + 0) * kMaxS;
-    const TabEntry* tx = s.tab + (cur.tb * 2 + 1) * kMaxS;
-
-    if (ablate & 2) {
-    } else if (kSR > 0) {
-      constexpr int kS = kSR > 0 ? kSR : 1;
-      for (int pw = slot; pw < aligned_width; pw += kSlots) {
-        float hx[kS], lx[kS];
-        unsigned xa[kS];
-#pragma unroll
-        for (int i = 0; i < kS; i++) {
-          const TabEntry ex = tx[pw * kS + i];
-          hx[i] = ex.hw;
-          lx[i] = ex.lw;
-          xa[i] = lds_addr_opaque(lds_at(img_c, ex.off - base_off));
-        }
-        // kN bin rows at a time: all their taps in flight before the first use
-        auto rows = [&](int ph, auto kn) {
-          constexpr int kN = decltype(kn)::value;
-          float v[kN][kS][2][kS][2];
-          float wy[kN][kS][2];
-#pragma unroll
-          for (int b = 0; b < kN; b++) {
-#pragma unroll
-            for (int iy = 0; iy < kS; iy++) {
-              const TabEntry ey = ty[(ph + b) * kS + iy];
-              wy[b][iy][0] = ey.hw;
-              wy[b][iy][1] = ey.lw;
-#pragma unroll
-              for (int ix = 0; ix < kS; ix++) {
-                const unsigned a = xa[ix] + (unsigned)ey.off;
-                lds_pair(a, v[b][iy][0][ix][0], v[b][iy][0][ix][1]);
-                lds_pair(a + (unsigned)pitch, v[b][iy][1][ix][0], v[b][iy][1][ix][1]);
-              }
-            }
-          }
-#pragma unroll
-          for (int b = 0; b < kN; b++) {
-            float acc = 0.f;
-#pragma unroll
-            for (int iy = 0; iy < kS; iy++) {
-#pragma unroll
-              for (int k = 0; k < 2; k++) {
-                float rsum = hx[0] * v[b][iy][k][0][0];
-                rsum = __builtin_fmaf(lx[0], v[b][iy][k][0][1], rsum);
-#pragma unroll
-                for (int ix = 1; ix < kS; ix++) {
-                  rsum = __builtin_fmaf(hx[ix], v[b][iy][k][ix][0], rsum);
-                  rsum = __builtin_fmaf(lx[ix], v[b][iy][k][ix][1], rsum);
-                }
-                acc = __builtin_fmaf(wy[b][iy][k], rsum, acc);
-              }
-            }
-            s.tile[cl * ts + (ph + b - cur.ph0) * aligned_width + pw] = acc;
-          }
-        };
-        int ph = cur.ph0;
-        for (; ph + 3 <= cur.ph1; ph += 3) rows(ph, std::integral_constant<int, 3>());
-        switch (cur.ph1 - ph) {
-          case 2: rows(ph, std::integral_constant<int, 2>()); break;
-          case 1: rows(ph, std::integral_constant<int, 1>()); break;
-          default: break;
-        }
-      }
-    } else {
-      for (int pw = slot; pw < aligned_width; pw += kSlots) {
-        for (int ph = cur.ph0; ph < cur.ph1; ph++) {
-          float acc = 0.f;
-          for (int iy = 0; iy < gh; iy++) {
-            const TabEntry ey = ty[ph * gh + iy];
-            float r0s = 0.f, r1s = 0.f;
-            for (int ix = 0; ix < gw; ix++) {
-              const TabEntry ex = tx[pw * gw + ix];
-              const float* a = lds_at(img_c, ey.off + ex.off - base_off);
-              const float* b = lds_at(a, pitch);
-              r0s = __builtin_fmaf(ex.hw, a[0], r0s);
-              r0s = __builtin_fmaf(ex.lw, a[1], r0s);
-              r1s = __builtin_fmaf(ex.hw, b[0], r1s);
-              r1s = __builtin_fmaf(ex.lw, b[1], r1s);
-            }
-            acc = __builtin_fmaf(ey.hw, r0s, acc);
-            acc = __builtin_fmaf(ey.lw, r1s, acc);
-          }
-          s.tile[cl * ts + (ph - cur.ph0) * aligned_width + pw] = acc;
-        }
-      }
-    }
-    stamp(4);
-    // ---- B2: the output tile is complete ----
-    __syncthreads();
-    stamp(5);
-    float* gdst = dst + cur.ph0 * aligned_width;
-    const bool vec_store = nb == bins && ts == nb && ((kCT * nb) & 3) == 0 &&
-                           (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && kCT * nb / 4 <= 2 * kThreads;
-    if (ablate & 4) {
-    } else if (vec_store) {
-      // tile -> registers now (LDS reads issued after a later LDS-DMA would be ordered behind its landing: the
-      // compiler cannot tell tile from image); stored under the next compute phase
-      const float4* t4 = reinterpret_cast<const float4*>(s.tile);
-      pend_n4 = kCT * nb / 4;
-      pend_dst = reinterpret_cast<float4*>(dst);
-      if (tid < pend_n4) o0 = t4[tid];
-      if (tid + kThreads < pend_n4) o1 = t4[tid + kThreads];
-    } else {
-      const unsigned nb_magic = (1u << 20) / (unsigned)nb + 1u;
-      for (int i = tid; i < kCT * nb; i += kThreads) {
-        const int c = (int)(((unsigned)i * nb_magic) >> 20), b = i - c * nb;
-        gdst[(long long)c * bins + b] = s.tile[c * ts + b];
-      }
-    }
-    stamp(6);
-    cur = next;
-    cur_issued = next_issued;
-    cur_off = next_off;
-    next = advance(cur);
-    stamp(7);
-    iter++;
-  }
-}
-
 // -------------------------------------------------------------------------------------------------------------------
-// One workgroup per (rank, channel tile): the non-persistent consumer of the same records.  Same data movement and
-// arithmetic; the per-RoI prologue of roi_align_fwd_tile.hip (geometry, tables, window) is replaced by one scalar
-// load of the record, and workgroups are dispatched in sweep order.
+// roi_align_fwd_records: one workgroup per (rank, channel tile).  Data movement and arithmetic of
+// roi_align_fwd_tile.hip; its per-RoI prologue (geometry, tables, window) is replaced by one scalar load of the
+// record, and workgroups are dispatched in sweep order.
 // -------------------------------------------------------------------------------------------------------------------
 template <int kSR, int kCap, int kCTt, int kHalves>
 __global__ void __launch_bounds__(kCTt * 8 * kHalves)
@@ -1185,14 +783,10 @@ roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__
 }
 
 int g_ablate_p = 0;
-long long* g_timeline_p = nullptr;
-bool g_persistent = false;
-int g_ct = 32;  // MI_ROI_ALIGN_CT=16|32: channels per workgroup of the record consumer
 int g_bwd_th = 16;  // MI_ROI_ALIGN_BWD_TH=8|16|32: rows per backward tile (16: 100 -> 79 us at config 2; 32: 95 us)
-int g_halves = 1;  // MI_ROI_ALIGN_HALVES=2 (with CT=16): 256 lanes per 16-channel workgroup
 size_t records_lds_bytes(int cap, int ct) {
   return 2 * kMaxS * sizeof(TabEntry) + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4;
-}  // MI_ROI_ALIGN_PERSIST=1: persistent consumer (tuning aid)
+}
 
 template <int kCap>
 int launch_cap(const float* features, const float* rois, float* output, int* ws, int batch, int channels, int height,
@@ -1200,45 +794,21 @@ int launch_cap(const float* features, const float* rois, float* output, int* ws,
                int sampling_ratio, hipStream_t stream) {
   const int max_rows_tile = kTileBins / aligned_width;
   roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
-      rois, num_rois, batch, height, width, aligned_height, aligned_width, spatial_scale, sampling_ratio, kCap,
-      g_persistent ? kCap / 2 : kCap, max_rows_tile, ws);
+      rois, num_rois, batch, height, width, aligned_height, aligned_width, spatial_scale, sampling_ratio, kCap, kCap,
+      max_rows_tile, ws);
   int rc = check_launch("roi_align_prepare");
   if (rc != MI_OK) return rc;
-  const int tiles = channels / kCT;
-  const long long items = (long long)num_rois * tiles;
-  int grid = 3 * 256;  // 3 workgroups per CU (LDS-bound)
-  grid -= grid % tiles;
-  if (grid > items) grid = (int)items;
-  if (grid < tiles) grid = tiles;
-  const size_t lds = Lds<kCap>::bytes();
-  if (!g_persistent) {
-#define MI_LAUNCH_REC(SR, CT, HV)                                                                                     \
-  roi_align_fwd_records<SR, kCap, CT, HV>                                                                             \
-      <<<num_rois * (channels / CT), CT * 8 * HV, records_lds_bytes(kCap, CT), stream>>>(                             \
+#define MI_LAUNCH_REC(SR)                                                                                             \
+  roi_align_fwd_records<SR, kCap, kCT, 1>                                                                             \
+      <<<num_rois * (channels / kCT), kCT * 8, records_lds_bytes(kCap, kCT), stream>>>(                               \
           features, rois, output, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width,       \
           spatial_scale, sampling_ratio, g_ablate_p)
-    if (g_ct == 16 && g_halves == 2 && sampling_ratio == 2)
-      MI_LAUNCH_REC(2, 16, 2);
-    else if (g_ct == 16 && sampling_ratio == 2)
-      MI_LAUNCH_REC(2, 16, 1);
-    else if (g_ct == 16)
-      MI_LAUNCH_REC(0, 16, 1);
-    else if (sampling_ratio == 2)
-      MI_LAUNCH_REC(2, 32, 1);
-    else
-      MI_LAUNCH_REC(0, 32, 1);
-#undef MI_LAUNCH_REC
-    return check_launch("roi_align_fwd_records");
-  }
   if (sampling_ratio == 2)
-    roi_align_fwd_persist<2, kCap><<<grid, kThreads, lds, stream>>>(
-        features, rois, output, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width,
-        spatial_scale, sampling_ratio, g_ablate_p, g_timeline_p);
+    MI_LAUNCH_REC(2);
   else
-    roi_align_fwd_persist<0, kCap><<<grid, kThreads, lds, stream>>>(
-        features, rois, output, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width,
-        spatial_scale, sampling_ratio, g_ablate_p, g_timeline_p);
-  return check_launch("roi_align_fwd_persist");
+    MI_LAUNCH_REC(0);
+#undef MI_LAUNCH_REC
+  return check_launch("roi_align_fwd_records");
 }
 
 template <int kCap>
@@ -1338,27 +908,21 @@ int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int 
                                   aligned_width, spatial_scale, sampling_ratio, stream);
 }
 
-void roi_align_fwd_persist_set_ablate(int mask) { g_ablate_p = mask; }
+void roi_align_records_set_ablate(int mask) { g_ablate_p = mask; }
 void roi_align_bwd_set_tile_rows(int rows) { g_bwd_th = (rows == 8 || rows == 32) ? rows : 16; }
-void roi_align_fwd_persist_set_mode(bool persistent, int ct) {
-  g_persistent = persistent;
-  g_ct = (ct == 16 || ct == 162) ? 16 : 32;
-  g_halves = ct == 162 ? 2 : 1;
-}
-void roi_align_fwd_persist_set_timeline(long long* device_buffer) { g_timeline_p = device_buffer; }
 
-size_t roi_align_fwd_persist_workspace_bytes(int num_rois) {
+size_t roi_align_records_workspace_bytes(int num_rois) {
   return ((size_t)kCounterDwords + (size_t)(num_rois > 0 ? num_rois : 0) * (kRecDwords + 4)) * sizeof(int);
 }
 
-bool roi_align_fwd_persist_supported(int channels, int height, int width, int num_rois, int aligned_height,
+bool roi_align_fwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width) {
   return channels > 0 && channels % kCT == 0 && channels / kCT <= kCounterDwords && aligned_width <= kTileBins &&
          aligned_height > 0 && aligned_width > 0 && num_rois <= kMaxRois &&
          (long long)kCT * height * width * 4 < (1LL << 31);
 }
 
-int launch_roi_align_fwd_persist(const float* features, const float* rois, float* output, void* workspace, int batch,
+int launch_roi_align_fwd_records(const float* features, const float* rois, float* output, void* workspace, int batch,
                                  int channels, int height, int width, int num_rois, int aligned_height,
                                  int aligned_width, float spatial_scale, int sampling_ratio, int cap_px,
                                  hipStream_t stream) {
