@@ -498,3 +498,20 @@ def test_soft_nms_contract_and_wrapper():
     t = to_dev(syn.boxes_uniform(300, seed=3))
     b, i = mi_nms.soft_nms(t, 0.5, 0.3, 0.001, 2)
     assert b.is_cuda and i.is_cuda and i.dtype == torch.int64
+
+
+# ---- RoIAlign: shapes at the edges of the fast paths ---------------------------------------------------------------
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("shape,nrois", [((1, 32, 1, 40), 40), ((1, 32, 30, 1), 40), ((2, 32, 2, 2), 30),
+                                         ((1, 32, 25, 42), 9000)])
+def test_roi_align_degenerate_maps_and_many_rois(oracle_mod, shape, nrois, channels_last):
+    """One-pixel-high / -wide maps (no bilinear neighbour: the records cannot describe them) and more RoIs than the
+    record path ranks (8192): both must fall through to the paths that keep the reference arithmetic."""
+    n, c, h, w = shape
+    scale = 1.0 / 16
+    feat = syn.feature_map(n, c, h, w, seed=5)
+    rois = syn.rois_adversarial(nrois, n, max(h, 2), max(w, 2), scale, seed=nrois)
+    gtop = np.random.RandomState(9).randn(nrois, c, 7, 7).astype(np.float32)
+    out, grad = _roi_align_gpu(feat, rois, 7, scale, 2, gtop, channels_last=channels_last)
+    assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2, threads=8), "fwd", exact=False)
+    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2, threads=8), "bwd")
