@@ -381,6 +381,24 @@ def nms_latency(device, iters):
 
     sec = time_kernel(launch_soft, 5, warmup=2)
     out["soft_nms_linear_uniform_n1000"] = {"us_per_call": round(sec * 1e6, 1), "kept": int(num.item())}
+    # the test-time caller of NMS (core/test.py:732-790): 1000 RoIs x 81 classes, classes batched, two host syncs
+    from detectron_pytorch_amd import detection
+
+    sc_np, bx_np = syn.detection_head_outputs(1000, 81, seed=7)
+    sc, bx = torch.from_numpy(sc_np).to(device), torch.from_numpy(bx_np).to(device)
+    post = {}
+    for name, soft in (("hard", False), ("soft_linear", True)):
+        sec = time_kernel(lambda: detection.box_results_with_nms_and_limit(sc, bx, soft_nms=soft), 10, warmup=3)
+        post[name + "_ms"] = round(sec * 1e3, 3)
+    try:  # the CPU restatement beside it (checker-side code, timed once)
+        from oracle import postprocess
+
+        t0 = time.perf_counter()
+        postprocess.box_results_with_nms_and_limit(sc_np, bx_np)
+        post["cpu_port_hard_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    except Exception:
+        pass
+    out["detection_postprocess_R1000_C81"] = post
     return out
 
 

@@ -42,6 +42,8 @@ SIGNATURES = {
                                _c_void_p]),
     "mi_soft_nms": (_c_int, [_c_void_p, _c_int, _c_float, _c_float, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p,
                             _c_void_p]),
+    "mi_soft_nms_segmented": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_float, _c_float, _c_int,
+                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "mi_bbox_overlaps": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "mi_dbg_roi_align_timeline": (None, [_c_void_p]),
 }

@@ -70,11 +70,25 @@ __device__ __forceinline__ unsigned long long below(int limit, int m) {
   return k <= 0 ? 0ull : (k >= 64 ? ~0ull : ((1ull << k) - 1ull));
 }
 
+// One workgroup per problem.  offsets == nullptr: a single problem of `n` rows.  Otherwise problem p = blockIdx.x owns
+// rows [offsets[p], offsets[p + 1]) of dets / out_dets / out_inds (indices are relative to the problem's first row) and
+// `n` is only the capacity the LDS image was sized for.
 __global__ void __launch_bounds__(kThreads)
-soft_nms_kernel(const float* __restrict__ dets, int n, float sigma, float Nt, float threshold, int method,
-                float* __restrict__ out_dets, long long* __restrict__ out_inds, int* __restrict__ num_out) {
+soft_nms_kernel(const float* __restrict__ dets, int n, const int* __restrict__ offsets, float sigma, float Nt,
+                float threshold, int method, float* __restrict__ out_dets, long long* __restrict__ out_inds,
+                int* __restrict__ num_out) {
   extern __shared__ __align__(16) unsigned char smem[];
-  Lds s(smem, n);
+  const int cap = n;
+  if (offsets != nullptr) {
+    const int first = offsets[blockIdx.x];
+    n = offsets[blockIdx.x + 1] - first;
+    dets += (long long)first * 5;
+    out_dets += (long long)first * 5;
+    out_inds += first;
+    num_out += blockIdx.x;
+    if (n > cap) n = cap;  // never reached through mi_soft_nms_segmented's contract (capacity >= longest segment)
+  }
+  Lds s(smem, cap);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int p = tid; p < n; p += kThreads) {  // boxes_in.copy(), inds = arange(N) (:108,:116)
     s.x1[p] = dets[p * 5 + 0];
@@ -270,7 +284,30 @@ extern "C" int mi_soft_nms(const float* dets, int n, float sigma, float overlap_
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&soft_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-  soft_nms_kernel<<<1, kThreads, lds, s>>>(dets, n, sigma, overlap_thresh, score_thresh, method, out_dets,
+  soft_nms_kernel<<<1, kThreads, lds, s>>>(dets, n, nullptr, sigma, overlap_thresh, score_thresh, method, out_dets,
                                            reinterpret_cast<long long*>(out_inds), num_out);
+  return mi::check_launch("soft_nms_kernel");
+}
+
+extern "C" int mi_soft_nms_segmented(const float* dets, const int32_t* offsets, int num_segments, int max_segment,
+                                     float sigma, float overlap_thresh, float score_thresh, int method,
+                                     float* out_dets, int64_t* out_inds, int32_t* num_out, mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(num_segments >= 0 && max_segment >= 0, "soft_nms_segmented: negative size");
+  MI_REQUIRE(max_segment <= kMaxBoxes, "soft_nms_segmented: segments of up to %d boxes, at most %d are supported",
+             max_segment, kMaxBoxes);
+  MI_REQUIRE(method >= 0 && method <= 2, "soft_nms_segmented: unknown method %d (0 hard, 1 linear, 2 gaussian)", method);
+  if (num_segments == 0) return MI_OK;
+  MI_REQUIRE(offsets != nullptr && num_out != nullptr, "soft_nms_segmented: null pointer");
+  MI_REQUIRE(max_segment == 0 || (dets != nullptr && out_dets != nullptr && out_inds != nullptr),
+             "soft_nms_segmented: null pointer");
+  const int cap = max_segment > 0 ? max_segment : 1;
+  const size_t lds = Lds::bytes(cap);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&soft_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  soft_nms_kernel<<<num_segments, kThreads, lds, mi::as_stream(stream)>>>(
+      dets, cap, reinterpret_cast<const int*>(offsets), sigma, overlap_thresh, score_thresh, method, out_dets,
+      reinterpret_cast<long long*>(out_inds), num_out);
   return mi::check_launch("soft_nms_kernel");
 }

@@ -131,3 +131,23 @@ def crop_grid(num_rois, gh, gw, seed=0, span=1.25):
     y = cy + sy * ly + 0 * lx
     x = cx + sx * lx + 0 * ly
     return np.stack([y, x], axis=3).astype(np.float32)
+
+
+def detection_head_outputs(num_rois=300, num_classes=21, seed=0, im_h=IM_H, im_w=IM_W):
+    """Inputs of the test-time post-processing (core/test.py:732-790): class scores [R, C] (softmax-like rows, a few
+    confident classes per RoI, many RoIs near duplicates of each other) and per-class boxes [R, 4C]."""
+    rng = np.random.RandomState(seed)
+    base = boxes_clustered(num_rois, seed=seed + 1)[:, :4].astype(np.float64)
+    logits = rng.randn(num_rois, num_classes) * 1.5
+    hot = rng.randint(1, num_classes, num_rois)
+    logits[np.arange(num_rois), hot] += rng.uniform(0, 6, num_rois)
+    logits[:, 0] += 2.0
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    scores = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    jitter = rng.uniform(-4, 4, (num_rois, num_classes, 4))
+    boxes = base[:, None, :] + jitter
+    boxes[..., 0::2] = np.clip(boxes[..., 0::2], 0, im_w - 1)
+    boxes[..., 1::2] = np.clip(boxes[..., 1::2], 0, im_h - 1)
+    boxes[..., 2] = np.maximum(boxes[..., 2], boxes[..., 0])
+    boxes[..., 3] = np.maximum(boxes[..., 3], boxes[..., 1])
+    return scores, boxes.reshape(num_rois, 4 * num_classes).astype(np.float32)

@@ -170,6 +170,15 @@ int mi_nms(const float* dets, int n, float thresh, int mode, void* keep, int32_t
 int mi_soft_nms(const float* dets, int n, float sigma, float overlap_thresh, float score_thresh, int method,
                 float* out_dets, int64_t* out_inds, int32_t* num_out, mi_stream_t stream);
 
+/* Many Soft-NMS problems in one launch (the per-class loop of core/test.py:748-760): problem p owns rows
+ * [offsets[p], offsets[p + 1]) of dets / out_dets / out_inds; `offsets` is a DEVICE array of num_segments + 1 int32
+ * (so the caller needs no host copy of the segment sizes), `max_segment` an upper bound of the longest segment
+ * (<= 4096; it sizes the LDS image).  Problem p writes its rows at its own offset, indices relative to its first row,
+ * and its row count to num_out[p].  One workgroup per problem: the classes run side by side. */
+int mi_soft_nms_segmented(const float* dets, const int32_t* offsets, int num_segments, int max_segment, float sigma,
+                          float overlap_thresh, float score_thresh, int method, float* out_dets, int64_t* out_inds,
+                          int32_t* num_out, mi_stream_t stream);
+
 /* Independent NMS problems in one call (no reference counterpart: the reference runs one cython_nms per FPN level and
  * image on the host, modeling/generate_proposals.py:91-99,161).  `dets`, `n`, `keep`, `num_keep` are HOST arrays of
  * `num_problems` entries (device pointers / box counts); each problem follows the mi_nms contract, with at most 4096

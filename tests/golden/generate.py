@@ -8,7 +8,7 @@ oracle and the HIP kernels against outputs of the reference's own code.
 
     python tests/golden/generate.py        # rewrites every fixture deterministically
 
-Each fixture stores inputs and reference outputs; sizes are kept small (total < 2 MB).
+Each fixture stores inputs and reference outputs; sizes are kept small (total < 3 MB).
 """
 import os
 import sys
@@ -121,6 +121,52 @@ def gen_soft_nms():
     save("soft_nms.npz", **out)
 
 
+def _reference_box_results():
+    """The reference's box_results_with_nms_and_limit, executed from its own source lines (lib/core/test.py): the module
+    cannot be imported here (cv2, pycocotools, the cffi extensions), so the function's text is compiled as it stands
+    against a namespace with numpy, a cfg carrying the values it reads, and utils.boxes' nms / soft_nms bodies bound to
+    the reference's own cython build (oracle/_ref)."""
+    import re
+    import types
+
+    src = open("/root/reference/lib/core/test.py").read()
+    body = re.search(r"^def box_results_with_nms_and_limit\(.*?(?=^def )", src, re.S | re.M).group(0)
+    bsrc = open("/root/reference/lib/utils/boxes.py").read()
+    nms_src = re.search(r"^def nms\(dets, thresh\):.*?(?=^def )", bsrc, re.S | re.M).group(0)
+    soft_src = re.search(r"^def soft_nms\(.*?(?=^def |\Z)", bsrc, re.S | re.M).group(0)
+    box_utils = types.ModuleType("box_utils")
+    box_utils.np = np
+    box_utils.cython_nms = ref._mod("cython_nms")
+    exec(compile(nms_src + soft_src, "/root/reference/lib/utils/boxes.py", "exec"), box_utils.__dict__)
+
+    def make(cfg):
+        ns = {"np": np, "cfg": cfg, "box_utils": box_utils}
+        exec(compile(body, "/root/reference/lib/core/test.py", "exec"), ns)
+        return ns["box_results_with_nms_and_limit"]
+
+    return make, types
+
+
+def gen_detection():
+    make, types = _reference_box_results()
+    out = {}
+    cases = {"c21": syn.detection_head_outputs(300, 21, seed=3), "c81": syn.detection_head_outputs(400, 81, seed=4)}
+    for name, (scores, boxes) in cases.items():
+        out["scores_" + name], out["boxes_" + name] = scores, boxes
+        for tag, soft, method in (("hard", False, "linear"), ("linear", True, "linear"), ("gaussian", True, "gaussian")):
+            cfg = types.SimpleNamespace(
+                MODEL=types.SimpleNamespace(NUM_CLASSES=scores.shape[1]),
+                TEST=types.SimpleNamespace(SCORE_THRESH=0.05, NMS=0.5, DETECTIONS_PER_IM=100,
+                                           SOFT_NMS=types.SimpleNamespace(ENABLED=soft, METHOD=method, SIGMA=0.5),
+                                           BBOX_VOTE=types.SimpleNamespace(ENABLED=False)))
+            s, b, cls_boxes = make(cfg)(scores, boxes)
+            key = "%s_%s" % (name, tag)
+            out["out_scores_" + key], out["out_boxes_" + key] = s, b
+            out["cls_counts_" + key] = np.array([len(c) for c in cls_boxes], dtype=np.int64)
+            out["cls_rows_" + key] = np.vstack([c for c in cls_boxes[1:]]).astype(np.float32)
+    save("detection.npz", **out)
+
+
 def _reference_fpn_module():
     """Import the reference's lib/utils/fpn.py as it lies under /root/reference.  Its two imports are satisfied
     without the reference's config machinery: `core.config.cfg` by a namespace carrying the two defaults it reads
@@ -181,6 +227,7 @@ def main():
     gen_roi_crop()
     gen_nms()
     gen_soft_nms()
+    gen_detection()
     gen_fpn()
 
 

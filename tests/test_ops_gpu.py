@@ -515,3 +515,65 @@ def test_roi_align_degenerate_maps_and_many_rois(oracle_mod, shape, nrois, chann
     out, grad = _roi_align_gpu(feat, rois, 7, scale, 2, gtop, channels_last=channels_last)
     assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2, threads=8), "fwd", exact=False)
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2, threads=8), "bwd")
+
+
+# ---- per-class detection post-processing on the device (core/test.py:732-790) -------------------------------------
+@pytest.mark.parametrize("name", ["c21", "c81"])
+@pytest.mark.parametrize("tag,soft,method", [("hard", False, "linear"), ("linear", True, "linear"),
+                                             ("gaussian", True, "gaussian")])
+def test_detection_postprocess_golden_bit_exact(name, tag, soft, method):
+    """Same rows, same order, same bits as the reference's own function (fixture from its source), classes batched."""
+    from detectron_pytorch_amd import detection
+
+    g = load_golden("detection.npz")
+    key = "%s_%s" % (name, tag)
+    s, b, cls_boxes = detection.box_results_with_nms_and_limit(g["scores_" + name], g["boxes_" + name], soft_nms=soft,
+                                                               soft_nms_method=method)
+    assert s.dtype == np.float32 and b.dtype == np.float32 and cls_boxes[0] == []
+    assert np.array_equal(np.array([len(c) for c in cls_boxes]), g["cls_counts_" + key])
+    assert np.array_equal(np.vstack(cls_boxes[1:]), g["cls_rows_" + key])
+    assert np.array_equal(s, g["out_scores_" + key]) and np.array_equal(b, g["out_boxes_" + key])
+
+
+@pytest.mark.parametrize("soft", [False, True])
+def test_detection_postprocess_vs_oracle(oracle_mod, soft):
+    from detectron_pytorch_amd import detection
+    from oracle import postprocess
+
+    for rois, classes, limit, seed in ((1000, 81, 100, 7), (60, 11, 0, 1), (5, 3, 100, 2)):
+        scores, boxes = syn.detection_head_outputs(rois, classes, seed=seed)
+        scores[:, 2] = 0.0                                   # an empty class
+        want = postprocess.box_results_with_nms_and_limit(scores, boxes, detections_per_im=limit, soft_nms=soft)
+        got = detection.box_results_with_nms_and_limit(scores, boxes, detections_per_im=limit, soft_nms=soft)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        for j in range(1, classes):
+            assert got[2][j].shape == want[2][j].shape and np.array_equal(got[2][j], want[2][j]), (rois, classes, j)
+    # tensors in -> tensors out, on the device
+    s, b, c = detection.box_results_with_nms_and_limit(to_dev(scores), to_dev(boxes), soft_nms=soft)
+    assert s.is_cuda and b.is_cuda and c[1].is_cuda
+    # nothing above the score threshold at all
+    s, b, c = detection.box_results_with_nms_and_limit(np.zeros((4, 3), np.float32), np.zeros((4, 12), np.float32),
+                                                       soft_nms=soft)
+    assert s.shape == (0,) and b.shape == (0, 4) and all(x.shape == (0, 5) for x in c[1:])
+
+
+def test_soft_nms_segmented_matches_single_calls(oracle_mod):
+    from detectron_pytorch_amd import _lib
+
+    lib = _lib.lib()
+    parts = [syn.boxes_uniform(n, seed=n) for n in (300, 0, 1, 65, 700)]
+    dets = to_dev(np.vstack(parts))
+    offsets = to_dev(np.cumsum([0] + [len(p) for p in parts]).astype(np.int32))
+    out_dets, out_inds = torch.empty_like(dets), torch.empty(dets.size(0), dtype=torch.int64, device=dev())
+    num_out = torch.zeros(len(parts), dtype=torch.int32, device=dev())
+    rc = lib.mi_soft_nms_segmented(dets.data_ptr(), offsets.data_ptr(), len(parts), 700, 0.5, 0.3, 0.01, 2,
+                                   out_dets.data_ptr(), out_inds.data_ptr(), num_out.data_ptr(),
+                                   _lib.current_stream_handle(dev()))
+    assert rc == 0
+    off = offsets.cpu().numpy()
+    for p, part in enumerate(parts):
+        boxes, inds = oracle_mod.soft_nms(part, 0.5, 0.3, 0.01, 2) if len(part) else (np.zeros((0, 5), np.float32), [])
+        k = int(num_out[p].item())
+        assert k == len(boxes)
+        assert np.array_equal(out_dets[off[p]:off[p] + k].cpu().numpy(), boxes)
+        assert np.array_equal(out_inds[off[p]:off[p] + k].cpu().numpy(), np.asarray(inds, dtype=np.int64))

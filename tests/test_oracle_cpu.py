@@ -253,3 +253,38 @@ def test_soft_nms_known_answers(oracle_mod):
     # a box that does not overlap is never dropped, even below the threshold (the test sits inside `if ih > 0`)
     dets = np.array([[0, 0, 9, 9, 0.9], [50, 50, 59, 59, 0.0001]], np.float32)
     assert oracle_mod.soft_nms(dets, 0.5, 0.3, 0.001, 1)[1].tolist() == [0, 1]
+
+
+# ---- per-class detection post-processing (core/test.py:732-790) ---------------------------------------------------
+DETECTION_CASES = [(name, tag, soft, method) for name in ("c21", "c81")
+                   for tag, soft, method in (("hard", False, "linear"), ("linear", True, "linear"),
+                                             ("gaussian", True, "gaussian"))]
+
+
+def test_detection_postprocess_matches_golden(oracle_mod):
+    """detection.npz holds the outputs of the reference's own function source (generate.py:gen_detection)."""
+    from oracle import postprocess
+
+    g = load_golden("detection.npz")
+    for name, tag, soft, method in DETECTION_CASES:
+        key = "%s_%s" % (name, tag)
+        s, b, cls_boxes = postprocess.box_results_with_nms_and_limit(g["scores_" + name], g["boxes_" + name],
+                                                                    soft_nms=soft, soft_nms_method=method)
+        assert np.array_equal(s, g["out_scores_" + key]) and np.array_equal(b, g["out_boxes_" + key]), key
+        assert np.array_equal(np.array([len(c) for c in cls_boxes]), g["cls_counts_" + key]), key
+        assert np.array_equal(np.vstack(cls_boxes[1:]), g["cls_rows_" + key]), key
+
+
+def test_detection_postprocess_without_limit_and_empty_classes(oracle_mod):
+    from oracle import postprocess
+
+    scores, boxes = syn.detection_head_outputs(60, 11, seed=1)
+    scores[:, 3] = 0.0                                      # a class nobody scores for: cls_boxes[3] is (0, 5)
+    s, b, cls_boxes = postprocess.box_results_with_nms_and_limit(scores, boxes, detections_per_im=0)
+    assert cls_boxes[3].shape == (0, 5) and cls_boxes[0] == []
+    assert len(s) == sum(len(c) for c in cls_boxes[1:]) and b.shape == (len(s), 4)
+    for j in range(1, 11):                                   # per class: exactly cython_nms over the thresholded rows
+        inds = np.where(scores[:, j] > 0.05)[0]
+        dets = np.hstack((boxes[inds, 4 * j:4 * j + 4], scores[inds, j][:, None])).astype(np.float32)
+        keep = oracle_mod.nms_cython(dets, 0.5) if len(dets) else []
+        assert np.array_equal(cls_boxes[j], dets[keep, :])
