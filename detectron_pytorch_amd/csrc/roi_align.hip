@@ -227,8 +227,9 @@ int ring_words() {
   const char* nv = std::getenv("MI_ROI_ALIGN_NHWC_V");
   const char* npb = std::getenv("MI_ROI_ALIGN_NHWC_PB");
   const char* nom = std::getenv("MI_ROI_ALIGN_NHWC_ORDER_MUL");
+  const char* nzz = std::getenv("MI_ROI_ALIGN_NHWC_ZIGZAG");
   mi::roi_align_fwd_nhwc_set_tuning(nv != nullptr ? std::atoi(nv) : 0, npb != nullptr ? std::atoi(npb) : 0,
-                                    nom != nullptr ? std::atoi(nom) : 1);
+                                    nom != nullptr ? std::atoi(nom) : 1, nzz != nullptr ? std::atoi(nzz) : 1);
   const char* v = std::getenv("MI_ROI_ALIGN_CAP");
   return v != nullptr ? std::atoi(v) : 336;
 }

@@ -112,7 +112,7 @@ int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int 
                              int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
                              hipStream_t stream);
 // channels-last features, record-driven (roi_align_nhwc.hip)
-void roi_align_fwd_nhwc_set_tuning(int channels_per_lane, int columns_in_flight, int order_mul);
+void roi_align_fwd_nhwc_set_tuning(int channels_per_lane, int columns_in_flight, int order_mul, int zigzag);
 void roi_align_fwd_nhwc_set_timeline(long long* device_buffer);
 bool roi_align_fwd_nhwc_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                   int aligned_width);

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(PW <= 7 ? 448 : 1024)
     __attribute__((amdgpu_waves_per_eu(PW <= 7 && PB <= 4 ? 4 : 1, PW <= 7 && PB <= 4 ? 4 : 8)))
 roi_align_fwd_nhwc(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
                    const int* __restrict__ ws, int batch, int channels, int height, int width, int aligned_height,
-                   float spatial_scale, int sampling_ratio, int chunks, int tile_stride, int order_mul,
+                   float spatial_scale, int sampling_ratio, int chunks, int tile_stride, int order_mul, int zigzag,
                    long long* __restrict__ timeline) {
   extern __shared__ float tile[];  // [V][64][tile_stride]
   // tuning aid (tools/timeline_nhwc.py): s_memtime stamps of wave 0 of every workgroup, null in normal operation
@@ -141,7 +141,13 @@ roi_align_fwd_nhwc(const float* __restrict__ feat, const float* __restrict__ roi
     if (flags & kFlagTabs) {
       const int row_first = ytab(3);
       const int row_last = ytab(4 * (gh - 1) + 3) + 1;
-      for (int row = row_first; row <= row_last; row++) {
+      // Neighbouring bin rows share their boundary feature row.  Even bin rows walk their rows downwards, odd ones
+      // upwards, so the two waves that need a shared row ask for it in the same step of their walk and the second
+      // request finds it in L1 (seven waves x 18 KB per step thrash a CU's L1 otherwise: 194 MB L2->L1 for 148 MB
+      // of window pixels).  MI_ROI_ALIGN_NHWC_ZIGZAG=0 walks every bin row downwards.
+      const int nrows = row_last - row_first + 1;
+      for (int step = 0; step < nrows; step++) {
+        const int row = (zigzag && (ph & 1)) ? row_last - step : row_first + step;
         // weight of this feature row in the bin row: sum over the y samples that tap it
         float wy = 0.f;
         bool touched = false;
@@ -279,6 +285,7 @@ roi_align_fwd_nhwc(const float* __restrict__ feat, const float* __restrict__ roi
 }
 
 int g_nhwc_vec = 0, g_nhwc_pb = 0;  // tuning overrides (MI_ROI_ALIGN_NHWC_V / _PB); 0 = default
+int g_nhwc_zigzag = 1;
 int g_nhwc_order_mul = 1;  // ablation: a multiplier coprime with num_rois scatters the sweep order
 long long* g_nhwc_timeline = nullptr;
 
@@ -294,7 +301,8 @@ int pick_vec(int channels, int aligned_height, int aligned_width) {
 
 }  // namespace
 
-void roi_align_fwd_nhwc_set_tuning(int vec, int pb, int order_mul) {
+void roi_align_fwd_nhwc_set_tuning(int vec, int pb, int order_mul, int zigzag) {
+  g_nhwc_zigzag = zigzag;
   g_nhwc_vec = vec;
   g_nhwc_pb = pb;
   g_nhwc_order_mul = order_mul > 0 ? order_mul : 1;
@@ -329,7 +337,7 @@ int launch_roi_align_fwd_nhwc(const float* features, const float* rois, float* o
 #define MI_LAUNCH_NHWC(SR, PW, V, PB)                                                                                 \
   roi_align_fwd_nhwc<SR, PW, V, PB><<<grid, 64 * nwaves, lds, stream>>>(                                              \
       features, rois, output, ws, batch, channels, height, width, aligned_height, spatial_scale, sampling_ratio,      \
-      chunks, stride, g_nhwc_order_mul, g_nhwc_timeline)
+      chunks, stride, g_nhwc_order_mul, g_nhwc_zigzag, g_nhwc_timeline)
 #define MI_LAUNCH_NHWC_V(PW, V)                                                                                       \
   do {                                                                                                                \
     if (sr2 && split)                                                                                                 \
