@@ -34,9 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="hot_path", choices=["hot_path", "e2e"])
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch", default="eager", choices=["graph", "eager"],
                     help="eager (default): the step is launched from Python; graph: captured once in a hipGraph and replayed -- measured equal (0.533 vs 0.526 ms), the step is GPU-bound")

@@ -27,9 +27,9 @@ def _to_device(a, device):
 
 
 def class_major_detections(scores, boxes, score_thresh):
-    """dets [M,5] of all (class >= 1, RoI) pairs with score > score_thresh, class-major and RoI-ascending inside a class
-    (the order `np.where(scores[:, j] > thresh)[0]` gives, core/test.py:749-752), plus the int32 segment offsets
-    [num_classes] (offsets[j - 1] .. offsets[j] = class j) as a device tensor."""
+    """All (class >= 1, RoI) pairs with score > score_thresh as ONE array, class-major and RoI-ascending inside a class
+    (the order `np.where(scores[:, j] > thresh)[0]` gives, core/test.py:749-752).  Returns dets [M,5], the 0-based
+    class of every row [M] and the int32 segment offsets [num_classes] (rows offsets[j-1] .. offsets[j] = class j)."""
     r, c = scores.shape
     valid = (scores[:, 1:] > score_thresh).t().contiguous()               # [C-1, R], class-major
     counts = valid.sum(dim=1, dtype=torch.int32)
@@ -38,14 +38,19 @@ def class_major_detections(scores, boxes, score_thresh):
     cls, roi = torch.nonzero(valid, as_tuple=True)                        # row-major: class, then RoI ascending
     box4 = boxes.view(r, c, 4)[roi, cls + 1]
     dets = torch.cat([box4, scores[roi, cls + 1].unsqueeze(1)], dim=1).contiguous()
-    return dets, offsets
+    return dets, cls, offsets
 
 
 def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=0.5, detections_per_im=100,
                                    soft_nms=False, soft_nms_sigma=0.5, soft_nms_method="linear", device=None):
     """core/test.py:732-790.  scores [R, C], boxes [R, 4C] (numpy or tensors; class 0 = background).  Returns
     (scores [D], boxes [D,4], cls_boxes) with cls_boxes[j] a float32 [k_j, 5] array (cls_boxes[0] == []), numpy out for
-    numpy in and device tensors out for tensors in -- the same rows in the same order as the reference."""
+    numpy in and device tensors out for tensors in -- the same rows in the same order as the reference.
+
+    Everything between the inputs and the final row selection works on the flat class-major array (a per-class Python
+    loop of 80 slice / gather / mask operations costs more than the NMS itself): the kept rows of all classes are one
+    boolean mask, the top-`detections_per_im` cut is one threshold, and the per-class results are views into the one
+    gathered result."""
     as_numpy = isinstance(scores, np.ndarray)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if as_numpy else scores.device
@@ -55,52 +60,60 @@ def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=
     if boxes_d.shape != (r, 4 * num_classes):
         raise ValueError("boxes must be [R, 4 * num_classes]")
     lib = _lib.lib()
-    dets, offsets = class_major_detections(scores_d, boxes_d, float(score_thresh))
-    off = offsets.cpu().numpy()                                            # sync 1: the segment sizes
-    ns = np.diff(off).astype(np.int64)
     nseg = num_classes - 1
+    dets, seg, offsets = class_major_detections(scores_d, boxes_d, float(score_thresh))
+    m = int(dets.size(0))
     stream = _lib.current_stream_handle(device)
-    if soft_nms:
+    row_off = offsets[:-1].long()[seg] if m else seg                       # first row of each row's segment
+    slot = torch.arange(m, device=device) - row_off if m else seg
+    if m == 0:
+        rows, kept_mask = dets, torch.zeros((0,), dtype=torch.bool, device=device)
+    elif soft_nms:
         if soft_nms_method not in SOFT_NMS_METHODS:
             raise AssertionError("Unknown soft_nms method: {}".format(soft_nms_method))
-        out_dets = torch.empty_like(dets)
-        out_inds = torch.empty((dets.size(0),), dtype=torch.int64, device=device)
+        rows = torch.empty_like(dets)
+        out_inds = torch.empty((m,), dtype=torch.int64, device=device)
         num_out = torch.zeros((nseg,), dtype=torch.int32, device=device)
-        with torch.cuda.device(device):
-            rc = lib.mi_soft_nms_segmented(dets.data_ptr(), offsets.data_ptr(), nseg, int(ns.max()) if nseg else 0,
+        with torch.cuda.device(device):  # a segment cannot be longer than the number of RoIs: no host copy of the sizes
+            rc = lib.mi_soft_nms_segmented(dets.data_ptr(), offsets.data_ptr(), nseg, min(r, 4096),
                                            float(soft_nms_sigma), float(nms_thresh), 0.0001,   # core/test.py:758
-                                           SOFT_NMS_METHODS[soft_nms_method], out_dets.data_ptr(), out_inds.data_ptr(),
+                                           SOFT_NMS_METHODS[soft_nms_method], rows.data_ptr(), out_inds.data_ptr(),
                                            num_out.data_ptr(), stream)
         _lib.check(rc, "mi_soft_nms_segmented")
-        kept = num_out.cpu().numpy()                                       # sync 2: rows per class
-        per_class = [out_dets[off[j]:off[j] + kept[j]] for j in range(nseg)]
+        kept_mask = slot < num_out[seg]                                    # each class's result is a prefix of its segment
     else:
-        keep_all = torch.empty((max(int(dets.size(0)), 1),), dtype=torch.int64, device=device)
+        off = offsets.cpu().numpy()                                        # the batched entry takes host-side sizes
+        ns = np.diff(off)
+        keep_all = torch.zeros((m,), dtype=torch.int64, device=device)
         num_all = torch.zeros((nseg,), dtype=torch.int32, device=device)
         live = [j for j in range(nseg) if ns[j] > 0]
-        if live:
-            p = len(live)
-            n_arr = (ctypes.c_int * p)(*[int(ns[j]) for j in live])
-            ws_bytes = lib.mi_nms_batched_workspace_bytes(p, n_arr)
-            workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=device)
-            dets_arr = (ctypes.c_void_p * p)(*[dets.data_ptr() + int(off[j]) * 20 for j in live])
-            keep_arr = (ctypes.c_void_p * p)(*[keep_all.data_ptr() + int(off[j]) * 8 for j in live])
-            num_arr = (ctypes.c_void_p * p)(*[num_all.data_ptr() + 4 * j for j in live])
-            with torch.cuda.device(device):
-                rc = lib.mi_nms_batched(p, dets_arr, n_arr, float(nms_thresh), _lib.NMS_GE_ORIG_ASC, keep_arr, num_arr,
-                                        workspace.data_ptr(), ws_bytes, stream)
-            _lib.check(rc, "mi_nms_batched")
-        kept = num_all.cpu().numpy()                                       # sync 2: rows per class
-        # nms_dets = dets_j[keep, :]  (:765) -- keep holds ascending indices into the class's segment
-        per_class = [dets[off[j]:off[j + 1]][keep_all[off[j]:off[j] + kept[j]]] for j in range(nseg)]
-    # limit to detections_per_im over all classes (:776-785)
-    if detections_per_im > 0 and int(kept.sum()) > detections_per_im:
-        image_scores = torch.cat([d[:, 4] for d in per_class])
-        image_thresh = torch.sort(image_scores)[0][-detections_per_im]
-        per_class = [d[d[:, 4] >= image_thresh] for d in per_class]
-    im_results = torch.cat(per_class, dim=0) if per_class else dets.new_zeros((0, 5))
-    out_boxes, out_scores = im_results[:, :4], im_results[:, 4]
+        p = len(live)
+        n_arr = (ctypes.c_int * p)(*[int(ns[j]) for j in live])
+        ws_bytes = lib.mi_nms_batched_workspace_bytes(p, n_arr)
+        workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=device)
+        dets_arr = (ctypes.c_void_p * p)(*[dets.data_ptr() + int(off[j]) * 20 for j in live])
+        keep_arr = (ctypes.c_void_p * p)(*[keep_all.data_ptr() + int(off[j]) * 8 for j in live])
+        num_arr = (ctypes.c_void_p * p)(*[num_all.data_ptr() + 4 * j for j in live])
+        with torch.cuda.device(device):
+            rc = lib.mi_nms_batched(p, dets_arr, n_arr, float(nms_thresh), _lib.NMS_GE_ORIG_ASC, keep_arr, num_arr,
+                                    workspace.data_ptr(), ws_bytes, stream)
+        _lib.check(rc, "mi_nms_batched")
+        # nms_dets = dets_j[keep, :] (:765): keep = ascending indices into the class's segment, the first num_all[j]
+        # slots of the segment's part of keep_all -> one mask over the flat array
+        rows = dets
+        src = torch.where(slot < num_all[seg], row_off + keep_all, torch.full_like(slot, m))
+        kept_mask = torch.zeros((m + 1,), dtype=torch.bool, device=device)
+        kept_mask[src] = True
+        kept_mask = kept_mask[:m]
+    # limit to detections_per_im over all classes (:776-785): image_thresh = the D-th largest kept score
+    if detections_per_im > 0 and m > detections_per_im:
+        masked = torch.where(kept_mask, rows[:, 4], torch.full_like(rows[:, 4], float("-inf")))
+        image_thresh = torch.topk(masked, detections_per_im).values[-1]    # -inf when fewer than D rows are kept
+        kept_mask = kept_mask & (rows[:, 4] >= image_thresh)
+    final = rows[kept_mask]                                                # class-major, original order inside a class
+    counts = torch.bincount(seg[kept_mask], minlength=nseg).cpu().tolist() if m else [0] * nseg
     if as_numpy:
-        return (out_scores.cpu().numpy(), out_boxes.cpu().numpy(),
-                [[]] + [d.cpu().numpy() for d in per_class])
-    return out_scores, out_boxes, [[]] + per_class
+        final_np = final.cpu().numpy()
+        per_class = np.split(final_np, np.cumsum(counts)[:-1]) if nseg else []
+        return final_np[:, 4], final_np[:, :4], [[]] + per_class
+    return final[:, 4], final[:, :4], [[]] + list(torch.split(final, counts))
