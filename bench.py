@@ -316,11 +316,23 @@ def fpn_variant(device, iters):
         feats.append(torch.from_numpy(syn.feature_map(1, syn.FPN_DIM, h, w, seed=lvl)).to(device))
         scales.append(scale)
 
-    def fwd():
+    def fwd(fused):
         with torch.no_grad():
-            roi_xform.roi_feature_transform(feats, blobs, "rois", "RoIAlign", 7, scales, 2)
+            return roi_xform.roi_feature_transform(feats, blobs, "rois", "RoIAlign", 7, scales, 2, fused=fused)
 
-    return {"fwd_us": round(time_kernel(fwd, iters) * 1e6, 1),
+    # fused call with the RoIs already in dataloader order (what a caller that keeps them on the device passes)
+    from detectron_pytorch_amd.roi_align import roi_align_fpn
+
+    rois_d = torch.from_numpy(rois).to(device)
+    lvl_d = torch.from_numpy((5 - lvls).astype(np.int32)).to(device)
+
+    def fused_direct():
+        with torch.no_grad():
+            roi_align_fpn(feats, scales, rois_d, lvl_d, 7, 7, 2)
+
+    return {"fwd_us": round(time_kernel(lambda: fwd(True), iters) * 1e6, 1),
+            "fwd_us_per_level_loop": round(time_kernel(lambda: fwd(False), iters) * 1e6, 1),
+            "fwd_us_fused_call_only": round(time_kernel(fused_direct, iters) * 1e6, 1),
             "rois_per_level": {int(l): int((lvls == l).sum()) for l in (2, 3, 4, 5)}}
 
 

@@ -40,6 +40,11 @@ SIGNATURES = {
     "mi_nms_batched_workspace_bytes": (_c_size_t, [_c_int, _c_void_p]),
     "mi_nms_batched": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t,
                                _c_void_p]),
+    "mi_roi_align_fpn_supported": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int]),
+    "mi_roi_align_forward_fpn": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                         _c_int, _c_void_p, _c_size_t, _c_void_p]),
+    "mi_roi_align_backward_fpn": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                          _c_int, _c_int, _c_void_p, _c_size_t, _c_int, _c_void_p]),
     "mi_soft_nms": (_c_int, [_c_void_p, _c_int, _c_float, _c_float, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p,
                             _c_void_p]),
     "mi_soft_nms_segmented": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_float, _c_float, _c_int,
@@ -47,6 +52,14 @@ SIGNATURES = {
     "mi_bbox_overlaps": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "mi_dbg_roi_align_timeline": (None, [_c_void_p]),
 }
+
+
+
+class FpnLevels(ctypes.Structure):
+    """mi_fpn_levels (include/mi_detectron_ops.h)."""
+    _fields_ = [("num_levels", ctypes.c_int), ("features", ctypes.c_void_p * 4), ("grads", ctypes.c_void_p * 4),
+                ("height", ctypes.c_int * 4), ("width", ctypes.c_int * 4), ("spatial_scale", ctypes.c_float * 4)]
+
 
 _lib = None
 

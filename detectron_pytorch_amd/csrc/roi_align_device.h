@@ -81,6 +81,30 @@ __device__ __forceinline__ float sample_x(const RoiGeom& g, int pw, int ix) {
 }
 
 
+// The feature maps one call works on: one level for the plain entry points, up to four FPN levels for the fused ones
+// (mi_roi_align_forward_fpn / _backward_fpn).  Passed to the record kernels by value.
+constexpr int kMaxLevels = 4;
+struct LevelTable {
+  int count;
+  int height[kMaxLevels], width[kMaxLevels];
+  float scale[kMaxLevels];
+  const float* feat[kMaxLevels];  // forward: features of the level
+  float* grad[kMaxLevels];        // backward: gradient map of the level
+  int row_base[kMaxLevels + 1];   // prefix sum of batch * height: the "global row" space windows and tiles live in
+  int tile_base[kMaxLevels + 1];  // backward: prefix sum of the levels' tile counts (filled by the launcher)
+};
+inline LevelTable single_level(const float* feat, float* grad, int batch, int height, int width, float scale) {
+  LevelTable t = {};
+  t.count = 1;
+  t.height[0] = height;
+  t.width[0] = width;
+  t.scale[0] = scale;
+  t.feat[0] = feat;
+  t.grad[0] = grad;
+  t.row_base[1] = batch * height;
+  return t;
+}
+
 // host-side launchers of the NCHW fast paths (roi_align_fwd_tile.hip, roi_align_stream.hip)
 bool roi_align_fwd_tile_supported(int channels, int height, int width, int aligned_height, int aligned_width);
 int launch_roi_align_fwd_tile(const float* features, const float* rois, float* output, int batch, int channels,
@@ -107,6 +131,14 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
                                  int sampling_ratio, int cap_px, hipStream_t stream);
 bool roi_align_bwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width);
+// the same two paths over up to kMaxLevels feature maps in one call (`levels`: device int32 per RoI, or nullptr)
+int launch_roi_align_fwd_records_levels(const LevelTable& lv, const float* rois, const int* levels, float* output,
+                                        void* workspace, int batch, int channels, int num_rois, int aligned_height,
+                                        int aligned_width, int sampling_ratio, int cap_px, hipStream_t stream);
+int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois, const int* levels, LevelTable lv,
+                                        void* workspace, bool records_ready, bool overwrite, bool nhwc, int batch,
+                                        int channels, int num_rois, int aligned_height, int aligned_width,
+                                        int sampling_ratio, int cap_px, hipStream_t stream);
 // records only (the first launch of the two-launch paths); `workspace` as roi_align_records_workspace_bytes
 int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,
                              int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,

@@ -10,7 +10,7 @@ constexpr int kMaxStages = 32;             // == max aligned_height on the fast 
 
 // ---- per-RoI record (dwords), stored at the RoI's rank along the sweep ---------------------------------------------
 constexpr int kRecHeader = 16;  // [0] flags [1] batch_ind [2] wx0 [3] ww [4] magic [5] nstages [6] gh [7] gw [8] roi
-                                // [9] wy0 [10] wy1 (last window row) [12..15] stage 0
+                                // [9] wy0 [10] wy1 (last window row) [11] level [12..15] stage 0
 constexpr int kRecStages = kRecHeader;                 // kMaxStages x {ph0 | ph1 << 16, row0, nrows, 0}
 constexpr int kRecY = kRecStages + 4 * kMaxStages;     // kMaxS x {row_lo * ww * 4, hw / count, lw / count, row_lo}
 constexpr int kRecX = kRecY + 4 * kMaxS;               // kMaxS x {(col_lo - wx0) * 4, hw, lw, col_lo}

@@ -59,9 +59,14 @@ __device__ __forceinline__ float coord(float start, float bin, int p, int i, int
 }
 
 // sweep key of a RoI: image, band of its centre row, x of its centre (reversed in odd bands)
-__device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, float spatial_scale, int height) {
+__device__ __forceinline__ int level_of(const int* __restrict__ levels, int i, const LevelTable& lv) {
+  return levels != nullptr ? min(max(levels[i], 0), lv.count - 1) : 0;
+}
+
+// level (2 bits) | image (6 bits) | band (8) | x (16): RoIs of one level and image are contiguous in the sweep
+__device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int lvl, float spatial_scale, int height) {
   const float cy = (roi[2] + roi[4]) * 0.5f * spatial_scale, cx = (roi[1] + roi[3]) * 0.5f * spatial_scale;
-  const int b = min(max((int)roi[0], 0), 255);
+  const int b = (lvl << 6) | min(max((int)roi[0], 0), 63);
   const int y = min(max((int)cy, 0), max(height - 1, 0)), band = min(y / kBandRows, 255);
   int x = min(max((int)(cx * 16.f), 0), 65535);
   if (band & 1) x = 65535 - x;
@@ -69,13 +74,16 @@ __device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, flo
 }
 
 __global__ void __launch_bounds__(256)
-roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int height, int width, int aligned_height,
-                  int aligned_width, float spatial_scale, int sampling_ratio, int cap_px, int stage_px, int max_rows_tile,
-                  int* __restrict__ ws) {
+roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels, int num_rois, int batch,
+                  const LevelTable lv, int aligned_height, int aligned_width, int sampling_ratio, int cap_px,
+                  int stage_px, int max_rows_tile, int* __restrict__ ws) {
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x < kCounterDwords) ws[threadIdx.x] = 0;
-  for (int i = threadIdx.x; i < num_rois; i += 256) keys[i] = sweep_key(rois + (long long)i * 5, spatial_scale, height);
+  for (int i = threadIdx.x; i < num_rois; i += 256) {
+    const int l = level_of(levels, i, lv);
+    keys[i] = sweep_key(rois + (long long)i * 5, l, lv.scale[l], lv.height[l]);
+  }
   __syncthreads();
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= num_rois) return;
@@ -94,6 +102,9 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
   // the RoI's five floats: wave-uniform address -> scalar loads
   using const_float_ptr = const __attribute__((address_space(4))) float*;
   const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)__builtin_amdgcn_readfirstlane(r) * 5);
+  const int lvl = __builtin_amdgcn_readfirstlane(level_of(levels, r, lv));
+  const int height = lv.height[lvl], width = lv.width[lvl];
+  const float spatial_scale = lv.scale[lvl];
   const int batch_ind = (int)roi[0];
   const float start_w = roi[1] * spatial_scale, start_h = roi[2] * spatial_scale;
   const float roi_width = fmaxf(roi[3] * spatial_scale - start_w, 1.f);
@@ -163,8 +174,8 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
     int4 bnd;
     bnd.x = bwd_ok ? wx0 : 0x3fffffff;  // an interval that overlaps no tile
     bnd.y = bwd_ok ? wx1 : -1;
-    bnd.z = batch_ind * height + wy0;
-    bnd.w = batch_ind * height + wy1;
+    bnd.z = lv.row_base[lvl] + batch_ind * height + wy0;  // "global rows": levels and images stacked
+    bnd.w = lv.row_base[lvl] + batch_ind * height + wy1;
     reinterpret_cast<int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords)[rank] = bnd;
   }
   // stages: consecutive bin rows whose window fits half the LDS image (so that the next stage can be prefetched while
@@ -217,7 +228,7 @@ roi_align_prepare(const float* __restrict__ rois, int num_rois, int batch, int h
     h2.x = r;
     h2.y = wy0;
     h2.z = wy1;
-    h2.w = 0;
+    h2.w = lvl;
     reinterpret_cast<int4*>(rec)[0] = h0;
     reinterpret_cast<int4*>(rec)[1] = h1;
     reinterpret_cast<int4*>(rec)[2] = h2;
@@ -283,9 +294,9 @@ __device__ __forceinline__ unsigned lds_addr_uniform(const void* p) {
 // -------------------------------------------------------------------------------------------------------------------
 template <int kSR, int kCap, int kCTt, int kHalves>
 __global__ void __launch_bounds__(kCTt * 8 * kHalves)
-roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
-                      const int* __restrict__ ws, int num_rois, int batch, int channels, int height, int width,
-                      int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio, int ablate) {
+roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
+                      const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height,
+                      int aligned_width, int sampling_ratio, int ablate) {
   // kCTt channels per workgroup (32: half-waves own output columns; 16: quarter-waves do, twice as many workgroups
   // fit a CU -- the per-workgroup chain record load -> DMA -> landing -> arithmetic -> store drain is latency, and
   // what hides it is the number of workgroups in flight)
@@ -309,12 +320,16 @@ roi_align_fwd_records(const float* __restrict__ feat, const float* __restrict__ 
   const int c0 = (blockIdx.x - pos * tiles) * kCT;
   const int wave = uniform(tid >> 6), lane = tid & 63;
   const int cl = tid % kCT, slot = (tid / kCT) & 7, half = tid / (kCT * 8);
-  const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
   const float* img_c = s.img + cl * kPlane;
   const int* __restrict__ records = ws + kCounterDwords;
   const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)pos * kRecDwords);
   const int flags = rec[0], batch_ind = rec[1], wx0 = rec[2], ww = rec[3], magic = rec[4], nstages = rec[5];
-  const int rgh = rec[6], rgw = rec[7], r = rec[8];
+  const int rgh = rec[6], rgw = rec[7], r = rec[8], lvl = rec[11];
+  // the feature map of the RoI's level (one entry unless the call is an FPN-fused one)
+  const float* __restrict__ feat = lv.feat[lvl];
+  const int height = lv.height[lvl], width = lv.width[lvl];
+  const float spatial_scale = lv.scale[lvl];
+  const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
   float* __restrict__ dst = out + ((long long)r * channels + c0) * bins;
 
   if (!(flags & kFlagFast)) {
@@ -526,10 +541,9 @@ struct BwdLds {
 
 template <int kSR, int KC, int kTH>
 __global__ void __launch_bounds__(kTH * 32)
-roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bottom_grad, const int* __restrict__ ws,
-                    int num_rois, int batch, int channels, int height, int width, int aligned_height,
-                    int aligned_width, int tiles_x, int tiles_y, int overwrite, int ablate, int g_words, int ah_pad,
-                    int g_cs) {
+roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, const int* __restrict__ ws,
+                    int num_rois, int batch, int channels, int aligned_height, int aligned_width, int overwrite,
+                    int ablate, int g_words, int ah_pad, int g_cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kTabDw = BwdLds<KC>::kTabDw;
   constexpr int kThreads = kTH * kTW, kNWaves = kThreads / 64;
@@ -549,12 +563,19 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
   const int bins = aligned_height * aligned_width;
   const int ncg = channels / KC;
   const int cg = blockIdx.x % ncg;
-  const int tile_lin = blockIdx.x / ncg;
+  int tile_lin = blockIdx.x / ncg;
+  int lvl = 0;  // the level this tile belongs to (tiles of all levels share the grid in an FPN-fused call)
+  while (lvl + 1 < lv.count && tile_lin >= lv.tile_base[lvl + 1]) lvl++;
+  tile_lin -= lv.tile_base[lvl];
+  float* __restrict__ bottom_grad = lv.grad[lvl];
+  const int height = lv.height[lvl], width = lv.width[lvl];
+  const int tiles_x = (width + kTW - 1) / kTW, tiles_y = (height + kTH - 1) / kTH;
   const int n = tile_lin / (tiles_x * tiles_y);
   const int trem = tile_lin - n * tiles_x * tiles_y;
   const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
   const int x0 = txi * kTW, y0 = tyi * kTH;            // tile origin in the feature map
-  const int gy0 = n * height + y0;                      // in "global rows" (image index folded in)
+  const int img_row0 = lv.row_base[lvl] + n * height;  // "global rows": levels and images stacked
+  const int gy0 = img_row0 + y0;
   const int c0 = cg * KC;
   const int* __restrict__ records = ws + kCounterDwords;
   const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
@@ -567,7 +588,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
     bool hit = false;
     if (i < num_rois) {
       const int4 b = bounds[i];
-      hit = b.y >= x0 && b.x < x0 + kTW && b.w >= gy0 && b.z < gy0 + kTH && b.z / height == n;
+      hit = b.y >= x0 && b.x < x0 + kTW && b.w >= gy0 && b.z < gy0 + kTH && b.z >= img_row0 && b.z < img_row0 + height;
     }
     const unsigned long long m = __ballot(hit);
     if (lane == 0) wave_count[wave] = __popcll(m);
@@ -746,15 +767,18 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, float* __restrict__ bott
 
 // RoIs the tile kernel does not cover: reference mapping, arithmetic and atomics (roi_align_kernel.cu:195-270).
 __global__ void __launch_bounds__(256)
-roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__ rois, float* __restrict__ bottom_grad,
-                   const int* __restrict__ ws, int num_rois, int batch, int channels, int height, int width,
-                   int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio, int nhwc) {
+roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__ rois, const LevelTable lv,
+                   const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height,
+                   int aligned_width, int sampling_ratio, int nhwc) {
   const int tiles = channels / kCT;
   const int pos = blockIdx.x / tiles;
   const int c0 = (blockIdx.x - pos * tiles) * kCT;
   const const_int_ptr rec = (const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)pos * kRecDwords);
-  const int flags = rec[0], r = rec[8];
+  const int flags = rec[0], r = rec[8], lvl = rec[11];
   if (flags & (kFlagBwd | kFlagZero)) return;
+  float* __restrict__ bottom_grad = lv.grad[lvl];
+  const int height = lv.height[lvl], width = lv.width[lvl];
+  const float spatial_scale = lv.scale[lvl];
   const int bins = aligned_height * aligned_width;
   const int tid = threadIdx.x;
   const float* __restrict__ gsrc = top_grad + ((long long)r * channels + c0) * bins;
@@ -788,21 +812,25 @@ size_t records_lds_bytes(int cap, int ct) {
   return 2 * kMaxS * sizeof(TabEntry) + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4;
 }
 
-template <int kCap>
-int launch_cap(const float* features, const float* rois, float* output, int* ws, int batch, int channels, int height,
-               int width, int num_rois, int aligned_height, int aligned_width, float spatial_scale,
-               int sampling_ratio, hipStream_t stream) {
+int launch_prepare(const float* rois, const int* levels, int* ws, int batch, const LevelTable& lv, int num_rois,
+                   int aligned_height, int aligned_width, int sampling_ratio, int cap_px, hipStream_t stream) {
   const int max_rows_tile = kTileBins / aligned_width;
   roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
-      rois, num_rois, batch, height, width, aligned_height, aligned_width, spatial_scale, sampling_ratio, kCap, kCap,
-      max_rows_tile, ws);
-  int rc = check_launch("roi_align_prepare");
+      rois, levels, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile, ws);
+  return check_launch("roi_align_prepare");
+}
+
+template <int kCap>
+int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float* output, int* ws, int batch,
+               int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
+               hipStream_t stream) {
+  int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio, kCap,
+                          stream);
   if (rc != MI_OK) return rc;
 #define MI_LAUNCH_REC(SR)                                                                                             \
   roi_align_fwd_records<SR, kCap, kCT, 1>                                                                             \
       <<<num_rois * (channels / kCT), kCT * 8, records_lds_bytes(kCap, kCT), stream>>>(                               \
-          features, rois, output, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width,       \
-          spatial_scale, sampling_ratio, g_ablate_p)
+          lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, g_ablate_p)
   if (sampling_ratio == 2)
     MI_LAUNCH_REC(2);
   else
@@ -811,34 +839,23 @@ int launch_cap(const float* features, const float* rois, float* output, int* ws,
   return check_launch("roi_align_fwd_records");
 }
 
-template <int kCap>
-int launch_prepare_only(const float* rois, int* ws, int batch, int height, int width, int num_rois, int aligned_height,
-                        int aligned_width, float spatial_scale, int sampling_ratio, hipStream_t stream) {
-  const int max_rows_tile = kTileBins / aligned_width;
-  roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
-      rois, num_rois, batch, height, width, aligned_height, aligned_width, spatial_scale, sampling_ratio, kCap, kCap,
-      max_rows_tile, ws);
-  return check_launch("roi_align_prepare");
-}
-
 }  // namespace
 
-int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float* bottom_grad, void* workspace,
-                                 bool records_ready, bool overwrite, bool nhwc, int batch, int channels, int height,
-                                 int width, int num_rois, int aligned_height, int aligned_width, float spatial_scale,
-                                 int sampling_ratio, int cap_px, hipStream_t stream) {
+// Backward over the records.  `lv` carries the gradient map of every level (grad[], height[], width[], scale[],
+// row_base[]); tile_base[] is filled here.  nhwc: the gradient maps are stored channels-last.
+int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois, const int* levels, LevelTable lv,
+                                        void* workspace, bool records_ready, bool overwrite, bool nhwc, int batch,
+                                        int channels, int num_rois, int aligned_height, int aligned_width,
+                                        int sampling_ratio, int cap_px, hipStream_t stream) {
   int* ws = static_cast<int*>(workspace);
   if (!records_ready) {
     // backward tables do not depend on the LDS capacity the forward stages were cut for
-    int rc = cap_px >= 336 ? launch_prepare_only<336>(rois, ws, batch, height, width, num_rois, aligned_height,
-                                                      aligned_width, spatial_scale, sampling_ratio, stream)
-                           : launch_prepare_only<192>(rois, ws, batch, height, width, num_rois, aligned_height,
-                                                      aligned_width, spatial_scale, sampling_ratio, stream);
+    int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio,
+                            cap_px >= 336 ? 336 : 192, stream);
     if (rc != MI_OK) return rc;
   }
   const int bins = aligned_height * aligned_width;
-  const int th = g_bwd_th;  // rows per tile (8 or 16): 32 * th lanes per workgroup
-  const int tiles_x = (width + kTW - 1) / kTW, tiles_y = (height + th - 1) / th;
+  const int th = g_bwd_th;  // rows per tile (8, 16 or 32): 32 * th lanes per workgroup
   // channels per workgroup: 32 accumulators per lane while the g block and T fit LDS comfortably, else 16
   const int kc = (bins <= 64) ? 32 : 16;
   const int ah_pad = (aligned_height + 3) & ~3;
@@ -846,15 +863,18 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
   const int g_words = kc * g_cs;
   const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
   const size_t lds = (32 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
-  const int grid = tiles_x * tiles_y * batch * (channels / kc);
+  lv.tile_base[0] = 0;
+  for (int l = 0; l < lv.count; l++)
+    lv.tile_base[l + 1] = lv.tile_base[l] + ((lv.width[l] + kTW - 1) / kTW) * ((lv.height[l] + th - 1) / th) * batch;
+  const int grid = lv.tile_base[lv.count] * (channels / kc);
 #define MI_LAUNCH_TILES_TH(SR, KC, TH)                                                                                \
   do {                                                                                                                \
     if (lds > 64 * 1024)                                                                                              \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC, TH>),                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
     roi_align_bwd_tiles<SR, KC, TH><<<grid, TH * 32, lds, stream>>>(                                                 \
-        top_grad, bottom_grad, ws, num_rois, batch, channels, height, width, aligned_height, aligned_width, tiles_x,  \
-        tiles_y, (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs);                                           \
+        top_grad, lv, ws, num_rois, batch, channels, aligned_height, aligned_width,                                   \
+        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs);                                 \
   } while (0)
 #define MI_LAUNCH_TILES(SR, KC)                                                                                       \
   do {                                                                                                                \
@@ -880,11 +900,20 @@ int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float
   int rc = check_launch("roi_align_bwd_tiles");
   if (rc != MI_OK) return rc;
   if (!(g_ablate_p & 16))
-    roi_align_bwd_slow<<<num_rois * (channels / kCT), 256, 0, stream>>>(top_grad, rois, bottom_grad, ws, num_rois, batch,
-                                                                    channels, height, width, aligned_height,
-                                                                    aligned_width, spatial_scale, sampling_ratio,
+    roi_align_bwd_slow<<<num_rois * (channels / kCT), 256, 0, stream>>>(top_grad, rois, lv, ws, num_rois, batch, channels,
+                                                                    aligned_height, aligned_width, sampling_ratio,
                                                                     nhwc ? 1 : 0);
   return check_launch("roi_align_bwd_slow");
+}
+
+int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float* bottom_grad, void* workspace,
+                                 bool records_ready, bool overwrite, bool nhwc, int batch, int channels, int height,
+                                 int width, int num_rois, int aligned_height, int aligned_width, float spatial_scale,
+                                 int sampling_ratio, int cap_px, hipStream_t stream) {
+  return launch_roi_align_bwd_records_levels(top_grad, rois, nullptr,
+                                             single_level(nullptr, bottom_grad, batch, height, width, spatial_scale),
+                                             workspace, records_ready, overwrite, nhwc, batch, channels, num_rois,
+                                             aligned_height, aligned_width, sampling_ratio, cap_px, stream);
 }
 
 bool roi_align_bwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
@@ -904,8 +933,9 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
 int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,
                              int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
                              hipStream_t stream) {
-  return launch_prepare_only<336>(rois, static_cast<int*>(workspace), batch, height, width, num_rois, aligned_height,
-                                  aligned_width, spatial_scale, sampling_ratio, stream);
+  return launch_prepare(rois, nullptr, static_cast<int*>(workspace), batch,
+                        single_level(nullptr, nullptr, batch, height, width, spatial_scale), num_rois, aligned_height,
+                        aligned_width, sampling_ratio, 336, stream);
 }
 
 void roi_align_records_set_ablate(int mask) { g_ablate_p = mask; }
@@ -922,25 +952,28 @@ bool roi_align_fwd_records_supported(int channels, int height, int width, int nu
          (long long)kCT * height * width * 4 < (1LL << 31);
 }
 
+int launch_roi_align_fwd_records_levels(const LevelTable& lv, const float* rois, const int* levels, float* output,
+                                        void* workspace, int batch, int channels, int num_rois, int aligned_height,
+                                        int aligned_width, int sampling_ratio, int cap_px, hipStream_t stream) {
+  int* ws = static_cast<int*>(workspace);
+#define MI_CAP(C)                                                                                                     \
+  return launch_cap<C>(lv, rois, levels, output, ws, batch, channels, num_rois, aligned_height, aligned_width,        \
+                       sampling_ratio, stream)
+  if (cap_px >= 640) MI_CAP(640);
+  if (cap_px >= 448) MI_CAP(448);
+  if (cap_px >= 336) MI_CAP(336);
+  if (cap_px >= 256) MI_CAP(256);
+  MI_CAP(192);
+#undef MI_CAP
+}
+
 int launch_roi_align_fwd_records(const float* features, const float* rois, float* output, void* workspace, int batch,
                                  int channels, int height, int width, int num_rois, int aligned_height,
                                  int aligned_width, float spatial_scale, int sampling_ratio, int cap_px,
                                  hipStream_t stream) {
-  int* ws = static_cast<int*>(workspace);
-  if (cap_px >= 640)
-    return launch_cap<640>(features, rois, output, ws, batch, channels, height, width, num_rois, aligned_height,
-                           aligned_width, spatial_scale, sampling_ratio, stream);
-  if (cap_px >= 448)
-    return launch_cap<448>(features, rois, output, ws, batch, channels, height, width, num_rois, aligned_height,
-                           aligned_width, spatial_scale, sampling_ratio, stream);
-  if (cap_px >= 336)
-    return launch_cap<336>(features, rois, output, ws, batch, channels, height, width, num_rois, aligned_height,
-                           aligned_width, spatial_scale, sampling_ratio, stream);
-  if (cap_px >= 256)
-    return launch_cap<256>(features, rois, output, ws, batch, channels, height, width, num_rois, aligned_height,
-                           aligned_width, spatial_scale, sampling_ratio, stream);
-  return launch_cap<192>(features, rois, output, ws, batch, channels, height, width, num_rois, aligned_height,
-                         aligned_width, spatial_scale, sampling_ratio, stream);
+  return launch_roi_align_fwd_records_levels(single_level(features, nullptr, batch, height, width, spatial_scale), rois,
+                                             nullptr, output, workspace, batch, channels, num_rois, aligned_height,
+                                             aligned_width, sampling_ratio, cap_px, stream);
 }
 
 }  // namespace mi

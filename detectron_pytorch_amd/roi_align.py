@@ -18,6 +18,8 @@ Behaviour preserved: CPU `features` -> NotImplementedError (:29-30); no gradient
 New: features stored channels_last are consumed in place (layout flag of the C-ABI) instead of
 being copied to NCHW.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 from torch.nn.modules.module import Module
@@ -136,6 +138,84 @@ class _RoIAlign(Function):
                                         channels_last=ctx.channels_last,
                                         workspace=workspace if workspace.numel() > 0 else None)
         return grad_input, None, None, None, None, None, None
+
+
+def _fpn_table(tensors, scales, grads=False):
+    t = _lib.FpnLevels()
+    t.num_levels = len(tensors)
+    for i, (x, sc) in enumerate(zip(tensors, scales)):
+        (t.grads if grads else t.features)[i] = x.data_ptr()
+        t.height[i], t.width[i], t.spatial_scale[i] = int(x.size(2)), int(x.size(3)), float(sc)
+    return t
+
+
+def roi_align_fpn_supported(features, num_rois, aligned_height, aligned_width):
+    """True when mi_roi_align_forward_fpn / _backward_fpn serve these maps in one call (NCHW, same batch and channels,
+    at most four levels); otherwise the caller loops over the levels."""
+    if not (1 <= len(features) <= 4) or num_rois <= 0:
+        return False
+    f0 = features[0]
+    for f in features:
+        if (not f.is_cuda or f.dtype != torch.float32 or f.dim() != 4 or not f.is_contiguous()
+                or f.size(0) != f0.size(0) or f.size(1) != f0.size(1) or f.device != f0.device):
+            return False
+    table = _fpn_table(features, [1.0] * len(features))
+    return bool(_lib.lib().mi_roi_align_fpn_supported(ctypes.byref(table), int(f0.size(1)), int(num_rois),
+                                                      int(aligned_height), int(aligned_width)))
+
+
+class _RoIAlignFPN(Function):
+    """RoIAlign over all FPN levels in one call: `.apply(rois, roi_levels, ah, aw, sampling_ratio, scales, *features)`.
+    roi_levels[i] = index into `features` of the map RoI i is pooled from; the output is in the order of `rois`."""
+
+    @staticmethod
+    def forward(ctx, rois, roi_levels, aligned_height, aligned_width, sampling_ratio, scales, *features):
+        lib = _lib.lib()
+        rois = rois.contiguous()
+        roi_levels = roi_levels.to(dtype=torch.int32).contiguous()
+        n, c = features[0].size(0), features[0].size(1)
+        r = rois.size(0)
+        output = torch.empty((r, c, aligned_height, aligned_width), dtype=torch.float32, device=rois.device)
+        ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=rois.device)
+        table = _fpn_table(features, scales)
+        with torch.cuda.device(rois.device):
+            rc = lib.mi_roi_align_forward_fpn(ctypes.byref(table), rois.data_ptr(), roi_levels.data_ptr(),
+                                              output.data_ptr(), n, c, r, int(aligned_height), int(aligned_width),
+                                              int(sampling_ratio), workspace.data_ptr(), ws_bytes,
+                                              _lib.current_stream_handle(rois.device))
+        _lib.check(rc, "mi_roi_align_forward_fpn")
+        ctx.cfg = (int(aligned_height), int(aligned_width), int(sampling_ratio), tuple(float(s) for s in scales))
+        ctx.shapes = [tuple(f.shape) for f in features]
+        ctx.save_for_backward(rois, roi_levels, workspace)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lib = _lib.lib()
+        rois, roi_levels, workspace = ctx.saved_tensors
+        ah, aw, sr, scales = ctx.cfg
+        grad_output = grad_output.contiguous()
+        grads = [torch.empty(shape, dtype=torch.float32, device=grad_output.device) for shape in ctx.shapes]
+        n, c = ctx.shapes[0][0], ctx.shapes[0][1]
+        table = _fpn_table(grads, scales, grads=True)
+        with torch.cuda.device(grad_output.device):  # every element of every level is written: no zero fill
+            rc = lib.mi_roi_align_backward_fpn(ctypes.byref(table), grad_output.data_ptr(), rois.data_ptr(),
+                                               roi_levels.data_ptr(), n, c, rois.size(0), ah, aw, sr,
+                                               workspace.data_ptr(), workspace.numel(),
+                                               _lib.ROI_ALIGN_RECORDS_READY | _lib.ROI_ALIGN_OVERWRITE,
+                                               _lib.current_stream_handle(grad_output.device))
+        _lib.check(rc, "mi_roi_align_backward_fpn")
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+def roi_align_fpn(features, scales, rois, roi_levels, aligned_height, aligned_width, sampling_ratio):
+    """Pool `rois` [R,5] from the FPN maps `features` (list, any order; `scales` alike) in one call; roi_levels [R]
+    (int tensor on the device) indexes into `features`.  Differentiable w.r.t. every map."""
+    for f in features:
+        _check_inputs(f, rois)
+    return _RoIAlignFPN.apply(rois, roi_levels, int(aligned_height), int(aligned_width), int(sampling_ratio),
+                              tuple(scales), *features)
 
 
 class RoIAlignFunction(object):

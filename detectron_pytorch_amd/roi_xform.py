@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .roi_align import RoIAlignFunction
+from .roi_align import RoIAlignFunction, roi_align_fpn, roi_align_fpn_supported
 from .roi_pool import RoIPoolFunction
 from .roi_crop import RoICropFunction
 
@@ -75,11 +75,13 @@ def _one_level(features, rois, method, resolution, scale, sampling_ratio, grid_s
 
 def roi_feature_transform(blobs_in, rpn_ret, blob_rois="rois", method="RoIPoolF", resolution=7,
                           spatial_scale=1.0 / 16.0, sampling_ratio=0, k_min=2, k_max=5, grid_size=14,
-                          crop_resize_with_max_pool=True):
+                          crop_resize_with_max_pool=True, fused=True):
     """model_builder.py:252-324. `blobs_in`: one [N,C,H,W] device tensor, or the FPN list ordered coarsest level
     first (then `spatial_scale` is a list in the same order). `rpn_ret[blob_rois]` / `rpn_ret[blob_rois+'_fpn<l>']`
     hold [R,5] rois (numpy, as the reference's data layer produces them, or device tensors). Levels without rois are
-    skipped; the level-major result is put back in dataloader order with `<blob_rois>_idx_restore_int32`."""
+    skipped; the level-major result is put back in dataloader order with `<blob_rois>_idx_restore_int32`.
+    RoIAlign over NCHW maps takes the FPN-fused entry point (one call for all levels, no concat / restore gather of the
+    pooled features) unless `fused=False`."""
     if method not in METHODS:
         raise AssertionError("Unknown pooling method: {}".format(method))
     if not isinstance(blobs_in, (list, tuple)):
@@ -88,17 +90,27 @@ def roi_feature_transform(blobs_in, rpn_ret, blob_rois="rois", method="RoIPoolF"
                           crop_resize_with_max_pool)
     if len(blobs_in) != k_max - k_min + 1:
         raise AssertionError("expected %d FPN levels, got %d" % (k_max - k_min + 1, len(blobs_in)))
-    pooled = []
-    for lvl in range(k_min, k_max + 1):
-        features = blobs_in[k_max - lvl]
-        level_rois = rpn_ret["%s_fpn%d" % (blob_rois, lvl)]
-        if len(level_rois) == 0:
-            continue
-        rois = _as_device_rois(level_rois, features.device)
-        pooled.append(_one_level(features, rois, method, resolution, spatial_scale[k_max - lvl], sampling_ratio,
-                                 grid_size, crop_resize_with_max_pool))
-    shuffled = torch.cat(pooled, dim=0)
+    level_rois = [rpn_ret["%s_fpn%d" % (blob_rois, lvl)] for lvl in range(k_min, k_max + 1)]
     restore = rpn_ret[blob_rois + "_idx_restore_int32"]
     if isinstance(restore, np.ndarray):
         restore = torch.from_numpy(restore.astype(np.int64, copy=False))
-    return shuffled[restore.to(device=shuffled.device, dtype=torch.int64)]
+    device = blobs_in[0].device
+    restore = restore.to(device=device, dtype=torch.int64)
+    num_rois = sum(len(x) for x in level_rois)
+    if fused and method == "RoIAlign" and roi_align_fpn_supported(list(blobs_in), num_rois, resolution, resolution):
+        # one call for the whole pyramid: the RoIs go back to dataloader order BEFORE pooling (a [R,5] gather instead
+        # of the [R,C,res,res] one at :306), each with the index of its map in blobs_in (coarsest level first)
+        rois_cat = torch.cat([_as_device_rois(x, device) for x in level_rois if len(x)], dim=0)
+        lvl_cat = torch.cat([torch.full((len(x),), k_max - lvl, dtype=torch.int32, device=device)
+                             for lvl, x in zip(range(k_min, k_max + 1), level_rois) if len(x)])
+        return roi_align_fpn(list(blobs_in), list(spatial_scale), rois_cat[restore], lvl_cat[restore], resolution,
+                             resolution, sampling_ratio)
+    pooled = []
+    for lvl, rois_l in zip(range(k_min, k_max + 1), level_rois):
+        features = blobs_in[k_max - lvl]
+        if len(rois_l) == 0:
+            continue
+        rois = _as_device_rois(rois_l, features.device)
+        pooled.append(_one_level(features, rois, method, resolution, spatial_scale[k_max - lvl], sampling_ratio,
+                                 grid_size, crop_resize_with_max_pool))
+    return torch.cat(pooled, dim=0)[restore]

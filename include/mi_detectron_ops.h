@@ -116,6 +116,35 @@ int mi_roi_align_forward_writes_records(int channels, int height, int width, int
 int mi_roi_align_backward_overwrites(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width, int variant, int layout);
 
+/* ---- RoIAlign over an FPN pyramid, one call ----------------------------------------------------------------------
+ * replaces the per-level loop of Generalized_RCNN.roi_feature_transform (lib/modeling/model_builder.py:266-306): one
+ * RoIAlignFunction call, one H2D copy and one output tensor per level, then torch.cat and a gather by
+ * `<rois>_idx_restore_int32`.  Here all levels are served by ONE pair of launches and the output is written directly in
+ * the order of `rois`: every RoI carries the index of its level (`roi_levels`, device int32 [R], values
+ * 0..num_levels-1 -- utils/fpn.py:11-28 computes the assignment on the host in the reference's data layer).
+ * Caffe2 semantics, NCHW maps that share batch and channels.  Same workspace, records and flags as the single-level
+ * _ws entry points (the records of a forward serve the backward over the same rois and roi_levels); the backward
+ * writes (MI_ROI_ALIGN_OVERWRITE) or accumulates into every level's gradient map, also those no RoI maps to.
+ * mi_roi_align_fpn_supported() == 0: shapes the fused path does not take -- loop over the levels instead. */
+#define MI_FPN_MAX_LEVELS 4
+typedef struct mi_fpn_levels {
+  int num_levels;                             /* 1 .. MI_FPN_MAX_LEVELS */
+  const float* features[MI_FPN_MAX_LEVELS];   /* forward: [N,C,height[l],width[l]]; ignored by the backward */
+  float* grads[MI_FPN_MAX_LEVELS];            /* backward: gradient map of level l; ignored by the forward */
+  int height[MI_FPN_MAX_LEVELS];
+  int width[MI_FPN_MAX_LEVELS];
+  float spatial_scale[MI_FPN_MAX_LEVELS];
+} mi_fpn_levels;
+int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
+                               int aligned_width);
+int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels, float* output,
+                             int batch, int channels, int num_rois, int aligned_height, int aligned_width,
+                             int sampling_ratio, void* workspace, size_t workspace_bytes, mi_stream_t stream);
+int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const float* top_grad, const float* rois,
+                              const int32_t* roi_levels, int batch, int channels, int num_rois, int aligned_height,
+                              int aligned_width, int sampling_ratio, void* workspace, size_t workspace_bytes, int flags,
+                              mi_stream_t stream);
+
 /* ---- RoIPool --------------------------------------------------------------------------
  * replaces ROIPoolForwardLaucher / ROIPoolBackwardLaucher (lib/model/roi_pooling/src/roi_pooling_kernel.h:8-20)
  * and roi_pooling_forward_cuda / roi_pooling_backward_cuda (roi_pooling_cuda.c:7,49).

@@ -577,3 +577,46 @@ def test_soft_nms_segmented_matches_single_calls(oracle_mod):
         assert k == len(boxes)
         assert np.array_equal(out_dets[off[p]:off[p] + k].cpu().numpy(), boxes)
         assert np.array_equal(out_inds[off[p]:off[p] + k].cpu().numpy(), np.asarray(inds, dtype=np.int64))
+
+
+def test_roi_align_fpn_fused_matches_per_level_loop_and_oracle(oracle_mod):
+    """mi_roi_align_forward_fpn / _backward_fpn: all levels in one call, output in dataloader order, a level without
+    RoIs gets a zero gradient; same numbers as the per-level loop (same per-RoI arithmetic, same summation order)."""
+    from detectron_pytorch_amd import roi_xform
+    from detectron_pytorch_amd.roi_align import roi_align_fpn, roi_align_fpn_supported
+
+    rois, lvls, blobs, scales, feats = _fpn_inputs(channels=64, num_rois=500, batch=2, seed=11)
+    gtop = np.random.RandomState(2).randn(500, 64, 7, 7).astype(np.float32)
+    outs, grads = [], []
+    for fused in (True, False):
+        dev_feats = [to_dev(f).requires_grad_(True) for f in feats]
+        out = roi_xform.roi_feature_transform(dev_feats, blobs, "rois", "RoIAlign", 7, scales, 2, fused=fused)
+        out.backward(to_dev(gtop))
+        outs.append(out.detach())
+        grads.append([f.grad for f in dev_feats])
+    assert roi_align_fpn_supported([to_dev(f) for f in feats], 500, 7, 7)
+    assert torch.equal(outs[0], outs[1])
+    for g_fused, g_loop in zip(grads[0], grads[1]):
+        assert_close(g_fused, g_loop.cpu().numpy(), "fused vs loop grad")
+    for lvl in range(2, 6):                                  # and against the oracle, level by level
+        idx = np.nonzero(lvls == lvl)[0]
+        feat, sc = feats[5 - lvl], scales[5 - lvl]
+        assert_fwd(outs[0][torch.from_numpy(idx).to(dev())], oracle_mod.roi_align_forward(feat, rois[idx], 7, 7, sc, 2),
+                   "fused fwd lvl %d" % lvl, exact=False)
+        assert_close(grads[0][5 - lvl], oracle_mod.roi_align_backward(gtop[idx], rois[idx], feat.shape, sc, 2, threads=8),
+                     "fused bwd lvl %d" % lvl)
+    # a level nobody maps to: its gradient is all zeros; adversarial RoIs take the in-kernel reference path
+    adv = np.vstack([syn.rois_adversarial(60, 2, 50, 84, 1.0 / 16, seed=3), rois[:40]])
+    adv_lvl = np.concatenate([np.full(60, 2, np.int32), (5 - lvls[:40]).astype(np.int32)])   # index 2 = P3 ... none on P5
+    adv_lvl[adv_lvl == 0] = 1
+    dev_feats = [to_dev(f).requires_grad_(True) for f in feats]
+    out = roi_align_fpn(dev_feats, scales, to_dev(adv), to_dev(adv_lvl), 7, 7, 2)
+    g2 = np.random.RandomState(4).randn(100, 64, 7, 7).astype(np.float32)
+    out.backward(to_dev(g2))
+    assert float(dev_feats[0].grad.abs().max()) == 0.0
+    for k in (1, 2, 3):
+        idx = np.nonzero(adv_lvl == k)[0]
+        assert_fwd(out.detach()[torch.from_numpy(idx).to(dev())],
+                   oracle_mod.roi_align_forward(feats[k], adv[idx], 7, 7, scales[k], 2), "adv fwd %d" % k, exact=False)
+        assert_close(dev_feats[k].grad, oracle_mod.roi_align_backward(g2[idx], adv[idx], feats[k].shape, scales[k], 2),
+                     "adv bwd %d" % k)
