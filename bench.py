@@ -308,7 +308,7 @@ def fpn_variant(device, iters):
     from detectron_pytorch_amd import roi_xform
 
     rois, lvls = syn.rois_fpn_distributed(1000, batch=1, seed=2)
-    blobs = roi_xform.add_multilevel_roi_blobs({}, "rois", rois, lvls, 2, 5)
+    blobs = roi_xform.add_multilevel_roi_blobs({"rois": rois}, "rois", rois, lvls, 2, 5)
     blobs = {k: torch.from_numpy(v).to(device) for k, v in blobs.items()}
     feats, scales = [], []
     for lvl in (5, 4, 3, 2):  # coarsest first, as the reference orders blobs_in

@@ -99,12 +99,24 @@ def roi_feature_transform(blobs_in, rpn_ret, blob_rois="rois", method="RoIPoolF"
     num_rois = sum(len(x) for x in level_rois)
     if fused and method == "RoIAlign" and roi_align_fpn_supported(list(blobs_in), num_rois, resolution, resolution):
         # one call for the whole pyramid: the RoIs go back to dataloader order BEFORE pooling (a [R,5] gather instead
-        # of the [R,C,res,res] one at :306), each with the index of its map in blobs_in (coarsest level first)
-        rois_cat = torch.cat([_as_device_rois(x, device) for x in level_rois if len(x)], dim=0)
-        lvl_cat = torch.cat([torch.full((len(x),), k_max - lvl, dtype=torch.int32, device=device)
-                             for lvl, x in zip(range(k_min, k_max + 1), level_rois) if len(x)])
-        return roi_align_fpn(list(blobs_in), list(spatial_scale), rois_cat[restore], lvl_cat[restore], resolution,
-                             resolution, sampling_ratio)
+        # of the [R,C,res,res] one at :306), each with the index of its map in blobs_in (coarsest level first).
+        # rpn_ret[blob_rois] -- the un-split blob the reference's data layer also provides -- already is that order.
+        counts = [len(x) for x in level_rois]
+        map_index = [k_max - lvl for lvl in range(k_min, k_max + 1)]
+        # level-major map indices from host-side counts only (slice fills: no host-to-device copy, no sync)
+        lvl_cat = torch.empty((num_rois,), dtype=torch.int32, device=device)
+        first = 0
+        for k, cnt in zip(map_index, counts):
+            if cnt:
+                lvl_cat[first:first + cnt] = k
+            first += cnt
+        lvl_of_roi = lvl_cat[restore]
+        if blob_rois in rpn_ret and len(rpn_ret[blob_rois]) == num_rois:
+            rois = _as_device_rois(rpn_ret[blob_rois], device)
+        else:
+            rois = torch.cat([_as_device_rois(x, device) for x in level_rois if len(x)], dim=0)[restore]
+        return roi_align_fpn(list(blobs_in), list(spatial_scale), rois, lvl_of_roi, resolution, resolution,
+                             sampling_ratio)
     pooled = []
     for lvl, rois_l in zip(range(k_min, k_max + 1), level_rois):
         features = blobs_in[k_max - lvl]

@@ -596,6 +596,13 @@ def test_roi_align_fpn_fused_matches_per_level_loop_and_oracle(oracle_mod):
         grads.append([f.grad for f in dev_feats])
     assert roi_align_fpn_supported([to_dev(f) for f in feats], 500, 7, 7)
     assert torch.equal(outs[0], outs[1])
+    # with the un-split blob present (as in the reference's rpn_ret) it is used directly; device-tensor blobs too
+    with torch.no_grad():
+        blobs_dev = {k: to_dev(v) for k, v in dict(blobs, rois=rois).items()}
+        assert torch.equal(roi_xform.roi_feature_transform([to_dev(f) for f in feats], dict(blobs, rois=rois), "rois",
+                                                           "RoIAlign", 7, scales, 2), outs[0])
+        assert torch.equal(roi_xform.roi_feature_transform([to_dev(f) for f in feats], blobs_dev, "rois", "RoIAlign", 7,
+                                                           scales, 2), outs[0])
     for g_fused, g_loop in zip(grads[0], grads[1]):
         assert_close(g_fused, g_loop.cpu().numpy(), "fused vs loop grad")
     for lvl in range(2, 6):                                  # and against the oracle, level by level
