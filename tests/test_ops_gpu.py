@@ -627,3 +627,25 @@ def test_roi_align_fpn_fused_matches_per_level_loop_and_oracle(oracle_mod):
                    oracle_mod.roi_align_forward(feats[k], adv[idx], 7, 7, scales[k], 2), "adv fwd %d" % k, exact=False)
         assert_close(dev_feats[k].grad, oracle_mod.roi_align_backward(g2[idx], adv[idx], feats[k].shape, scales[k], 2),
                      "adv bwd %d" % k)
+
+
+@pytest.mark.parametrize("res,sr,channels", [(14, 2, 32), (7, 0, 64), (7, 3, 32)])
+def test_roi_align_fpn_fused_other_resolutions(oracle_mod, res, sr, channels):
+    """Mask-head resolution (16-channel backward tiles), adaptive and odd sampling grids through the fused entry points."""
+    from detectron_pytorch_amd.roi_align import roi_align_fpn
+
+    rois, lvls, _, scales, feats = _fpn_inputs(channels=channels, num_rois=160, batch=2, seed=res + sr)
+    keep = lvls >= 3                                          # three levels only: P5, P4, P3
+    rois, lvls = rois[keep], lvls[keep]
+    feats, scales = feats[:3], scales[:3]
+    idx_of = (5 - lvls).astype(np.int32)
+    dev_feats = [to_dev(f).requires_grad_(True) for f in feats]
+    out = roi_align_fpn(dev_feats, scales, to_dev(rois), to_dev(idx_of), res, res, sr)
+    gtop = np.random.RandomState(1).randn(len(rois), channels, res, res).astype(np.float32)
+    out.backward(to_dev(gtop))
+    for k in range(3):
+        idx = np.nonzero(idx_of == k)[0]
+        assert_fwd(out.detach()[torch.from_numpy(idx).to(dev())],
+                   oracle_mod.roi_align_forward(feats[k], rois[idx], res, res, scales[k], sr, threads=8), "fwd", exact=False)
+        assert_close(dev_feats[k].grad, oracle_mod.roi_align_backward(gtop[idx], rois[idx], feats[k].shape, scales[k], sr,
+                                                                      threads=8), "bwd")
