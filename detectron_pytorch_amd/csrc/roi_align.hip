@@ -422,23 +422,25 @@ bool to_level_table(const mi_fpn_levels* in, int batch, bool forward, mi::LevelT
 }  // namespace
 
 extern "C" int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
-                                          int aligned_width) {
+                                          int aligned_width, int layout) {
   if (levels == nullptr || levels->num_levels < 1 || levels->num_levels > mi::kMaxLevels || force_direct() ||
-      std::getenv("MI_ROI_ALIGN_NO_WS") != nullptr || num_rois <= 0)
+      std::getenv("MI_ROI_ALIGN_NO_WS") != nullptr || num_rois <= 0 || num_rois > 8192 ||
+      (layout != MI_LAYOUT_NCHW && layout != MI_LAYOUT_NHWC))
     return 0;
-  for (int l = 0; l < levels->num_levels; l++)
-    if (!mi::roi_align_fwd_records_supported(channels, levels->height[l], levels->width[l], num_rois, aligned_height,
-                                             aligned_width) ||
-        !mi::roi_align_bwd_records_supported(channels, levels->height[l], levels->width[l], num_rois, aligned_height,
-                                             aligned_width))
-      return 0;
+  for (int l = 0; l < levels->num_levels; l++) {
+    const int h = levels->height[l], w = levels->width[l];
+    const bool fwd = layout == MI_LAYOUT_NCHW
+                         ? mi::roi_align_fwd_records_supported(channels, h, w, num_rois, aligned_height, aligned_width)
+                         : mi::roi_align_fwd_nhwc_supported(channels, h, w, num_rois, aligned_height, aligned_width);
+    if (!fwd || !mi::roi_align_bwd_records_supported(channels, h, w, num_rois, aligned_height, aligned_width)) return 0;
+  }
   return 1;
 }
 
 extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels,
                                         float* output, int batch, int channels, int num_rois, int aligned_height,
-                                        int aligned_width, int sampling_ratio, void* workspace, size_t workspace_bytes,
-                                        mi_stream_t stream) {
+                                        int aligned_width, int sampling_ratio, int layout, void* workspace,
+                                        size_t workspace_bytes, mi_stream_t stream) {
   mi::begin_call();
   MI_REQUIRE(batch > 0 && channels > 0 && num_rois >= 0 && aligned_height > 0 && aligned_width > 0,
              "roi_align_fpn: bad size");
@@ -447,21 +449,29 @@ extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float
   MI_REQUIRE(to_level_table(levels, batch, true, &lv), "roi_align_fpn: malformed level table");
   MI_REQUIRE(rois != nullptr && roi_levels != nullptr && output != nullptr && workspace != nullptr,
              "roi_align_fpn: null pointer");
-  MI_REQUIRE(mi_roi_align_fpn_supported(levels, channels, num_rois, aligned_height, aligned_width) == 1,
+  MI_REQUIRE(mi_roi_align_fpn_supported(levels, channels, num_rois, aligned_height, aligned_width, layout) == 1,
              "roi_align_fpn: shapes not served by the fused path (mi_roi_align_fpn_supported() == 0)");
   MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
              "roi_align_fpn: workspace of %zu bytes, %zu needed", workspace_bytes,
              mi::roi_align_records_workspace_bytes(num_rois));
   MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align_fpn: workspace must be 16-byte aligned");
+  const int cap = ring_words();
+  if (layout == MI_LAYOUT_NHWC) {
+    int rc = mi::launch_roi_align_prepare_levels(lv, rois, roi_levels, workspace, batch, num_rois, aligned_height,
+                                                 aligned_width, sampling_ratio, mi::as_stream(stream));
+    if (rc != MI_OK) return rc;
+    return mi::launch_roi_align_fwd_nhwc_levels(lv, rois, output, workspace, batch, channels, num_rois, aligned_height,
+                                                aligned_width, sampling_ratio, mi::as_stream(stream));
+  }
   return mi::launch_roi_align_fwd_records_levels(lv, rois, roi_levels, output, workspace, batch, channels, num_rois,
-                                                 aligned_height, aligned_width, sampling_ratio, ring_words(),
+                                                 aligned_height, aligned_width, sampling_ratio, cap,
                                                  mi::as_stream(stream));
 }
 
 extern "C" int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const float* top_grad, const float* rois,
                                          const int32_t* roi_levels, int batch, int channels, int num_rois,
-                                         int aligned_height, int aligned_width, int sampling_ratio, void* workspace,
-                                         size_t workspace_bytes, int flags, mi_stream_t stream) {
+                                         int aligned_height, int aligned_width, int sampling_ratio, int layout,
+                                         void* workspace, size_t workspace_bytes, int flags, mi_stream_t stream) {
   mi::begin_call();
   MI_REQUIRE(batch > 0 && channels > 0 && num_rois >= 0 && aligned_height > 0 && aligned_width > 0,
              "roi_align_fpn: bad size");
@@ -470,14 +480,15 @@ extern "C" int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const floa
   if (num_rois == 0) return MI_OK;
   MI_REQUIRE(rois != nullptr && roi_levels != nullptr && top_grad != nullptr && workspace != nullptr,
              "roi_align_fpn: null pointer");
-  MI_REQUIRE(mi_roi_align_fpn_supported(levels, channels, num_rois, aligned_height, aligned_width) == 1,
+  MI_REQUIRE(mi_roi_align_fpn_supported(levels, channels, num_rois, aligned_height, aligned_width, layout) == 1,
              "roi_align_fpn: shapes not served by the fused path (mi_roi_align_fpn_supported() == 0)");
   MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
              "roi_align_fpn: workspace of %zu bytes, %zu needed", workspace_bytes,
              mi::roi_align_records_workspace_bytes(num_rois));
   MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align_fpn: workspace must be 16-byte aligned");
   return mi::launch_roi_align_bwd_records_levels(top_grad, rois, roi_levels, lv, workspace, (flags & 1) != 0,
-                                                 (flags & 2) != 0, false, batch, channels, num_rois, aligned_height,
+                                                 (flags & 2) != 0, layout == MI_LAYOUT_NHWC, batch, channels, num_rois,
+                                                 aligned_height,
                                                  aligned_width, sampling_ratio, ring_words(), mi::as_stream(stream));
 }
 

@@ -151,6 +151,13 @@ bool roi_align_fwd_nhwc_supported(int channels, int height, int width, int num_r
 int launch_roi_align_fwd_nhwc(const float* features, const float* rois, float* output, const void* workspace,
                               int batch, int channels, int height, int width, int num_rois, int aligned_height,
                               int aligned_width, float spatial_scale, int sampling_ratio, hipStream_t stream);
+int launch_roi_align_fwd_nhwc_levels(const LevelTable& lv, const float* rois, float* output, const void* workspace,
+                                     int batch, int channels, int num_rois, int aligned_height, int aligned_width,
+                                     int sampling_ratio, hipStream_t stream);
+// records of `rois` for a table of levels (first launch of the fused paths)
+int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, const int* levels, void* workspace,
+                                    int batch, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
+                                    hipStream_t stream);
 bool roi_align_stream_supported(int channels, int aligned_height, int aligned_width);
 int launch_roi_align_bwd_stream(const float* top_grad, const float* rois, float* bottom_grad, int batch,
                                 int channels, int height, int width, int num_rois, int aligned_height,

@@ -73,9 +73,9 @@ __device__ __forceinline__ void load_tap<1>(__amdgpu_buffer_rsrc_t img, unsigned
 template <int kSR, int PW, int V, int PB>
 __global__ void __launch_bounds__(PW <= 7 ? 448 : 1024)
     __attribute__((amdgpu_waves_per_eu(PW <= 7 && PB <= 4 ? 4 : 1, PW <= 7 && PB <= 4 ? 4 : 8)))
-roi_align_fwd_nhwc(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
-                   const int* __restrict__ ws, int batch, int channels, int height, int width, int aligned_height,
-                   float spatial_scale, int sampling_ratio, int chunks, int tile_stride, int order_mul, int zigzag,
+roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
+                   const int* __restrict__ ws, int batch, int channels, int aligned_height, int sampling_ratio,
+                   int chunks, int tile_stride, int order_mul, int zigzag,
                    long long* __restrict__ timeline) {
   extern __shared__ float tile[];  // [V][64][tile_stride]
   // tuning aid (tools/timeline_nhwc.py): s_memtime stamps of wave 0 of every workgroup, null in normal operation
@@ -109,7 +109,11 @@ roi_align_fwd_nhwc(const float* __restrict__ feat, const float* __restrict__ roi
     if constexpr (kSR > 0) return i < 64 ? __builtin_amdgcn_readlane(x_v0, i) : __builtin_amdgcn_readlane(x_v1, i - 64);
     else return rec[kRecX + i];
   };
-  const int flags = hdr(0), batch_ind = hdr(1), r = hdr(8);
+  const int flags = hdr(0), batch_ind = hdr(1), r = hdr(8), lvl = hdr(11);
+  // the (channels-last) map of the RoI's level: one entry unless the call is an FPN-fused one
+  const float* __restrict__ feat = lv.feat[lvl];
+  const int height = lv.height[lvl], width = lv.width[lvl];
+  const float spatial_scale = lv.scale[lvl];
   const int gh = kSR > 0 ? kSR : rec[6], gw = kSR > 0 ? kSR : rec[7];
   if (flags >= 0) stamp(1);  // record words have arrived
   const int cl = c0 + lane * V;
@@ -319,9 +323,9 @@ bool roi_align_fwd_nhwc_supported(int channels, int height, int width, int num_r
 }
 
 // The records of `rois` must already be in `workspace` (launch_roi_align_prepare on the same stream).
-int launch_roi_align_fwd_nhwc(const float* features, const float* rois, float* output, const void* workspace,
-                              int batch, int channels, int height, int width, int num_rois, int aligned_height,
-                              int aligned_width, float spatial_scale, int sampling_ratio, hipStream_t stream) {
+int launch_roi_align_fwd_nhwc_levels(const LevelTable& lv, const float* rois, float* output, const void* workspace,
+                                     int batch, int channels, int num_rois, int aligned_height, int aligned_width,
+                                     int sampling_ratio, hipStream_t stream) {
   const int* ws = static_cast<const int*>(workspace);
   const int v = pick_vec(channels, aligned_height, aligned_width);
   const int per = 64 * v, chunks = (channels + per - 1) / per;
@@ -336,8 +340,8 @@ int launch_roi_align_fwd_nhwc(const float* features, const float* rois, float* o
   const bool split = g_nhwc_pb != 7;
 #define MI_LAUNCH_NHWC(SR, PW, V, PB)                                                                                 \
   roi_align_fwd_nhwc<SR, PW, V, PB><<<grid, 64 * nwaves, lds, stream>>>(                                              \
-      features, rois, output, ws, batch, channels, height, width, aligned_height, spatial_scale, sampling_ratio,      \
-      chunks, stride, g_nhwc_order_mul, g_nhwc_zigzag, g_nhwc_timeline)
+      lv, rois, output, ws, batch, channels, aligned_height, sampling_ratio, chunks, stride, g_nhwc_order_mul,        \
+      g_nhwc_zigzag, g_nhwc_timeline)
 #define MI_LAUNCH_NHWC_V(PW, V)                                                                                       \
   do {                                                                                                                \
     if (sr2 && split)                                                                                                 \
@@ -365,6 +369,14 @@ int launch_roi_align_fwd_nhwc(const float* features, const float* rois, float* o
 #undef MI_LAUNCH_NHWC_V
 #undef MI_LAUNCH_NHWC
   return check_launch("roi_align_fwd_nhwc");
+}
+
+int launch_roi_align_fwd_nhwc(const float* features, const float* rois, float* output, const void* workspace,
+                              int batch, int channels, int height, int width, int num_rois, int aligned_height,
+                              int aligned_width, float spatial_scale, int sampling_ratio, hipStream_t stream) {
+  return launch_roi_align_fwd_nhwc_levels(single_level(features, nullptr, batch, height, width, spatial_scale), rois,
+                                          output, workspace, batch, channels, num_rois, aligned_height, aligned_width,
+                                          sampling_ratio, stream);
 }
 
 }  // namespace mi

@@ -938,6 +938,13 @@ int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int 
                         aligned_width, sampling_ratio, 336, stream);
 }
 
+int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, const int* levels, void* workspace,
+                                    int batch, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
+                                    hipStream_t stream) {
+  return launch_prepare(rois, levels, static_cast<int*>(workspace), batch, lv, num_rois, aligned_height, aligned_width,
+                        sampling_ratio, 336, stream);
+}
+
 void roi_align_records_set_ablate(int mask) { g_ablate_p = mask; }
 void roi_align_bwd_set_tile_rows(int rows) { g_bwd_th = (rows == 8 || rows == 32) ? rows : 16; }
 

@@ -149,19 +149,31 @@ def _fpn_table(tensors, scales, grads=False):
     return t
 
 
+def _common_layout(features):
+    """LAYOUT_NCHW / LAYOUT_NHWC when every map is stored that way (dense), else None."""
+    if all(f.is_contiguous() for f in features):
+        return _lib.LAYOUT_NCHW
+    if all(f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last) for f in features):
+        return _lib.LAYOUT_NHWC
+    return None
+
+
 def roi_align_fpn_supported(features, num_rois, aligned_height, aligned_width):
-    """True when mi_roi_align_forward_fpn / _backward_fpn serve these maps in one call (NCHW, same batch and channels,
-    at most four levels); otherwise the caller loops over the levels."""
+    """True when mi_roi_align_forward_fpn / _backward_fpn serve these maps in one call (at most four levels, same
+    batch, channels and storage layout -- all NCHW or all channels_last); otherwise the caller loops over the levels."""
     if not (1 <= len(features) <= 4) or num_rois <= 0:
         return False
     f0 = features[0]
     for f in features:
-        if (not f.is_cuda or f.dtype != torch.float32 or f.dim() != 4 or not f.is_contiguous()
-                or f.size(0) != f0.size(0) or f.size(1) != f0.size(1) or f.device != f0.device):
+        if (not f.is_cuda or f.dtype != torch.float32 or f.dim() != 4 or f.size(0) != f0.size(0)
+                or f.size(1) != f0.size(1) or f.device != f0.device):
             return False
+    layout = _common_layout(features)
+    if layout is None:
+        return False
     table = _fpn_table(features, [1.0] * len(features))
     return bool(_lib.lib().mi_roi_align_fpn_supported(ctypes.byref(table), int(f0.size(1)), int(num_rois),
-                                                      int(aligned_height), int(aligned_width)))
+                                                      int(aligned_height), int(aligned_width), layout))
 
 
 class _RoIAlignFPN(Function):
@@ -179,14 +191,18 @@ class _RoIAlignFPN(Function):
         ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=rois.device)
         table = _fpn_table(features, scales)
+        layout = _common_layout(features)
+        if layout is None:
+            raise ValueError("the FPN maps must share one storage layout (all contiguous or all channels_last)")
         with torch.cuda.device(rois.device):
             rc = lib.mi_roi_align_forward_fpn(ctypes.byref(table), rois.data_ptr(), roi_levels.data_ptr(),
                                               output.data_ptr(), n, c, r, int(aligned_height), int(aligned_width),
-                                              int(sampling_ratio), workspace.data_ptr(), ws_bytes,
+                                              int(sampling_ratio), layout, workspace.data_ptr(), ws_bytes,
                                               _lib.current_stream_handle(rois.device))
         _lib.check(rc, "mi_roi_align_forward_fpn")
         ctx.cfg = (int(aligned_height), int(aligned_width), int(sampling_ratio), tuple(float(s) for s in scales))
         ctx.shapes = [tuple(f.shape) for f in features]
+        ctx.layout = layout
         ctx.save_for_backward(rois, roi_levels, workspace)
         return output
 
@@ -196,12 +212,14 @@ class _RoIAlignFPN(Function):
         rois, roi_levels, workspace = ctx.saved_tensors
         ah, aw, sr, scales = ctx.cfg
         grad_output = grad_output.contiguous()
-        grads = [torch.empty(shape, dtype=torch.float32, device=grad_output.device) for shape in ctx.shapes]
+        fmt = torch.channels_last if ctx.layout == _lib.LAYOUT_NHWC else torch.contiguous_format
+        grads = [torch.empty(shape, dtype=torch.float32, device=grad_output.device, memory_format=fmt)
+                 for shape in ctx.shapes]
         n, c = ctx.shapes[0][0], ctx.shapes[0][1]
         table = _fpn_table(grads, scales, grads=True)
         with torch.cuda.device(grad_output.device):  # every element of every level is written: no zero fill
             rc = lib.mi_roi_align_backward_fpn(ctypes.byref(table), grad_output.data_ptr(), rois.data_ptr(),
-                                               roi_levels.data_ptr(), n, c, rois.size(0), ah, aw, sr,
+                                               roi_levels.data_ptr(), n, c, rois.size(0), ah, aw, sr, ctx.layout,
                                                workspace.data_ptr(), workspace.numel(),
                                                _lib.ROI_ALIGN_RECORDS_READY | _lib.ROI_ALIGN_OVERWRITE,
                                                _lib.current_stream_handle(grad_output.device))

@@ -122,7 +122,8 @@ int mi_roi_align_backward_overwrites(int channels, int height, int width, int nu
  * `<rois>_idx_restore_int32`.  Here all levels are served by ONE pair of launches and the output is written directly in
  * the order of `rois`: every RoI carries the index of its level (`roi_levels`, device int32 [R], values
  * 0..num_levels-1 -- utils/fpn.py:11-28 computes the assignment on the host in the reference's data layer).
- * Caffe2 semantics, NCHW maps that share batch and channels.  Same workspace, records and flags as the single-level
+ * Caffe2 semantics; the maps share batch, channels and `layout` (MI_LAYOUT_NCHW, or MI_LAYOUT_NHWC for channels-last
+ * storage of maps and gradient maps; output / top_grad are dense [R,C,PH,PW] either way).  Same workspace, records and flags as the single-level
  * _ws entry points (the records of a forward serve the backward over the same rois and roi_levels); the backward
  * writes (MI_ROI_ALIGN_OVERWRITE) or accumulates into every level's gradient map, also those no RoI maps to.
  * mi_roi_align_fpn_supported() == 0: shapes the fused path does not take -- loop over the levels instead. */
@@ -136,14 +137,15 @@ typedef struct mi_fpn_levels {
   float spatial_scale[MI_FPN_MAX_LEVELS];
 } mi_fpn_levels;
 int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
-                               int aligned_width);
+                               int aligned_width, int layout);
 int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels, float* output,
                              int batch, int channels, int num_rois, int aligned_height, int aligned_width,
-                             int sampling_ratio, void* workspace, size_t workspace_bytes, mi_stream_t stream);
+                             int sampling_ratio, int layout, void* workspace, size_t workspace_bytes,
+                             mi_stream_t stream);
 int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const float* top_grad, const float* rois,
                               const int32_t* roi_levels, int batch, int channels, int num_rois, int aligned_height,
-                              int aligned_width, int sampling_ratio, void* workspace, size_t workspace_bytes, int flags,
-                              mi_stream_t stream);
+                              int aligned_width, int sampling_ratio, int layout, void* workspace,
+                              size_t workspace_bytes, int flags, mi_stream_t stream);
 
 /* ---- RoIPool --------------------------------------------------------------------------
  * replaces ROIPoolForwardLaucher / ROIPoolBackwardLaucher (lib/model/roi_pooling/src/roi_pooling_kernel.h:8-20)

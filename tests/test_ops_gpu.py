@@ -629,8 +629,9 @@ def test_roi_align_fpn_fused_matches_per_level_loop_and_oracle(oracle_mod):
                      "adv bwd %d" % k)
 
 
-@pytest.mark.parametrize("res,sr,channels", [(14, 2, 32), (7, 0, 64), (7, 3, 32)])
-def test_roi_align_fpn_fused_other_resolutions(oracle_mod, res, sr, channels):
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("res,sr,channels", [(14, 2, 32), (7, 0, 64), (7, 3, 32), (7, 2, 256)])
+def test_roi_align_fpn_fused_other_resolutions(oracle_mod, res, sr, channels, channels_last):
     """Mask-head resolution (16-channel backward tiles), adaptive and odd sampling grids through the fused entry points."""
     from detectron_pytorch_amd.roi_align import roi_align_fpn
 
@@ -639,10 +640,12 @@ def test_roi_align_fpn_fused_other_resolutions(oracle_mod, res, sr, channels):
     rois, lvls = rois[keep], lvls[keep]
     feats, scales = feats[:3], scales[:3]
     idx_of = (5 - lvls).astype(np.int32)
-    dev_feats = [to_dev(f).requires_grad_(True) for f in feats]
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    dev_feats = [to_dev(f).contiguous(memory_format=fmt).requires_grad_(True) for f in feats]
     out = roi_align_fpn(dev_feats, scales, to_dev(rois), to_dev(idx_of), res, res, sr)
     gtop = np.random.RandomState(1).randn(len(rois), channels, res, res).astype(np.float32)
     out.backward(to_dev(gtop))
+    assert all(f.grad.is_contiguous(memory_format=fmt) for f in dev_feats)
     for k in range(3):
         idx = np.nonzero(idx_of == k)[0]
         assert_fwd(out.detach()[torch.from_numpy(idx).to(dev())],
