@@ -75,8 +75,9 @@ int mi_roi_align_forward(const float* features, const float* rois, float* output
                          int aligned_height, int aligned_width, float spatial_scale,
                          int sampling_ratio, int variant, int layout, mi_stream_t stream);
 
-/* Same operation with caller-provided device scratch (the fast path on NCHW features): a first launch condenses each
- * RoI into a record in `workspace` (window, tap tables, LDS stages), persistent workgroups then consume the records.
+/* Same operation with caller-provided device scratch (the fast paths: roi_align_fwd_records on NCHW features,
+ * roi_align_fwd_nhwc on channels-last ones): a first launch condenses each RoI into a record in `workspace` (window,
+ * tap tables, LDS stages) at its rank along a sweep of the image, a second launch consumes the records.
  * `workspace` must hold mi_roi_align_forward_workspace_bytes(num_rois) bytes, 16-byte aligned; its contents are
  * scratch (no initialisation needed, overwritten by every call; two calls that may run concurrently on different
  * streams need distinct workspaces).  workspace == NULL behaves exactly like mi_roi_align_forward. */
