@@ -352,10 +352,8 @@ def pmc_traffic(direction):
 
 
 def touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr):
-    """U of the algorithmic-bytes formula, counted by the oracle (a checker-side computation, not timed)."""
-    import oracle
-
-    return oracle.roi_align_touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr)
+    """U of the algorithmic-bytes formula (a workload descriptor computed on the host, not timed)."""
+    return syn.roi_align_touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr)
 
 
 def nms_latency(device, iters):
@@ -401,23 +399,16 @@ def nms_latency(device, iters):
     for name, soft in (("hard", False), ("soft_linear", True)):
         sec = time_kernel(lambda: detection.box_results_with_nms_and_limit(sc, bx, soft_nms=soft), 10, warmup=3)
         post[name + "_ms"] = round(sec * 1e3, 3)
-    try:  # the CPU restatement beside it (checker-side code, timed once)
-        from oracle import postprocess
-
-        t0 = time.perf_counter()
-        postprocess.box_results_with_nms_and_limit(sc_np, bx_np)
-        post["cpu_port_hard_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
-    except Exception:
-        pass
     out["detection_postprocess_R1000_C81"] = post
     return out
 
 
 def cpu_baseline(images_per_rank):
-    """The oracle (a C port of the reference kernels, kind="port") on the host cores of this box, on a
-    bounded sample: ONE image's worth of the hot-path step (512-RoI 7x7 and 128-RoI 14x14 RoIAlign fwd+bwd on
-    a 1x256x200x336 map + 5 NMS calls of 2000 boxes), all OpenMP threads for RoIAlign, NMS single-threaded
-    (the reference's cython_nms is serial)."""
+    """The oracle (a C port of the reference kernels, kind="port") on the host cores of this box, on a bounded sample of
+    the same workload: the hot-path step of ONE image (512-RoI 7x7 and 128-RoI 14x14 RoIAlign fwd+bwd on a 1x256x200x336
+    map + 5 NMS calls of 2000 boxes) repeated until about 10 s of CPU work are spent (at most 64 images); all OpenMP
+    threads for RoIAlign, NMS single-threaded (the reference's cython_nms is serial).  The only place of this file that
+    touches oracle/."""
     import oracle
 
     threads = oracle.num_threads_available()
@@ -427,19 +418,28 @@ def cpu_baseline(images_per_rank):
     box_g = np.random.RandomState(0).randn(512, syn.FPN_DIM, 7, 7).astype(np.float32)
     mask_g = np.random.RandomState(1).randn(128, syn.FPN_DIM, 14, 14).astype(np.float32)
     dets = [syn.boxes_clustered(2000, seed=10 + i) for i in range(5)]
-    t0 = time.perf_counter()
-    oracle.roi_align_forward(feat, box_rois, 7, 7, scale, 2, threads=threads)
-    t_fwd = time.perf_counter() - t0
-    oracle.roi_align_backward(box_g, box_rois, feat.shape, scale, 2, threads=threads)
-    oracle.roi_align_forward(feat, mask_rois, 14, 14, scale, 2, threads=threads)
-    oracle.roi_align_backward(mask_g, mask_rois, feat.shape, scale, 2, threads=threads)
-    t1 = time.perf_counter()
-    for d in dets:
-        oracle.nms_cython(d, 0.7)
-    t2 = time.perf_counter()
-    total = t2 - t0
-    extra = {"roi_align_fwd_cfg2_ms": round(t_fwd * 1e3, 2), "roi_align_all_ms": round((t1 - t0) * 1e3, 2),
-             "nms_5x2000_ms": round((t2 - t1) * 1e3, 2)}
+
+    def one_image():
+        t0 = time.perf_counter()
+        oracle.roi_align_forward(feat, box_rois, 7, 7, scale, 2, threads=threads)
+        t_fwd = time.perf_counter() - t0
+        oracle.roi_align_backward(box_g, box_rois, feat.shape, scale, 2, threads=threads)
+        oracle.roi_align_forward(feat, mask_rois, 14, 14, scale, 2, threads=threads)
+        oracle.roi_align_backward(mask_g, mask_rois, feat.shape, scale, 2, threads=threads)
+        t1 = time.perf_counter()
+        for d in dets:
+            oracle.nms_cython(d, 0.7)
+        t2 = time.perf_counter()
+        return t2 - t0, t_fwd, t1 - t0, t2 - t1
+
+    one_image()  # page in the library and the buffers
+    first = one_image()
+    images = int(min(64, max(1, np.ceil(10.0 / first[0]))))
+    runs = [first] + [one_image() for _ in range(images - 1)]
+    total = sum(r[0] for r in runs)
+    extra = {"roi_align_fwd_cfg2_ms": round(float(np.median([r[1] for r in runs])) * 1e3, 2),
+             "roi_align_all_ms": round(float(np.median([r[2] for r in runs])) * 1e3, 2),
+             "nms_5x2000_ms": round(float(np.median([r[3] for r in runs])) * 1e3, 2)}
     try:  # the reference's own cython_nms (kind "reference") when the prebuilt module travelled with the snapshot
         from oracle import ref
 
@@ -454,10 +454,20 @@ def cpu_baseline(images_per_rank):
             extra["reference_cython_nms_cfg1_n1000_t0.5_ms"] = round(float(np.median(ts)) * 1e3, 3)
     except Exception as e:  # pragma: no cover
         extra["reference_cython_nms_error"] = str(e)
-    return {"value": round(1.0 / total, 3), "unit": "images/s (hot path only)", "cores": threads, "kind": "port",
-            "sample": "one image of the hot-path step: RoIAlign fwd+bwd 512x256x7x7 and 128x256x14x14 on 1x256x200x336 "
-                      "(OpenMP, %d threads) + 5 x cython-semantics NMS n=2000 thr=0.7 (1 thread); %.2f s of CPU work"
-                      % (threads, total),
+    try:  # the test-time post-processing (core/test.py:732-790) beside nms.detection_postprocess_R1000_C81
+        from oracle import postprocess
+
+        sc_np, bx_np = syn.detection_head_outputs(1000, 81, seed=7)
+        postprocess.box_results_with_nms_and_limit(sc_np, bx_np)
+        t = time.perf_counter()
+        postprocess.box_results_with_nms_and_limit(sc_np, bx_np)
+        extra["detection_postprocess_R1000_C81_hard_ms"] = round((time.perf_counter() - t) * 1e3, 3)
+    except Exception as e:  # pragma: no cover
+        extra["detection_postprocess_error"] = str(e)
+    return {"value": round(images / total, 3), "unit": "images/s (hot path only)", "cores": threads, "kind": "port",
+            "sample": "%d x the hot-path step of one image: RoIAlign fwd+bwd 512x256x7x7 and 128x256x14x14 on "
+                      "1x256x200x336 (OpenMP, %d threads) + 5 x cython-semantics NMS n=2000 thr=0.7 (1 thread); "
+                      "%.1f s of CPU work" % (images, threads, total),
             **extra}
 
 

@@ -151,3 +151,47 @@ def detection_head_outputs(num_rois=300, num_classes=21, seed=0, im_h=IM_H, im_w
     boxes[..., 2] = np.maximum(boxes[..., 2], boxes[..., 0])
     boxes[..., 3] = np.maximum(boxes[..., 3], boxes[..., 1])
     return scores, boxes.reshape(num_rois, 4 * num_classes).astype(np.float32)
+
+
+def roi_align_touched_pixels(rois, batch, height, width, aligned_height, aligned_width, spatial_scale, sampling_ratio):
+    """U of the algorithmic-bytes formula: the number of distinct feature pixels (n, y, x) that
+    any sample of any RoI references with a non-zero weight.  float32 sampling arithmetic of roi_align_kernel.cu:74-110
+    and :16-52 (same operation order), evaluated per axis; a workload descriptor, not a kernel."""
+    f32 = np.float32
+    seen = np.zeros((batch, height, width), dtype=bool)
+
+    def axis(start, bin_size, pooled, grid, size):
+        p = np.repeat(np.arange(pooled, dtype=f32), grid)
+        i = np.tile(np.arange(grid, dtype=f32), pooled)
+        v = (start + p * bin_size) + ((i + f32(0.5)) * bin_size) / f32(grid)
+        ok = ~((v < f32(-1.0)) | (v > f32(size)))
+        v = np.where(v <= 0, f32(0), v)
+        lo = v.astype(np.int32)
+        edge = lo >= size - 1
+        lo = np.where(edge, size - 1, lo)
+        hi = np.where(edge, size - 1, lo + 1)
+        v = np.where(edge, lo.astype(f32), v)
+        lw = v - lo.astype(f32)
+        hw = f32(1.0) - lw
+        return ok, lo, hi, hw.astype(f32), lw.astype(f32)
+
+    for r in np.asarray(rois, dtype=f32):
+        b = int(r[0])
+        if b < 0 or b >= batch:
+            continue
+        sw, sh = r[1] * f32(spatial_scale), r[2] * f32(spatial_scale)
+        rw = max(r[3] * f32(spatial_scale) - sw, f32(1.0))
+        rh = max(r[4] * f32(spatial_scale) - sh, f32(1.0))
+        bh, bw = f32(rh / f32(aligned_height)), f32(rw / f32(aligned_width))
+        gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rh / f32(aligned_height)))
+        gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rw / f32(aligned_width)))
+        oky, yl, yh, hy, ly = axis(sh, bh, aligned_height, gh, height)
+        okx, xl, xh, hx, lx = axis(sw, bw, aligned_width, gw, width)
+        ok = oky[:, None] & okx[None, :]
+        plane = seen[b]
+        for ys, wy in ((yl, hy), (yh, ly)):
+            for xs, wx in ((xl, hx), (xh, lx)):
+                hit = ok & ((wy[:, None] * wx[None, :]) != 0)
+                yy, xx = np.nonzero(hit)
+                plane[ys[yy], xs[xx]] = True
+    return int(seen.sum())

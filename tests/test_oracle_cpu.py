@@ -288,3 +288,14 @@ def test_detection_postprocess_without_limit_and_empty_classes(oracle_mod):
         dets = np.hstack((boxes[inds, 4 * j:4 * j + 4], scores[inds, j][:, None])).astype(np.float32)
         keep = oracle_mod.nms_cython(dets, 0.5) if len(dets) else []
         assert np.array_equal(cls_boxes[j], dets[keep, :])
+
+
+def test_touched_pixel_count_of_the_workload_descriptor_matches_oracle(oracle_mod):
+    """bench.py derives the algorithmic bytes of the roofline from synthetic.roi_align_touched_pixels (numpy): it must
+    count exactly what the oracle's sampling arithmetic touches."""
+    cases = [(syn.rois_canonical(512, 1, seed=0), 1, 200, 336, 7, 0.25, 2),
+             (syn.rois_adversarial(300, 2, 50, 84, 1.0 / 16, seed=1), 2, 50, 84, 14, 1.0 / 16, 0),
+             (syn.rois_adversarial(200, 3, 13, 21, 1.0 / 32, seed=2), 3, 13, 21, 7, 1.0 / 32, 3)]
+    for rois, b, h, w, res, scale, sr in cases:
+        assert syn.roi_align_touched_pixels(rois, b, h, w, res, res, scale, sr) == \
+            oracle_mod.roi_align_touched_pixels(rois, b, h, w, res, res, scale, sr)
