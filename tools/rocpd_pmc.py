@@ -9,10 +9,12 @@ import sys
 
 
 def short(name):
-    """`void mi::(anonymous namespace)::roi_align_fwd_records<2, 336, 32, 1>(float const*, ...)` -> `roi_align_fwd_records<2,336,32,1>`"""
-    name = name or ""
-    head = name.split("(float")[0].split("(int")[0].split("(long")[0]
-    m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)(<[^()]*>)?\s*$", head.replace("(anonymous namespace)::", ""))
+    """`void mi::(anonymous namespace)::roi_align_fwd_records<2, 336, 32, 1>(mi::LevelTable, ...)` ->
+    `roi_align_fwd_records<2,336,32,1>`"""
+    name = (name or "").replace("(anonymous namespace)::", "").replace("mi::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    m = re.match(r"([A-Za-z_][A-Za-z0-9_]*)(<[^()]*>)?\(", name)
     return (m.group(1) + (m.group(2) or "")).replace(" ", "") if m else name[-50:]
 
 
