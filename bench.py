@@ -400,6 +400,16 @@ def nms_latency(device, iters):
         sec = time_kernel(lambda: detection.box_results_with_nms_and_limit(sc, bx, soft_nms=soft), 10, warmup=3)
         post[name + "_ms"] = round(sec * 1e3, 3)
     out["detection_postprocess_R1000_C81"] = post
+    # the RPN-side caller of NMS (generate_proposals.py:12-182) for one P2-sized level, 2 images, train-time top-k
+    from detectron_pytorch_amd import generate_proposals as gp
+
+    anchors = gp.generate_anchors(4, (32,), (0.5, 1, 2))
+    sc_np, dl_np = syn.rpn_head_outputs(2, 3, 200, 336, seed=4)
+    sc, dl = torch.from_numpy(sc_np).to(device), torch.from_numpy(dl_np).to(device)
+    info = torch.tensor([[800, 1344, 1.0], [800, 1344, 1.0]], dtype=torch.float32, device=device)
+    op = gp.GenerateProposalsOp(anchors, 0.25, 2000, 2000, 0.7, 0, as_numpy=False)
+    sec = time_kernel(lambda: op(sc, dl, info), 10, warmup=3)
+    out["generate_proposals_P2_2img_top2000"] = {"ms": round(sec * 1e3, 3)}
     return out
 
 
@@ -464,6 +474,17 @@ def cpu_baseline(images_per_rank):
         extra["detection_postprocess_R1000_C81_hard_ms"] = round((time.perf_counter() - t) * 1e3, 3)
     except Exception as e:  # pragma: no cover
         extra["detection_postprocess_error"] = str(e)
+    try:  # proposal generation of one P2-sized level, 2 images (beside nms.generate_proposals_P2_2img_top2000)
+        from oracle import proposals
+
+        anchors = proposals.generate_anchors(4, (32,), (0.5, 1, 2))
+        sc_np, dl_np = syn.rpn_head_outputs(2, 3, 200, 336, seed=4)
+        info = np.array([[800, 1344, 1.0], [800, 1344, 1.0]], np.float32)
+        t = time.perf_counter()
+        proposals.generate_proposals(sc_np, dl_np, info, anchors, 0.25, 2000, 2000, 0.7, 0)
+        extra["generate_proposals_P2_2img_top2000_ms"] = round((time.perf_counter() - t) * 1e3, 3)
+    except Exception as e:  # pragma: no cover
+        extra["generate_proposals_error"] = str(e)
     return {"value": round(images / total, 3), "unit": "images/s (hot path only)", "cores": threads, "kind": "port",
             "sample": "%d x the hot-path step of one image: RoIAlign fwd+bwd 512x256x7x7 and 128x256x14x14 on "
                       "1x256x200x336 (OpenMP, %d threads) + 5 x cython-semantics NMS n=2000 thr=0.7 (1 thread); "

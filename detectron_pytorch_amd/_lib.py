@@ -45,6 +45,9 @@ SIGNATURES = {
                                          _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "mi_roi_align_backward_fpn": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                           _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_int, _c_void_p]),
+    "mi_rpn_decode_proposals": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                        _c_int, _c_int, ctypes.c_double, _c_float, ctypes.c_double, _c_void_p, _c_void_p,
+                                        _c_void_p]),
     "mi_soft_nms": (_c_int, [_c_void_p, _c_int, _c_float, _c_float, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p,
                             _c_void_p]),
     "mi_soft_nms_segmented": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_float, _c_float, _c_int,

@@ -195,3 +195,19 @@ def roi_align_touched_pixels(rois, batch, height, width, aligned_height, aligned
                 yy, xx = np.nonzero(hit)
                 plane[ys[yy], xs[xx]] = True
     return int(seen.sum())
+
+
+def rpn_head_outputs(batch=2, num_anchors=3, height=50, width=84, seed=0):
+    """Inputs of GenerateProposalsOp (lib/modeling/generate_proposals.py:19-45): objectness probabilities [N,A,H,W] in
+    (0,1) with UNIQUE values per image (the reference's argsort has no defined order for ties) and box deltas
+    [N,4A,H,W] (dx, dy ~ N(0, 0.5); dw, dh ~ N(0, 0.4) with a few beyond the BBOX_XFORM_CLIP)."""
+    rng = np.random.RandomState(seed)
+    n = num_anchors * height * width
+    scores = np.stack([rng.permutation(n).astype(np.float64) for _ in range(batch)])
+    scores = ((scores + 0.5) / n).astype(np.float32).reshape(batch, num_anchors, height, width)
+    deltas = rng.normal(0, 0.5, (batch, 4 * num_anchors, height, width))
+    deltas[:, 2::4] *= 0.8
+    deltas[:, 3::4] *= 0.8
+    big = rng.rand(*deltas.shape) < 0.002
+    deltas = np.where(big, deltas * 20, deltas)
+    return scores, deltas.astype(np.float32)

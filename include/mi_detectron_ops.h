@@ -181,6 +181,22 @@ int mi_roi_crop_backward(const float* input, const float* grid_yx, const float* 
                          int batch, int channels, int height, int width,
                          int num_rois, int grid_height, int grid_width, mi_stream_t stream);
 
+/* ---- RPN proposal decode ------------------------------------------------------------------------------------------
+ * steps 1-3 of GenerateProposalsOp.proposals_for_one_image (lib/modeling/generate_proposals.py:105-153; helpers
+ * lib/utils/boxes.py:156-196 bbox_transform, :138-153 clip_tiled_boxes, generate_proposals.py:170-182 _filter_boxes)
+ * for the pre-NMS top-k anchors of every image of one level, in one launch.  The reference does this in numpy on the
+ * host after copying the RPN outputs back (:58-63).
+ *   bbox_pred [N,4A,H,W]; topk_scores / topk_idx [N,k]: the k best scores of each image in descending order and their
+ *   flat indices into that image's [A,H,W] score map; im_info [N,3] (height, width, scale), device; base_anchors_host
+ *   [A,4] float64 on the HOST (generate_anchors.py output, A <= 16); feat_stride = 1 / spatial_scale; xform_clip =
+ *   cfg.BBOX_XFORM_CLIP.  Writes dets [N,k,5] (x1,y1,x2,y2,score), ready for mi_nms / mi_nms_batched, and valid [N,k]:
+ *   boxes the min-size / centre filter rejects become a far-away degenerate box with valid = 0 (IoU 0 with every real
+ *   box); drop them AFTER the NMS. */
+int mi_rpn_decode_proposals(const float* bbox_pred, const float* topk_scores, const int64_t* topk_idx,
+                            const float* im_info, const double* base_anchors_host, int num_images, int num_anchors,
+                            int height, int width, int k, double feat_stride, float min_size, double xform_clip,
+                            float* dets, int32_t* valid, mi_stream_t stream);
+
 /* ---- NMS -------------------------------------------------------------------------------
  * replaces nms_cuda_compute (lib/model/nms/src/nms_cuda_kernel.h:5-6) / nms_cuda (nms_cuda.c:8-19) in
  * mode GT_SORTED_POS and reproduces utils.cython_nms.nms (cython_nms.pyx:37-87) in mode GE_ORIG_ASC.

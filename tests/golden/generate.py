@@ -167,6 +167,66 @@ def gen_detection():
     save("detection.npz", **out)
 
 
+def _reference_generate_proposals():
+    """The reference's GenerateProposalsOp and generate_anchors, executed from their own source text.
+    generate_anchors.py uses np.float (removed from numpy); the same one-token patch as for cython_nms.pyx
+    (np.float -> float, no arithmetic touched) lets it run.  generate_proposals.py runs as it stands against a cfg
+    carrying the values it reads and a utils.boxes namespace made of the reference's own bbox_transform /
+    clip_tiled_boxes / nms bodies (the latter bound to its cython build in oracle/_ref)."""
+    import re
+    import types
+
+    lib = "/root/reference/lib"
+    ga_src = open(lib + "/modeling/generate_anchors.py").read().replace("np.float)", "float)")
+    ga = types.ModuleType("generate_anchors")
+    exec(compile(ga_src, lib + "/modeling/generate_anchors.py", "exec"), ga.__dict__)
+    bsrc = open(lib + "/utils/boxes.py").read()
+
+    def fn(name):
+        return re.search(r"^def %s\(.*?(?=^def |\Z)" % name, bsrc, re.S | re.M).group(0)
+
+    def make(train_cfg):
+        class Cfg(dict):  # the reference reads cfg both as attributes and as cfg['TRAIN'] / cfg['TEST']
+            __getattr__ = dict.__getitem__
+
+        cfg = Cfg(BBOX_XFORM_CLIP=np.log(1000. / 16.), TRAIN=train_cfg, TEST=train_cfg)
+        box_utils = types.ModuleType("box_utils")
+        box_utils.np, box_utils.cfg, box_utils.cython_nms = np, cfg, ref._mod("cython_nms")
+        exec(compile(fn("bbox_transform") + fn("clip_tiled_boxes") + fn("nms"), lib + "/utils/boxes.py", "exec"),
+             box_utils.__dict__)
+        gp_src = open(lib + "/modeling/generate_proposals.py").read()
+        gp_src = gp_src.replace("from core.config import cfg", "").replace("import utils.boxes as box_utils", "")
+        gp = types.ModuleType("generate_proposals")
+        gp.cfg, gp.box_utils = cfg, box_utils
+        exec(compile(gp_src, lib + "/modeling/generate_proposals.py", "exec"), gp.__dict__)
+        return gp.GenerateProposalsOp
+
+    return ga.generate_anchors, make, types
+
+
+def gen_proposals():
+    import torch
+
+    generate_anchors, make, types = _reference_generate_proposals()
+    out = {}
+    out["anchors_s4"] = generate_anchors(stride=4, sizes=(32,), aspect_ratios=(0.5, 1, 2))
+    out["anchors_s16_default"] = generate_anchors()
+    cases = {"p4": (16, (128,), 50, 84, 300, 120, 0), "p5": (32, (256,), 25, 42, 12000, 2000, 0),
+             "p3min": (8, (64,), 40, 60, 500, 200, 16)}
+    for name, (stride, sizes, h, w, pre, post, min_size) in cases.items():
+        anchors = generate_anchors(stride=stride, sizes=sizes, aspect_ratios=(0.5, 1, 2))
+        scores, deltas = syn.rpn_head_outputs(2, anchors.shape[0], h, w, seed=stride)
+        im_info = np.array([[h * stride, w * stride, 1.0], [h * stride - 37, w * stride - 50, 1.6]], np.float32)
+        op_cls = make(types.SimpleNamespace(RPN_PRE_NMS_TOP_N=pre, RPN_POST_NMS_TOP_N=post, RPN_NMS_THRESH=0.7,
+                                            RPN_MIN_SIZE=min_size))
+        op = op_cls(anchors, 1.0 / stride)
+        rois, probs = op.forward(torch.from_numpy(scores), torch.from_numpy(deltas), torch.from_numpy(im_info))
+        out["cfg_" + name] = np.array([stride, sizes[0], h, w, pre, post, min_size], np.int64)
+        out["im_info_" + name] = im_info
+        out["rois_" + name], out["probs_" + name] = rois.astype(np.float32), probs.astype(np.float32)
+    save("proposals.npz", **out)
+
+
 def _reference_fpn_module():
     """Import the reference's lib/utils/fpn.py as it lies under /root/reference.  Its two imports are satisfied
     without the reference's config machinery: `core.config.cfg` by a namespace carrying the two defaults it reads
@@ -228,6 +288,7 @@ def main():
     gen_nms()
     gen_soft_nms()
     gen_detection()
+    gen_proposals()
     gen_fpn()
 
 

@@ -22,7 +22,7 @@ def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
     for required in ["mi_roi_align_forward", "mi_roi_align_forward_ws", "mi_roi_align_forward_workspace_bytes",
                      "mi_roi_align_backward", "mi_roi_align_backward_ws", "mi_roi_align_backward_overwrites", "mi_roi_pool_forward", "mi_roi_pool_backward",
-                     "mi_roi_crop_forward", "mi_roi_crop_backward", "mi_nms", "mi_nms_workspace_bytes", "mi_nms_batched", "mi_nms_batched_workspace_bytes", "mi_soft_nms", "mi_roi_align_fpn_supported", "mi_roi_align_forward_fpn", "mi_roi_align_backward_fpn", "mi_soft_nms_segmented", "mi_roi_align_forward_writes_records",
+                     "mi_roi_crop_forward", "mi_roi_crop_backward", "mi_nms", "mi_nms_workspace_bytes", "mi_nms_batched", "mi_nms_batched_workspace_bytes", "mi_soft_nms", "mi_rpn_decode_proposals", "mi_roi_align_fpn_supported", "mi_roi_align_forward_fpn", "mi_roi_align_backward_fpn", "mi_soft_nms_segmented", "mi_roi_align_forward_writes_records",
                      "mi_bbox_overlaps", "mi_last_error", "mi_abi_version"]:
         assert required in syms
 
@@ -100,3 +100,31 @@ def test_dropin_overlay_resolves_reference_import_paths(hip_lib_path):
         sys.path.remove(overlay)
         for k in [k for k in sys.modules if k.split(".")[0] in ("modeling", "model", "utils")]:
             del sys.modules[k]
+
+
+def test_dropin_overlay_merges_with_the_reference_tree(tmp_path, monkeypatch):
+    """With dropin/lib in front of the reference's lib/ on sys.path, modules the overlay does not provide must still be
+    found in the reference tree, and the ones it provides must win."""
+    import importlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    overlay = os.path.join(root, "detectron_pytorch_amd", "dropin", "lib")
+    fake = tmp_path / "lib"
+    for pkg in ("modeling", "utils", "core"):
+        (fake / pkg).mkdir(parents=True)
+        (fake / pkg / "__init__.py").write_text("")
+    (fake / "modeling" / "model_builder.py").write_text("WHO = 'reference model_builder'\n")
+    (fake / "modeling" / "generate_anchors.py").write_text("WHO = 'reference generate_anchors'\n")
+    (fake / "utils" / "blob.py").write_text("WHO = 'reference blob'\n")
+    for name in [m for m in sys.modules if m.split(".")[0] in ("modeling", "utils", "core", "model")]:
+        monkeypatch.delitem(sys.modules, name)
+    monkeypatch.setattr(sys, "path", [overlay, str(fake)] + sys.path)
+    assert importlib.import_module("modeling.model_builder").WHO == "reference model_builder"
+    assert importlib.import_module("utils.blob").WHO == "reference blob"
+    anchors_mod = importlib.import_module("modeling.generate_anchors")
+    assert not hasattr(anchors_mod, "WHO") and anchors_mod.generate_anchors().shape == (15, 4)
+    assert importlib.import_module("utils.cython_nms").soft_nms.__module__ == "detectron_pytorch_amd.nms"
+    for name in [m for m in sys.modules if m.split(".")[0] in ("modeling", "utils", "core", "model")]:
+        monkeypatch.delitem(sys.modules, name, raising=False)

@@ -652,3 +652,53 @@ def test_roi_align_fpn_fused_other_resolutions(oracle_mod, res, sr, channels, ch
                    oracle_mod.roi_align_forward(feats[k], rois[idx], res, res, scales[k], sr, threads=8), "fwd", exact=False)
         assert_close(dev_feats[k].grad, oracle_mod.roi_align_backward(gtop[idx], rois[idx], feats[k].shape, scales[k], sr,
                                                                       threads=8), "bwd")
+
+
+# ---- RPN proposal generation on the device (generate_proposals.py:12-182) -----------------------------------------
+@pytest.mark.parametrize("name", ["p4", "p5", "p3min"])
+def test_generate_proposals_golden(name):
+    """Fixture = the reference's GenerateProposalsOp executed from its own source: same RoIs, same order, same bits."""
+    from detectron_pytorch_amd import generate_proposals as gp
+
+    g = load_golden("proposals.npz")
+    stride, size, h, w, pre, post, min_size = (int(v) for v in g["cfg_" + name])
+    anchors = gp.generate_anchors(stride, (size,), (0.5, 1, 2))
+    scores, deltas = syn.rpn_head_outputs(2, anchors.shape[0], h, w, seed=stride)
+    op = gp.GenerateProposalsOp(anchors, 1.0 / stride, pre, post, 0.7, min_size)
+    rois, probs = op(to_dev(scores), to_dev(deltas), g["im_info_" + name])
+    assert rois.dtype == np.float32 and probs.shape == (rois.shape[0], 1)
+    assert np.array_equal(probs, g["probs_" + name]), "kept set / order differs"
+    assert np.array_equal(rois, g["rois_" + name]), "max |diff| %g" % np.abs(rois - g["rois_" + name]).max()
+
+
+def test_generate_proposals_vs_oracle_p2_sized_level(oracle_mod):
+    """A P2-sized level (201 600 anchors), train-time top-k (2000 -> 2000), two images, tensors out."""
+    from detectron_pytorch_amd import generate_proposals as gp
+    from oracle import proposals
+
+    anchors = gp.generate_anchors(4, (32,), (0.5, 1, 2))
+    scores, deltas = syn.rpn_head_outputs(2, 3, 200, 336, seed=4)
+    im_info = np.array([[800, 1344, 1.0], [768, 1216, 1.3]], np.float32)
+    want_rois, want_probs = proposals.generate_proposals(scores, deltas, im_info, anchors, 0.25, 2000, 2000, 0.7, 0)
+    op = gp.GenerateProposalsOp(anchors, 0.25, 2000, 2000, 0.7, 0, as_numpy=False)
+    rois, probs = op(to_dev(scores), to_dev(deltas), to_dev(im_info))
+    assert rois.is_cuda and probs.is_cuda
+    assert np.array_equal(probs.cpu().numpy(), want_probs) and np.array_equal(rois.cpu().numpy(), want_rois)
+    # no NMS: thresholded top-k only
+    op = gp.GenerateProposalsOp(anchors, 0.25, 500, 0, 0.0, 8)
+    r2, p2 = op(to_dev(scores), to_dev(deltas), im_info)
+    w2 = proposals.generate_proposals(scores, deltas, im_info, anchors, 0.25, 500, 0, 0.0, 8)
+    assert np.array_equal(r2, w2[0]) and np.array_equal(p2, w2[1])
+
+
+def test_generate_proposals_more_than_4096_pre_nms_boxes(oracle_mod):
+    """The non-FPN (C4) settings keep 6000 / 12000 boxes before NMS: beyond the batched NMS entry (4096), through mi_nms."""
+    from detectron_pytorch_amd import generate_proposals as gp
+    from oracle import proposals
+
+    anchors = gp.generate_anchors(16, (32, 64, 128, 256, 512), (0.5, 1, 2))
+    scores, deltas = syn.rpn_head_outputs(1, 15, 38, 50, seed=6)
+    im_info = np.array([[600, 800, 1.0]], np.float32)
+    want = proposals.generate_proposals(scores, deltas, im_info, anchors, 1.0 / 16, 6000, 1000, 0.7, 0)
+    got = gp.GenerateProposalsOp(anchors, 1.0 / 16, 6000, 1000, 0.7, 0)(to_dev(scores), to_dev(deltas), im_info)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])

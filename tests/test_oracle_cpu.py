@@ -299,3 +299,32 @@ def test_touched_pixel_count_of_the_workload_descriptor_matches_oracle(oracle_mo
     for rois, b, h, w, res, scale, sr in cases:
         assert syn.roi_align_touched_pixels(rois, b, h, w, res, res, scale, sr) == \
             oracle_mod.roi_align_touched_pixels(rois, b, h, w, res, res, scale, sr)
+
+
+# ---- RPN proposal generation (generate_proposals.py / generate_anchors.py) -----------------------------------------
+def test_anchors_match_reference_fixture_and_known_answer():
+    from detectron_pytorch_amd import generate_proposals as gp
+    from oracle import proposals
+
+    g = load_golden("proposals.npz")
+    for fn in (gp.generate_anchors, proposals.generate_anchors):
+        assert np.array_equal(fn(4, (32,), (0.5, 1, 2)), g["anchors_s4"])
+        assert np.array_equal(fn(), g["anchors_s16_default"])
+        # stride 16, scales 8/16/32: the table in the reference's comment (generate_anchors.py:26-51, 1-based matlab
+        # coordinates) shifted by the -1 of the code's 0-based base anchor (:78)
+        table = fn(16, (128, 256, 512), (0.5, 1, 2))
+        assert table[0].tolist() == [-84.0, -40.0, 99.0, 55.0] and table[-1].tolist() == [-168.0, -344.0, 183.0, 359.0]
+
+
+def test_generate_proposals_oracle_matches_reference_fixture(oracle_mod):
+    """proposals.npz: outputs of the reference's GenerateProposalsOp executed from its own source (generate.py)."""
+    from oracle import proposals
+
+    g = load_golden("proposals.npz")
+    for name in ("p4", "p5", "p3min"):
+        stride, size, h, w, pre, post, min_size = (int(v) for v in g["cfg_" + name])
+        anchors = proposals.generate_anchors(stride, (size,), (0.5, 1, 2))
+        scores, deltas = syn.rpn_head_outputs(2, anchors.shape[0], h, w, seed=stride)
+        rois, probs = proposals.generate_proposals(scores, deltas, g["im_info_" + name], anchors, 1.0 / stride, pre, post,
+                                                   0.7, min_size)
+        assert np.array_equal(rois, g["rois_" + name]) and np.array_equal(probs, g["probs_" + name]), name
