@@ -413,6 +413,42 @@ def nms_latency(device, iters):
     return out
 
 
+def inference_path(device, iters=10):
+    """One test-time image through everything between the RPN / box-head convolutions that this repository provides,
+    without a host round trip in between: GenerateProposals on P2..P6 (TEST: 1000 pre-NMS / 1000 post-NMS per level,
+    configs/baselines/e2e_mask_rcnn_R-50-FPN_1x.yaml:41-43) -> collect the 1000 best -> RoIAlign 7x7 over P2..P5 in one
+    fused call -> per-class NMS + top-100 on (synthetic) box-head outputs for those RoIs."""
+    from detectron_pytorch_amd import detection, fpn_proposals, generate_proposals as gp
+    from detectron_pytorch_amd.roi_align import roi_align_fpn
+
+    levels = [(2, 200, 336, 4, 32), (3, 100, 168, 8, 64), (4, 50, 84, 16, 128), (5, 25, 42, 32, 256), (6, 13, 21, 64, 512)]
+    ops, heads = [], []
+    for lvl, h, w, stride, size in levels:
+        anchors = gp.generate_anchors(stride, (size,), (0.5, 1, 2))
+        sc, dl = syn.rpn_head_outputs(1, 3, h, w, seed=lvl)
+        ops.append(gp.GenerateProposalsOp(anchors, 1.0 / stride, 1000, 1000, 0.7, 0, as_numpy=False))
+        heads.append((torch.from_numpy(sc).to(device), torch.from_numpy(dl).to(device)))
+    info = torch.tensor([[800, 1344, 1.0]], dtype=torch.float32, device=device)
+    feats = [torch.from_numpy(syn.feature_map(1, syn.FPN_DIM, h, w, seed=l)).to(device) for l, h, w, _, _ in levels[3::-1]]
+    scales = [1.0 / s for _, _, _, s, _ in levels[3::-1]]
+    cls_np, box_np = syn.detection_head_outputs(1000, 81, seed=7)
+    cls, box = torch.from_numpy(cls_np).to(device), torch.from_numpy(box_np).to(device)
+    stats = {}
+
+    def run():
+        rois = fpn_proposals.generate_and_collect(ops, heads, info, 1000)
+        lv = fpn_proposals.map_rois_to_fpn_levels(rois[:, 1:5])
+        with torch.no_grad():
+            pooled = roi_align_fpn(feats, scales, rois, 5 - lv, 7, 7, 2)
+        dets = detection.box_results_with_nms_and_limit(cls[:rois.size(0)], box[:rois.size(0)])
+        stats["rois"], stats["detections"] = int(rois.size(0)), int(dets[0].numel())
+        return pooled
+
+    sec = time_kernel(run, iters, warmup=3)
+    return {"ms_per_image": round(sec * 1e3, 3), **stats,
+            "what": "GenerateProposals P2-P6 + collect + fused RoIAlign P2-P5 + class-batched NMS/top-100, one image"}
+
+
 def cpu_baseline(images_per_rank):
     """The oracle (a C port of the reference kernels, kind="port") on the host cores of this box, on a bounded sample of
     the same workload: the hot-path step of ONE image (512-RoI 7x7 and 128-RoI 14x14 RoIAlign fwd+bwd on a 1x256x200x336
@@ -535,6 +571,7 @@ def main():
                        "launch": launch_mode},
             "roofline": roof,
             "nms": nms_info,
+            "inference_path": inference_path(device),
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(images_per_rank)

@@ -1,0 +1,86 @@
+"""Collect the per-level RPN proposals and hand them to the RoI heads without leaving the device: the inference path of
+`CollectAndDistributeFpnRpnProposalsOp` (lib/modeling/collect_and_distribute_fpn_rpn_proposals.py:42-119; SURVEY.md
+section 8f row 2, test-time half -- the training half samples with np.random and is not reproduced).
+
+    collect      concatenate the levels' (rois, probs), keep the post_nms_topN best         (:83-98)
+    distribute   FPN level of every RoI (utils/fpn.py:11-28), per-level blobs, restore permutation   (:101-119)
+
+With the fused RoIAlign (`roi_align.roi_align_fpn`) the per-level blobs and the permutation are not needed at all --
+it takes the collected RoIs and their level indices as they are; `distribute` still builds the reference's blob dict
+for callers that want it.
+
+Parity: `collect` is exact for untied scores.  The level of a RoI is floor(4 + log2(sqrt(area) / 224 + 1e-6)) in fp32;
+sqrt, the division and the sum are correctly rounded on both sides, log2 is not (neither numpy's nor the device's), so
+a RoI whose scale sits within an ulp of a power of two may land on the neighbouring level -- none does on the test
+sets, and the fixture from the reference's own utils/fpn.py is matched.
+"""
+import torch
+
+from . import _lib
+from .nms import nms_device_many
+
+
+def collect(rois_list, scores_list, post_nms_topN):
+    """:83-98.  rois_list[i] [R_i,5], scores_list[i] [R_i,1] or [R_i] device tensors (one entry per RPN level).
+    Returns the post_nms_topN best rois [R,5] in descending score order (the order of tied scores is as undefined as
+    np.argsort(-scores) is there)."""
+    rois = torch.cat(list(rois_list), dim=0)
+    scores = torch.cat([s.reshape(-1) for s in scores_list], dim=0)
+    k = min(int(post_nms_topN), scores.numel()) if post_nms_topN > 0 else scores.numel()
+    inds = torch.topk(scores, k, largest=True, sorted=True).indices
+    return rois[inds]
+
+
+def map_rois_to_fpn_levels(rois_xyxy, k_min=2, k_max=5, s0=224.0, lvl0=4):
+    """utils/fpn.py:11-28 on the device: int32 level of every box [R,4] (fp32 operations in the reference's order)."""
+    w = rois_xyxy[:, 2] - rois_xyxy[:, 0] + 1
+    h = rois_xyxy[:, 3] - rois_xyxy[:, 1] + 1
+    areas = torch.clamp_min(w * h, 0)                       # areas[neg_idx] = 0 (:18)
+    s = torch.sqrt(areas)
+    lvls = torch.floor(lvl0 + torch.log2(s / s0 + 1e-6))
+    return torch.clamp(lvls, k_min, k_max).to(torch.int32)
+
+
+def distribute(rois, k_min=2, k_max=5):
+    """:101-119 for inference: {'rois', 'rois_fpn<l>'..., 'rois_idx_restore_int32'} as device tensors, plus
+    'roi_levels' (int32 level of every RoI in the order of 'rois')."""
+    lvls = map_rois_to_fpn_levels(rois[:, 1:5], k_min, k_max)
+    order = torch.argsort(lvls, stable=True)                 # level-major, original order inside a level
+    counts = torch.bincount(lvls - k_min, minlength=k_max - k_min + 1).cpu().tolist()
+    blobs = {"rois": rois, "roi_levels": lvls}
+    for lvl, part in zip(range(k_min, k_max + 1), torch.split(rois[order], counts)):
+        blobs["rois_fpn%d" % lvl] = part
+    blobs["rois_idx_restore_int32"] = torch.argsort(order).to(torch.int32)
+    return blobs
+
+
+def collect_and_distribute(rois_list, scores_list, post_nms_topN, k_min=2, k_max=5):
+    """CollectAndDistributeFpnRpnProposalsOp.forward in eval mode (:61-80)."""
+    return distribute(collect(rois_list, scores_list, post_nms_topN), k_min, k_max)
+
+
+def generate_and_collect(ops, heads, im_info, post_nms_topN):
+    """GenerateProposals on every RPN level followed by `collect`, as ONE asynchronous pipeline: per level top-k + decode,
+    then a single batched NMS over all (level, image) problems, then one global top-k over the scores of the boxes that
+    survived (the others are masked to -inf) -- the per-level RoI lists of :83-95 are never materialised, and the only
+    host synchronisation is the final count.  `ops`: one generate_proposals.GenerateProposalsOp per level (same
+    nms_thresh); `heads`: the matching (rpn_cls_prob, rpn_bbox_pred) pairs.  Returns rois [R,5] in descending score
+    order, R <= post_nms_topN -- what `collect` returns for the reference's per-level outputs."""
+    decoded = [op.decode(sc, dl, im_info) for op, (sc, dl) in zip(ops, heads)]
+    thresh = ops[0].nms_thresh
+    if thresh > 0:
+        problems = [dets[i] for dets, _ in decoded for i in range(dets.size(0))]
+        kept = nms_device_many(problems, thresh, _lib.NMS_GE_ORIG_ASC)
+    boxes, scores, first = [], [], 0
+    for op, (dets, valid) in zip(ops, decoded):
+        n, k = valid.shape
+        take = op.select(dets, valid, kept[first:first + n] if thresh > 0 else None)
+        first += n
+        img = torch.arange(n, device=dets.device, dtype=torch.float32).view(n, 1, 1).expand(n, k, 1)
+        boxes.append(torch.cat([img, dets[:, :, :4]], dim=2).reshape(n * k, 5))
+        scores.append(torch.where(take, dets[:, :, 4], torch.full_like(dets[:, :, 4], float("-inf"))).reshape(n * k))
+    boxes, scores = torch.cat(boxes), torch.cat(scores)
+    k = min(int(post_nms_topN), scores.numel()) if post_nms_topN > 0 else scores.numel()
+    best, inds = torch.topk(scores, k, largest=True, sorted=True)
+    count = int((best > float("-inf")).sum().item())            # the one synchronisation
+    return boxes[inds[:count]]

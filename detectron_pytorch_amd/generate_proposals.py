@@ -57,7 +57,9 @@ class GenerateProposalsOp(object):
     def __call__(self, rpn_cls_prob, rpn_bbox_pred, im_info):
         return self.forward(rpn_cls_prob, rpn_bbox_pred, im_info)
 
-    def forward(self, rpn_cls_prob, rpn_bbox_pred, im_info):
+    def decode(self, rpn_cls_prob, rpn_bbox_pred, im_info):
+        """Steps 1-5 (:113-153): top-k, decode, clip, filter.  Returns dets [N,k,5] (score-descending, rejected boxes
+        parked far away) and valid [N,k] int32; nothing is copied to the host."""
         _lib.require_cuda(rpn_cls_prob, "rpn_cls_prob")
         scores = rpn_cls_prob.detach().contiguous()
         deltas = rpn_bbox_pred.detach().contiguous()
@@ -74,25 +76,35 @@ class GenerateProposalsOp(object):
         top_scores, top_idx = torch.topk(scores.view(n, total), k, dim=1, largest=True, sorted=True)     # :131-142
         dets = torch.empty((n, k, 5), dtype=torch.float32, device=device)
         valid = torch.empty((n, k), dtype=torch.int32, device=device)
-        lib = _lib.lib()
         with torch.cuda.device(device):
-            rc = lib.mi_rpn_decode_proposals(deltas.data_ptr(), top_scores.data_ptr(), top_idx.data_ptr(),
-                                             im_info.data_ptr(), self._anchors.ctypes.data_as(ctypes.c_void_p), n, a, h, w,
-                                             k, float(self._feat_stride), self.min_size, BBOX_XFORM_CLIP,
-                                             dets.data_ptr(), valid.data_ptr(), _lib.current_stream_handle(device))
+            rc = _lib.lib().mi_rpn_decode_proposals(
+                deltas.data_ptr(), top_scores.data_ptr(), top_idx.data_ptr(), im_info.data_ptr(),
+                self._anchors.ctypes.data_as(ctypes.c_void_p), n, a, h, w, k, float(self._feat_stride), self.min_size,
+                BBOX_XFORM_CLIP, dets.data_ptr(), valid.data_ptr(), _lib.current_stream_handle(device))
         _lib.check(rc, "mi_rpn_decode_proposals")
-        pos = torch.arange(k, device=device)
-        if self.nms_thresh > 0:                                                                            # :155-161
-            kept = nms_device_many([dets[i] for i in range(n)], self.nms_thresh, _lib.NMS_GE_ORIG_ASC)
-            take = torch.zeros((n, k + 1), dtype=torch.bool, device=device)    # column k absorbs the unused tail of `keep`
-            for i, (keep, num_keep) in enumerate(kept):                        # keep = ascending positions = descending score
-                take[i, torch.where(pos < num_keep.to(torch.int64), keep, torch.full_like(keep, k))] = True
-            take = take[:, :k]
-            take &= valid.bool()
-            if self.post_nms_topN > 0:
-                take &= torch.cumsum(take, dim=1) <= self.post_nms_topN
-        else:
-            take = valid.bool()
+        return dets, valid
+
+    def select(self, dets, valid, kept):
+        """Steps 6-8 (:155-161) as a mask [N,k]: kept by the NMS (`kept`: one (keep, num_keep) per image, or None when
+        nms_thresh <= 0), passed the filter, among the first post_nms_topN of those."""
+        n, k = valid.shape
+        if kept is None:
+            return valid.bool()
+        pos = torch.arange(k, device=valid.device)
+        take = torch.zeros((n, k + 1), dtype=torch.bool, device=valid.device)  # column k absorbs the unused tail of `keep`
+        for i, (keep, num_keep) in enumerate(kept):                            # keep = ascending positions = descending score
+            take[i, torch.where(pos < num_keep.to(torch.int64), keep, torch.full_like(keep, k))] = True
+        take = take[:, :k] & valid.bool()
+        if self.post_nms_topN > 0:
+            take &= torch.cumsum(take, dim=1) <= self.post_nms_topN
+        return take
+
+    def forward(self, rpn_cls_prob, rpn_bbox_pred, im_info):
+        dets, valid = self.decode(rpn_cls_prob, rpn_bbox_pred, im_info)
+        n = dets.size(0)
+        kept = (nms_device_many([dets[i] for i in range(n)], self.nms_thresh, _lib.NMS_GE_ORIG_ASC)
+                if self.nms_thresh > 0 else None)
+        take = self.select(dets, valid, kept)
         img, col = torch.nonzero(take, as_tuple=True)                        # image-major, score-descending
         boxes = dets[img, col]
         rois = torch.cat([img.to(torch.float32).unsqueeze(1), boxes[:, :4]], dim=1)

@@ -702,3 +702,67 @@ def test_generate_proposals_more_than_4096_pre_nms_boxes(oracle_mod):
     want = proposals.generate_proposals(scores, deltas, im_info, anchors, 1.0 / 16, 6000, 1000, 0.7, 0)
     got = gp.GenerateProposalsOp(anchors, 1.0 / 16, 6000, 1000, 0.7, 0)(to_dev(scores), to_dev(deltas), im_info)
     assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+
+
+def test_collect_and_distribute_inference_path(oracle_mod):
+    """collect_and_distribute_fpn_rpn_proposals.py:83-119 on the device, then the fused RoIAlign straight from its output."""
+    from detectron_pytorch_amd import fpn_proposals, roi_xform
+    from detectron_pytorch_amd.roi_align import roi_align_fpn
+
+    # fixture from the reference's utils/fpn.py: level of every RoI, per-level blobs, restore permutation
+    g = load_golden("fpn.npz")
+    rois = g["rois"]
+    blobs = fpn_proposals.distribute(to_dev(rois))
+    assert np.array_equal(blobs["roi_levels"].cpu().numpy(), g["levels"].astype(np.int32))
+    for key in ("rois_fpn2", "rois_fpn3", "rois_fpn4", "rois_fpn5", "rois_idx_restore_int32"):
+        assert np.array_equal(blobs[key].cpu().numpy(), g[key]), key
+    # collect: five levels of proposals with distinct scores -> the N best in descending order
+    rng = np.random.RandomState(0)
+    all_scores = rng.permutation(5 * 700).astype(np.float32) / 3500
+    parts = [(syn.rois_fpn_distributed(700, batch=2, seed=l)[0], all_scores[700 * l:700 * (l + 1), None]) for l in range(5)]
+    want = np.concatenate([p[0] for p in parts])[np.argsort(-all_scores)[:1000]]
+    got = fpn_proposals.collect([to_dev(p[0]) for p in parts], [to_dev(p[1]) for p in parts], 1000)
+    assert np.array_equal(got.cpu().numpy(), want)
+    lv = fpn_proposals.map_rois_to_fpn_levels(got[:, 1:5])
+    assert np.array_equal(lv.cpu().numpy(), roi_xform.map_rois_to_fpn_levels(want[:, 1:5]).astype(np.int32))
+    # ... and pooled in one call from exactly these tensors
+    scales = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4]
+    feats = [syn.feature_map(2, 32, int(np.ceil(syn.IM_H * s)), int(np.ceil(syn.IM_W * s)), seed=9 + i)
+             for i, s in enumerate(scales)]
+    out = roi_align_fpn([to_dev(f) for f in feats], scales, got, 5 - lv, 7, 7, 2).cpu().numpy()
+    lv_np = lv.cpu().numpy()
+    for lvl in range(2, 6):
+        idx = np.nonzero(lv_np == lvl)[0]
+        assert_fwd(out[idx], oracle_mod.roi_align_forward(feats[5 - lvl], want[idx], 7, 7, scales[5 - lvl], 2, threads=8),
+                   "lvl %d" % lvl, exact=False)
+
+
+def test_generate_and_collect_matches_per_level_ops_then_collect(oracle_mod):
+    """The single-pipeline form (one batched NMS for all levels and images, global top-k over masked scores) gives what
+    the reference's sequence gives: GenerateProposalsOp per level, then collect (collect_and_distribute...py:83-98)."""
+    from detectron_pytorch_amd import fpn_proposals, generate_proposals as gp
+    from oracle import proposals
+
+    levels = [(3, 100, 168, 8, 64), (4, 50, 84, 16, 128), (5, 25, 42, 32, 256)]
+    im_info = np.array([[800, 1344, 1.0], [760, 1200, 1.5]], np.float32)
+    ops, heads, want_rois, want_probs = [], [], [], []
+    sizes = [2 * 3 * h * w for _, h, w, _, _ in levels]
+    ranks = np.random.RandomState(3).permutation(sum(sizes))                 # scores distinct across levels AND images,
+    first = 0                                                                # exactly representable: (rank + 1) / 2^22
+    for (lvl, h, w, stride, size), cnt in zip(levels, sizes):
+        anchors = gp.generate_anchors(stride, (size,), (0.5, 1, 2))
+        _, dl = syn.rpn_head_outputs(2, 3, h, w, seed=20 + lvl)
+        sc = ((ranks[first:first + cnt] + 1).astype(np.float32) / np.float32(1 << 22)).reshape(2, 3, h, w)
+        first += cnt
+        ops.append(gp.GenerateProposalsOp(anchors, 1.0 / stride, 1000, 300, 0.7, 0, as_numpy=False))
+        heads.append((to_dev(sc), to_dev(dl)))
+        r, p = proposals.generate_proposals(sc, dl, im_info, anchors, 1.0 / stride, 1000, 300, 0.7, 0)
+        want_rois.append(r)
+        want_probs.append(p)
+    all_rois, all_probs = np.concatenate(want_rois), np.concatenate(want_probs).squeeze()
+    assert len(np.unique(all_probs)) == len(all_probs)
+    want = all_rois[np.argsort(-all_probs)[:500]]
+    got = fpn_proposals.generate_and_collect(ops, heads, to_dev(im_info), 500)
+    assert np.array_equal(got.cpu().numpy(), want)
+    few = fpn_proposals.generate_and_collect(ops, heads, to_dev(im_info), 100000)   # fewer proposals than asked for
+    assert np.array_equal(few.cpu().numpy(), all_rois[np.argsort(-all_probs)])
