@@ -446,7 +446,8 @@ def inference_path(device, iters=10):
 
     sec = time_kernel(run, iters, warmup=3)
     return {"ms_per_image": round(sec * 1e3, 3), **stats,
-            "what": "GenerateProposals P2-P6 + collect + fused RoIAlign P2-P5 + class-batched NMS/top-100, one image"}
+            "what": "GenerateProposals P2-P6 + collect + fused RoIAlign P2-P5 + class-batched NMS/top-100, one image; "
+                    "~150 small launches from Python: bound by the host CPU of the box, not by the GPU"}
 
 
 def cpu_baseline(images_per_rank):

@@ -5,7 +5,8 @@
 TAG=${1:-r01}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/bench -o b -f csv -- python $R/bench.py > $O/bench_stdout.log 2>&1
 cp $O/bench/*kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null
-grep '^{' $O/bench_stdout.log | tail -1 > $O/bench_line.json
+# the judged line comes from a plain run: the tracer's per-launch overhead inflates the launch-bound entries
+(cd $R && timeout 900 python bench.py 2> $O/bench_plain.err | grep '^{' | tail -1 > $O/bench_line.json)
 j=0
 for grp in "FETCH_SIZE" "WRITE_SIZE TCC_EA0_RDREQ_sum" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
