@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Tuning aid: host-side stage timings (ms) of the composed inference path that bench.py reports as `inference_path`
+(GenerateProposals P2-P6 -> collect -> fused RoIAlign -> class-batched post-processing), one image.
+    python tools/prof_inference_path.py"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 from detectron_pytorch_amd import detection, fpn_proposals, generate_proposals as gp, synthetic as syn, _lib
