@@ -80,12 +80,19 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x < kCounterDwords) ws[threadIdx.x] = 0;
+  // This wave's RoI: its five floats and its level are fetched FIRST (wave-uniform address -> scalar loads), so that
+  // their latency passes under the key phase below instead of after the barrier.
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  using const_float_ptr = const __attribute__((address_space(4))) float*;
+  const int r_safe = __builtin_amdgcn_readfirstlane(min(r, num_rois - 1));
+  const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)r_safe * 5);
+  const float roi_b = roi[0], roi_x1 = roi[1], roi_y1 = roi[2], roi_x2 = roi[3], roi_y2 = roi[4];
+  const int lvl = __builtin_amdgcn_readfirstlane(level_of(levels, r_safe, lv));
   for (int i = threadIdx.x; i < num_rois; i += 256) {
     const int l = level_of(levels, i, lv);
     keys[i] = sweep_key(rois + (long long)i * 5, l, lv.scale[l], lv.height[l]);
   }
   __syncthreads();
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= num_rois) return;
   // rank of this RoI in the sweep (ties by index): the record index
   int rank = 0;
@@ -99,16 +106,12 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
     for (int d = 32; d >= 1; d >>= 1) rank += __shfl_xor(rank, d);
   }
   int* __restrict__ rec = ws + kCounterDwords + (long long)rank * kRecDwords;
-  // the RoI's five floats: wave-uniform address -> scalar loads
-  using const_float_ptr = const __attribute__((address_space(4))) float*;
-  const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)__builtin_amdgcn_readfirstlane(r) * 5);
-  const int lvl = __builtin_amdgcn_readfirstlane(level_of(levels, r, lv));
   const int height = lv.height[lvl], width = lv.width[lvl];
   const float spatial_scale = lv.scale[lvl];
-  const int batch_ind = (int)roi[0];
-  const float start_w = roi[1] * spatial_scale, start_h = roi[2] * spatial_scale;
-  const float roi_width = fmaxf(roi[3] * spatial_scale - start_w, 1.f);
-  const float roi_height = fmaxf(roi[4] * spatial_scale - start_h, 1.f);
+  const int batch_ind = (int)roi_b;
+  const float start_w = roi_x1 * spatial_scale, start_h = roi_y1 * spatial_scale;
+  const float roi_width = fmaxf(roi_x2 * spatial_scale - start_w, 1.f);
+  const float roi_height = fmaxf(roi_y2 * spatial_scale - start_h, 1.f);
   const float bin_h = roi_height / (float)aligned_height, bin_w = roi_width / (float)aligned_width;
   const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)aligned_height);
   const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)aligned_width);
