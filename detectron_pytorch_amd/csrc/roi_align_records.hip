@@ -542,8 +542,11 @@ struct BwdLds {
   static constexpr int kGWords = KC * kTileBins * 4;               // g block: up to 224 bins per channel
 };
 
+// 16-row tiles with 32 channels: 84 VGPRs would cap a SIMD at 5 waves = two 8-wave workgroups per CU; pinning the
+// kernel to 6 waves per SIMD (<= 80 VGPRs) lets the third workgroup the LDS budget allows become resident.
 template <int kSR, int KC, int kTH>
 __global__ void __launch_bounds__(kTH * 32)
+    __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
 roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, const int* __restrict__ ws,
                     int num_rois, int batch, int channels, int aligned_height, int aligned_width, int overwrite,
                     int ablate, int g_words, int ah_pad, int g_cs) {
@@ -552,12 +555,12 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
   constexpr int kThreads = kTH * kTW, kNWaves = kThreads / 64;
   constexpr int kCS = KC + 4;  // words per (bin row, column) of T
   // LDS (all of it in the dynamic region, 16-byte aligned pieces):
-  //   ctl[32] | list[num_rois] | tab[2][kTabDw] | g[2][g_words] | T[aligned_height][kTW][KC + 4]
+  //   ctl[32] | list[num_rois] (16-bit ranks) | tab[2][kTabDw] | g[2][g_words] | T[aligned_height][kTW][KC + 4]
   int* wave_count = reinterpret_cast<int*>(smem);
   int& list_len = wave_count[kNWaves];
-  int* list = wave_count + 32;
-  const int list_words = (num_rois + 3) & ~3;
-  int* tab0 = list + list_words;
+  unsigned short* list = reinterpret_cast<unsigned short*>(wave_count + 32);  // ranks < kMaxRois = 8192
+  const int list_words = ((num_rois + 1) / 2 + 3) & ~3;
+  int* tab0 = wave_count + 32 + list_words;
   float* g0 = reinterpret_cast<float*>(tab0 + 2 * kTabDw);
   float* T = g0 + 2 * g_words;
 
@@ -598,7 +601,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
     __syncthreads();
     int off = list_len;
     for (int w = 0; w < wave; w++) off += wave_count[w];
-    if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
     __syncthreads();
     if (tid == 0) {
       int add = 0;
@@ -865,7 +868,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);  // channel stride of the transposed g block: 4 * odd
   const int g_words = kc * g_cs;
   const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
-  const size_t lds = (32 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
+  const size_t lds = (32 + (size_t)(((num_rois + 1) / 2 + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
   lv.tile_base[0] = 0;
   for (int l = 0; l < lv.count; l++)
     lv.tile_base[l + 1] = lv.tile_base[l] + ((lv.width[l] + kTW - 1) / kTW) * ((lv.height[l] + th - 1) / th) * batch;
@@ -926,7 +929,7 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
   const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
   const int ah_pad = (aligned_height + 3) & ~3;
   const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);
-  const size_t lds = (32 + (size_t)((num_rois + 3) & ~3) + 2 * tab_dw + 2 * (size_t)kc * g_cs +
+  const size_t lds = (32 + (size_t)(((num_rois + 1) / 2 + 3) & ~3) + 2 * tab_dw + 2 * (size_t)kc * g_cs +
                       (size_t)aligned_height * kTW * (kc + 4)) * 4;
   return channels > 0 && channels % 32 == 0 && aligned_height > 0 && aligned_width > 0 &&
          aligned_height <= kMaxStages && num_rois <= kMaxRois && lds <= 160 * 1024 - 4096 &&
