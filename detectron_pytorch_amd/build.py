@@ -21,7 +21,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libmi_detectron_ops.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["abi.hip", "roi_align.hip", "roi_align_fwd_tile.hip", "roi_align_records.hip", "roi_align_nhwc.hip", "roi_align_stream.hip", "roi_pool.hip", "roi_crop.hip", "nms.hip", "soft_nms.hip", "proposals.hip"]
+SOURCES = ["abi.hip", "roi_align.hip", "roi_align_fwd_tile.hip", "roi_align_records.hip", "roi_align_nhwc.hip", "roi_pool.hip", "roi_crop.hip", "nms.hip", "soft_nms.hip", "proposals.hip"]
 ARCH = "gfx950"
 
 
@@ -33,16 +33,19 @@ def hipcc():
 
 
 def flags():
-    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
-            "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    out = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
+           "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    if os.environ.get("MI_TUNING_BUILD"):  # tools/ only: keeps the MI_ROI_ALIGN_ABLATE switches alive in the kernels
+        out.append("-DMI_TUNING=1")
+    return out
 
 
 def stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "mi_detectron_ops.h"),
-                                                                os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps += [os.path.join(ROOT, "include", "mi_detectron_ops.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -1,6 +1,9 @@
 // abi.hip -- version / error-string entry points of the C-ABI (include/mi_detectron_ops.h).
 #include "common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace mi {
 namespace {
 thread_local char g_error[512] = {0};
@@ -13,6 +16,36 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 void clear_error() { g_error[0] = 0; }
+
+namespace {
+int env_int(const char* name, int fallback) {
+  const char* v = std::getenv(name);
+  return v != nullptr ? std::atoi(v) : fallback;
+}
+Tuning read_tuning() {
+  Tuning t = {};
+  const char* impl = std::getenv("MI_ROI_ALIGN_IMPL");
+  t.force_direct = impl != nullptr && std::strcmp(impl, "direct") == 0;
+  t.no_ws = std::getenv("MI_ROI_ALIGN_NO_WS") != nullptr;
+  t.cap_px = env_int("MI_ROI_ALIGN_CAP", 336);
+  const int th = env_int("MI_ROI_ALIGN_BWD_TH", 16);
+  t.bwd_tile_rows = (th == 8 || th == 32) ? th : 16;
+  t.nhwc_vec = env_int("MI_ROI_ALIGN_NHWC_V", 0);
+  t.nhwc_pb = env_int("MI_ROI_ALIGN_NHWC_PB", 0);
+  const int om = env_int("MI_ROI_ALIGN_NHWC_ORDER_MUL", 1);
+  t.nhwc_order_mul = om > 0 ? om : 1;
+  t.nhwc_zigzag = env_int("MI_ROI_ALIGN_NHWC_ZIGZAG", 1);
+  t.ablate = MI_ABLATE(env_int("MI_ROI_ALIGN_ABLATE", 0));
+  t.fwd_group = env_int("MI_ROI_ALIGN_FWD_GROUP", 0);
+  t.bwd_batch = env_int("MI_ROI_ALIGN_BWD_BATCH", 0);
+  return t;
+}
+}  // namespace
+
+const Tuning& tuning() {
+  static const Tuning t = read_tuning();  // C++11: initialised once, thread-safe
+  return t;
+}
 }  // namespace mi
 
 extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }

@@ -45,6 +45,31 @@ inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
   return static_cast<int>(g);
 }
 
+// Tuning knobs of the RoIAlign launchers.  Read ONCE from the environment at first use (thread-safe static
+// initialisation) and immutable afterwards: launchers take them by value from tuning(), nothing on the launch path calls
+// getenv or writes process-wide state, so concurrent calls from several host threads (the reference's thread-per-GPU
+// convention, nn/parallel/parallel_apply.py:41-59) see one consistent configuration.
+//   MI_ROI_ALIGN_IMPL=direct   generic one-lane-per-output kernels only (tests of the generic path, A/B baselines)
+//   MI_ROI_ALIGN_NO_WS=1       ignore the caller's workspace (no records path)
+//   MI_ROI_ALIGN_CAP=192|256|336|448|640   window pixels per channel of the NCHW forward LDS image
+//   MI_ROI_ALIGN_BWD_TH=8|16|32            rows per backward tile
+//   MI_ROI_ALIGN_NHWC_V / _PB / _ORDER_MUL / _ZIGZAG   channels-last forward variants
+//   MI_ROI_ALIGN_ABLATE=mask   only honoured by builds with -DMI_TUNING (tools/); release kernels compile it out
+struct Tuning {
+  bool force_direct, no_ws;
+  int cap_px, bwd_tile_rows;
+  int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag;
+  int ablate;
+  int fwd_group, bwd_batch;  // experimental variants (0 = default)
+};
+const Tuning& tuning();
+
+#ifdef MI_TUNING
+#define MI_ABLATE(mask) (mask)
+#else
+#define MI_ABLATE(mask) 0
+#endif
+
 #define MI_REQUIRE(cond, ...)          \
   do {                                 \
     if (!(cond)) {                     \

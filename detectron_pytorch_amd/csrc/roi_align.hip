@@ -209,30 +209,9 @@ roi_align_legacy_bwd(long long total, const float* __restrict__ top_diff,
   }
 }
 
-// MI_ROI_ALIGN_IMPL=direct forces the generic kernels (A/B measurements and tests of the generic path).
-bool force_direct() {
-  const char* impl = std::getenv("MI_ROI_ALIGN_IMPL");
-  return impl != nullptr && std::strcmp(impl, "direct") == 0;
-}
-bool use_stream_path(int channels, int aligned_height, int aligned_width) {
-  return !force_direct() && mi::roi_align_stream_supported(channels, aligned_height, aligned_width);
-}
-// MI_ROI_ALIGN_CAP=192|256|320|384: window pixels per channel of the forward LDS image (tuning knob)
-int ring_words() {
-  const char* ab = std::getenv("MI_ROI_ALIGN_ABLATE");
-  mi::roi_align_fwd_tile_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
-  mi::roi_align_records_set_ablate(ab != nullptr ? std::atoi(ab) : 0);
-  const char* th = std::getenv("MI_ROI_ALIGN_BWD_TH");
-  mi::roi_align_bwd_set_tile_rows(th != nullptr ? std::atoi(th) : 16);
-  const char* nv = std::getenv("MI_ROI_ALIGN_NHWC_V");
-  const char* npb = std::getenv("MI_ROI_ALIGN_NHWC_PB");
-  const char* nom = std::getenv("MI_ROI_ALIGN_NHWC_ORDER_MUL");
-  const char* nzz = std::getenv("MI_ROI_ALIGN_NHWC_ZIGZAG");
-  mi::roi_align_fwd_nhwc_set_tuning(nv != nullptr ? std::atoi(nv) : 0, npb != nullptr ? std::atoi(npb) : 0,
-                                    nom != nullptr ? std::atoi(nom) : 1, nzz != nullptr ? std::atoi(nzz) : 1);
-  const char* v = std::getenv("MI_ROI_ALIGN_CAP");
-  return v != nullptr ? std::atoi(v) : 336;
-}
+bool force_direct() { return mi::tuning().force_direct; }
+bool no_ws() { return mi::tuning().no_ws; }
+int ring_words() { return mi::tuning().cap_px; }
 
 int check_common(const void* a, const void* rois, const void* b, int batch, int channels,
                  int height, int width, int num_rois, int ah, int aw, int variant, int layout) {
@@ -287,12 +266,12 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
                mi::roi_align_records_workspace_bytes(num_rois));
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
-    if (layout == MI_LAYOUT_NCHW && !force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
+    if (layout == MI_LAYOUT_NCHW && !force_direct() && !no_ws() &&
         mi::roi_align_fwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
       return mi::launch_roi_align_fwd_records(features, rois, output, workspace, batch, channels, height, width,
                                               num_rois, aligned_height, aligned_width, spatial_scale,
                                               sampling_ratio, cap, s);
-    if (layout == MI_LAYOUT_NHWC && !force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
+    if (layout == MI_LAYOUT_NHWC && !force_direct() && !no_ws() &&
         num_rois <= 8192 &&
         mi::roi_align_fwd_nhwc_supported(channels, height, width, num_rois, aligned_height, aligned_width)) {
       rc = mi::launch_roi_align_prepare(rois, workspace, batch, height, width, num_rois, aligned_height,
@@ -347,8 +326,15 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
                         aligned_height, aligned_width, variant, layout);
   if (rc != MI_OK) return rc;
   const long long total = (long long)num_rois * channels * aligned_height * aligned_width;
-  if (total == 0) return MI_OK;
   hipStream_t s = mi::as_stream(stream);
+  if (total == 0) {
+    // no RoI contributes: with the OVERWRITE contract the caller did not zero-fill, so the zeros are ours to write
+    const long long in_elems = (long long)batch * channels * height * width;
+    if ((records_ready & 2) != 0 && in_elems > 0 && bottom_grad != nullptr &&
+        hipMemsetAsync(bottom_grad, 0, (size_t)in_elems * sizeof(float), s) != hipSuccess)
+      return mi::check_launch("roi_align_backward: zero fill");
+    return MI_OK;
+  }
   const int block = 256;
   if (variant == MI_ROI_ALIGN_LEGACY) {
     roi_align_legacy_bwd<<<mi::grid_for(total, block), block, 0, s>>>(
@@ -361,17 +347,13 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
                mi::roi_align_records_workspace_bytes(num_rois));
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
-    if (!force_direct() && std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
+    if (!force_direct() && !no_ws() &&
         mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
       return mi::launch_roi_align_bwd_records(top_grad, rois, bottom_grad, workspace, (records_ready & 1) != 0,
                                               (records_ready & 2) != 0, layout == MI_LAYOUT_NHWC, batch, channels,
                                               height, width, num_rois, aligned_height, aligned_width, spatial_scale,
                                               sampling_ratio, ring_words(), s);
   }
-  if (layout == MI_LAYOUT_NCHW && use_stream_path(channels, aligned_height, aligned_width))
-    return mi::launch_roi_align_bwd_stream(top_grad, rois, bottom_grad, batch, channels, height, width,
-                                           num_rois, aligned_height, aligned_width, spatial_scale,
-                                           sampling_ratio, s);
   FeatStrides st = make_strides(layout, channels, height, width);
   roi_align_bwd_direct<<<mi::grid_for(total, block), block, 0, s>>>(
       total, top_grad, rois, bottom_grad, batch, channels, height, width, aligned_height,
@@ -424,7 +406,7 @@ bool to_level_table(const mi_fpn_levels* in, int batch, bool forward, mi::LevelT
 extern "C" int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
                                           int aligned_width, int layout) {
   if (levels == nullptr || levels->num_levels < 1 || levels->num_levels > mi::kMaxLevels || force_direct() ||
-      std::getenv("MI_ROI_ALIGN_NO_WS") != nullptr || num_rois <= 0 || num_rois > 8192 ||
+      no_ws() || num_rois <= 0 || num_rois > 8192 ||
       (layout != MI_LAYOUT_NCHW && layout != MI_LAYOUT_NHWC))
     return 0;
   for (int l = 0; l < levels->num_levels; l++) {
@@ -477,7 +459,15 @@ extern "C" int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const floa
              "roi_align_fpn: bad size");
   mi::LevelTable lv;
   MI_REQUIRE(to_level_table(levels, batch, false, &lv), "roi_align_fpn: malformed level table");
-  if (num_rois == 0) return MI_OK;
+  if (num_rois == 0) {
+    // an empty RoI set (e.g. no foreground RoI for the mask head): every level's gradient is all zeros
+    if ((flags & 2) != 0)
+      for (int l = 0; l < lv.count; l++)
+        if (hipMemsetAsync(lv.grad[l], 0, (size_t)batch * channels * lv.height[l] * lv.width[l] * sizeof(float),
+                           mi::as_stream(stream)) != hipSuccess)
+          return mi::check_launch("roi_align_backward_fpn: zero fill");
+    return MI_OK;
+  }
   MI_REQUIRE(rois != nullptr && roi_levels != nullptr && top_grad != nullptr && workspace != nullptr,
              "roi_align_fpn: null pointer");
   MI_REQUIRE(mi_roi_align_fpn_supported(levels, channels, num_rois, aligned_height, aligned_width, layout) == 1,
@@ -494,7 +484,7 @@ extern "C" int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const floa
 
 extern "C" int mi_roi_align_forward_writes_records(int channels, int height, int width, int num_rois,
                                                    int aligned_height, int aligned_width, int variant, int layout) {
-  if (variant != MI_ROI_ALIGN_CAFFE2 || force_direct() || std::getenv("MI_ROI_ALIGN_NO_WS") != nullptr || num_rois <= 0)
+  if (variant != MI_ROI_ALIGN_CAFFE2 || force_direct() || no_ws() || num_rois <= 0)
     return 0;
   if (layout == MI_LAYOUT_NCHW)
     return mi::roi_align_fwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width) ? 1 : 0;
@@ -509,7 +499,7 @@ extern "C" int mi_roi_align_forward_writes_records(int channels, int height, int
 extern "C" int mi_roi_align_backward_overwrites(int channels, int height, int width, int num_rois, int aligned_height,
                                                 int aligned_width, int variant, int layout) {
   return variant == MI_ROI_ALIGN_CAFFE2 && (layout == MI_LAYOUT_NCHW || layout == MI_LAYOUT_NHWC) && !force_direct() &&
-                 std::getenv("MI_ROI_ALIGN_NO_WS") == nullptr &&
+                 !no_ws() &&
                  mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width)
              ? 1
              : 0;

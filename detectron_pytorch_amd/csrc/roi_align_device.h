@@ -1,4 +1,4 @@
-// roi_align_device.h -- device helpers shared by the RoIAlign kernels (roi_align.hip, roi_align_stream.hip).
+// roi_align_device.h -- device helpers shared by the RoIAlign kernels (roi_align*.hip).
 // Each function restates one piece of lib/modeling/roi_xfrom/roi_align/src/roi_align_kernel.cu in fp32,
 // operation for operation (the library is compiled with -ffp-contract=off).
 #pragma once
@@ -105,16 +105,13 @@ inline LevelTable single_level(const float* feat, float* grad, int batch, int he
   return t;
 }
 
-// host-side launchers of the NCHW fast paths (roi_align_fwd_tile.hip, roi_align_stream.hip)
+// host-side launchers of the NCHW fast paths (roi_align_fwd_tile.hip)
 bool roi_align_fwd_tile_supported(int channels, int height, int width, int aligned_height, int aligned_width);
 int launch_roi_align_fwd_tile(const float* features, const float* rois, float* output, int batch, int channels,
                               int height, int width, int num_rois, int aligned_height, int aligned_width,
                               float spatial_scale, int sampling_ratio, int ring_words, hipStream_t stream);
 void roi_align_fwd_tile_set_timeline(long long* device_buffer);
-void roi_align_fwd_tile_set_ablate(int mask);
 // two-launch forward fast path with caller scratch (roi_align_records.hip)
-void roi_align_records_set_ablate(int mask);
-void roi_align_bwd_set_tile_rows(int rows);
 size_t roi_align_records_workspace_bytes(int num_rois);
 bool roi_align_fwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width);
@@ -144,7 +141,6 @@ int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int 
                              int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
                              hipStream_t stream);
 // channels-last features, record-driven (roi_align_nhwc.hip)
-void roi_align_fwd_nhwc_set_tuning(int channels_per_lane, int columns_in_flight, int order_mul, int zigzag);
 void roi_align_fwd_nhwc_set_timeline(long long* device_buffer);
 bool roi_align_fwd_nhwc_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                   int aligned_width);
@@ -158,10 +154,5 @@ int launch_roi_align_fwd_nhwc_levels(const LevelTable& lv, const float* rois, fl
 int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, const int* levels, void* workspace,
                                     int batch, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
                                     hipStream_t stream);
-bool roi_align_stream_supported(int channels, int aligned_height, int aligned_width);
-int launch_roi_align_bwd_stream(const float* top_grad, const float* rois, float* bottom_grad, int batch,
-                                int channels, int height, int width, int num_rois, int aligned_height,
-                                int aligned_width, float spatial_scale, int sampling_ratio,
-                                hipStream_t stream);
 
 }  // namespace mi

@@ -130,7 +130,8 @@ template <int kSR, int kCap, int kAH>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 roi_align_fwd_tile(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
                    int batch, int channels, int height, int width, int aligned_height, int aligned_width,
-                   float spatial_scale, int sampling_ratio, long long* __restrict__ timeline, int ablate) {
+                   float spatial_scale, int sampling_ratio, long long* __restrict__ timeline, int ablate_arg) {
+  const int ablate = MI_ABLATE(ablate_arg);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Lds<kCap> s(smem);
   constexpr int kPlane = Lds<kCap>::kPlane;
@@ -434,7 +435,6 @@ roi_align_fwd_tile(const float* __restrict__ feat, const float* __restrict__ roi
 }
 
 long long* g_timeline = nullptr;
-int g_ablate = 0;  // tuning aid: MI_ROI_ALIGN_ABLATE bit0 = no DMA, bit1 = no compute, bit2 = no store
 
 template <int kCap>
 int launch_cap(const float* features, const float* rois, float* output, int batch, int channels, int height,
@@ -445,22 +445,21 @@ int launch_cap(const float* features, const float* rois, float* output, int batc
   if (sampling_ratio == 2 && aligned_height == 7)
     roi_align_fwd_tile<2, kCap, 7><<<grid, kThreads, lds, stream>>>(features, rois, output, batch, channels, height,
                                                                     width, aligned_height, aligned_width,
-                                                                    spatial_scale, sampling_ratio, g_timeline, g_ablate);
+                                                                    spatial_scale, sampling_ratio, g_timeline, tuning().ablate);
   else if (sampling_ratio == 2)
     roi_align_fwd_tile<2, kCap, 0><<<grid, kThreads, lds, stream>>>(features, rois, output, batch, channels, height,
                                                                     width, aligned_height, aligned_width,
-                                                                    spatial_scale, sampling_ratio, g_timeline, g_ablate);
+                                                                    spatial_scale, sampling_ratio, g_timeline, tuning().ablate);
   else
     roi_align_fwd_tile<0, kCap, 0><<<grid, kThreads, lds, stream>>>(features, rois, output, batch, channels, height,
                                                                     width, aligned_height, aligned_width,
-                                                                    spatial_scale, sampling_ratio, g_timeline, g_ablate);
+                                                                    spatial_scale, sampling_ratio, g_timeline, tuning().ablate);
   return check_launch("roi_align_fwd_tile");
 }
 
 }  // namespace
 
 void roi_align_fwd_tile_set_timeline(long long* device_buffer) { g_timeline = device_buffer; }
-void roi_align_fwd_tile_set_ablate(int mask) { g_ablate = mask; }
 
 bool roi_align_fwd_tile_supported(int channels, int height, int width, int aligned_height, int aligned_width) {
   // 32-bit byte offsets inside one (image, channel tile) slab of the DMA descriptor; a bin row fits the staging tile

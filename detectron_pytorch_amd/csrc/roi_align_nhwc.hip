@@ -288,29 +288,20 @@ roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* _
   stamp(5);
 }
 
-int g_nhwc_vec = 0, g_nhwc_pb = 0;  // tuning overrides (MI_ROI_ALIGN_NHWC_V / _PB); 0 = default
-int g_nhwc_zigzag = 1;
-int g_nhwc_order_mul = 1;  // ablation: a multiplier coprime with num_rois scatters the sweep order
 long long* g_nhwc_timeline = nullptr;
 
 int pick_vec(int channels, int aligned_height, int aligned_width) {
   const int stride = (aligned_height * aligned_width) | 1;
   const auto fits = [&](int v) { return channels % (64 * v) == 0 && (size_t)64 * v * stride * 4 <= 64 * 1024; };
-  if (g_nhwc_vec == 2 && fits(2)) return 2;
-  if (g_nhwc_vec != 1 && fits(4)) return 4;
-  if (g_nhwc_vec != 1 && fits(2)) return 2;
+  const int want = tuning().nhwc_vec;
+  if (want == 2 && fits(2)) return 2;
+  if (want != 1 && fits(4)) return 4;
+  if (want != 1 && fits(2)) return 2;
   if ((size_t)64 * stride * 4 <= 64 * 1024) return 1;
   return 0;
 }
 
 }  // namespace
-
-void roi_align_fwd_nhwc_set_tuning(int vec, int pb, int order_mul, int zigzag) {
-  g_nhwc_zigzag = zigzag;
-  g_nhwc_vec = vec;
-  g_nhwc_pb = pb;
-  g_nhwc_order_mul = order_mul > 0 ? order_mul : 1;
-}
 
 void roi_align_fwd_nhwc_set_timeline(long long* device_buffer) { g_nhwc_timeline = device_buffer; }
 
@@ -337,11 +328,11 @@ int launch_roi_align_fwd_nhwc_levels(const LevelTable& lv, const float* rois, fl
   const bool sr2 = sampling_ratio == 2;
   // taps of 4 (then 3) output columns in flight (106 VGPRs: two 7-wave workgroups per CU) unless the whole row is
   // asked for (MI_ROI_ALIGN_NHWC_PB=7: 156 VGPRs, one workgroup per CU); measured equal at 512 RoIs
-  const bool split = g_nhwc_pb != 7;
+  const bool split = tuning().nhwc_pb != 7;
 #define MI_LAUNCH_NHWC(SR, PW, V, PB)                                                                                 \
   roi_align_fwd_nhwc<SR, PW, V, PB><<<grid, 64 * nwaves, lds, stream>>>(                                              \
-      lv, rois, output, ws, batch, channels, aligned_height, sampling_ratio, chunks, stride, g_nhwc_order_mul,        \
-      g_nhwc_zigzag, g_nhwc_timeline)
+      lv, rois, output, ws, batch, channels, aligned_height, sampling_ratio, chunks, stride, tuning().nhwc_order_mul,  \
+      tuning().nhwc_zigzag, g_nhwc_timeline)
 #define MI_LAUNCH_NHWC_V(PW, V)                                                                                       \
   do {                                                                                                                \
     if (sr2 && split)                                                                                                 \

@@ -299,7 +299,8 @@ template <int kSR, int kCap, int kCTt, int kHalves>
 __global__ void __launch_bounds__(kCTt * 8 * kHalves)
 roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
                       const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height,
-                      int aligned_width, int sampling_ratio, int ablate) {
+                      int aligned_width, int sampling_ratio, int ablate_arg) {
+  const int ablate = MI_ABLATE(ablate_arg);
   // kCTt channels per workgroup (32: half-waves own output columns; 16: quarter-waves do, twice as many workgroups
   // fit a CU -- the per-workgroup chain record load -> DMA -> landing -> arithmetic -> store drain is latency, and
   // what hides it is the number of workgroups in flight)
@@ -549,7 +550,8 @@ __global__ void __launch_bounds__(kTH * 32)
     __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
 roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, const int* __restrict__ ws,
                     int num_rois, int batch, int channels, int aligned_height, int aligned_width, int overwrite,
-                    int ablate, int g_words, int ah_pad, int g_cs) {
+                    int ablate_arg, int g_words, int ah_pad, int g_cs) {
+  const int ablate = MI_ABLATE(ablate_arg);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kTabDw = BwdLds<KC>::kTabDw;
   constexpr int kThreads = kTH * kTW, kNWaves = kThreads / 64;
@@ -812,8 +814,6 @@ roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__
   }
 }
 
-int g_ablate_p = 0;
-int g_bwd_th = 16;  // MI_ROI_ALIGN_BWD_TH=8|16|32: rows per backward tile (16: 100 -> 79 us at config 2; 32: 95 us)
 size_t records_lds_bytes(int cap, int ct) {
   return 2 * kMaxS * sizeof(TabEntry) + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4;
 }
@@ -836,7 +836,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
 #define MI_LAUNCH_REC(SR)                                                                                             \
   roi_align_fwd_records<SR, kCap, kCT, 1>                                                                             \
       <<<num_rois * (channels / kCT), kCT * 8, records_lds_bytes(kCap, kCT), stream>>>(                               \
-          lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, g_ablate_p)
+          lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, tuning().ablate)
   if (sampling_ratio == 2)
     MI_LAUNCH_REC(2);
   else
@@ -861,7 +861,8 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
     if (rc != MI_OK) return rc;
   }
   const int bins = aligned_height * aligned_width;
-  const int th = g_bwd_th;  // rows per tile (8, 16 or 32): 32 * th lanes per workgroup
+  const int th = tuning().bwd_tile_rows;  // rows per tile (16; 8 and 32 measured slower): 32 * th lanes per workgroup
+  const int g_ablate_p = tuning().ablate;
   // channels per workgroup: 32 accumulators per lane while the g block and T fit LDS comfortably, else 16
   const int kc = (bins <= 64) ? 32 : 16;
   const int ah_pad = (aligned_height + 3) & ~3;
@@ -950,9 +951,6 @@ int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, con
   return launch_prepare(rois, levels, static_cast<int*>(workspace), batch, lv, num_rois, aligned_height, aligned_width,
                         sampling_ratio, 336, stream);
 }
-
-void roi_align_records_set_ablate(int mask) { g_ablate_p = mask; }
-void roi_align_bwd_set_tile_rows(int rows) { g_bwd_th = (rows == 8 || rows == 32) ? rows : 16; }
 
 size_t roi_align_records_workspace_bytes(int num_rois) {
   return ((size_t)kCounterDwords + (size_t)(num_rois > 0 ? num_rois : 0) * (kRecDwords + 4)) * sizeof(int);

@@ -74,8 +74,12 @@ def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=
         rows = torch.empty_like(dets)
         out_inds = torch.empty((m,), dtype=torch.int64, device=device)
         num_out = torch.zeros((nseg,), dtype=torch.int32, device=device)
-        with torch.cuda.device(device):  # a segment cannot be longer than the number of RoIs: no host copy of the sizes
-            rc = lib.mi_soft_nms_segmented(dets.data_ptr(), offsets.data_ptr(), nseg, min(r, 4096),
+        # a segment cannot be longer than the number of RoIs: no host copy of the sizes unless R exceeds the kernel's
+        # capacity (4096 rows per class), in which case the true longest segment decides -- and an oversized class is an
+        # explicit error (the library's), never a silently truncated one
+        max_seg = r if r <= 4096 else int((offsets[1:] - offsets[:-1]).max().item())
+        with torch.cuda.device(device):
+            rc = lib.mi_soft_nms_segmented(dets.data_ptr(), offsets.data_ptr(), nseg, max_seg,
                                            float(soft_nms_sigma), float(nms_thresh), 0.0001,   # core/test.py:758
                                            SOFT_NMS_METHODS[soft_nms_method], rows.data_ptr(), out_inds.data_ptr(),
                                            num_out.data_ptr(), stream)

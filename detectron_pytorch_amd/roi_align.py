@@ -91,7 +91,7 @@ def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_
     # The NCHW tile path writes every element itself; everywhere else the kernels accumulate into a zero-filled
     # buffer like the reference (functions/roi_align.py:39-44).
     overwrite = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, int(aligned_height), int(aligned_width),
-                                                          int(variant), layout)) and r > 0
+                                                          int(variant), layout))
     grad_input = torch.empty((n, c, h, w), dtype=grad_output.dtype, device=grad_output.device, memory_format=fmt)
     if not overwrite:
         grad_input.zero_()
