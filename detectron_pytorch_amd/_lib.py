@@ -54,6 +54,7 @@ SIGNATURES = {
                                       _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "mi_bbox_overlaps": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "mi_dbg_roi_align_timeline": (None, [_c_void_p]),
+    "mi_dbg_reload_tuning": (None, []),
 }
 
 

@@ -3,6 +3,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace mi {
 namespace {
@@ -42,11 +43,25 @@ Tuning read_tuning() {
 }
 }  // namespace
 
+namespace {
+Tuning g_tuning;
+std::once_flag g_tuning_once;
+}  // namespace
+
 const Tuning& tuning() {
-  static const Tuning t = read_tuning();  // C++11: initialised once, thread-safe
-  return t;
+  std::call_once(g_tuning_once, [] { g_tuning = read_tuning(); });
+  return g_tuning;
+}
+void reload_tuning() {
+  (void)tuning();
+  g_tuning = read_tuning();
 }
 }  // namespace mi
+
+// Test / tuning aid, not part of include/mi_detectron_ops.h: re-read the MI_ROI_ALIGN_* environment into the tuning
+// struct.  The only writer of that struct after its one-time initialisation; call it with no launch in flight on any
+// thread (the tests do, between cases).
+extern "C" void mi_dbg_reload_tuning(void) { mi::reload_tuning(); }
 
 extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }
 extern "C" const char* mi_last_error(void) { return mi::g_error; }

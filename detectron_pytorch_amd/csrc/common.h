@@ -63,6 +63,7 @@ struct Tuning {
   int fwd_group, bwd_batch;  // experimental variants (0 = default)
 };
 const Tuning& tuning();
+void reload_tuning();  // mi_dbg_reload_tuning() only
 
 #ifdef MI_TUNING
 #define MI_ABLATE(mask) (mask)

@@ -59,13 +59,14 @@ def collect_and_distribute(rois_list, scores_list, post_nms_topN, k_min=2, k_max
     return distribute(collect(rois_list, scores_list, post_nms_topN), k_min, k_max)
 
 
-def generate_and_collect(ops, heads, im_info, post_nms_topN):
+def generate_and_collect(ops, heads, im_info, post_nms_topN, static=False):
     """GenerateProposals on every RPN level followed by `collect`, as ONE asynchronous pipeline: per level top-k + decode,
     then a single batched NMS over all (level, image) problems, then one global top-k over the scores of the boxes that
     survived (the others are masked to -inf) -- the per-level RoI lists of :83-95 are never materialised, and the only
     host synchronisation is the final count.  `ops`: one generate_proposals.GenerateProposalsOp per level (same
     nms_thresh); `heads`: the matching (rpn_cls_prob, rpn_bbox_pred) pairs.  Returns rois [R,5] in descending score
-    order, R <= post_nms_topN -- what `collect` returns for the reference's per-level outputs."""
+    order, R <= post_nms_topN -- what `collect` returns for the reference's per-level outputs.  `static=True`: (rois
+    [k,5], valid [k]) with k = min(post_nms_topN, candidates) fixed by the shapes alone and no host synchronisation."""
     decoded = [op.decode(sc, dl, im_info) for op, (sc, dl) in zip(ops, heads)]
     thresh = ops[0].nms_thresh
     if thresh > 0:
@@ -82,5 +83,8 @@ def generate_and_collect(ops, heads, im_info, post_nms_topN):
     boxes, scores = torch.cat(boxes), torch.cat(scores)
     k = min(int(post_nms_topN), scores.numel()) if post_nms_topN > 0 else scores.numel()
     best, inds = torch.topk(scores, k, largest=True, sorted=True)
+    if static:
+        # static-shape form for the training step: always k rows plus a validity mask, no host synchronisation at all
+        return boxes[inds], best > float("-inf")
     count = int((best > float("-inf")).sum().item())            # the one synchronisation
     return boxes[inds[:count]]

@@ -90,6 +90,14 @@ def roi_feature_transform(blobs_in, rpn_ret, blob_rois="rois", method="RoIPoolF"
                           crop_resize_with_max_pool)
     if len(blobs_in) != k_max - k_min + 1:
         raise AssertionError("expected %d FPN levels, got %d" % (k_max - k_min + 1, len(blobs_in)))
+    levels = rpn_ret.get(blob_rois + "_levels") if hasattr(rpn_ret, "get") else None
+    if levels is not None and method == "RoIAlign" and fused:
+        # device-side producers (fpn_proposals.distribute, rcnn.targets.label_proposals) hand over the un-split RoIs and
+        # the FPN level of each: nothing to split, concatenate or restore -- one fused call, output in the order of the rois
+        rois = _as_device_rois(rpn_ret[blob_rois], blobs_in[0].device)
+        if roi_align_fpn_supported(list(blobs_in), rois.size(0), resolution, resolution):
+            return roi_align_fpn(list(blobs_in), list(spatial_scale), rois, (k_max - levels).to(torch.int32), resolution,
+                                 resolution, sampling_ratio)
     level_rois = [rpn_ret["%s_fpn%d" % (blob_rois, lvl)] for lvl in range(k_min, k_max + 1)]
     restore = rpn_ret[blob_rois + "_idx_restore_int32"]
     if isinstance(restore, np.ndarray):

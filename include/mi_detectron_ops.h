@@ -12,7 +12,8 @@
  *   - the caller owns every buffer; backward entry points ACCUMULATE into `bottom_grad`
  *     (the reference caller zero-fills it first: roi_xfrom/roi_align/functions/roi_align.py:39-40);
  *   - work is enqueued on `stream` (reference: THCState_getCurrentStream, roi_align_cuda.c:31);
- *     calls are re-entrant and hold no global mutable state besides the last-error string;
+ *     calls are re-entrant: the only process-wide state is the per-thread last-error string and a tuning struct that is
+ *     initialised once from the environment and read-only afterwards (see mi_dbg_reload_tuning at the end);
  *   - return value: MI_OK (0) on success, a positive MI_ERR_* code otherwise.  The
  *     reference printed to stderr and called exit(-1) on a launch failure
  *     (roi_align_kernel.cu:135-139) and returned 0 for a malformed rois tensor
@@ -247,6 +248,10 @@ int mi_bbox_overlaps(const float* boxes, int num_boxes, const float* query, int 
  * Tuning aid used by tools/timeline.py: while a non-NULL device buffer of 8 int64 per forward workgroup is set,
  * the self-contained RoIAlign forward kernel stamps s_memtime at its phase boundaries into it. */
 void mi_dbg_roi_align_timeline(long long* device_buffer);
+/* The MI_ROI_ALIGN_* tuning variables (csrc/common.h) are read from the environment ONCE, at the first RoIAlign call, and
+ * never on the launch path.  Tests and tuning scripts that change them inside a process make the change visible with this
+ * call -- the only writer of that state; call it with no RoIAlign launch in flight on any thread. */
+void mi_dbg_reload_tuning(void);
 
 #ifdef __cplusplus
 }

@@ -48,14 +48,30 @@ def assert_fwd(actual, expected, what, exact):
         assert_close(actual, expected, what, atol=FAST_ATOL, rtol=FAST_ATOL)
 
 
+@pytest.fixture
+def tuning_env(monkeypatch):
+    """Set MI_ROI_ALIGN_* variables for one test.  The library reads them once and never again on the launch path, so a
+    change is made visible through the explicit debug entry `mi_dbg_reload_tuning` (and undone the same way)."""
+    from detectron_pytorch_amd import _lib
+
+    def set_env(**env):
+        for k, v in env.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        _lib.lib().mi_dbg_reload_tuning()
+
+    yield set_env
+    monkeypatch.undo()
+    _lib.lib().mi_dbg_reload_tuning()
+
+
 @pytest.fixture(params=["stream", "direct"])
-def roi_align_impl(request, monkeypatch):
-    """Run a test against both RoIAlign implementations behind mi_roi_align_*: the LDS-streaming NCHW fast
-    path (default when C % 32 == 0) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
-    if request.param == "direct":
-        monkeypatch.setenv("MI_ROI_ALIGN_IMPL", "direct")
-    else:
-        monkeypatch.delenv("MI_ROI_ALIGN_IMPL", raising=False)
+def roi_align_impl(request, tuning_env):
+    """Run a test against both RoIAlign implementations behind mi_roi_align_*: the record-driven fast paths (default)
+    and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
+    tuning_env(MI_ROI_ALIGN_IMPL="direct" if request.param == "direct" else None)
     return request.param
 
 
@@ -131,10 +147,10 @@ def test_roi_align_channels_last_storage(oracle_mod, roi_align_impl):
     ((1, 100, 30, 40), 7, 3, 40, 1.0 / 16),     # partial last chunk, sampling_ratio 3 (generic loops)
     ((3, 128, 13, 21), 14, 1, 30, 1.0 / 32),    # tiny map, one sample per bin
 ])
-def test_roi_align_nhwc_kernel_vs_oracle(oracle_mod, monkeypatch, vec, shape, res, sr, nrois, scale):
+def test_roi_align_nhwc_kernel_vs_oracle(oracle_mod, tuning_env, vec, shape, res, sr, nrois, scale):
     """roi_align_fwd_nhwc (channels-last features, NCHW output) with every channels-per-lane variant, on RoIs that
     include the ones the record tables cannot describe (reference-order path inside the kernel)."""
-    monkeypatch.setenv("MI_ROI_ALIGN_NHWC_V", vec)
+    tuning_env(MI_ROI_ALIGN_NHWC_V=vec)
     n, c, h, w = shape
     feat = syn.feature_map(n, c, h, w, seed=res + sr)
     rois = np.vstack([syn.rois_adversarial(nrois // 2, n, h, w, scale, seed=nrois),
@@ -145,7 +161,7 @@ def test_roi_align_nhwc_kernel_vs_oracle(oracle_mod, monkeypatch, vec, shape, re
     assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=8), "nhwc fwd", exact=False)
 
 
-def test_roi_align_nhwc_config2_full_shape(oracle_mod, monkeypatch):
+def test_roi_align_nhwc_config2_full_shape(oracle_mod, tuning_env):
     """BASELINE configs[1] with the features stored channels-last: forward through roi_align_fwd_nhwc (both tap
     batch sizes), backward through the NCHW tile kernel + layout change."""
     feat = syn.feature_map(1, 256, 200, 336, seed=0)
@@ -157,7 +173,7 @@ def test_roi_align_nhwc_config2_full_shape(oracle_mod, monkeypatch):
     assert_fwd(out, ref_out, "config-2 nhwc fwd", exact=False)
     assert grad.is_contiguous(memory_format=torch.channels_last)
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, 0.25, 2, threads=threads), "nhwc bwd")
-    monkeypatch.setenv("MI_ROI_ALIGN_NHWC_PB", "7")
+    tuning_env(MI_ROI_ALIGN_NHWC_PB=7)
     out7, _ = _roi_align_gpu(feat, rois, 7, 0.25, 2, channels_last=True)
     assert torch.equal(out7, out.detach())  # same arithmetic, different load batching
     nchw, _ = _roi_align_gpu(feat, rois, 7, 0.25, 2)
