@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- the measurement contract of this repository (see DESIGN.md section "Measurement").
+"""bench.py -- the measurement contract of this repository (DESIGN.md section "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W          (N=1 default)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N=1 default; for N>1 this file starts the N ranks itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
-One JSON line on rank 0.  A *step* is one pass of the hot path over one rank's batch of synthetic
-input, inputs resident in HBM before the timed region.  `roofline` is measured live with HIP events
-on the launch stream for the dominant kernel (RoIAlign forward, BASELINE configs[1] shape; one call of
-the C-ABI = the record launch + the gather launch); its `traffic` is the HBM byte count of the same call
-from the committed rocprofv3 PMC summary (profiles/*_pmc_roi_align.json: FETCH_SIZE doubled as the gfx950
-correction prescribes, + WRITE_SIZE), null when no summary is in the tree.  `cpu_baseline` times the CPU
-oracle (oracle/, test infrastructure) on the host cores of the same box on a bounded sample.  The oracle is
-never on the measured GPU path.
+One JSON line on rank 0.
+
+A *step* is one training iteration of e2e_mask_rcnn_R-50-FPN_1x (BASELINE.json config 4, the model `metric` is quoted
+on) on one rank's minibatch: 2 synthetic images of 1333x800 padded to [2,3,800,1344] with 8 ground-truth boxes each, the
+RPN target blobs of the reference's data layer, reference initialisers under RNG_SEED 3; forward (ResNet-50-FPN, RPN,
+device-side proposal generation / NMS / labelling with 512 RoIs per image, RoIAlign, box and mask heads, all losses),
+backward, the averaged-gradient all-reduce over RCCL (N > 1), SGD step.  Inputs are resident in HBM before the timed
+region; nothing is skipped inside it.  `value` = images of all ranks / max-over-ranks time.
+
+Beside the headline (sub-objects, rank 0, N = 1 only; outside the timed region):
+  * `roofline`     the RoIAlign forward at BASELINE config 2, measured live with HIP events on the launch stream
+                   (algorithmic bytes / average call time), with the backward, the other shapes of the step and the
+                   channels-last variant; `traffic` from the committed rocprofv3 PMC summary;
+  * `breakdown`    one eager step cut at stage boundaries with HIP events (backbone / RPN convs / proposals+labelling /
+                   box head / mask head / backward / optimizer);
+  * `inference`    BASELINE config 3: e2e_faster_rcnn_R-50-FPN test-time detection of one image, images/s;
+  * `nms`, `inference_path`  the hot-path latencies of round 1 (BASELINE config 1 and the post-convolution glue);
+  * `bf16_autocast` the same step with the convolutions / GEMMs under bf16 autocast (RoI operators stay fp32);
+  * `cpu_baseline` the CPU oracle (test infrastructure) on the host cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,428 +40,303 @@ import torch  # noqa: E402
 
 from detectron_pytorch_amd import synthetic as syn  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+IMAGES_PER_RANK = 2          # TRAIN.IMS_PER_BATCH (core/config.py:52): bs 16 on 8 GPUs
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 (default): the reference's arithmetic; bf16: convolutions / GEMMs under autocast")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
-                    help="graph (default): the step is captured once in a hipGraph and replayed, which keeps the "
-                         "measurement independent of the host's Python speed (falls back to eager if capture fails); "
-                         "eager: relaunched from Python every step -- measured equal on a fast host (0.526 vs 0.533 ms)")
+                    help="graph (default): forward+backward (and, on one rank, the optimizer) are captured once in a "
+                         "hipGraph and replayed -- the training step is static-shaped and sync-free by construction; with "
+                         "N > 1 the bucket all-reduces run between the backward graph and the optimizer graph.  eager: "
+                         "launched from Python every step, all-reduce issued from autograd hooks during the backward")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (no roofline / breakdown / inference objects)")
     ap.add_argument("--kernel-iters", type=int, default=200, help="back-to-back launches per roofline timing")
     ap.add_argument("--only-roofline", action="store_true", help="tuning aid: print only the roofline object")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="harness self-test without a GPU (tests/): a toy model through the same rank / reducer / timing "
+                         "/ JSON code on the gloo backend")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks (one process per GPU) and pass
+    their exit code on.  The harness cannot silently run one rank and print n_gpus: 1."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    backend = "gloo" if args.selftest_cpu else "nccl"
+    if not args.selftest_cpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        kw = {} if args.selftest_cpu else {"device_id": torch.device("cuda", local_rank)}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        world = dist.get_world_size()          # what RCCL sees, not what the flag says
     return rank, world, local_rank
 
 
-def barrier(world):
+def barrier(world, cpu=False):
     if world > 1:
         import torch.distributed as dist
 
         dist.barrier()
-    torch.cuda.synchronize()
+    if not cpu:
+        torch.cuda.synchronize()
 
 
-# ------------------------------------------------------------------------------------------------
-# Hot-path workload: what one image of e2e_mask_rcnn_R-50-FPN asks of the RoI/NMS operators
-# (SURVEY.md section 8a/8d): box-head RoIAlign 512 RoIs x 256 x 7x7 fwd+bwd on P2, mask-head RoIAlign
-# 128 RoIs x 256 x 14x14 fwd+bwd, and the 5 per-level RPN NMS calls (n = 2000 pre-NMS, thresh 0.7).
-# ------------------------------------------------------------------------------------------------
-class HotPath:
-    def __init__(self, device, images_per_rank=2, seed=0):
-        from detectron_pytorch_amd import nms as mi_nms
-        from detectron_pytorch_amd.roi_align import roi_align_backward, roi_align_forward
+# ----------------------------------------------------------------------------------------------------------------------
+# the end-to-end training step
+# ----------------------------------------------------------------------------------------------------------------------
+class TrainHarness:
+    """One rank of the data-parallel job: model, resident minibatch, optimizer, gradient reducer, and the step in its
+    two launch forms."""
 
-        self.device = device
-        self.images = images_per_rank
-        self.fwd, self.bwd, self.nms_many = roi_align_forward, roi_align_backward, mi_nms.nms_device_many
-        h, w, scale = syn.FPN_LEVELS[2]
-        self.scale = scale
-        n = images_per_rank
-        self.feat_np = syn.feature_map(n, syn.FPN_DIM, h, w, seed=seed)
-        self.feat = torch.from_numpy(self.feat_np).to(device)
-        self.box_rois_np = syn.rois_canonical(512 * n, n, seed=seed)
-        self.box_rois = torch.from_numpy(self.box_rois_np).to(device)
-        self.mask_rois_np = syn.rois_canonical(128 * n, n, seed=seed + 1)
-        self.mask_rois = torch.from_numpy(self.mask_rois_np).to(device)
-        g = torch.Generator(device="cpu").manual_seed(seed)
-        self.box_gtop = torch.randn(512 * n, syn.FPN_DIM, 7, 7, generator=g).to(device)
-        self.mask_gtop = torch.randn(128 * n, syn.FPN_DIM, 14, 14, generator=g).to(device)
-        self.dets = [torch.from_numpy(syn.sort_by_score(syn.boxes_clustered(2000, seed=seed + 10 + i))[0]).to(device)
-                     for i in range(5 * n)]
+    def __init__(self, device, rank, world, dtype, launch):
+        from detectron_pytorch_amd import parallel
+        from detectron_pytorch_amd.rcnn import config, data as rdata, model as rmodel, train as rtrain
+
+        self.device, self.world, self.launch = device, world, launch
+        self.rtrain = rtrain
+        cfg = config.mask_rcnn_r50_fpn()
+        cfg.NUM_GPUS = world
+        self.cfg = cfg
+        torch.manual_seed(cfg.RNG_SEED)                   # every rank starts from the same weights (a replica)
+        self.net = rmodel.GeneralizedRCNN(cfg).to(device)
+        self.net.train()
+        self.autocast = torch.bfloat16 if dtype == "bf16" else None
+        batch = rdata.synthetic_minibatch(cfg, IMAGES_PER_RANK, seed=rank)      # per-rank images (weak scaling)
+        self.data, self.im_info, self.roidb, self.rpn_targets = rdata.to_device(batch, device)
+        # first-iteration learning rate of the reference's warm-up (SOLVER.WARM_UP_FACTOR = 1/3, config.py:560)
+        self.opt = rtrain.make_optimizer(self.net, cfg, lr=cfg.SOLVER.BASE_LR / 3.0)
+        self.reducer = parallel.GradientAllReducer(self.net.parameters(), overlap=(launch == "eager"))
+        self.params = sum(p.numel() for p in self.net.parameters() if p.requires_grad)
+        self.last = None
+        self.mode = "eager"
+        self._replay = None
+
+    def forward_backward(self):
+        if self.autocast is not None:
+            with torch.autocast("cuda", dtype=self.autocast):
+                ret = self.net(self.data, self.im_info, roidb=self.roidb, rpn_targets=self.rpn_targets)
+        else:
+            ret = self.net(self.data, self.im_info, roidb=self.roidb, rpn_targets=self.rpn_targets)
+        loss = sum(ret["losses"].values())
+        loss.backward()
+        return loss.detach(), ret
+
+    def eager_step(self):
+        self.opt.zero_grad(set_to_none=True)
+        self.reducer.begin_step()
+        loss, ret = self.forward_backward()
+        self.reducer.finish_step()
+        self.opt.step()
+        self.last = loss
+        return loss
+
+    def capture(self):
+        """hipGraph form of the step.  One rank: a single graph (forward, backward, SGD).  Several ranks: graph A =
+        zero-fill of the gradient buckets + forward + backward (autograd accumulates straight into the bucket views),
+        then the bucket all-reduces on the stream, then graph B = averaging + SGD.  Falls back to eager launching if
+        capture fails (capture is a property of the harness, not of the kernels)."""
+        dev = self.device
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):                       # MIOpen solver selection, momentum buffers, allocator warm-up
+                    eager_loss = self.eager_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            self.opt.zero_grad(set_to_none=True)
+            if self.reducer.active:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, capture_error_mode="relaxed"):
+                    self.reducer.begin_step()
+                    loss, _ = self.forward_backward()
+                self.reducer.reduce_now()
+                with torch.cuda.graph(gb, capture_error_mode="relaxed"):
+                    self.reducer.average_()
+                    self.opt.step()
+
+                def replay():
+                    ga.replay()
+                    self.reducer.reduce_now()
+                    gb.replay()
+                    self.last = loss
+                    return loss
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="relaxed"):
+                    loss, _ = self.forward_backward()
+                    self.opt.step()
+
+                def replay():
+                    g.replay()
+                    self.last = loss
+                    return loss
+            replay()
+            torch.cuda.synchronize()
+            got, want = float(loss), float(eager_loss)
+            if not (np.isfinite(got) and abs(got - want) <= 0.5 * abs(want) + 0.5):
+                raise RuntimeError("replayed loss %.4f vs eager %.4f" % (got, want))
+            self._replay, self.mode = replay, "hipGraph"
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("bench: hipGraph capture failed (%s: %s); launching eagerly\n" % (type(exc).__name__, exc))
+            torch.cuda.synchronize()
+            self.reducer.overlap = True
+            self._replay, self.mode = None, "eager"
 
     def step(self):
-        fs = tuple(self.feat.shape)
-        # forward returns its per-RoI records; the backward over the same RoIs reuses them (as the autograd
-        # Function does through ctx)
-        out, ws = self.fwd(self.feat, self.box_rois, 7, 7, self.scale, 2, return_workspace=True)
-        gin = self.bwd(self.box_gtop, self.box_rois, fs, 7, 7, self.scale, 2, workspace=ws)
-        out2, ws2 = self.fwd(self.feat, self.mask_rois, 14, 14, self.scale, 2, return_workspace=True)
-        gin2 = self.bwd(self.mask_gtop, self.mask_rois, fs, 14, 14, self.scale, 2, workspace=ws2)
-        # the per-level, per-image RPN NMS problems are independent: fanned out over side streams
-        keeps = self.nms_many(self.dets, 0.7)
-        return out, gin, out2, gin2, keeps
+        return self._replay() if self._replay is not None else self.eager_step()
+
+    def breakdown(self, reps=5):
+        """One eager step cut at the model's stage marks with HIP events (average of `reps`), milliseconds."""
+        names, events = [], []
+
+        def mark(label):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            names.append(label)
+            events.append(e)
+
+        acc = {}
+        self.net.mark = mark
+        try:
+            for _ in range(reps):
+                names.clear()
+                events.clear()
+                self.opt.zero_grad(set_to_none=True)
+                self.reducer.begin_step()
+                if self.autocast is not None:
+                    with torch.autocast("cuda", dtype=self.autocast):
+                        ret = self.net(self.data, self.im_info, roidb=self.roidb, rpn_targets=self.rpn_targets)
+                else:
+                    ret = self.net(self.data, self.im_info, roidb=self.roidb, rpn_targets=self.rpn_targets)
+                loss = sum(ret["losses"].values())
+                mark("loss_sum")
+                loss.backward()
+                self.reducer.finish_step()
+                mark("backward")
+                self.opt.step()
+                mark("optimizer")
+                torch.cuda.synchronize()
+                for i in range(1, len(events)):
+                    acc[names[i]] = acc.get(names[i], 0.0) + events[i - 1].elapsed_time(events[i])
+        finally:
+            self.net.mark = None
+        out = {k + "_ms": round(v / reps, 3) for k, v in acc.items()}
+        out["sum_ms"] = round(sum(acc.values()) / reps, 3)
+        out["what"] = ("GPU-timeline intervals between stage marks of an eagerly launched step (the host may run ahead: "
+                       "intervals are GPU-side, the sum is the GPU time of the step)")
+        return out
 
 
-def make_stepper(work, mode, device):
-    """The step of the timed loop.  graph: the ~20 launches of one step (two RoIAlign shapes fwd+bwd, batched NMS, their
-    allocations) are captured once in a hipGraph on a side stream and replayed -- the step is launch-bound from Python
-    otherwise.  Every replay executes all kernels on the same static inputs; the captured outputs are checked against an
-    eager step before the graph is trusted.  Falls back to eager launching if capture is not possible."""
-    if mode == "eager":
-        return work.step, "eager"
-    try:
-        side = torch.cuda.Stream(device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                work.step()
-        torch.cuda.current_stream(device).wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="relaxed"):
-            captured = work.step()
-        eager = work.step()
-        for t in captured[:4]:
-            t.fill_(float("nan"))
-        graph.replay()
-        torch.cuda.synchronize()
-        for got, want in zip(captured[:4], eager[:4]):
-            assert torch.equal(got, want), "hipGraph replay does not reproduce the eager step"
-        for (keep_g, num_g), (keep_e, num_e) in zip(captured[4], eager[4]):
-            k = int(num_e.item())
-            assert int(num_g.item()) == k and torch.equal(keep_g[:k], keep_e[:k]), "hipGraph replay: NMS differs"
-        work.captured = captured  # keep the static outputs alive
-        return graph.replay, "hipGraph"
-    except Exception as exc:  # capture is an optimisation of the harness, not of the measured kernels
-        sys.stderr.write("bench: hipGraph capture failed (%s: %s); launching eagerly\n" % (type(exc).__name__, exc))
-        torch.cuda.synchronize()
-        return work.step, "eager"
-
-
-def time_kernel(fn, iters, warmup=10):
-    """Average duration (s) of one call of `fn` over `iters` back-to-back launches, HIP events recorded
-    on the stream the kernels are launched on (torch's current stream)."""
+def timed_loop(step, steps, warmup, world, device, cpu=False):
     for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
+        step()
+    barrier(world, cpu)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier(world, cpu)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def allreduce_bandwidth(reducer, world, device, iters=10):
+    """The gradient exchange alone: all buckets back to back, algbw = payload / time, busbw = algbw * 2 (W-1) / W."""
+    if not reducer.active:
+        return None
+    for _ in range(3):
+        reducer.reduce_now()
+    barrier(world)
+    t0 = time.perf_counter()
     for _ in range(iters):
-        fn()
-    stop.record()
-    stop.synchronize()
-    return start.elapsed_time(stop) * 1e-3 / iters
+        reducer.reduce_now()
+    barrier(world)
+    sec = (time.perf_counter() - t0) / iters
+    algbw = reducer.payload_bytes / sec / 1e9
+    return {"payload_bytes": reducer.payload_bytes, "buckets": len(reducer.buckets), "ms": round(sec * 1e3, 3),
+            "algbw_GBs": round(algbw, 1), "busbw_GBs": round(algbw * 2 * (world - 1) / max(world, 1), 1)}
 
 
-def roofline_roi_align_forward(device, iters):
-    """BASELINE configs[1]: RoIAlign forward, 512 RoIs x 256 ch x 7x7, sampling_ratio 2, P2 map of one image.
-    Algorithmic bytes: 4*R*C*PH*PW (write) + 4*C*U (read, U distinct pixels) + 20*R."""
-    from detectron_pytorch_amd import _lib
+def inference_e2e(device, dtype, iters=10, warmup=3):
+    """BASELINE config 3: e2e_faster_rcnn_R-50-FPN_1x test-time detection of one 1333x800 image ([1,3,800,1344] blob,
+    TEST cfg of the yaml: 1000 pre-NMS / level, 1000 post-NMS, NMS 0.5, score 0.05, 100 detections), reference
+    initialisers, seed 3; from the resident image blob to the final per-class detections."""
+    from detectron_pytorch_amd.rcnn import config, inference, model as rmodel
 
-    h, w, scale = syn.FPN_LEVELS[2]
-    c, r, res, sr = syn.FPN_DIM, 512, 7, 2
-    feat = torch.from_numpy(syn.feature_map(1, c, h, w, seed=0)).to(device)
-    rois_np = syn.rois_canonical(r, 1, seed=0)
-    if os.environ.get("MI_BENCH_SORT_ROIS"):  # tuning experiment only: spatially sorted RoI order
-        key = (rois_np[:, 2] + rois_np[:, 4]) // (2 * 64) * 4096 + (rois_np[:, 1] + rois_np[:, 3]) / 2
-        rois_np = np.ascontiguousarray(rois_np[np.argsort(key, kind="stable")])
-    rois = torch.from_numpy(rois_np).to(device)
-    out = torch.empty((r, c, res, res), device=device)
-    lib = _lib.lib()
-    stream = _lib.current_stream_handle(device)
+    cfg = config.faster_rcnn_r50_fpn()
+    torch.manual_seed(cfg.RNG_SEED)
+    net = rmodel.GeneralizedRCNN(cfg).to(device).eval()
+    rng = np.random.RandomState(0)
+    data = torch.from_numpy((rng.randn(1, 3, 800, 1344) * 50).astype(np.float32)).to(device)
+    im_info = torch.tensor([[800.0, 1344.0, 1.0]])
+    autocast = torch.bfloat16 if dtype == "bf16" else None
+    names, events = [], []
 
-    layout = _lib.LAYOUT_NCHW
-    if os.environ.get("MI_BENCH_NHWC"):  # tuning experiment only: channels_last storage of the same logical tensor
-        feat = feat.permute(0, 2, 3, 1).contiguous()
-        layout = _lib.LAYOUT_NHWC
-
-    ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-
-    def launch():  # one call of the C-ABI = both launches of the fast path (RoI records, then the gather)
-        rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res,
-                                         scale, sr, _lib.ROI_ALIGN_CAFFE2, layout, ws.data_ptr(), ws_bytes, stream)
-        assert rc == 0
-
-    seconds = time_kernel(launch, iters)
-    touched = touched_pixels(rois_np, 1, h, w, res, res, scale, sr)
-    alg_bytes = 4 * r * c * res * res + 4 * c * touched + 20 * r
-    achieved = alg_bytes / seconds / 1e9
-    traffic, traffic_src = pmc_traffic("forward")
-    info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
-            "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
-            "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
-    # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
-    gtop = torch.randn(r, c, res, res, device=device)
-    gin = torch.zeros(1, c, h, w, device=device)
-
-    overwrite = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
-    bwd_flags = _lib.ROI_ALIGN_RECORDS_READY | (_lib.ROI_ALIGN_OVERWRITE if overwrite else 0)
-
-    def launch_bwd():  # records of the forward above are still in `ws`; zero fill only where the path accumulates
-        if not overwrite:
-            gin.zero_()
-        rc = lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
-                                          scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, ws.data_ptr(), ws_bytes,
-                                          bwd_flags, stream)
-        assert rc == 0
-
-    sec_bwd = time_kernel(launch_bwd, max(iters // 4, 10))
-    bwd_bytes = 4 * r * c * res * res + 4 * c * h * w + 20 * r
-    info["backward"] = {"zero_fill_needed": not overwrite, "avg_us_incl_zero_fill": round(sec_bwd * 1e6, 2),
-                        "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
-                        "algorithmic_bytes": int(bwd_bytes)}
-    info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
-    if layout == _lib.LAYOUT_NCHW:
-        info["channels_last"] = channels_last_variant(device, lib, stream, feat, rois, out, ws, alg_bytes, gtop, iters)
-    copy_gbs = copy_ceiling(device)
-    info["copy_ceiling"] = {"measured": round(copy_gbs, 1), "unit": "GB/s", "frac_of_copy": round(achieved / copy_gbs, 4),
-                            "what": "torch device-to-device copy of 256 MiB, read + write bytes / time"}
-    return info
-
-
-def channels_last_variant(device, lib, stream, feat_nchw, rois, out, ws, alg_bytes, gtop, iters):
-    """Same logical input with the features stored channels-last (what MIOpen's NHWC convolutions hand over on gfx950):
-    forward = roi_align_prepare + roi_align_fwd_nhwc, output still dense [R,C,PH,PW]; backward = the tile kernel writing
-    the gradient channels-last (through roi_align.roi_align_backward, allocation included).  Reported beside the NCHW
-    headline, not as it."""
-    from detectron_pytorch_amd import _lib, roi_align as ra
-
-    n, c, h, w = feat_nchw.shape
-    r, _, res, _ = out.shape
-    feat = feat_nchw.permute(0, 2, 3, 1).contiguous()
-    scale, sr = syn.FPN_LEVELS[2][2], 2
-
-    def launch():
-        rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), n, c, h, w, r, res, res,
-                                         scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NHWC, ws.data_ptr(), ws.numel(),
-                                         stream)
-        assert rc == 0
-
-    sec = time_kernel(launch, iters)
-
-    def bwd():  # records of the forward above are reused; the tile kernel writes the channels-last gradient itself
-        ra.roi_align_backward(gtop, rois, (n, c, h, w), res, res, scale, sr, channels_last=True, workspace=ws)
-
-    sec_bwd = time_kernel(bwd, max(iters // 8, 5))
-    gbs = alg_bytes / sec / 1e9
-    return {"kernel": "roi_align_prepare + roi_align_fwd_nhwc", "avg_launch_us": round(sec * 1e6, 2),
-            "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "bwd_us": round(sec_bwd * 1e6, 2)}
-
-
-def copy_ceiling(device):
-    """The box's own streaming ceiling (SURVEY.md section 8d asks for both denominators): a plain device copy."""
-    a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=device)
-    b = torch.empty_like(a)
-    sec = time_kernel(lambda: b.copy_(a), 20)
-    return 2 * a.numel() * 4 / sec / 1e9
-
-
-def other_shapes(device, lib, stream, iters):
-    """Per-call times of the other RoIAlign shapes of the step (not roofline-gated): the mask head (128 x 256 x 14x14) and
-    the two-image box head (1024 RoIs, N = 2), forward and backward through the workspace entry points."""
-    from detectron_pytorch_amd import _lib
-
-    out = {}
-    h, w, scale = syn.FPN_LEVELS[2]
-    c, sr = syn.FPN_DIM, 2
-    for name, n, r, res in [("mask_128x256x14x14", 1, 128, 14), ("box_1024x256x7x7_2img", 2, 1024, 7)]:
-        feat = torch.from_numpy(syn.feature_map(n, c, h, w, seed=0)).to(device)
-        rois = torch.from_numpy(syn.rois_canonical(r, n, seed=1)).to(device)
-        o = torch.empty((r, c, res, res), device=device)
-        gtop = torch.randn(r, c, res, res, device=device)
-        gin = torch.empty(n, c, h, w, device=device)
-        ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        over = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
-        flags = _lib.ROI_ALIGN_RECORDS_READY | (_lib.ROI_ALIGN_OVERWRITE if over else 0)
-
-        def fwd():
-            assert lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), o.data_ptr(), n, c, h, w, r, res, res, scale,
-                                               sr, 0, 0, ws.data_ptr(), ws_bytes, stream) == 0
-
-        def bwd():
-            if not over:
-                gin.zero_()
-            assert lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), n, c, h, w, r, res, res,
-                                                scale, sr, 0, 0, ws.data_ptr(), ws_bytes, flags, stream) == 0
-
-        out[name] = {"fwd_us": round(time_kernel(fwd, iters) * 1e6, 1), "bwd_us": round(time_kernel(bwd, iters) * 1e6, 1)}
-    out["fpn_1000rois_P2-P5_7x7"] = fpn_variant(device, iters)
-    return out
-
-
-def fpn_variant(device, iters):
-    """Config-2 variant (ii): 1000 RoIs distributed over P2..P5 by the FPN heuristic, pooled by
-    roi_xform.roi_feature_transform (one RoIAlign call per level + concat + restore permutation), RoIs on the device."""
-    from detectron_pytorch_amd import roi_xform
-
-    rois, lvls = syn.rois_fpn_distributed(1000, batch=1, seed=2)
-    blobs = roi_xform.add_multilevel_roi_blobs({"rois": rois}, "rois", rois, lvls, 2, 5)
-    blobs = {k: torch.from_numpy(v).to(device) for k, v in blobs.items()}
-    feats, scales = [], []
-    for lvl in (5, 4, 3, 2):  # coarsest first, as the reference orders blobs_in
-        h, w, scale = syn.FPN_LEVELS[lvl]
-        feats.append(torch.from_numpy(syn.feature_map(1, syn.FPN_DIM, h, w, seed=lvl)).to(device))
-        scales.append(scale)
-
-    def fwd(fused):
-        with torch.no_grad():
-            return roi_xform.roi_feature_transform(feats, blobs, "rois", "RoIAlign", 7, scales, 2, fused=fused)
-
-    # fused call with the RoIs already in dataloader order (what a caller that keeps them on the device passes)
-    from detectron_pytorch_amd.roi_align import roi_align_fpn
-
-    rois_d = torch.from_numpy(rois).to(device)
-    lvl_d = torch.from_numpy((5 - lvls).astype(np.int32)).to(device)
-
-    def fused_direct():
-        with torch.no_grad():
-            roi_align_fpn(feats, scales, rois_d, lvl_d, 7, 7, 2)
-
-    return {"fwd_us": round(time_kernel(lambda: fwd(True), iters) * 1e6, 1),
-            "fwd_us_per_level_loop": round(time_kernel(lambda: fwd(False), iters) * 1e6, 1),
-            "fwd_us_fused_call_only": round(time_kernel(fused_direct, iters) * 1e6, 1),
-            "rois_per_level": {int(l): int((lvls == l).sum()) for l in (2, 3, 4, 5)}}
-
-
-def pmc_traffic(direction):
-    """HBM bytes per call from the newest committed PMC summary (profiles/rNN_pmc_roi_align.json), or None."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_roi_align.json")))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        return int(d[direction]["hbm_bytes_per_call"]), os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
-
-
-def touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr):
-    """U of the algorithmic-bytes formula (a workload descriptor computed on the host, not timed)."""
-    return syn.roi_align_touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr)
-
-
-def nms_latency(device, iters):
-    from detectron_pytorch_amd import _lib
-
-    out = {}
-    lib = _lib.lib()
-    stream = _lib.current_stream_handle(device)
-    for name, dets_np, thresh in [("cfg1_uniform_n1000_t0.5", syn.boxes_uniform(1000, seed=0), 0.5),
-                                  ("rpn_clustered_n2000_t0.7", syn.boxes_clustered(2000, seed=0), 0.7)]:
-        dets = torch.from_numpy(dets_np).to(device)
-        n = dets.shape[0]
-        keep = torch.empty(n, dtype=torch.int64, device=device)
-        num = torch.empty(1, dtype=torch.int32, device=device)
-        ws_bytes = lib.mi_nms_workspace_bytes(n)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-
-        def launch():
-            rc = lib.mi_nms(dets.data_ptr(), n, thresh, _lib.NMS_GE_ORIG_ASC, keep.data_ptr(), num.data_ptr(),
-                            ws.data_ptr(), ws_bytes, stream)
-            assert rc == 0
-
-        sec = time_kernel(launch, max(iters // 4, 10))
-        out[name] = {"us_per_call": round(sec * 1e6, 1), "kept": int(num.item()),
-                     "pair_tests_per_s": round(n * (n - 1) / 2 / sec, 0)}
-    # Soft-NMS (off by default in the reference, core/config.py:362): one sequential pick per kept box, all in LDS
-    dets = torch.from_numpy(syn.boxes_uniform(1000, seed=0)).to(device)
-    od, oi = torch.empty((1000, 5), device=device), torch.empty(1000, dtype=torch.int64, device=device)
-    num = torch.empty(1, dtype=torch.int32, device=device)
-
-    def launch_soft():
-        assert lib.mi_soft_nms(dets.data_ptr(), 1000, 0.5, 0.3, 0.001, 1, od.data_ptr(), oi.data_ptr(), num.data_ptr(),
-                               stream) == 0
-
-    sec = time_kernel(launch_soft, 5, warmup=2)
-    out["soft_nms_linear_uniform_n1000"] = {"us_per_call": round(sec * 1e6, 1), "kept": int(num.item())}
-    # the test-time caller of NMS (core/test.py:732-790): 1000 RoIs x 81 classes, classes batched, two host syncs
-    from detectron_pytorch_amd import detection
-
-    sc_np, bx_np = syn.detection_head_outputs(1000, 81, seed=7)
-    sc, bx = torch.from_numpy(sc_np).to(device), torch.from_numpy(bx_np).to(device)
-    post = {}
-    for name, soft in (("hard", False), ("soft_linear", True)):
-        sec = time_kernel(lambda: detection.box_results_with_nms_and_limit(sc, bx, soft_nms=soft), 10, warmup=3)
-        post[name + "_ms"] = round(sec * 1e3, 3)
-    out["detection_postprocess_R1000_C81"] = post
-    # the RPN-side caller of NMS (generate_proposals.py:12-182) for one P2-sized level, 2 images, train-time top-k
-    from detectron_pytorch_amd import generate_proposals as gp
-
-    anchors = gp.generate_anchors(4, (32,), (0.5, 1, 2))
-    sc_np, dl_np = syn.rpn_head_outputs(2, 3, 200, 336, seed=4)
-    sc, dl = torch.from_numpy(sc_np).to(device), torch.from_numpy(dl_np).to(device)
-    info = torch.tensor([[800, 1344, 1.0], [800, 1344, 1.0]], dtype=torch.float32, device=device)
-    op = gp.GenerateProposalsOp(anchors, 0.25, 2000, 2000, 0.7, 0, as_numpy=False)
-    sec = time_kernel(lambda: op(sc, dl, info), 10, warmup=3)
-    out["generate_proposals_P2_2img_top2000"] = {"ms": round(sec * 1e3, 3)}
-    return out
-
-
-def inference_path(device, iters=10):
-    """One test-time image through everything between the RPN / box-head convolutions that this repository provides,
-    without a host round trip in between: GenerateProposals on P2..P6 (TEST: 1000 pre-NMS / 1000 post-NMS per level,
-    configs/baselines/e2e_mask_rcnn_R-50-FPN_1x.yaml:41-43) -> collect the 1000 best -> RoIAlign 7x7 over P2..P5 in one
-    fused call -> per-class NMS + top-100 on (synthetic) box-head outputs for those RoIs."""
-    from detectron_pytorch_amd import detection, fpn_proposals, generate_proposals as gp
-    from detectron_pytorch_amd.roi_align import roi_align_fpn
-
-    levels = [(2, 200, 336, 4, 32), (3, 100, 168, 8, 64), (4, 50, 84, 16, 128), (5, 25, 42, 32, 256), (6, 13, 21, 64, 512)]
-    ops, heads = [], []
-    for lvl, h, w, stride, size in levels:
-        anchors = gp.generate_anchors(stride, (size,), (0.5, 1, 2))
-        sc, dl = syn.rpn_head_outputs(1, 3, h, w, seed=lvl)
-        ops.append(gp.GenerateProposalsOp(anchors, 1.0 / stride, 1000, 1000, 0.7, 0, as_numpy=False))
-        heads.append((torch.from_numpy(sc).to(device), torch.from_numpy(dl).to(device)))
-    info = torch.tensor([[800, 1344, 1.0]], dtype=torch.float32, device=device)
-    feats = [torch.from_numpy(syn.feature_map(1, syn.FPN_DIM, h, w, seed=l)).to(device) for l, h, w, _, _ in levels[3::-1]]
-    scales = [1.0 / s for _, _, _, s, _ in levels[3::-1]]
-    cls_np, box_np = syn.detection_head_outputs(1000, 81, seed=7)
-    cls, box = torch.from_numpy(cls_np).to(device), torch.from_numpy(box_np).to(device)
-    stats = {}
+    def mark(label):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        names.append(label)
+        events.append(e)
 
     def run():
-        rois = fpn_proposals.generate_and_collect(ops, heads, info, 1000)
-        lv = fpn_proposals.map_rois_to_fpn_levels(rois[:, 1:5])
-        with torch.no_grad():
-            pooled = roi_align_fpn(feats, scales, rois, 5 - lv, 7, 7, 2)
-        dets = detection.box_results_with_nms_and_limit(cls[:rois.size(0)], box[:rois.size(0)])
-        stats["rois"], stats["detections"] = int(rois.size(0)), int(dets[0].numel())
-        return pooled
+        return inference.im_detect_all(net, data, im_info, autocast_dtype=autocast)
 
-    sec = time_kernel(run, iters, warmup=3)
-    return {"ms_per_image": round(sec * 1e3, 3), **stats,
-            "what": "GenerateProposals P2-P6 + collect + fused RoIAlign P2-P5 + class-batched NMS/top-100, one image; "
-                    "~150 small launches from Python: bound by the host CPU of the box, not by the GPU"}
+    for _ in range(warmup):
+        dets = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dets = run()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / iters
+    acc = {}
+    net.mark = mark
+    for _ in range(3):
+        names.clear()
+        events.clear()
+        run()
+        mark("postproc")
+        torch.cuda.synchronize()
+        for i in range(1, len(events)):
+            acc[names[i]] = acc.get(names[i], 0.0) + events[i - 1].elapsed_time(events[i]) / 3
+    net.mark = None
+    return {"workload": "e2e_faster_rcnn_R-50-FPN_1x inference, 1 image 1333x800 (blob 1x3x800x1344), synthetic, "
+                        "random-init weights (seed 3)", "images_per_s": round(1.0 / sec, 2),
+            "ms_per_image": round(sec * 1e3, 3), "detections": int(dets[0].numel()), "launch": "eager",
+            "breakdown_ms": {"backbone": round(acc.get("backbone", 0), 3), "rpn_convs": round(acc.get("rpn_convs", 0), 3),
+                             "proposals_nms_collect": round(acc.get("proposals", 0), 3),
+                             "roialign_box_head": round(acc.get("box_head", 0), 3),
+                             "bbox_decode_class_nms_top100": round(acc.get("postproc", 0), 3)}}
 
 
 def cpu_baseline(images_per_rank):
@@ -531,53 +418,106 @@ def cpu_baseline(images_per_rank):
             **extra}
 
 
-def main():
-    args = parse_args()
-    rank, world, local_rank = init_dist(args)
-    device = torch.device("cuda", local_rank)
-    if args.only_roofline:
-        print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("MI_")},
-                          "roofline": roofline_roi_align_forward(device, args.kernel_iters)}), flush=True)
-        return
-    images_per_rank = 2
-    work = HotPath(device, images_per_rank=images_per_rank, seed=rank)
-    step, launch_mode = make_stepper(work, args.launch, device)
-    for _ in range(args.warmup):
-        step()
-    barrier(world)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier(world)
-    elapsed = time.perf_counter() - t0
+def selftest_cpu(args, rank, world):
+    """The rank / reducer / timing / JSON plumbing on the gloo backend with a toy model (no GPU, no HIP operator)."""
+    from detectron_pytorch_amd import parallel
+
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 8))
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+    reducer = parallel.GradientAllReducer(net.parameters(), bucket_bytes=32 << 10)
+    x = torch.randn(16, 64, generator=torch.Generator().manual_seed(rank))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        reducer.begin_step()
+        net(x).square().mean().backward()
+        reducer.finish_step()
+        opt.step()
+
+    elapsed = timed_loop(step, args.steps, args.warmup, world, torch.device("cpu"), cpu=True)
+    checksum = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).double().sum().reshape(1)
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = images_per_rank * world * args.steps / elapsed
-
-    line = None
+        both = [torch.zeros_like(checksum) for _ in range(world)]
+        dist.all_gather(both, checksum)
+        assert all(torch.equal(b, both[0]) for b in both), "replicas diverged: gradients were not averaged identically"
     if rank == 0:
-        roof = roofline_roi_align_forward(device, args.kernel_iters)
-        nms_info = nms_latency(device, args.kernel_iters)
+        print(json.dumps({"metric": "selftest", "value": round(16 * world * args.steps / elapsed, 2), "unit": "samples/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "collectives_per_step": len(reducer.buckets) if reducer.active else 0}), flush=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
+    rank, world, local_rank = init_dist(args)
+    if args.selftest_cpu:
+        selftest_cpu(args, rank, world)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    device = torch.device("cuda", local_rank)
+    from tools import hot_path_bench as hp
+
+    if args.only_roofline:
+        print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("MI_")},
+                          "roofline": hp.roofline_roi_align_forward(device, args.kernel_iters)}), flush=True)
+        return
+    work = TrainHarness(device, rank, world, args.dtype, args.launch)
+    if args.launch == "graph":
+        work.capture()
+    else:
+        work.eager_step()
+    first_loss = float(work.step())
+    elapsed = timed_loop(work.step, args.steps, args.warmup, world, device)
+    last_loss = float(work.last)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = IMAGES_PER_RANK * world * args.steps / elapsed
+    comm = allreduce_bandwidth(work.reducer, world, device)
+
+    if rank == 0:
         line = {
-            "metric": "images/sec, RoIAlign+NMS hot path of e2e_mask_rcnn_R-50-FPN (1333x800, 512 RoIs/image)",
-            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "hot_path: per image RoIAlign fwd+bwd 512x256x7x7 + 128x256x14x14 on P2 200x336, "
-                                   "5 RPN NMS n=2000 thr=0.7; %d images/rank" % images_per_rank,
-                       "images_per_rank": images_per_rank, "parallelism": "dp%d (independent shards)" % world,
-                       "launch": launch_mode},
-            "roofline": roof,
-            "nms": nms_info,
-            "inference_path": inference_path(device),
+            "metric": "images/sec e2e_mask_rcnn_R-50-FPN 1333x800", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "e2e_mask_rcnn_R-50-FPN_1x training step (BASELINE config 4): forward + losses + "
+                                   "backward + gradient all-reduce + SGD; %d images/rank of 1333x800 (blob 800x1344), "
+                                   "512 RoIs/image, <=128 mask RoIs/image, 8 gt boxes/image, random-init weights (seed 3)"
+                                   % IMAGES_PER_RANK,
+                       "global_batch": IMAGES_PER_RANK * world, "images_per_rank": IMAGES_PER_RANK,
+                       "parallelism": "dp%d" % world, "launch": work.mode,
+                       "trainable_params": work.params, "gradient_payload_bytes": work.params * 4,
+                       "loss_first": round(first_loss, 4), "loss_last": round(last_loss, 4)},
         }
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(images_per_rank)
+        if comm is not None:
+            line["allreduce"] = comm
+        if not args.no_extras and world == 1:
+            line["roofline"] = hp.roofline_roi_align_forward(device, args.kernel_iters)
+            line["breakdown"] = work.breakdown()
+            del work
+            torch.cuda.empty_cache()
+            line["inference"] = inference_e2e(device, args.dtype)
+            if args.dtype == "f32":
+                try:
+                    alt = TrainHarness(device, rank, world, "bf16", args.launch)
+                    if args.launch == "graph":
+                        alt.capture()
+                    sec = timed_loop(alt.step, max(args.steps // 2, 5), 3, 1, device) / max(args.steps // 2, 5)
+                    line["bf16_autocast"] = {"images_per_s": round(IMAGES_PER_RANK / sec, 2),
+                                             "ms_per_step": round(sec * 1e3, 3), "launch": alt.mode,
+                                             "what": "same step, convolutions / GEMMs under torch.autocast(bfloat16), fp32 "
+                                                     "master weights, RoI operators and losses in fp32"}
+                    del alt
+                    torch.cuda.empty_cache()
+                except Exception as exc:  # noqa: BLE001
+                    line["bf16_autocast"] = {"error": repr(exc)}
+            line["nms"] = hp.nms_latency(device, args.kernel_iters)
+            line["inference_path"] = hp.inference_path(device)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(IMAGES_PER_RANK)
         print(json.dumps(line), flush=True)
     barrier(world)
     if world > 1:

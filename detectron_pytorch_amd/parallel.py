@@ -109,8 +109,11 @@ class GradientAllReducer(object):
     (use `optimizer.zero_grad(set_to_none=False)` or none at all: begin_step() zero-fills the buckets and re-attaches the
     views)."""
 
-    def __init__(self, params, bucket_bytes=BUCKET_BYTES, group=None, force=False):
+    def __init__(self, params, bucket_bytes=BUCKET_BYTES, group=None, force=False, overlap=True):
+        """`overlap=False`: the hooks only count; every bucket is reduced in finish_step() (the mode a hipGraph-captured
+        backward needs: collectives stay outside the captured region -- see reduce_now())."""
         self.group = group
+        self.overlap = overlap
         self.params = [p for p in params if p.requires_grad]
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
@@ -150,7 +153,7 @@ class GradientAllReducer(object):
     def _make_hook(self, b):
         def hook(_param):
             self._pending[b] -= 1
-            if self._pending[b] == 0:
+            if self._pending[b] == 0 and self.overlap:
                 self._launch(b)
         return hook
 
@@ -168,13 +171,30 @@ class GradientAllReducer(object):
             for p, off in slots:
                 p.grad = flat[off:off + p.numel()].view_as(p)
 
+    def reduce_now(self):
+        """All buckets, now, on the current stream (the graph-replay step: the backward that filled the buckets was a
+        hipGraph launch, no hook ran).  Returns the number of collectives."""
+        if not self.active:
+            return 0
+        handles = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                   for flat, _ in self.buckets]
+        for h in handles:
+            h.wait()
+        return len(handles)
+
+    def average_(self):
+        """Sums -> means, in place (captured into the optimizer graph in replay mode)."""
+        if self.active and self.world > 1:
+            for flat, _ in self.buckets:
+                flat.div_(self.world)
+
     def finish_step(self):
         """Wait for every bucket (a bucket whose hooks never all fired -- a parameter without gradient this step -- is
         reduced now, so that all ranks issue the same collectives) and average.  Returns the number of collectives."""
         if not self.active:
             return 0
         for b in range(len(self.buckets)):
-            if self._pending[b] > 0:
+            if self._pending[b] > 0 or not self.overlap:
                 self._pending[b] = 0
                 self._launch(b)
         for h in self._handles:

@@ -67,6 +67,11 @@ class GeneralizedRCNN(nn.Module):
             for p in self.Conv_Body.parameters():
                 p.requires_grad = False
         self.iou_fn = nms.bbox_overlaps                 # mi_bbox_overlaps; tests on CPU tensors inject the oracle's
+        self.mark = None                                # optional callable(label) invoked at stage boundaries (bench.py)
+
+    def _mark(self, label):
+        if self.mark is not None:
+            self.mark(label)
 
     # ---- the boundary the reference's heads call (model_builder.py:252-324) ------------------------------------------
     def roi_feature_transform(self, blobs_in, rpn_ret, blob_rois="rois", method="RoIPoolF", resolution=7,
@@ -97,8 +102,11 @@ class GeneralizedRCNN(nn.Module):
             return self._forward(data, im_info, roidb, rpn_targets, priority)
 
     def _forward(self, data, im_info, roidb, rpn_targets, priority):
+        self._mark("start")
         blob_conv = self.Conv_Body(data)
+        self._mark("backbone")
         rpn_ret = self.RPN(blob_conv)
+        self._mark("rpn_convs")
         return self.forward_from_features(blob_conv, rpn_ret, im_info, roidb, rpn_targets, priority)
 
     def forward_from_features(self, blob_conv, rpn_ret, im_info, roidb=None, rpn_targets=None, priority=None):
@@ -119,7 +127,9 @@ class GeneralizedRCNN(nn.Module):
                 rois = self.proposals(rpn_ret, im_info_d, static=False)
                 blobs = fpn_proposals.distribute(rois, cfg.FPN.ROI_MIN_LEVEL, cfg.FPN.ROI_MAX_LEVEL)
                 blobs["rois_levels"] = blobs["roi_levels"]
+            self._mark("proposals")
             cls_score, bbox_pred = self.Box_Outs(self.Box_Head(roi_blobs, blobs))
+            self._mark("box_head")
             ret.update(blob_conv=roi_blobs, rois=blobs["rois"], cls_score=cls_score, bbox_pred=bbox_pred)
             return ret
         with torch.no_grad():
@@ -129,6 +139,7 @@ class GeneralizedRCNN(nn.Module):
             blobs = targets.label_proposals(cfg, rois, roidb["gt_boxes"], roidb["gt_classes"], roidb["gt_image"],
                                             im_info_d[:, 2], priority, n_img, self.iou_fn, roi_valid=valid,
                                             gt_mask_boxes=roidb.get("gt_mask_boxes"))
+        self._mark("proposals_labelling")
         box_feat = self.Box_Head(roi_blobs, blobs)
         cls_score, bbox_pred = self.Box_Outs(box_feat)
         losses, metrics = {}, {}
@@ -141,12 +152,14 @@ class GeneralizedRCNN(nn.Module):
             blobs["bbox_inside_weights"], blobs["bbox_outside_weights"])
         losses["loss_cls"], losses["loss_bbox"] = loss_cls, loss_bbox
         metrics["accuracy_cls"] = accuracy
+        self._mark("box_head_losses")
         if cfg.MODEL.MASK_ON:
             mask_pred = self.Mask_Outs(self.Mask_Head(roi_blobs, blobs))
             losses["loss_mask"] = heads.mask_rcnn_losses_compact(mask_pred.float(), blobs["masks_int32"],
                                                                  blobs["mask_class"], cfg.MRCNN.WEIGHT_LOSS_MASK) \
                 if cfg.MRCNN.CLS_SPECIFIC_MASK else \
                 heads.mask_rcnn_losses(mask_pred.float(), blobs["masks_int32"], cfg.MRCNN.WEIGHT_LOSS_MASK)
+            self._mark("mask_head_loss")
         ret["losses"], ret["metrics"] = losses, metrics
         ret["blobs"], ret["collected_rois"], ret["collected_valid"] = blobs, rois, valid
         return ret

@@ -141,7 +141,8 @@ def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, im_scales, priori
     seg = cand_img * 3 + group
     by_prio = torch.argsort(priority, stable=True)
     order = by_prio[torch.argsort(seg[by_prio], stable=True)]                 # (image, group, priority)-sorted candidates
-    counts = torch.bincount(seg, minlength=3 * n_img).view(n_img, 3)
+    # (torch.bincount sizes its output on the host -- a synchronisation; a comparison against the 3N segment ids is not)
+    counts = (seg.view(-1, 1) == torch.arange(3 * n_img, device=dev).view(1, -1)).sum(dim=0).view(n_img, 3)
     starts = (torch.cumsum(counts.view(-1), 0) - counts.view(-1)).view(n_img, 3)
     n_fg = torch.clamp_max(counts[:, 0], fg_per_image)
     n_bg = torch.minimum(per_image - n_fg, counts[:, 1])
@@ -164,7 +165,9 @@ def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, im_scales, priori
                                                                       torch.zeros_like(targets)),
                                                2 if cfg.MODEL.CLS_AGNOSTIC_BBOX_REG else num_classes)
     outside = (inside > 0).to(f32)
-    img_col = torch.arange(n_img, device=dev, dtype=f32).view(-1, 1).expand(n_img, per_image).reshape(-1, 1)
+    # padding rows carry image index -1: the RoI operators pool zeros for a RoI outside the batch and send it no gradient
+    # (include/mi_detectron_ops.h) -- and, unlike a dummy box, they do not pile up on one tile of the backward
+    img_col = torch.where(real, torch.arange(n_img, device=dev).view(-1, 1), -1).to(f32).reshape(-1, 1)
     scale_col = im_scales.to(f32).view(-1, 1).expand(n_img, per_image).reshape(-1, 1)
     out = {
         "rois": torch.cat([img_col, boxes * scale_col], dim=1),              # fast_rcnn.py:183-185
@@ -190,7 +193,7 @@ def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, im_scales, priori
         else:
             masks = torch.zeros((n_img * fg_per_image, m * m), dtype=torch.int32, device=dev)
         masks = torch.where(has.view(-1, 1), masks, torch.full_like(masks, -1))
-        fimg_col = torch.arange(n_img, device=dev, dtype=f32).view(-1, 1).expand(n_img, fg_per_image).reshape(-1, 1)
+        fimg_col = torch.where(has, torch.arange(n_img, device=dev).view(-1, 1), -1).to(f32).reshape(-1, 1)
         fscale = im_scales.to(f32).view(-1, 1).expand(n_img, fg_per_image).reshape(-1, 1)
         out["mask_rois"] = torch.cat([fimg_col, fboxes * fscale], dim=1)     # mask_rcnn.py:99-101
         out["mask_class"] = fcls.to(torch.int32)

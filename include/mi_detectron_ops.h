@@ -19,6 +19,8 @@
  *     (roi_align_kernel.cu:135-139) and returned 0 for a malformed rois tensor
  *     (roi_align_cuda.c:19-22); here both become error codes and the Python shim raises.
  *   - rois are [R,5] float32 rows (batch_index, x1, y1, x2, y2) in input-image pixels.
+ *     A RoI whose batch_index lies outside [0, batch) pools zeros and receives no gradient (the reference would read
+ *     out of bounds there); callers that pad a RoI set to a static size mark the padding rows with batch_index -1.
  *   - `layout` selects the memory order of the 4-D feature / gradient tensor:
  *     MI_LAYOUT_NCHW (the reference's only layout) or MI_LAYOUT_NHWC (torch
  *     channels_last storage of the same logical [N,C,H,W] tensor).  Outputs of the

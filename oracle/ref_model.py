@@ -168,3 +168,95 @@ def bind_rect_rasterizer(fn):
     import utils.segms as segm_utils
 
     segm_utils.polys_to_mask_wrt_box = fn
+
+
+# ---- executing the reference's training forward on the CPU --------------------------------------------------------------
+def roidb_entry(height, width, boxes, classes, num_classes):
+    """A ground-truth-only roidb entry as datasets/json_dataset.py:178-262 builds it (rectangular polygon masks)."""
+    import numpy as np
+    import scipy.sparse
+
+    boxes = np.asarray(boxes, dtype=np.float32)
+    classes = np.asarray(classes, dtype=np.int32)
+    n = boxes.shape[0]
+    ov = np.zeros((n, num_classes), dtype=np.float32)
+    ov[np.arange(n), classes] = 1.0
+    segms = [[[float(b[0]), float(b[1]), float(b[2]), float(b[1]), float(b[2]), float(b[3]), float(b[0]), float(b[3])]]
+             for b in boxes]
+    return dict(height=height, width=width, flipped=False, boxes=boxes, segms=segms,
+                seg_areas=((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).astype(np.float32),
+                gt_classes=classes, gt_overlaps=scipy.sparse.csr_matrix(ov), is_crowd=np.zeros(n, dtype=bool),
+                box_to_gt_ind_map=np.arange(n, dtype=np.int32))
+
+
+def rpn_blobs(entries, im_scales, seed):
+    """roi_data/rpn.py:40-113 executed from source: (blobs dict incl. 'im_info' and the minimal 'roidb')."""
+    import numpy as np
+
+    load()
+    import roi_data.rpn as rpn
+
+    blobs = {k: [] for k in rpn.get_rpn_blob_names(is_training=True)}
+    np.random.seed(seed)
+    rpn.add_rpn_blobs(blobs, im_scales, entries)
+    return blobs
+
+
+def train_forward(model, data, blobs, priority, rasterizer):
+    """`Generalized_RCNN.forward` in training mode on CPU tensors, with the two things that cannot run here replaced:
+    `npr.choice(inds, size, replace=False)` in roi_data/fast_rcnn.py:146,160 draws "the first `size` of the permutation
+    given by `priority`" (global candidate numbering: all gt boxes, then the collected proposals in collect order), and
+    pycocotools' polygon rasteriser is `rasterizer(polygons, box, M)`.
+    Returns (return_dict, captured) with captured['rois'] = the collected proposals and captured['blobs'] = the
+    labelled RoI blobs (numpy)."""
+    import pickle
+
+    import numpy as np
+    import torch
+
+    load()
+    import datasets.json_dataset as json_dataset
+    import roi_data.fast_rcnn as frcn
+    import utils.segms as segm_utils
+
+    captured, state = {}, {}
+    minimal = blobs["roidb"]
+    n_gt = [int((e["gt_classes"] > 0).sum()) for e in minimal]
+    gt_off = np.concatenate([[0], np.cumsum(n_gt)])
+    orig_add, orig_sample, orig_npr, orig_rast = (json_dataset.add_proposals, frcn._sample_rois, frcn.npr,
+                                                  segm_utils.polys_to_mask_wrt_box)
+    orig_add_blobs = frcn.add_fast_rcnn_blobs
+
+    def add_proposals(roidb, rois, scales, crowd_thresh):
+        captured["rois"] = rois.copy()
+        state["pos"] = [np.where(rois[:, 0] == i)[0] for i in range(len(roidb))]
+        return orig_add(roidb, rois, scales, crowd_thresh)
+
+    def sample_rois(entry, im_scale, batch_idx):
+        state["im"] = batch_idx
+        return orig_sample(entry, im_scale, batch_idx)
+
+    class Npr(object):
+        @staticmethod
+        def choice(a, size=None, replace=True):
+            assert replace is False
+            i = state["im"]
+            a = np.asarray(a)
+            glob = np.where(a < n_gt[i], gt_off[i] + a, gt_off[-1] + state["pos"][i][np.maximum(a - n_gt[i], 0)])
+            return a[np.argsort(priority[glob], kind="stable")[:int(size)]]
+
+    def add_blobs(b, im_scales, roidb):
+        out = orig_add_blobs(b, im_scales, roidb)
+        captured["blobs"] = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in b.items()}
+        return out
+
+    json_dataset.add_proposals, frcn._sample_rois, frcn.npr = add_proposals, sample_rois, Npr
+    segm_utils.polys_to_mask_wrt_box, frcn.add_fast_rcnn_blobs = rasterizer, add_blobs
+    try:
+        roidb_in = [np.frombuffer(pickle.dumps([e]), dtype=np.uint8).astype(np.float32) for e in minimal]   # blob.py:165-169
+        kwargs = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in blobs.items() if k.startswith("rpn_")}
+        ret = model(data, torch.from_numpy(blobs["im_info"]), roidb_in, **kwargs)
+    finally:
+        json_dataset.add_proposals, frcn._sample_rois, frcn.npr = orig_add, orig_sample, orig_npr
+        segm_utils.polys_to_mask_wrt_box, frcn.add_fast_rcnn_blobs = orig_rast, orig_add_blobs
+    return ret, captured

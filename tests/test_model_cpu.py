@@ -1,0 +1,229 @@
+"""The R-CNN graph against the REFERENCE'S OWN model code, executed on the CPU from /root/reference
+(oracle/ref_model.py; skipped where the reference is absent, i.e. on the GPU box).
+
+What is pinned here:
+  * a build under torch.manual_seed(RNG_SEED) draws bit-identical initial weights under identical parameter names, with
+    the same set of trainable parameters ("reference initialisers, seed 3");
+  * the synthetic data layer's RPN target blobs equal roi_data/rpn.py's under the same seed;
+  * the WIRING of the training forward -- proposals -> collect -> labelling / sampling / targets -> RoI heads -> losses --
+    and of the backward equals Generalized_RCNN._forward's, with the HIP operators replaced on both sides by CPU
+    implementations of the same arithmetic (tests/cpu_backend.py: the oracle; oracle/ref_model.py: the reference's own
+    kernels built for the host).  The operators themselves are pinned on the GPU (test_ops_gpu.py, test_e2e_gpu.py);
+  * the inference forward and the box decoding of im_detect_bbox.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from oracle import ref_model  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not ref_model.available(), reason="needs /root/reference and oracle/_ref")
+
+H, W, NUM_GT = 256, 320, 4
+
+
+def scenario(seed=5):
+    """Two small images with gt boxes that spread over FPN levels 2-4."""
+    rng = np.random.RandomState(seed)
+    boxes, classes = [], []
+    for _ in range(2):
+        bw, bh = rng.uniform(24, 250, NUM_GT), rng.uniform(24, 200, NUM_GT)
+        x1, y1 = rng.uniform(0, W - 1 - bw), rng.uniform(0, H - 1 - bh)
+        boxes.append(np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32))
+        classes.append(rng.randint(1, 81, NUM_GT).astype(np.int32))
+    data = (rng.randn(2, 3, H, W) * 50).astype(np.float32)
+    return boxes, classes, data
+
+
+@pytest.fixture(scope="module")
+def ref_cfg():
+    warnings.filterwarnings("ignore")
+    return ref_model.configure("configs/baselines/e2e_mask_rcnn_R-50-FPN_1x.yaml",
+                               MODEL__LOAD_IMAGENET_PRETRAINED_WEIGHTS=False, MODEL__NUM_CLASSES=81)
+
+
+@pytest.fixture(scope="module")
+def models(ref_cfg):
+    from detectron_pytorch_amd.rcnn import config, model
+
+    ref = ref_model.build_model(seed=3)
+    cfg = config.mask_rcnn_r50_fpn()
+    torch.manual_seed(cfg.RNG_SEED)
+    mine = model.GeneralizedRCNN(cfg)
+    return ref, mine, cfg
+
+
+def rect_rasterizer(polygons, box, m):
+    from detectron_pytorch_amd.rcnn import targets
+
+    p = np.array(polygons[0], dtype=np.float32)
+    mb = torch.tensor([[p[0::2].min(), p[1::2].min(), p[0::2].max(), p[1::2].max()]])
+    roi = torch.from_numpy(np.asarray(box, dtype=np.float32)).view(1, 4)
+    return targets.rasterize_boxes(mb, roi, m).view(m, m).numpy().astype(np.float32)
+
+
+def test_yaml_merge_equals_the_builtin_config(ref_cfg):
+    from detectron_pytorch_amd.rcnn import config
+
+    c = config.default_config().merge_from_file(
+        os.path.join(ref_model.REFERENCE, "configs/baselines/e2e_mask_rcnn_R-50-FPN_1x.yaml"))
+    b = config.mask_rcnn_r50_fpn()
+    for sec in ("MODEL", "FPN", "FAST_RCNN", "MRCNN", "TRAIN", "TEST", "RPN"):
+        for k, v in b[sec].items():
+            assert c[sec][k] == v, (sec, k, c[sec][k], v)
+            if sec in ref_cfg and k in ref_cfg[sec] and not isinstance(v, dict):
+                rv = ref_cfg[sec][k]
+                assert (tuple(rv) if isinstance(rv, (list, tuple)) else rv) == v, (sec, k, rv, v)
+
+
+def test_seeded_initial_weights_equal_the_reference(models):
+    ref, mine, _ = models
+    a, b = ref.state_dict(), mine.state_dict()
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    trainable = lambda m: {k for k, p in m.named_parameters() if p.requires_grad}  # noqa: E731
+    assert trainable(ref) == trainable(mine)
+    assert sum(p.numel() for p in mine.parameters() if p.requires_grad) == 44125173     # ~44.1 M
+
+
+def test_rpn_target_blobs_equal_the_reference_data_layer(ref_cfg, models):
+    from detectron_pytorch_amd.rcnn import data as rdata
+
+    _, _, cfg = models
+    boxes, classes, _ = scenario()
+    entries = [ref_model.roidb_entry(H, W, b, c, 81) for b, c in zip(boxes, classes)]
+    want = ref_model.rpn_blobs(entries, [1.0, 1.0], seed=11)
+    mine_entries = [dict(height=H, width=W, boxes=b, gt_classes=c, is_crowd=np.zeros(len(c), bool))
+                    for b, c in zip(boxes, classes)]
+    from oracle import ref
+
+    got = rdata.add_rpn_blobs(cfg, mine_entries, [1.0, 1.0], np.random.RandomState(11),
+                              bbox_overlaps=ref._mod("cython_bbox").bbox_overlaps)
+    assert np.array_equal(got["im_info"], want["im_info"])
+    keys = [k for k in want if k.startswith("rpn_")]
+    assert len(keys) == 20
+    for k in keys:
+        assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), k
+    # the in-repo IoU restatement the benchmark's data layer uses gives the same blobs
+    got2 = rdata.add_rpn_blobs(cfg, mine_entries, [1.0, 1.0], np.random.RandomState(11))
+    for k in keys:
+        assert np.array_equal(got2[k], want[k]), k
+
+
+GRAD_PARAMS = ["Box_Head.fc1.weight", "Box_Outs.bbox_pred.weight", "Mask_Head.conv_fcn.0.weight", "Mask_Outs.classify.bias",
+               "RPN.FPN_RPN_conv.weight", "Conv_Body.posthoc_modules.3.weight", "Conv_Body.topdown_lateral_modules.0.conv_lateral.weight",
+               "Conv_Body.conv_body.res5.2.conv3.weight", "Conv_Body.conv_body.res3.0.conv1.weight"]
+
+
+def test_training_forward_and_backward_equal_the_reference(ref_cfg, models):
+    import cpu_backend
+    from detectron_pytorch_amd.rcnn import targets
+
+    ref, mine, cfg = models
+    ref.train()
+    mine.train()
+    boxes, classes, data_np = scenario()
+    entries = [ref_model.roidb_entry(H, W, b, c, 81) for b, c in zip(boxes, classes)]
+    blobs = ref_model.rpn_blobs(entries, [1.0, 1.0], seed=11)
+    data = torch.from_numpy(data_np)
+    g = 2 * NUM_GT
+    priority = np.random.RandomState(7).permutation(g + 2000).astype(np.float32)
+    ref.zero_grad()
+    ret_ref, cap = ref_model.train_forward(ref, data, blobs, priority, rect_rasterizer)
+    sum(v.sum() for v in ret_ref["losses"].values()).backward()
+
+    roidb = {"gt_boxes": torch.from_numpy(np.concatenate(boxes)), "gt_classes": torch.from_numpy(np.concatenate(classes)).long(),
+             "gt_image": torch.tensor([0] * NUM_GT + [1] * NUM_GT)}
+    rpn_t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in blobs.items() if k.startswith("rpn_")}
+    mine.zero_grad()
+    with cpu_backend.cpu_ops(mine):
+        # Proposals: the same rows.  Their ORDER is undefined among tied scores on both sides (np.argsort without a stable
+        # kind at generate_proposals.py:131-138 and collect_and...py:85; fp32 sigmoid outputs of ~40 k anchors do collide),
+        # and the sampling depends on the order, so the rest of the comparison runs on the reference's order.
+        from detectron_pytorch_amd import fpn_proposals
+        inner = fpn_proposals.generate_and_collect
+
+        def collect_in_reference_order(*a, **k):
+            rois, valid = inner(*a, **k)
+            key = lambda x: x[np.lexsort(x.T[::-1])]  # noqa: E731
+            assert np.array_equal(key(rois.numpy()), key(cap["rois"])), "collected proposals differ as a set"
+            assert (rois.numpy() != cap["rois"]).any(1).mean() < 0.02, "more than tie-swaps differ"
+            return torch.from_numpy(cap["rois"]), valid
+
+        fpn_proposals.generate_and_collect = collect_in_reference_order
+        ret = mine(data, torch.from_numpy(blobs["im_info"]), roidb=roidb, rpn_targets=rpn_t,
+                   priority=torch.from_numpy(priority[:g + cap["rois"].shape[0]]))
+        sum(ret["losses"].values()).backward()
+    assert np.array_equal(ret["collected_rois"].numpy(), cap["rois"])
+    # labelling: the reference's rows are the real rows of every image's block
+    b, want = ret["blobs"], cap["blobs"]
+    per, fper = cfg.TRAIN.BATCH_SIZE_PER_IM, int(round(cfg.TRAIN.FG_FRACTION * cfg.TRAIN.BATCH_SIZE_PER_IM))
+    rows = torch.cat([i * per + torch.arange(int(n)) for i, n in enumerate(b["num_rois"])])
+    assert rows.numel() == want["rois"].shape[0]
+    assert np.array_equal(b["rois"][rows].numpy(), want["rois"])
+    assert np.array_equal(b["labels_int32"][rows].numpy(), want["labels_int32"])
+    assert (b["labels_int32"][rows] > 0).sum() >= g and (b["labels_int32"] == -1).sum() == 2 * per - rows.numel()
+    np.testing.assert_allclose(b["bbox_targets"][rows].numpy(), want["bbox_targets"], rtol=0, atol=2e-6)
+    assert np.array_equal(b["bbox_inside_weights"][rows].numpy(), want["bbox_inside_weights"])
+    assert np.array_equal(b["bbox_outside_weights"][rows].numpy(), want["bbox_outside_weights"])
+    frows = torch.cat([i * fper + torch.arange(int(n)) for i, n in enumerate(b["num_fg"])])
+    assert np.array_equal(b["mask_rois"][frows].numpy(), want["mask_rois"])
+    full = targets.expand_to_class_specific_mask_targets(b["masks_int32"], b["mask_class"], cfg.MODEL.NUM_CLASSES)
+    assert np.array_equal(full[frows].numpy(), want["masks_int32"])
+    assert np.array_equal(b["roi_has_mask_int32"][rows].numpy(), want["roi_has_mask_int32"])
+    # FPN levels: the reference's per-level blobs are the rows of each level, in order
+    for lvl in range(2, 6):
+        sel = rows[b["rois_levels"][rows] == lvl]
+        assert np.array_equal(b["rois"][sel].numpy(), want["rois_fpn%d" % lvl]), lvl
+    assert len({int(x) for x in b["rois_levels"][rows]}) >= 2, "scenario should exercise several pyramid levels"
+    # losses and metric
+    for k, v in ret_ref["losses"].items():
+        np.testing.assert_allclose(float(ret["losses"][k]), float(v), rtol=2e-5, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(float(ret["metrics"]["accuracy_cls"]), float(ret_ref["metrics"]["accuracy_cls"]), rtol=1e-6)
+    # gradients of the summed loss
+    pr, pm = dict(ref.named_parameters()), dict(mine.named_parameters())
+    for name in GRAD_PARAMS:
+        a, bb = pr[name].grad, pm[name].grad
+        assert a is not None and bb is not None, name
+        err = (a - bb).abs().max().item() / max(a.abs().max().item(), 1e-12)
+        assert err <= 2e-4, (name, err)
+
+
+def test_inference_forward_and_box_decoding_equal_the_reference(ref_cfg, models):
+    import cpu_backend
+    from detectron_pytorch_amd.rcnn import inference
+
+    ref, mine, cfg = models
+    ref.eval()
+    mine.eval()
+    _, _, data_np = scenario(seed=9)
+    data = torch.from_numpy(data_np[:1])
+    im_info = torch.tensor([[float(H), float(W), 1.0]])
+    with torch.no_grad():
+        want = ref(data, im_info)
+    with cpu_backend.cpu_ops(mine):
+        got = mine(data, im_info)
+    assert np.array_equal(got["rois"].numpy(), want["rois"])
+    assert want["rois"].shape[0] > 100
+    np.testing.assert_allclose(got["cls_score"].numpy(), want["cls_score"].numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(got["bbox_pred"].numpy(), want["bbox_pred"].numpy(), rtol=1e-5, atol=1e-7)
+    # core/test.py:155-180: decode + clip, the reference's numpy functions against the device-side restatement
+    import utils.boxes as box_utils
+
+    boxes = want["rois"][:, 1:5]
+    deltas = want["bbox_pred"].numpy() * 30      # large enough that some boxes leave the image / hit the exp clip
+    ref_boxes = box_utils.clip_tiled_boxes(box_utils.bbox_transform(boxes, deltas, ref_cfg.MODEL.BBOX_REG_WEIGHTS), (H, W))
+    mine_boxes = inference.clip_tiled_boxes(inference.bbox_transform(torch.from_numpy(boxes), torch.from_numpy(deltas),
+                                                                     cfg.MODEL.BBOX_REG_WEIGHTS, cfg.BBOX_XFORM_CLIP), H, W)
+    assert ref_boxes.dtype == np.float32
+    np.testing.assert_allclose(mine_boxes.numpy(), ref_boxes, rtol=0, atol=1e-4)
+    assert (np.abs(mine_boxes.numpy() - ref_boxes) > 0).mean() < 0.01   # numpy's fp64 exp vs torch's: last-bit cases only

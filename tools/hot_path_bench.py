@@ -1,0 +1,401 @@
+"""Measurements of the RoIAlign / NMS hot path alone (BASELINE configs 1-2 and the per-kernel roofline), used by
+bench.py as sub-objects of its JSON line: the roofline object of the RoIAlign forward (HIP events on the launch stream),
+the other RoIAlign shapes of a step, NMS latencies, the post-convolution inference glue.  No oracle import here: the CPU
+baseline lives in bench.py."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from detectron_pytorch_amd import synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+# ------------------------------------------------------------------------------------------------
+# Hot-path workload: what one image of e2e_mask_rcnn_R-50-FPN asks of the RoI/NMS operators
+# (SURVEY.md section 8a/8d): box-head RoIAlign 512 RoIs x 256 x 7x7 fwd+bwd on P2, mask-head RoIAlign
+# 128 RoIs x 256 x 14x14 fwd+bwd, and the 5 per-level RPN NMS calls (n = 2000 pre-NMS, thresh 0.7).
+# ------------------------------------------------------------------------------------------------
+class HotPath:
+    def __init__(self, device, images_per_rank=2, seed=0):
+        from detectron_pytorch_amd import nms as mi_nms
+        from detectron_pytorch_amd.roi_align import roi_align_backward, roi_align_forward
+
+        self.device = device
+        self.images = images_per_rank
+        self.fwd, self.bwd, self.nms_many = roi_align_forward, roi_align_backward, mi_nms.nms_device_many
+        h, w, scale = syn.FPN_LEVELS[2]
+        self.scale = scale
+        n = images_per_rank
+        self.feat_np = syn.feature_map(n, syn.FPN_DIM, h, w, seed=seed)
+        self.feat = torch.from_numpy(self.feat_np).to(device)
+        self.box_rois_np = syn.rois_canonical(512 * n, n, seed=seed)
+        self.box_rois = torch.from_numpy(self.box_rois_np).to(device)
+        self.mask_rois_np = syn.rois_canonical(128 * n, n, seed=seed + 1)
+        self.mask_rois = torch.from_numpy(self.mask_rois_np).to(device)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.box_gtop = torch.randn(512 * n, syn.FPN_DIM, 7, 7, generator=g).to(device)
+        self.mask_gtop = torch.randn(128 * n, syn.FPN_DIM, 14, 14, generator=g).to(device)
+        self.dets = [torch.from_numpy(syn.sort_by_score(syn.boxes_clustered(2000, seed=seed + 10 + i))[0]).to(device)
+                     for i in range(5 * n)]
+
+    def step(self):
+        fs = tuple(self.feat.shape)
+        # forward returns its per-RoI records; the backward over the same RoIs reuses them (as the autograd
+        # Function does through ctx)
+        out, ws = self.fwd(self.feat, self.box_rois, 7, 7, self.scale, 2, return_workspace=True)
+        gin = self.bwd(self.box_gtop, self.box_rois, fs, 7, 7, self.scale, 2, workspace=ws)
+        out2, ws2 = self.fwd(self.feat, self.mask_rois, 14, 14, self.scale, 2, return_workspace=True)
+        gin2 = self.bwd(self.mask_gtop, self.mask_rois, fs, 14, 14, self.scale, 2, workspace=ws2)
+        # the per-level, per-image RPN NMS problems are independent: fanned out over side streams
+        keeps = self.nms_many(self.dets, 0.7)
+        return out, gin, out2, gin2, keeps
+
+
+def make_stepper(work, mode, device):
+    """The step of the timed loop.  graph: the ~20 launches of one step (two RoIAlign shapes fwd+bwd, batched NMS, their
+    allocations) are captured once in a hipGraph on a side stream and replayed -- the step is launch-bound from Python
+    otherwise.  Every replay executes all kernels on the same static inputs; the captured outputs are checked against an
+    eager step before the graph is trusted.  Falls back to eager launching if capture is not possible."""
+    if mode == "eager":
+        return work.step, "eager"
+    try:
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                work.step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+            captured = work.step()
+        eager = work.step()
+        for t in captured[:4]:
+            t.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        for got, want in zip(captured[:4], eager[:4]):
+            assert torch.equal(got, want), "hipGraph replay does not reproduce the eager step"
+        for (keep_g, num_g), (keep_e, num_e) in zip(captured[4], eager[4]):
+            k = int(num_e.item())
+            assert int(num_g.item()) == k and torch.equal(keep_g[:k], keep_e[:k]), "hipGraph replay: NMS differs"
+        work.captured = captured  # keep the static outputs alive
+        return graph.replay, "hipGraph"
+    except Exception as exc:  # capture is an optimisation of the harness, not of the measured kernels
+        sys.stderr.write("bench: hipGraph capture failed (%s: %s); launching eagerly\n" % (type(exc).__name__, exc))
+        torch.cuda.synchronize()
+        return work.step, "eager"
+
+
+def time_kernel(fn, iters, warmup=10):
+    """Average duration (s) of one call of `fn` over `iters` back-to-back launches, HIP events recorded
+    on the stream the kernels are launched on (torch's current stream)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e-3 / iters
+
+
+def roofline_roi_align_forward(device, iters):
+    """BASELINE configs[1]: RoIAlign forward, 512 RoIs x 256 ch x 7x7, sampling_ratio 2, P2 map of one image.
+    Algorithmic bytes: 4*R*C*PH*PW (write) + 4*C*U (read, U distinct pixels) + 20*R."""
+    from detectron_pytorch_amd import _lib
+
+    h, w, scale = syn.FPN_LEVELS[2]
+    c, r, res, sr = syn.FPN_DIM, 512, 7, 2
+    feat = torch.from_numpy(syn.feature_map(1, c, h, w, seed=0)).to(device)
+    rois_np = syn.rois_canonical(r, 1, seed=0)
+    if os.environ.get("MI_BENCH_SORT_ROIS"):  # tuning experiment only: spatially sorted RoI order
+        key = (rois_np[:, 2] + rois_np[:, 4]) // (2 * 64) * 4096 + (rois_np[:, 1] + rois_np[:, 3]) / 2
+        rois_np = np.ascontiguousarray(rois_np[np.argsort(key, kind="stable")])
+    rois = torch.from_numpy(rois_np).to(device)
+    out = torch.empty((r, c, res, res), device=device)
+    lib = _lib.lib()
+    stream = _lib.current_stream_handle(device)
+
+    layout = _lib.LAYOUT_NCHW
+    if os.environ.get("MI_BENCH_NHWC"):  # tuning experiment only: channels_last storage of the same logical tensor
+        feat = feat.permute(0, 2, 3, 1).contiguous()
+        layout = _lib.LAYOUT_NHWC
+
+    ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+
+    def launch():  # one call of the C-ABI = both launches of the fast path (RoI records, then the gather)
+        rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res,
+                                         scale, sr, _lib.ROI_ALIGN_CAFFE2, layout, ws.data_ptr(), ws_bytes, stream)
+        assert rc == 0
+
+    seconds = time_kernel(launch, iters)
+    touched = touched_pixels(rois_np, 1, h, w, res, res, scale, sr)
+    alg_bytes = 4 * r * c * res * res + 4 * c * touched + 20 * r
+    achieved = alg_bytes / seconds / 1e9
+    traffic, traffic_src = pmc_traffic("forward")
+    info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
+            "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
+            "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
+    # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
+    gtop = torch.randn(r, c, res, res, device=device)
+    gin = torch.zeros(1, c, h, w, device=device)
+
+    overwrite = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
+    bwd_flags = _lib.ROI_ALIGN_RECORDS_READY | (_lib.ROI_ALIGN_OVERWRITE if overwrite else 0)
+
+    def launch_bwd():  # records of the forward above are still in `ws`; zero fill only where the path accumulates
+        if not overwrite:
+            gin.zero_()
+        rc = lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
+                                          scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, ws.data_ptr(), ws_bytes,
+                                          bwd_flags, stream)
+        assert rc == 0
+
+    sec_bwd = time_kernel(launch_bwd, max(iters // 4, 10))
+    bwd_bytes = 4 * r * c * res * res + 4 * c * h * w + 20 * r
+    info["backward"] = {"zero_fill_needed": not overwrite, "avg_us_incl_zero_fill": round(sec_bwd * 1e6, 2),
+                        "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
+                        "algorithmic_bytes": int(bwd_bytes)}
+    info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
+    if layout == _lib.LAYOUT_NCHW:
+        info["channels_last"] = channels_last_variant(device, lib, stream, feat, rois, out, ws, alg_bytes, gtop, iters)
+    copy_gbs = copy_ceiling(device)
+    info["copy_ceiling"] = {"measured": round(copy_gbs, 1), "unit": "GB/s", "frac_of_copy": round(achieved / copy_gbs, 4),
+                            "what": "torch device-to-device copy of 256 MiB, read + write bytes / time"}
+    return info
+
+
+def channels_last_variant(device, lib, stream, feat_nchw, rois, out, ws, alg_bytes, gtop, iters):
+    """Same logical input with the features stored channels-last (what MIOpen's NHWC convolutions hand over on gfx950):
+    forward = roi_align_prepare + roi_align_fwd_nhwc, output still dense [R,C,PH,PW]; backward = the tile kernel writing
+    the gradient channels-last (through roi_align.roi_align_backward, allocation included).  Reported beside the NCHW
+    headline, not as it."""
+    from detectron_pytorch_amd import _lib, roi_align as ra
+
+    n, c, h, w = feat_nchw.shape
+    r, _, res, _ = out.shape
+    feat = feat_nchw.permute(0, 2, 3, 1).contiguous()
+    scale, sr = syn.FPN_LEVELS[2][2], 2
+
+    def launch():
+        rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), n, c, h, w, r, res, res,
+                                         scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NHWC, ws.data_ptr(), ws.numel(),
+                                         stream)
+        assert rc == 0
+
+    sec = time_kernel(launch, iters)
+
+    def bwd():  # records of the forward above are reused; the tile kernel writes the channels-last gradient itself
+        ra.roi_align_backward(gtop, rois, (n, c, h, w), res, res, scale, sr, channels_last=True, workspace=ws)
+
+    sec_bwd = time_kernel(bwd, max(iters // 8, 5))
+    gbs = alg_bytes / sec / 1e9
+    return {"kernel": "roi_align_prepare + roi_align_fwd_nhwc", "avg_launch_us": round(sec * 1e6, 2),
+            "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "bwd_us": round(sec_bwd * 1e6, 2)}
+
+
+def copy_ceiling(device):
+    """The box's own streaming ceiling (SURVEY.md section 8d asks for both denominators): a plain device copy."""
+    a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=device)
+    b = torch.empty_like(a)
+    sec = time_kernel(lambda: b.copy_(a), 20)
+    return 2 * a.numel() * 4 / sec / 1e9
+
+
+def other_shapes(device, lib, stream, iters):
+    """Per-call times of the other RoIAlign shapes of the step (not roofline-gated): the mask head (128 x 256 x 14x14) and
+    the two-image box head (1024 RoIs, N = 2), forward and backward through the workspace entry points."""
+    from detectron_pytorch_amd import _lib
+
+    out = {}
+    h, w, scale = syn.FPN_LEVELS[2]
+    c, sr = syn.FPN_DIM, 2
+    for name, n, r, res in [("mask_128x256x14x14", 1, 128, 14), ("box_1024x256x7x7_2img", 2, 1024, 7)]:
+        feat = torch.from_numpy(syn.feature_map(n, c, h, w, seed=0)).to(device)
+        rois = torch.from_numpy(syn.rois_canonical(r, n, seed=1)).to(device)
+        o = torch.empty((r, c, res, res), device=device)
+        gtop = torch.randn(r, c, res, res, device=device)
+        gin = torch.empty(n, c, h, w, device=device)
+        ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        over = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
+        flags = _lib.ROI_ALIGN_RECORDS_READY | (_lib.ROI_ALIGN_OVERWRITE if over else 0)
+
+        def fwd():
+            assert lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), o.data_ptr(), n, c, h, w, r, res, res, scale,
+                                               sr, 0, 0, ws.data_ptr(), ws_bytes, stream) == 0
+
+        def bwd():
+            if not over:
+                gin.zero_()
+            assert lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), n, c, h, w, r, res, res,
+                                                scale, sr, 0, 0, ws.data_ptr(), ws_bytes, flags, stream) == 0
+
+        out[name] = {"fwd_us": round(time_kernel(fwd, iters) * 1e6, 1), "bwd_us": round(time_kernel(bwd, iters) * 1e6, 1)}
+    out["fpn_1000rois_P2-P5_7x7"] = fpn_variant(device, iters)
+    return out
+
+
+def fpn_variant(device, iters):
+    """Config-2 variant (ii): 1000 RoIs distributed over P2..P5 by the FPN heuristic, pooled by
+    roi_xform.roi_feature_transform (one RoIAlign call per level + concat + restore permutation), RoIs on the device."""
+    from detectron_pytorch_amd import roi_xform
+
+    rois, lvls = syn.rois_fpn_distributed(1000, batch=1, seed=2)
+    blobs = roi_xform.add_multilevel_roi_blobs({"rois": rois}, "rois", rois, lvls, 2, 5)
+    blobs = {k: torch.from_numpy(v).to(device) for k, v in blobs.items()}
+    feats, scales = [], []
+    for lvl in (5, 4, 3, 2):  # coarsest first, as the reference orders blobs_in
+        h, w, scale = syn.FPN_LEVELS[lvl]
+        feats.append(torch.from_numpy(syn.feature_map(1, syn.FPN_DIM, h, w, seed=lvl)).to(device))
+        scales.append(scale)
+
+    def fwd(fused):
+        with torch.no_grad():
+            return roi_xform.roi_feature_transform(feats, blobs, "rois", "RoIAlign", 7, scales, 2, fused=fused)
+
+    # fused call with the RoIs already in dataloader order (what a caller that keeps them on the device passes)
+    from detectron_pytorch_amd.roi_align import roi_align_fpn
+
+    rois_d = torch.from_numpy(rois).to(device)
+    lvl_d = torch.from_numpy((5 - lvls).astype(np.int32)).to(device)
+
+    def fused_direct():
+        with torch.no_grad():
+            roi_align_fpn(feats, scales, rois_d, lvl_d, 7, 7, 2)
+
+    return {"fwd_us": round(time_kernel(lambda: fwd(True), iters) * 1e6, 1),
+            "fwd_us_per_level_loop": round(time_kernel(lambda: fwd(False), iters) * 1e6, 1),
+            "fwd_us_fused_call_only": round(time_kernel(fused_direct, iters) * 1e6, 1),
+            "rois_per_level": {int(l): int((lvls == l).sum()) for l in (2, 3, 4, 5)}}
+
+
+def pmc_traffic(direction):
+    """HBM bytes per call from the newest committed PMC summary (profiles/rNN_pmc_roi_align.json), or None."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_roi_align.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return int(d[direction]["hbm_bytes_per_call"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr):
+    """U of the algorithmic-bytes formula (a workload descriptor computed on the host, not timed)."""
+    return syn.roi_align_touched_pixels(rois_np, batch, h, w, ph, pw, scale, sr)
+
+
+def nms_latency(device, iters):
+    from detectron_pytorch_amd import _lib
+
+    out = {}
+    lib = _lib.lib()
+    stream = _lib.current_stream_handle(device)
+    for name, dets_np, thresh in [("cfg1_uniform_n1000_t0.5", syn.boxes_uniform(1000, seed=0), 0.5),
+                                  ("rpn_clustered_n2000_t0.7", syn.boxes_clustered(2000, seed=0), 0.7)]:
+        dets = torch.from_numpy(dets_np).to(device)
+        n = dets.shape[0]
+        keep = torch.empty(n, dtype=torch.int64, device=device)
+        num = torch.empty(1, dtype=torch.int32, device=device)
+        ws_bytes = lib.mi_nms_workspace_bytes(n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+
+        def launch():
+            rc = lib.mi_nms(dets.data_ptr(), n, thresh, _lib.NMS_GE_ORIG_ASC, keep.data_ptr(), num.data_ptr(),
+                            ws.data_ptr(), ws_bytes, stream)
+            assert rc == 0
+
+        sec = time_kernel(launch, max(iters // 4, 10))
+        out[name] = {"us_per_call": round(sec * 1e6, 1), "kept": int(num.item()),
+                     "pair_tests_per_s": round(n * (n - 1) / 2 / sec, 0)}
+    # Soft-NMS (off by default in the reference, core/config.py:362): one sequential pick per kept box, all in LDS
+    dets = torch.from_numpy(syn.boxes_uniform(1000, seed=0)).to(device)
+    od, oi = torch.empty((1000, 5), device=device), torch.empty(1000, dtype=torch.int64, device=device)
+    num = torch.empty(1, dtype=torch.int32, device=device)
+
+    def launch_soft():
+        assert lib.mi_soft_nms(dets.data_ptr(), 1000, 0.5, 0.3, 0.001, 1, od.data_ptr(), oi.data_ptr(), num.data_ptr(),
+                               stream) == 0
+
+    sec = time_kernel(launch_soft, 5, warmup=2)
+    out["soft_nms_linear_uniform_n1000"] = {"us_per_call": round(sec * 1e6, 1), "kept": int(num.item())}
+    # the test-time caller of NMS (core/test.py:732-790): 1000 RoIs x 81 classes, classes batched, two host syncs
+    from detectron_pytorch_amd import detection
+
+    sc_np, bx_np = syn.detection_head_outputs(1000, 81, seed=7)
+    sc, bx = torch.from_numpy(sc_np).to(device), torch.from_numpy(bx_np).to(device)
+    post = {}
+    for name, soft in (("hard", False), ("soft_linear", True)):
+        sec = time_kernel(lambda: detection.box_results_with_nms_and_limit(sc, bx, soft_nms=soft), 10, warmup=3)
+        post[name + "_ms"] = round(sec * 1e3, 3)
+    out["detection_postprocess_R1000_C81"] = post
+    # the RPN-side caller of NMS (generate_proposals.py:12-182) for one P2-sized level, 2 images, train-time top-k
+    from detectron_pytorch_amd import generate_proposals as gp
+
+    anchors = gp.generate_anchors(4, (32,), (0.5, 1, 2))
+    sc_np, dl_np = syn.rpn_head_outputs(2, 3, 200, 336, seed=4)
+    sc, dl = torch.from_numpy(sc_np).to(device), torch.from_numpy(dl_np).to(device)
+    info = torch.tensor([[800, 1344, 1.0], [800, 1344, 1.0]], dtype=torch.float32, device=device)
+    op = gp.GenerateProposalsOp(anchors, 0.25, 2000, 2000, 0.7, 0, as_numpy=False)
+    sec = time_kernel(lambda: op(sc, dl, info), 10, warmup=3)
+    out["generate_proposals_P2_2img_top2000"] = {"ms": round(sec * 1e3, 3)}
+    return out
+
+
+def inference_path(device, iters=10):
+    """One test-time image through everything between the RPN / box-head convolutions that this repository provides,
+    without a host round trip in between: GenerateProposals on P2..P6 (TEST: 1000 pre-NMS / 1000 post-NMS per level,
+    configs/baselines/e2e_mask_rcnn_R-50-FPN_1x.yaml:41-43) -> collect the 1000 best -> RoIAlign 7x7 over P2..P5 in one
+    fused call -> per-class NMS + top-100 on (synthetic) box-head outputs for those RoIs."""
+    from detectron_pytorch_amd import detection, fpn_proposals, generate_proposals as gp
+    from detectron_pytorch_amd.roi_align import roi_align_fpn
+
+    levels = [(2, 200, 336, 4, 32), (3, 100, 168, 8, 64), (4, 50, 84, 16, 128), (5, 25, 42, 32, 256), (6, 13, 21, 64, 512)]
+    ops, heads = [], []
+    for lvl, h, w, stride, size in levels:
+        anchors = gp.generate_anchors(stride, (size,), (0.5, 1, 2))
+        sc, dl = syn.rpn_head_outputs(1, 3, h, w, seed=lvl)
+        ops.append(gp.GenerateProposalsOp(anchors, 1.0 / stride, 1000, 1000, 0.7, 0, as_numpy=False))
+        heads.append((torch.from_numpy(sc).to(device), torch.from_numpy(dl).to(device)))
+    info = torch.tensor([[800, 1344, 1.0]], dtype=torch.float32, device=device)
+    feats = [torch.from_numpy(syn.feature_map(1, syn.FPN_DIM, h, w, seed=l)).to(device) for l, h, w, _, _ in levels[3::-1]]
+    scales = [1.0 / s for _, _, _, s, _ in levels[3::-1]]
+    cls_np, box_np = syn.detection_head_outputs(1000, 81, seed=7)
+    cls, box = torch.from_numpy(cls_np).to(device), torch.from_numpy(box_np).to(device)
+    stats = {}
+
+    def run():
+        rois = fpn_proposals.generate_and_collect(ops, heads, info, 1000)
+        lv = fpn_proposals.map_rois_to_fpn_levels(rois[:, 1:5])
+        with torch.no_grad():
+            pooled = roi_align_fpn(feats, scales, rois, 5 - lv, 7, 7, 2)
+        dets = detection.box_results_with_nms_and_limit(cls[:rois.size(0)], box[:rois.size(0)])
+        stats["rois"], stats["detections"] = int(rois.size(0)), int(dets[0].numel())
+        return pooled
+
+    sec = time_kernel(run, iters, warmup=3)
+    return {"ms_per_image": round(sec * 1e3, 3), **stats,
+            "what": "GenerateProposals P2-P6 + collect + fused RoIAlign P2-P5 + class-batched NMS/top-100, one image; "
+                    "~150 small launches from Python: bound by the host CPU of the box, not by the GPU"}
+
+
