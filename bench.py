@@ -50,11 +50,13 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 (default): the reference's arithmetic; bf16: convolutions / GEMMs under autocast")
-    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
-                    help="graph (default): forward+backward (and, on one rank, the optimizer) are captured once in a "
-                         "hipGraph and replayed -- the training step is static-shaped and sync-free by construction; with "
-                         "N > 1 the bucket all-reduces run between the backward graph and the optimizer graph.  eager: "
-                         "launched from Python every step, all-reduce issued from autograd hooks during the backward")
+    ap.add_argument("--launch", default="eager", choices=["graph", "eager"],
+                    help="eager (default): launched from Python every step, the bucket all-reduces are issued from "
+                         "autograd hooks while the backward still runs; the step is GPU-bound (rocprofv3: kernel time ~= "
+                         "step time), so this is also the fast form.  graph: forward+backward (and, on one rank, the "
+                         "optimizer) are captured once in a hipGraph and replayed -- the training step is static-shaped "
+                         "and sync-free by construction; with N > 1 the all-reduces run between the backward graph and the "
+                         "optimizer graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no roofline / breakdown / inference objects)")
     ap.add_argument("--kernel-iters", type=int, default=200, help="back-to-back launches per roofline timing")
@@ -127,8 +129,11 @@ class TrainHarness:
         self.autocast = torch.bfloat16 if dtype == "bf16" else None
         batch = rdata.synthetic_minibatch(cfg, IMAGES_PER_RANK, seed=rank)      # per-rank images (weak scaling)
         self.data, self.im_info, self.roidb, self.rpn_targets = rdata.to_device(batch, device)
-        # first-iteration learning rate of the reference's warm-up (SOLVER.WARM_UP_FACTOR = 1/3, config.py:560)
-        self.opt = rtrain.make_optimizer(self.net, cfg, lr=cfg.SOLVER.BASE_LR / 3.0)
+        # the reference's learning-rate rule: the yaml's BASE_LR is for NUM_GPUS x IMS_PER_BATCH = 16 images and is
+        # rescaled linearly to the actual batch (tools/train_net_step.py:166-201); first iteration of the warm-up
+        # (SOLVER.WARM_UP_FACTOR = 1/3, config.py:560)
+        lr = cfg.SOLVER.BASE_LR * (IMAGES_PER_RANK * world) / 16.0 / 3.0
+        self.opt = rtrain.make_optimizer(self.net, cfg, lr=lr)
         self.reducer = parallel.GradientAllReducer(self.net.parameters(), overlap=(launch == "eager"))
         self.params = sum(p.numel() for p in self.net.parameters() if p.requires_grad)
         self.last = None
@@ -157,8 +162,8 @@ class TrainHarness:
     def capture(self):
         """hipGraph form of the step.  One rank: a single graph (forward, backward, SGD).  Several ranks: graph A =
         zero-fill of the gradient buckets + forward + backward (autograd accumulates straight into the bucket views),
-        then the bucket all-reduces on the stream, then graph B = averaging + SGD.  Falls back to eager launching if
-        capture fails (capture is a property of the harness, not of the kernels)."""
+        then the bucket all-reduces on the stream, then graph B = averaging + SGD.  If capture fails the process restarts itself
+        in eager mode (one rank) or stops (several ranks)."""
         dev = self.device
         try:
             side = torch.cuda.Stream(dev)
@@ -202,10 +207,15 @@ class TrainHarness:
                 raise RuntimeError("replayed loss %.4f vs eager %.4f" % (got, want))
             self._replay, self.mode = replay, "hipGraph"
         except Exception as exc:  # noqa: BLE001
-            sys.stderr.write("bench: hipGraph capture failed (%s: %s); launching eagerly\n" % (type(exc).__name__, exc))
-            torch.cuda.synchronize()
-            self.reducer.overlap = True
-            self._replay, self.mode = None, "eager"
+            # a failed capture leaves the allocator's graph pool and the stream in an undefined state: do not go on in
+            # this process image
+            sys.stderr.write("bench: hipGraph capture failed (%s: %s)\n" % (type(exc).__name__, str(exc)[:300]))
+            if self.world > 1:
+                raise SystemExit("bench: --launch graph failed on a multi-rank job; rerun with --launch eager")
+            argv = [a for a in sys.argv if a not in ("graph",) and a != "--launch"] + ["--launch", "eager"]
+            sys.stderr.write("bench: restarting with --launch eager\n")
+            sys.stderr.flush()
+            os.execv(sys.executable, [sys.executable] + argv)
 
     def step(self):
         return self._replay() if self._replay is not None else self.eager_step()

@@ -90,6 +90,9 @@ __device__ __forceinline__ void prepare_body(const float* __restrict__ dets, int
     x2 = d[2];
     y2 = d[3];
     score = d[4];
+    // a NaN score (a diverged network) must not break the rank sort: it compares as the lowest score, ties by index, so
+    // that the ranks stay a permutation and nothing downstream indexes with an uninitialised slot
+    if (!(score == score)) score = -__builtin_inff();
   }
   int rank = i;
   if (kSort) {
@@ -99,7 +102,12 @@ __device__ __forceinline__ void prepare_body(const float* __restrict__ dets, int
       const int lim4 = (lim + 15) & ~15;  // padded with NaN (never greater, never equal): four scores per LDS read
       __syncthreads();
       for (int t = tid; t < lim4; t += 256)
-        s_scores[t] = t < lim ? dets[(long long)(base + t) * 5 + 4] : __builtin_nanf("");
+        if (t < lim) {
+          const float v = dets[(long long)(base + t) * 5 + 4];
+          s_scores[t] = (v == v) ? v : -__builtin_inff();
+        } else {
+          s_scores[t] = __builtin_nanf("");
+        }
       __syncthreads();
       const int per = lim4 / 4;  // a multiple of 4
       const int t0 = part * per, t1 = t0 + per;

@@ -86,14 +86,16 @@ class GenerateProposalsOp(object):
 
     def select(self, dets, valid, kept):
         """Steps 6-8 (:155-161) as a mask [N,k]: kept by the NMS (`kept`: one (keep, num_keep) per image, or None when
-        nms_thresh <= 0), passed the filter, among the first post_nms_topN of those."""
+        nms_thresh <= 0), passed the filter, among the first post_nms_topN of those.  All images at once, tensor-only
+        arguments (no host scalar is uploaded: the sequence can be captured in a hipGraph)."""
         n, k = valid.shape
         if kept is None:
             return valid.bool()
-        pos = torch.arange(k, device=valid.device)
-        take = torch.zeros((n, k + 1), dtype=torch.bool, device=valid.device)  # column k absorbs the unused tail of `keep`
-        for i, (keep, num_keep) in enumerate(kept):                            # keep = ascending positions = descending score
-            take[i, torch.where(pos < num_keep.to(torch.int64), keep, torch.full_like(keep, k))] = True
+        keep = torch.stack([kp[:k] for kp, _ in kept])                        # [N,k] ascending positions = descending score
+        num_keep = torch.cat([nm.reshape(1) for _, nm in kept]).view(n, 1).to(torch.int64)
+        pos = torch.arange(k, device=valid.device).view(1, k)
+        idx = torch.where(pos < num_keep, keep, torch.full_like(keep, k))     # column k absorbs the unused tail of `keep`
+        take = torch.zeros((n, k + 1), dtype=torch.bool, device=valid.device).scatter_(1, idx, True)
         take = take[:, :k] & valid.bool()
         if self.post_nms_topN > 0:
             take &= torch.cumsum(take, dim=1) <= self.post_nms_topN

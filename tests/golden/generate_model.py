@@ -6,10 +6,12 @@ and of an inference step.  Run here (the GPU box has no /root/reference):
 
 Scenario (tests/test_model_cpu.py:scenario): 2 images of 256x320, 4 gt boxes each, weights = reference initialisers
 under torch.manual_seed(3), RPN blobs from roi_data/rpn.py under np.random.seed(11), sampling permutation
-RandomState(7).  Inputs are regenerated from these seeds by the tests; the file stores only what the reference computed:
-collected proposals, labelled RoI blobs (compact), losses, gradient samples.  tests/test_e2e_gpu.py feeds the SAME
-convolution outputs (computed on the CPU with this package's graph, which test_model_cpu.py pins bit-for-bit to the
-reference's) to the HIP path on the GPU and compares.
+RandomState(7).  The OUTPUTS OF THE CONVOLUTIONS (pyramid P6..P2, RPN logits and deltas of every level) are seeded
+numpy arrays (`synthetic_conv_outputs`) substituted for the reference's backbone / RPN convolutions: CPU convolution
+results differ in the last bits between machines (oneDNN picks kernels by ISA and thread count), and the fixture must be
+reproducible on the GPU box.  Everything after the convolutions is the reference's own code.  Inputs are regenerated from
+the seeds by the tests; the file stores only what the reference computed: collected proposals, labelled RoI blobs
+(compact), losses, gradient samples.  tests/test_e2e_gpu.py feeds the same arrays to the HIP path on the GPU.
 """
 import os
 import sys
@@ -25,14 +27,44 @@ warnings.filterwarnings("ignore")
 
 from oracle import ref_model  # noqa: E402
 import test_model_cpu as T  # noqa: E402
+from scenarios import synthetic_conv_outputs  # noqa: E402
 
 HEAD_PARAMS = ["Box_Head.fc1.weight", "Box_Head.fc2.bias", "Box_Outs.cls_score.weight", "Box_Outs.bbox_pred.weight",
                "Mask_Head.conv_fcn.0.weight", "Mask_Head.upconv.weight", "Mask_Outs.classify.weight",
-               "Mask_Outs.classify.bias", "RPN.FPN_RPN_conv.weight", "RPN.FPN_RPN_bbox_pred.bias"]
+               "Mask_Outs.classify.bias"]
 
 
 def sample_index(numel, count=256, seed=0):
     return np.random.RandomState(seed).randint(0, numel, size=min(count, numel))
+
+
+class _Replay(torch.nn.Module):
+    """Stands in for a convolution shared by all RPN levels (FPN.py:387-389): returns the next preset tensor."""
+
+    def __init__(self, tensors):
+        super().__init__()
+        self.tensors, self.i = tensors, 0
+
+    def forward(self, x):
+        t = self.tensors[self.i % len(self.tensors)]
+        self.i += 1
+        assert t.shape[2:] == x.shape[2:]
+        return t
+
+
+def substitute_convolutions(ref, feats, logits_np, deltas_np):
+    """Make the reference model see the preset convolution outputs; returns the function that restores it."""
+    body_forward = ref.Conv_Body.forward
+    cls, bbox = ref.RPN.FPN_RPN_cls_score, ref.RPN.FPN_RPN_bbox_pred
+    ref.Conv_Body.forward = lambda x: list(feats)
+    ref.RPN.FPN_RPN_cls_score = _Replay([torch.from_numpy(a).requires_grad_() for a in logits_np])
+    ref.RPN.FPN_RPN_bbox_pred = _Replay([torch.from_numpy(a).requires_grad_() for a in deltas_np])
+
+    def undo():
+        ref.Conv_Body.forward = body_forward
+        ref.RPN.FPN_RPN_cls_score, ref.RPN.FPN_RPN_bbox_pred = cls, bbox
+
+    return undo
 
 
 def main():
@@ -46,26 +78,14 @@ def main():
     entries = [ref_model.roidb_entry(T.H, T.W, b, c, 81) for b, c in zip(boxes, classes)]
     blobs = ref_model.rpn_blobs(entries, [1.0, 1.0], seed=11)
     priority = np.random.RandomState(7).permutation(2 * T.NUM_GT + 2000).astype(np.float32)
-    feats = {}
-    body_forward = ref.Conv_Body.forward
-
-    def keep_features(x):
-        res = body_forward(x)
-        for i, b in enumerate(res):
-            feats[i] = b
-        return res
-
-    ref.Conv_Body.forward = keep_features
+    blobs_np, logits_np, deltas_np = synthetic_conv_outputs(seed=21, n=2)
+    feats = [torch.from_numpy(b).requires_grad_() for b in blobs_np]
+    undo = substitute_convolutions(ref, feats, logits_np, deltas_np)
     ref.zero_grad()
     ret, cap = ref_model.train_forward(ref, torch.from_numpy(data_np), blobs, priority, T.rect_rasterizer)
-    # gradients of the RoI-head losses w.r.t. the pyramid (what the RoIAlign backward delivers; the RPN head's own
-    # contribution to the same maps is left out so that the post-convolution half can be compared in isolation)
-    head_loss = sum(ret["losses"][k].sum() for k in ("loss_cls", "loss_bbox", "loss_mask"))
-    roi_feats = [feats[i] for i in sorted(feats) if i >= len(feats) - 4]
-    feat_grads = torch.autograd.grad(head_loss, roi_feats, retain_graph=True, allow_unused=True)
-    feat_grads = [torch.zeros_like(f) if g is None else g for f, g in zip(roi_feats, feat_grads)]   # level without RoIs
     sum(v.sum() for v in ret["losses"].values()).backward()
-    ref.Conv_Body.forward = body_forward
+    undo()
+    feat_grads = [torch.zeros_like(f) if f.grad is None else f.grad for f in feats[-4:]]   # P5, P4, P3, P2
     out["train_collected_rois"] = cap["rois"]
     b = cap["blobs"]
     out["train_rois"] = b["rois"]
@@ -99,8 +119,11 @@ def main():
     # ---- inference ----
     ref.eval()
     _, _, data_eval = T.scenario(seed=9)
+    blobs_np, logits_np, deltas_np = synthetic_conv_outputs(seed=22, n=1)
+    undo = substitute_convolutions(ref, [torch.from_numpy(b) for b in blobs_np], logits_np, deltas_np)
     with torch.no_grad():
         want = ref(torch.from_numpy(data_eval[:1]), torch.tensor([[float(T.H), float(T.W), 1.0]]))
+    undo()
     out["eval_rois"] = want["rois"]
     cls = want["cls_score"].numpy()
     bbox = want["bbox_pred"].numpy()

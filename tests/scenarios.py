@@ -1,0 +1,29 @@
+"""Seeded inputs shared by tests/test_model_cpu.py, tests/test_e2e_gpu.py and tests/golden/generate_model.py (numpy
+RandomState streams are identical on every machine)."""
+import numpy as np
+
+H, W, NUM_GT = 256, 320, 4
+
+
+def scenario(seed=5):
+    """Two small images with gt boxes that spread over FPN levels 2-4: (boxes per image, classes per image, image blob)."""
+    rng = np.random.RandomState(seed)
+    boxes, classes = [], []
+    for _ in range(2):
+        bw, bh = rng.uniform(24, 250, NUM_GT), rng.uniform(24, 200, NUM_GT)
+        x1, y1 = rng.uniform(0, W - 1 - bw), rng.uniform(0, H - 1 - bh)
+        boxes.append(np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32))
+        classes.append(rng.randint(1, 81, NUM_GT).astype(np.int32))
+    data = (rng.randn(2, 3, H, W) * 50).astype(np.float32)
+    return boxes, classes, data
+
+
+def synthetic_conv_outputs(seed, n, h=H, w=W):
+    """Seeded stand-ins for the outputs of the convolutions: pyramid blobs [P6, P5, P4, P3, P2] (256 channels), and per
+    RPN level 2..6 the objectness logits [n,3,h,w] and box deltas [n,12,h,w]."""
+    rng = np.random.RandomState(seed)
+    sizes = [(h // s, w // s) for s in (64, 32, 16, 8, 4)]
+    blobs = [(rng.randn(n, 256, a, b) * 0.5).astype(np.float32) for a, b in sizes]
+    logits = [(rng.randn(n, 3, a, b) * 2.0).astype(np.float32) for a, b in reversed(sizes)]        # level 2 .. 6
+    deltas = [(rng.randn(n, 12, a, b) * 0.3).astype(np.float32) for a, b in reversed(sizes)]
+    return blobs, logits, deltas

@@ -27,20 +27,7 @@ from oracle import ref_model  # noqa: E402
 
 pytestmark = pytest.mark.skipif(not ref_model.available(), reason="needs /root/reference and oracle/_ref")
 
-H, W, NUM_GT = 256, 320, 4
-
-
-def scenario(seed=5):
-    """Two small images with gt boxes that spread over FPN levels 2-4."""
-    rng = np.random.RandomState(seed)
-    boxes, classes = [], []
-    for _ in range(2):
-        bw, bh = rng.uniform(24, 250, NUM_GT), rng.uniform(24, 200, NUM_GT)
-        x1, y1 = rng.uniform(0, W - 1 - bw), rng.uniform(0, H - 1 - bh)
-        boxes.append(np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32))
-        classes.append(rng.randint(1, 81, NUM_GT).astype(np.int32))
-    data = (rng.randn(2, 3, H, W) * 50).astype(np.float32)
-    return boxes, classes, data
+from scenarios import H, W, NUM_GT, scenario  # noqa: E402
 
 
 @pytest.fixture(scope="module")
