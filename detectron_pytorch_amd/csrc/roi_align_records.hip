@@ -63,20 +63,30 @@ __device__ __forceinline__ int level_of(const int* __restrict__ levels, int i, c
   return levels != nullptr ? min(max(levels[i], 0), lv.count - 1) : 0;
 }
 
-// level (2 bits) | image (6 bits) | band (8) | x (16): RoIs of one level and image are contiguous in the sweep
-__device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int lvl, float spatial_scale, int height) {
+// level (2 bits) | image (6 bits) | band (8) | x (16): RoIs of one level and image are contiguous in the sweep.
+// order_mode (tuning, MI_ROI_ALIGN_FWD_GROUP): 0 = plain sweep; 1 = largest window first (longest-processing-time order:
+// tests how much of the kernel time is the tail of the biggest RoIs; no locality); 2 = three size classes, large first,
+// sweep order inside a class (band in 6 bits).
+__device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int lvl, float spatial_scale, int height,
+                                              int order_mode) {
   const float cy = (roi[2] + roi[4]) * 0.5f * spatial_scale, cx = (roi[1] + roi[3]) * 0.5f * spatial_scale;
   const int b = (lvl << 6) | min(max((int)roi[0], 0), 63);
   const int y = min(max((int)cy, 0), max(height - 1, 0)), band = min(y / kBandRows, 255);
   int x = min(max((int)(cx * 16.f), 0), 65535);
   if (band & 1) x = 65535 - x;
+  if (order_mode != 0) {
+    const float area = fmaxf((roi[3] - roi[1]) * spatial_scale, 1.f) * fmaxf((roi[4] - roi[2]) * spatial_scale, 1.f);
+    if (order_mode == 1) return ((unsigned)b << 24) | (0xffffffu - (unsigned)min(max((int)area, 0), 0xffffff));
+    const unsigned cls = area >= 400.f ? 0u : (area >= 144.f ? 1u : 2u);
+    return ((unsigned)b << 24) | (cls << 22) | ((unsigned)min(band, 63) << 16) | (unsigned)x;
+  }
   return ((unsigned)b << 24) | ((unsigned)band << 16) | (unsigned)x;
 }
 
 __global__ void __launch_bounds__(256)
 roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels, int num_rois, int batch,
                   const LevelTable lv, int aligned_height, int aligned_width, int sampling_ratio, int cap_px,
-                  int stage_px, int max_rows_tile, int* __restrict__ ws) {
+                  int stage_px, int max_rows_tile, int order_mode, int* __restrict__ ws) {
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x < kCounterDwords) ws[threadIdx.x] = 0;
@@ -90,7 +100,7 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
   const int lvl = __builtin_amdgcn_readfirstlane(level_of(levels, r_safe, lv));
   for (int i = threadIdx.x; i < num_rois; i += 256) {
     const int l = level_of(levels, i, lv);
-    keys[i] = sweep_key(rois + (long long)i * 5, l, lv.scale[l], lv.height[l]);
+    keys[i] = sweep_key(rois + (long long)i * 5, l, lv.scale[l], lv.height[l], order_mode);
   }
   __syncthreads();
   if (r >= num_rois) return;
@@ -722,10 +732,14 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
       if (lr >= 0 && lr <= wy1 - wy0 && lc >= 0 && lc < ww) {
         const int sa = yfirst[lr], sb = yfirst[lr + 1];
         const int sp = lr > 0 ? yfirst[lr - 1] : 0;
-        for (int sidx = sp; sidx < sb; sidx++) {
-          const TabEntry ey = ty[sidx];
-          const float wgt = sidx < sa ? ey.lw : ey.hw;
-          const int ph = kSR > 0 ? sidx / (kSR > 0 ? kSR : 1) : sidx / gh;
+        const int gdiv = kSR > 0 ? kSR : gh;
+        for (int sidx = sp; sidx < sb;) {
+          // the samples of one bin row that tap this feature row share T[ph]: their weights are summed first, so that the
+          // KC-channel row of T is read once per (pixel, bin row) instead of once per sample (pass 2 is LDS-bound)
+          const int ph = sidx / gdiv;
+          const int send = min(sb, (ph + 1) * gdiv);
+          float wgt = 0.f;
+          for (; sidx < send; sidx++) wgt += sidx < sa ? ty[sidx].lw : ty[sidx].hw;
           // T is [ph][col][channel] with a column stride of KC + 4 words: the lane's KC channels are KC / 4
           // conflict-free ds_read_b128 (16-lane groups land on 16 distinct 4-bank slots)
           const float4* tp = reinterpret_cast<const float4*>(T + (ph * kTW + pcol) * kCS);
@@ -822,7 +836,8 @@ int launch_prepare(const float* rois, const int* levels, int* ws, int batch, con
                    int aligned_height, int aligned_width, int sampling_ratio, int cap_px, hipStream_t stream) {
   const int max_rows_tile = kTileBins / aligned_width;
   roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
-      rois, levels, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile, ws);
+      rois, levels, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile,
+      tuning().fwd_group, ws);
   return check_launch("roi_align_prepare");
 }
 
@@ -864,7 +879,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   const int th = tuning().bwd_tile_rows;  // rows per tile (16; 8 and 32 measured slower): 32 * th lanes per workgroup
   const int g_ablate_p = tuning().ablate;
   // channels per workgroup: 32 accumulators per lane while the g block and T fit LDS comfortably, else 16
-  const int kc = (bins <= 64) ? 32 : 16;
+  const int kc = (bins <= 64 && tuning().bwd_batch != 16) ? 32 : 16;   // MI_ROI_ALIGN_BWD_BATCH=16: tuning override
   const int ah_pad = (aligned_height + 3) & ~3;
   const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);  // channel stride of the transposed g block: 4 * odd
   const int g_words = kc * g_cs;

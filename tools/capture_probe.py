@@ -66,8 +66,11 @@ g = torch.cuda.CUDAGraph()
 try:
     with torch.cuda.graph(g, capture_error_mode="relaxed"):
         out = fn()
-    g.replay()
-    torch.cuda.synchronize()
+    for i in range(int(os.environ.get("REPLAYS", "1"))):
+        g.replay()
+        torch.cuda.synchronize()
+        if piece in ("fwd_bwd", "full_step") and i % 5 == 0:
+            print("replay", i, "loss", float(out[0] if isinstance(out, tuple) else out), flush=True)
     print("CAPTURE_OK", piece, flush=True)
 except Exception as e:  # noqa: BLE001
     import traceback
