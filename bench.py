@@ -21,6 +21,7 @@ Beside the headline (sub-objects, rank 0, N = 1 only; outside the timed region):
                    box head / mask head / backward / optimizer);
   * `inference`    BASELINE config 3: e2e_faster_rcnn_R-50-FPN test-time detection of one image, images/s;
   * `nms`, `inference_path`  the hot-path latencies of round 1 (BASELINE config 1 and the post-convolution glue);
+  * `config5_x101_mask_keypoint`  BASELINE config 5 on one rank (X-101-64x4d-FPN, mask + keypoint heads), images/s;
   * `bf16_autocast` the same step with the convolutions / GEMMs under bf16 autocast (RoI operators stay fp32);
   * `cpu_baseline` the CPU oracle (test infrastructure) on the host cores on a bounded sample.
 """
@@ -114,25 +115,26 @@ class TrainHarness:
     """One rank of the data-parallel job: model, resident minibatch, optimizer, gradient reducer, and the step in its
     two launch forms."""
 
-    def __init__(self, device, rank, world, dtype, launch):
+    def __init__(self, device, rank, world, dtype, launch, cfg=None, images_per_rank=IMAGES_PER_RANK):
         from detectron_pytorch_amd import parallel
         from detectron_pytorch_amd.rcnn import config, data as rdata, model as rmodel, train as rtrain
 
         self.device, self.world, self.launch = device, world, launch
         self.rtrain = rtrain
-        cfg = config.mask_rcnn_r50_fpn()
+        self.images = images_per_rank
+        cfg = config.mask_rcnn_r50_fpn() if cfg is None else cfg
         cfg.NUM_GPUS = world
         self.cfg = cfg
         torch.manual_seed(cfg.RNG_SEED)                   # every rank starts from the same weights (a replica)
         self.net = rmodel.GeneralizedRCNN(cfg).to(device)
         self.net.train()
         self.autocast = torch.bfloat16 if dtype == "bf16" else None
-        batch = rdata.synthetic_minibatch(cfg, IMAGES_PER_RANK, seed=rank)      # per-rank images (weak scaling)
+        batch = rdata.synthetic_minibatch(cfg, images_per_rank, seed=rank)      # per-rank images (weak scaling)
         self.data, self.im_info, self.roidb, self.rpn_targets = rdata.to_device(batch, device)
         # the reference's learning-rate rule: the yaml's BASE_LR is for NUM_GPUS x IMS_PER_BATCH = 16 images and is
         # rescaled linearly to the actual batch (tools/train_net_step.py:166-201); first iteration of the warm-up
         # (SOLVER.WARM_UP_FACTOR = 1/3, config.py:560)
-        lr = cfg.SOLVER.BASE_LR * (IMAGES_PER_RANK * world) / 16.0 / 3.0
+        lr = cfg.SOLVER.BASE_LR * (images_per_rank * world) / 16.0 / 3.0
         self.opt = rtrain.make_optimizer(self.net, cfg, lr=lr)
         self.reducer = parallel.GradientAllReducer(self.net.parameters(), overlap=(launch == "eager"))
         self.params = sum(p.numel() for p in self.net.parameters() if p.requires_grad)
@@ -428,6 +430,30 @@ def cpu_baseline(images_per_rank):
             **extra}
 
 
+def config5(device, rank, args, steps=5):
+    """BASELINE config 5 on one rank: e2e_mask_rcnn_X-101-64x4d-FPN (grouped 3x3 convolutions, 64 groups x 4) with the
+    keypoint head of e2e_keypoint_rcnn_X-101-64x4d-FPN (8 x 3x3 512 + 4x4 deconv + 2x bilinear -> 56x56), 1 image per
+    rank (TRAIN.IMS_PER_BATCH 1 in the yaml), box + mask + keypoint RoIAlign, 8 instances with 17 keypoints each."""
+    from detectron_pytorch_amd.rcnn import config
+
+    try:
+        work = TrainHarness(device, rank, 1, args.dtype, "eager", cfg=config.mask_keypoint_rcnn_x101_64x4d_fpn(),
+                            images_per_rank=1)
+        for _ in range(3):
+            work.eager_step()
+        first = float(work.last)
+        sec = timed_loop(work.step, steps, 1, 1, device) / steps
+        out = {"workload": "e2e_mask_rcnn_X-101-64x4d-FPN + keypoint head training step, 1 image/rank 1333x800, 512 RoIs, "
+                           "<=128 mask and <=128 keypoint RoIs", "images_per_s": round(1.0 / sec, 2),
+               "ms_per_step": round(sec * 1e3, 2), "trainable_params": work.params, "dtype": args.dtype,
+               "loss_first": round(first, 4), "loss_last": round(float(work.last), 4)}
+        del work
+        torch.cuda.empty_cache()
+        return out
+    except Exception as exc:  # noqa: BLE001
+        return {"error": repr(exc)[:300]}
+
+
 def selftest_cpu(args, rank, world):
     """The rank / reducer / timing / JSON plumbing on the gloo backend with a toy model (no GPU, no HIP operator)."""
     from detectron_pytorch_amd import parallel
@@ -524,6 +550,7 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as exc:  # noqa: BLE001
                     line["bf16_autocast"] = {"error": repr(exc)}
+            line["config5_x101_mask_keypoint"] = config5(device, rank, args)
             line["nms"] = hp.nms_latency(device, args.kernel_iters)
             line["inference_path"] = hp.inference_path(device)
         if not args.no_cpu_baseline and world == 1:

@@ -156,7 +156,7 @@ def add_rpn_blobs(cfg, roidb, im_scales, rng, bbox_overlaps=bbox_overlaps_np):
     return out
 
 
-def synthetic_roidb(num_images, height=800, width=1333, boxes_per_image=8, num_classes=81, seed=0):
+def synthetic_roidb(num_images, height=800, width=1333, boxes_per_image=8, num_classes=81, seed=0, num_keypoints=0):
     """`boxes_per_image` ground-truth boxes per image with sides U(32, 400), classes
     U{1..num_classes-1}, no crowd regions; each instance's mask is its own rectangle."""
     rng = np.random.RandomState(seed)
@@ -167,9 +167,15 @@ def synthetic_roidb(num_images, height=800, width=1333, boxes_per_image=8, num_c
         x1 = rng.uniform(0, width - 1 - bw)
         y1 = rng.uniform(0, height - 1 - bh)
         boxes = np.stack([x1, y1, x1 + bw, y1 + bh], axis=1).astype(np.float32)
-        roidb.append(dict(height=height, width=width, boxes=boxes,
-                          gt_classes=rng.randint(1, num_classes, boxes_per_image).astype(np.int32),
-                          is_crowd=np.zeros(boxes_per_image, dtype=bool)))
+        entry = dict(height=height, width=width, boxes=boxes,
+                     gt_classes=rng.randint(1, num_classes, boxes_per_image).astype(np.int32),
+                     is_crowd=np.zeros(boxes_per_image, dtype=bool))
+        if num_keypoints:
+            # (x, y, visibility) per keypoint, uniformly inside the instance's box, all labelled visible (COCO v = 2)
+            kx = boxes[:, 0:1] + rng.uniform(0, 1, (boxes_per_image, num_keypoints)) * bw[:, None]
+            ky = boxes[:, 1:2] + rng.uniform(0, 1, (boxes_per_image, num_keypoints)) * bh[:, None]
+            entry["gt_keypoints"] = np.stack([kx, ky, np.full_like(kx, 2.0)], axis=1).astype(np.int32)
+        roidb.append(entry)
     return roidb
 
 
@@ -178,12 +184,15 @@ def synthetic_minibatch(cfg, num_images, seed=0, blob_height=800, blob_width=134
     the wide RPN blobs and the roidb tensors the labelling needs.  Scale 1.0: a 1333x800 image padded to the /32 blob
     (utils/blob.py:97-100)."""
     rng = np.random.RandomState(seed + 1000)
-    roidb = synthetic_roidb(num_images, blob_height, image_width, num_classes=cfg.MODEL.NUM_CLASSES, seed=seed)
+    roidb = synthetic_roidb(num_images, blob_height, image_width, num_classes=cfg.MODEL.NUM_CLASSES, seed=seed,
+                            num_keypoints=cfg.KRCNN.NUM_KEYPOINTS if cfg.MODEL.KEYPOINTS_ON else 0)
     batch = add_rpn_blobs(cfg, roidb, [1.0] * num_images, rng)
     batch["data"] = (rng.randn(num_images, 3, blob_height, blob_width) * 50).astype(np.float32)
     batch["gt_boxes"] = np.concatenate([e["boxes"] for e in roidb])
     batch["gt_classes"] = np.concatenate([e["gt_classes"] for e in roidb]).astype(np.int64)
     batch["gt_image"] = np.concatenate([np.full(len(e["boxes"]), i, dtype=np.int64) for i, e in enumerate(roidb)])
+    if cfg.MODEL.KEYPOINTS_ON:
+        batch["gt_keypoints"] = np.concatenate([e["gt_keypoints"] for e in roidb])
     return batch
 
 
@@ -194,6 +203,7 @@ def to_device(batch, device, channels_last=False):
     data = torch.from_numpy(batch["data"]).to(device)
     if channels_last:
         data = data.contiguous(memory_format=torch.channels_last)
-    roidb = {k: torch.from_numpy(batch[k]).to(device) for k in ("gt_boxes", "gt_classes", "gt_image")}
+    roidb = {k: torch.from_numpy(batch[k]).to(device) for k in ("gt_boxes", "gt_classes", "gt_image", "gt_keypoints")
+             if k in batch}
     rpn = {k: torch.from_numpy(v).to(device) for k, v in batch.items() if k.startswith("rpn_")}
     return data, torch.from_numpy(batch["im_info"]).to(device), roidb, rpn

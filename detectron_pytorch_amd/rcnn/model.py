@@ -138,7 +138,8 @@ class GeneralizedRCNN(nn.Module):
                 priority = torch.rand(roidb["gt_boxes"].size(0) + rois.size(0), device=device)
             blobs = targets.label_proposals(cfg, rois, roidb["gt_boxes"], roidb["gt_classes"], roidb["gt_image"],
                                             im_info_d[:, 2], priority, n_img, self.iou_fn, roi_valid=valid,
-                                            gt_mask_boxes=roidb.get("gt_mask_boxes"))
+                                            gt_mask_boxes=roidb.get("gt_mask_boxes"),
+                                            gt_keypoints=roidb.get("gt_keypoints"))
         self._mark("proposals_labelling")
         box_feat = self.Box_Head(roi_blobs, blobs)
         cls_score, bbox_pred = self.Box_Outs(box_feat)
@@ -160,6 +161,13 @@ class GeneralizedRCNN(nn.Module):
                 if cfg.MRCNN.CLS_SPECIFIC_MASK else \
                 heads.mask_rcnn_losses(mask_pred.float(), blobs["masks_int32"], cfg.MRCNN.WEIGHT_LOSS_MASK)
             self._mark("mask_head_loss")
+        if cfg.MODEL.KEYPOINTS_ON:
+            kps_pred = self.Keypoint_Outs(self.Keypoint_Head(roi_blobs, blobs))
+            norm = None if cfg.KRCNN.NORMALIZE_BY_VISIBLE_KEYPOINTS else blobs["keypoint_loss_normalizer"]
+            losses["loss_kps"] = heads.keypoint_losses(kps_pred.float(), blobs["keypoint_locations_int32"],
+                                                       blobs["keypoint_weights"], cfg.KRCNN.HEATMAP_SIZE,
+                                                       cfg.KRCNN.LOSS_WEIGHT, norm)
+            self._mark("keypoint_head_loss")
         ret["losses"], ret["metrics"] = losses, metrics
         ret["blobs"], ret["collected_rois"], ret["collected_valid"] = blobs, rois, valid
         return ret

@@ -88,8 +88,27 @@ def expand_to_class_specific_mask_targets(masks, mask_class_labels, num_classes)
     return out.reshape(n, num_classes * mm)
 
 
+def keypoints_to_heatmap_labels(keypoints, rois, heatmap_size):
+    """utils/keypoints.py:160-211: keypoints [n,3,K] (x, y, visibility) and their RoIs [n,4] (same coordinates) ->
+    (heat-map cell index [n,K] float32, weight [n,K] float32).  A keypoint exactly on the RoI's right / bottom edge is
+    moved into the last cell (:184-197); invisible keypoints and keypoints outside the map weigh 0."""
+    x, y, vis = keypoints[:, 0, :].to(torch.float32), keypoints[:, 1, :].to(torch.float32), keypoints[:, 2, :] > 0
+    off_x, off_y = rois[:, 0:1], rois[:, 1:2]
+    scale_x = heatmap_size / (rois[:, 2:3] - rois[:, 0:1])
+    scale_y = heatmap_size / (rois[:, 3:4] - rois[:, 1:2])
+    on_right, on_bottom = x == rois[:, 2:3], y == rois[:, 3:4]
+    hx = torch.floor((x - off_x) * scale_x)
+    hy = torch.floor((y - off_y) * scale_y)
+    hx = torch.where(on_right, torch.full_like(hx, heatmap_size - 1), hx)
+    hy = torch.where(on_bottom, torch.full_like(hy, heatmap_size - 1), hy)
+    valid = (hx >= 0) & (hy >= 0) & (hx < heatmap_size) & (hy < heatmap_size) & vis
+    validf = valid.to(torch.float32)
+    lin = hy * heatmap_size + hx
+    return torch.where(valid, lin, torch.zeros_like(lin)), validf
+
+
 def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, im_scales, priority, num_images, iou_fn,
-                    roi_valid=None, gt_mask_boxes=None):
+                    roi_valid=None, gt_mask_boxes=None, gt_keypoints=None):
     """Label and sample the collected proposals of a minibatch.
 
     rois       [R,5] float32  (image index, x1, y1, x2, y2) in network-input coordinates, collect order
@@ -99,13 +118,17 @@ def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, im_scales, priori
     priority   [G+R] float32  sampling priority of every candidate, gt first (unique values; lower = drawn first)
     roi_valid  [R] bool       rows of `rois` that are real (static-shape collect); None = all
     gt_mask_boxes [G,4]       the rectangles that are the instances' masks (default: the gt boxes themselves)
+    gt_keypoints [G,3,K]      (x, y, visibility) of every instance's keypoints in original image coordinates
+                              (MODEL.KEYPOINTS_ON)
 
     Returns a dict of device tensors, rows [i * B, (i + 1) * B) belonging to image i (B = BATCH_SIZE_PER_IM, F mask rows
     per image):
       rois [N*B,5], labels_int32 [N*B] (-1 = padding), bbox_targets / bbox_inside_weights / bbox_outside_weights [N*B,4K],
       num_rois [N] (real rows per image), num_fg [N],
       mask_rois [N*F,5], mask_class [N*F] (0 = padding), masks_int32 [N*F, M*M] (-1 rows = padding), roi_has_mask_int32,
-      rois_levels / mask_rois_levels (int32 FPN level of every row, utils/fpn.py:11-28)
+      rois_levels / mask_rois_levels (int32 FPN level of every row, utils/fpn.py:11-28);
+      with keypoints: keypoint_rois [N*F,5], keypoint_locations_int32 / keypoint_weights [N*F*K], keypoint_rois_levels,
+      keypoint_loss_normalizer (roi_data/keypoint_rcnn.py:33-106)
     """
     t = cfg.TRAIN
     dev, f32 = rois.device, torch.float32
@@ -201,4 +224,45 @@ def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, im_scales, priori
         out["roi_has_mask_int32"] = (labels > 0).to(torch.int32)
         out["mask_rois_levels"] = map_rois_to_fpn_levels(out["mask_rois"][:, 1:5], cfg.FPN.ROI_MIN_LEVEL,
                                                          cfg.FPN.ROI_MAX_LEVEL)
+    if cfg.MODEL.KEYPOINTS_ON:
+        # --- roi_data/keypoint_rcnn.py:33-89: candidates with IoU >= FG_THRESH whose assigned instance has a visible
+        # keypoint inside the candidate box; at most fg_per_image of them per image -- all of them in candidate order
+        # when they fit, else "the first fg_per_image of the permutation" (np.random.choice, :52-54)
+        hm = cfg.KRCNN.HEATMAP_SIZE
+        kps = gt_keypoints.to(f32)                                            # [G,3,K]
+        nk = kps.size(2)
+        ckp = kps[assign]                                                     # candidate -> its instance's keypoints
+        inside = (ckp[:, 0, :] >= cand_boxes[:, 0:1]) & (ckp[:, 0, :] <= cand_boxes[:, 2:3]) \
+            & (ckp[:, 1, :] >= cand_boxes[:, 1:2]) & (ckp[:, 1, :] <= cand_boxes[:, 3:4])
+        is_visible = ((ckp[:, 2, :] > 0) & inside).any(dim=1)
+        kfg = (max_ov >= t.FG_THRESH) & is_visible & cand_valid
+        kseg = torch.where(kfg, cand_img, torch.full_like(cand_img, n_img))
+        kcounts = (kseg.view(-1, 1) == torch.arange(n_img, device=dev).view(1, -1)).sum(dim=0)      # [N]
+        too_many = (kcounts > fg_per_image)[cand_img.clamp_max(n_img - 1)]
+        index_key = torch.arange(g + r, device=dev, dtype=f32)
+        prio_rank = torch.empty(g + r, device=dev, dtype=f32)
+        prio_rank[by_prio] = index_key
+        key = torch.where(too_many, prio_rank, index_key)
+        k1 = torch.argsort(key, stable=True)
+        korder = k1[torch.argsort(kseg[k1], stable=True)]                     # (image, key)-sorted; non-candidates last
+        kstarts = torch.cumsum(kcounts, 0) - kcounts
+        n_kp = torch.clamp_max(kcounts, fg_per_image)
+        kslot = torch.arange(fg_per_image, device=dev).view(1, -1)
+        khas = kslot < n_kp.view(-1, 1)
+        ksrc = korder[torch.where(khas, kstarts.view(-1, 1) + kslot, torch.zeros_like(kslot)).clamp_(0, max(g + r - 1, 0))]
+        kboxes = cand_boxes[ksrc.reshape(-1)] * khas.view(-1, 1).to(f32)
+        skp = ckp[ksrc.reshape(-1)]                                           # [N*F,3,K]
+        heats, kweights = keypoints_to_heatmap_labels(skp, kboxes, hm)
+        kweights = kweights * khas.view(-1, 1).to(f32)
+        heats = heats * khas.view(-1, 1).to(f32)
+        kimg_col = torch.where(khas, torch.arange(n_img, device=dev).view(-1, 1), -1).to(f32).reshape(-1, 1)
+        kscale = im_scales.to(f32).view(-1, 1).expand(n_img, fg_per_image).reshape(-1, 1)
+        out["keypoint_rois"] = torch.cat([kimg_col, kboxes * kscale], dim=1)
+        out["keypoint_locations_int32"] = heats.reshape(-1).to(torch.int32)
+        out["keypoint_weights"] = kweights.reshape(-1)
+        out["num_keypoint_rois"] = n_kp
+        out["keypoint_rois_levels"] = map_rois_to_fpn_levels(out["keypoint_rois"][:, 1:5], cfg.FPN.ROI_MIN_LEVEL,
+                                                             cfg.FPN.ROI_MAX_LEVEL)
+        # keypoint_rcnn.py:92-106 (used when KRCNN.NORMALIZE_BY_VISIBLE_KEYPOINTS is off)
+        out["keypoint_loss_normalizer"] = kweights.sum() / (t.IMS_PER_BATCH * t.BATCH_SIZE_PER_IM * t.FG_FRACTION * nk)
     return out

@@ -180,7 +180,7 @@ def bind_rect_rasterizer(fn):
 
 
 # ---- executing the reference's training forward on the CPU --------------------------------------------------------------
-def roidb_entry(height, width, boxes, classes, num_classes):
+def roidb_entry(height, width, boxes, classes, num_classes, keypoints=None):
     """A ground-truth-only roidb entry as datasets/json_dataset.py:178-262 builds it (rectangular polygon masks)."""
     import numpy as np
     import scipy.sparse
@@ -192,10 +192,14 @@ def roidb_entry(height, width, boxes, classes, num_classes):
     ov[np.arange(n), classes] = 1.0
     segms = [[[float(b[0]), float(b[1]), float(b[2]), float(b[1]), float(b[2]), float(b[3]), float(b[0]), float(b[3])]]
              for b in boxes]
-    return dict(height=height, width=width, flipped=False, boxes=boxes, segms=segms,
-                seg_areas=((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).astype(np.float32),
-                gt_classes=classes, gt_overlaps=scipy.sparse.csr_matrix(ov), is_crowd=np.zeros(n, dtype=bool),
-                box_to_gt_ind_map=np.arange(n, dtype=np.int32))
+    entry = dict(height=height, width=width, flipped=False, boxes=boxes, segms=segms,
+                 seg_areas=((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).astype(np.float32),
+                 gt_classes=classes, gt_overlaps=scipy.sparse.csr_matrix(ov), is_crowd=np.zeros(n, dtype=bool),
+                 box_to_gt_ind_map=np.arange(n, dtype=np.int32))
+    if keypoints is not None:          # json_dataset.py:264-272: [n, 3, K] int32 (x, y, visibility)
+        entry["gt_keypoints"] = np.asarray(keypoints, dtype=np.int32)
+        entry["has_visible_keypoints"] = bool((entry["gt_keypoints"][:, 2, :] > 0).any())
+    return entry
 
 
 def rpn_blobs(entries, im_scales, seed):
@@ -261,11 +265,25 @@ def train_forward(model, data, blobs, priority, rasterizer):
 
     json_dataset.add_proposals, frcn._sample_rois, frcn.npr = add_proposals, sample_rois, Npr
     segm_utils.polys_to_mask_wrt_box, frcn.add_fast_rcnn_blobs = rasterizer, add_blobs
+    # roi_data/keypoint_rcnn.py:52-54 calls np.random.choice directly: same permutation rule
+    import roi_data.keypoint_rcnn as kprcnn
+
+    class _Random(object):
+        choice = staticmethod(Npr.choice)
+
+    class _NumpyProxy(object):
+        random = _Random()
+
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+    orig_kp_np, kprcnn.np = kprcnn.np, _NumpyProxy()
     try:
         roidb_in = [np.frombuffer(pickle.dumps([e]), dtype=np.uint8).astype(np.float32) for e in minimal]   # blob.py:165-169
         kwargs = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in blobs.items() if k.startswith("rpn_")}
         ret = model(data, torch.from_numpy(blobs["im_info"]), roidb_in, **kwargs)
     finally:
+        kprcnn.np = orig_kp_np
         json_dataset.add_proposals, frcn._sample_rois, frcn.npr = orig_add, orig_sample, orig_npr
         segm_utils.polys_to_mask_wrt_box, frcn.add_fast_rcnn_blobs = orig_rast, orig_add_blobs
     return ret, captured

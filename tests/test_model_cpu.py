@@ -214,3 +214,14 @@ def test_inference_forward_and_box_decoding_equal_the_reference(ref_cfg, models)
     assert ref_boxes.dtype == np.float32
     np.testing.assert_allclose(mine_boxes.numpy(), ref_boxes, rtol=0, atol=1e-4)
     assert (np.abs(mine_boxes.numpy() - ref_boxes) > 0).mean() < 0.01   # numpy's fp64 exp vs torch's: last-bit cases only
+
+
+def test_keypoint_branch_equals_the_reference():
+    """tests/ref_keypoint_check.py in a process of its own (the reference's global cfg is configured differently there):
+    e2e_keypoint_rcnn_R-50-FPN_1x.yaml -- seeded weights, Detectron names, keypoint RoI sampling, heat-map targets, loss,
+    gradients."""
+    import subprocess
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_keypoint_check.py")], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "KEYPOINT_PARITY_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
