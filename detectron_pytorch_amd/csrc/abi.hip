@@ -37,8 +37,6 @@ Tuning read_tuning() {
   t.nhwc_order_mul = om > 0 ? om : 1;
   t.nhwc_zigzag = env_int("MI_ROI_ALIGN_NHWC_ZIGZAG", 1);
   t.ablate = MI_ABLATE(env_int("MI_ROI_ALIGN_ABLATE", 0));
-  t.fwd_group = env_int("MI_ROI_ALIGN_FWD_GROUP", 0);
-  t.bwd_batch = env_int("MI_ROI_ALIGN_BWD_BATCH", 0);
   return t;
 }
 }  // namespace

@@ -60,7 +60,6 @@ struct Tuning {
   int cap_px, bwd_tile_rows;
   int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag;
   int ablate;
-  int fwd_group, bwd_batch;  // experimental variants (0 = default)
 };
 const Tuning& tuning();
 void reload_tuning();  // mi_dbg_reload_tuning() only

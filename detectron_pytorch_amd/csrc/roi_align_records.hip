@@ -63,30 +63,20 @@ __device__ __forceinline__ int level_of(const int* __restrict__ levels, int i, c
   return levels != nullptr ? min(max(levels[i], 0), lv.count - 1) : 0;
 }
 
-// level (2 bits) | image (6 bits) | band (8) | x (16): RoIs of one level and image are contiguous in the sweep.
-// order_mode (tuning, MI_ROI_ALIGN_FWD_GROUP): 0 = plain sweep; 1 = largest window first (longest-processing-time order:
-// tests how much of the kernel time is the tail of the biggest RoIs; no locality); 2 = three size classes, large first,
-// sweep order inside a class (band in 6 bits).
-__device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int lvl, float spatial_scale, int height,
-                                              int order_mode) {
+// level (2 bits) | image (6 bits) | band (8) | x (16): RoIs of one level and image are contiguous in the sweep
+__device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int lvl, float spatial_scale, int height) {
   const float cy = (roi[2] + roi[4]) * 0.5f * spatial_scale, cx = (roi[1] + roi[3]) * 0.5f * spatial_scale;
   const int b = (lvl << 6) | min(max((int)roi[0], 0), 63);
   const int y = min(max((int)cy, 0), max(height - 1, 0)), band = min(y / kBandRows, 255);
   int x = min(max((int)(cx * 16.f), 0), 65535);
   if (band & 1) x = 65535 - x;
-  if (order_mode != 0) {
-    const float area = fmaxf((roi[3] - roi[1]) * spatial_scale, 1.f) * fmaxf((roi[4] - roi[2]) * spatial_scale, 1.f);
-    if (order_mode == 1) return ((unsigned)b << 24) | (0xffffffu - (unsigned)min(max((int)area, 0), 0xffffff));
-    const unsigned cls = area >= 400.f ? 0u : (area >= 144.f ? 1u : 2u);
-    return ((unsigned)b << 24) | (cls << 22) | ((unsigned)min(band, 63) << 16) | (unsigned)x;
-  }
   return ((unsigned)b << 24) | ((unsigned)band << 16) | (unsigned)x;
 }
 
 __global__ void __launch_bounds__(256)
 roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels, int num_rois, int batch,
                   const LevelTable lv, int aligned_height, int aligned_width, int sampling_ratio, int cap_px,
-                  int stage_px, int max_rows_tile, int order_mode, int* __restrict__ ws) {
+                  int stage_px, int max_rows_tile, int* __restrict__ ws) {
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x < kCounterDwords) ws[threadIdx.x] = 0;
@@ -100,7 +90,7 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
   const int lvl = __builtin_amdgcn_readfirstlane(level_of(levels, r_safe, lv));
   for (int i = threadIdx.x; i < num_rois; i += 256) {
     const int l = level_of(levels, i, lv);
-    keys[i] = sweep_key(rois + (long long)i * 5, l, lv.scale[l], lv.height[l], order_mode);
+    keys[i] = sweep_key(rois + (long long)i * 5, l, lv.scale[l], lv.height[l]);
   }
   __syncthreads();
   if (r >= num_rois) return;
@@ -555,7 +545,7 @@ struct BwdLds {
 
 // 16-row tiles with 32 channels: 84 VGPRs would cap a SIMD at 5 waves = two 8-wave workgroups per CU; pinning the
 // kernel to 6 waves per SIMD (<= 80 VGPRs) lets the third workgroup the LDS budget allows become resident.
-template <int kSR, int KC, int kTH, bool kV2 = false>
+template <int kSR, int KC, int kTH>
 __global__ void __launch_bounds__(kTH * 32)
     __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
 roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, const int* __restrict__ ws,
@@ -638,14 +628,6 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
 #pragma unroll
     for (int kk = 0; kk < kGP; kk++) {
       const int i = (wave + kNWaves * kk) * 64 + lane;  // LDS word index
-      if (kV2) {
-        // v2 block: [pw][ph][c], channels contiguous (pass 1 reads four channels of one bin with one ds_read_b128);
-        // no padding: a step in pw is aligned_height * KC words = 32 banks (mod 64) for the 7 x 7 x 32 block
-        const int c = i % KC, q = i / KC;
-        const int ph = q % aligned_height, pw = q / aligned_height;
-        gsrc_off[kk] = pw < aligned_width ? (unsigned)(c * bins + ph * aligned_width + pw) * 4u : 0xffffffffu;
-        continue;
-      }
       const int c = i / g_cs, rem = i - c * g_cs;
       const int pw = rem / ah_pad, ph = rem - pw * ah_pad;
       gsrc_off[kk] = (c < KC && rem < per_c && ph < aligned_height) ? (unsigned)(c * bins + ph * aligned_width + pw) * 4u
@@ -669,7 +651,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
 #pragma unroll
     for (int kk = 0; kk < kGP; kk++) {
       const int k = wave + kNWaves * kk;
-      if (k * 64 < g_words && gsrc_off[kk] != 0xffffffffu) dma_dword(gsrd, gdst + (unsigned)k * 256u, gsrc_off[kk], 0u);
+      if (k * 64 < KC * g_cs && gsrc_off[kk] != 0xffffffffu) dma_dword(gsrd, gdst + (unsigned)k * 256u, gsrc_off[kk], 0u);
     }
   };
 
@@ -690,69 +672,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
     const float* g = g0 + buf * g_words;
 
     // ---- pass 1: T[ph][col][c] for the tile columns inside the window ----
-    if (kV2) {
-      // v2: lane = (tile column, four channels): kTW * KC / 4 lanes (half of the workgroup for KC = 32) expand one column
-      // each, reading g with ds_read_b128 ([pw][ph][c] block) and writing T with ds_write_b128 -- 2.7x fewer LDS
-      // instructions than the one-channel mapping below (pass 1 is LDS-instruction bound)
-      constexpr int kC4 = KC / 4;
-      if (tid < kTW * kC4) {
-        const int c4 = tid % kC4, col = tid / kC4;
-        const int lc = x0 + col - wx0;
-        if (lc >= 0 && lc < ww) {
-          const int sa = xfirst[lc], sb = xfirst[lc + 1];
-          const int sp = lc > 0 ? xfirst[lc - 1] : 0;
-          const int kg = kSR > 0 ? kSR : gw;
-          const float4* g4 = reinterpret_cast<const float4*>(g);
-          // merged weight of each output column pw whose samples tap this feature column (the first four in registers;
-          // more only for RoIs narrower than ~5 feature pixels)
-          auto weight_of = [&](int pw) {
-            float wgt = 0.f;
-            for (int ix = 0; ix < kg; ix++) {
-              const int sidx = pw * kg + ix;
-              if (sidx >= sp && sidx < sb) wgt += sidx < sa ? tx[sidx].lw : tx[sidx].hw;
-            }
-            return wgt;
-          };
-          const int pw_lo = sp / kg;
-          float w[4];
-          int npw = 0;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            w[k] = 0.f;
-            if ((pw_lo + k) * kg < sb) {
-              w[k] = weight_of(pw_lo + k);
-              npw = k + 1;
-            }
-          }
-          const bool more = (pw_lo + 4) * kg < sb;
-          for (int ph = 0; ph < aligned_height; ph++) {
-            float4 t = float4{0.f, 0.f, 0.f, 0.f};
-            const float4* gp = g4 + (pw_lo * aligned_height + ph) * kC4 + c4;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              if (k < npw) {
-                const float4 gv = gp[k * aligned_height * kC4];
-                t.x = __builtin_fmaf(w[k], gv.x, t.x);
-                t.y = __builtin_fmaf(w[k], gv.y, t.y);
-                t.z = __builtin_fmaf(w[k], gv.z, t.z);
-                t.w = __builtin_fmaf(w[k], gv.w, t.w);
-              }
-            }
-            if (more) {
-              for (int pw = pw_lo + 4; pw * kg < sb; pw++) {
-                const float wgt = weight_of(pw);
-                const float4 gv = g4[(pw * aligned_height + ph) * kC4 + c4];
-                t.x = __builtin_fmaf(wgt, gv.x, t.x);
-                t.y = __builtin_fmaf(wgt, gv.y, t.y);
-                t.z = __builtin_fmaf(wgt, gv.z, t.z);
-                t.w = __builtin_fmaf(wgt, gv.w, t.w);
-              }
-            }
-            *reinterpret_cast<float4*>(T + (ph * kTW + col) * kCS + c4 * 4) = t;
-          }
-        }
-      }
-    } else if (!(ablate & 1)) {
+    if (!(ablate & 1)) {
       const int c = tid % KC, slot = tid / KC;
       constexpr int kColStep = kThreads / KC;
       for (int col = slot; col < kTW; col += kColStep) {
@@ -805,7 +725,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
         const int gdiv = kSR > 0 ? kSR : gh;
         for (int sidx = sp; sidx < sb;) {
           // the samples of one bin row that tap this feature row share T[ph]: their weights are summed first, so that the
-          // KC-channel row of T is read once per (pixel, bin row) instead of once per sample (pass 2 is LDS-bound)
+          // KC-channel row of T is read once per (pixel, bin row) instead of once per sample
           const int ph = sidx / gdiv;
           const int send = min(sb, (ph + 1) * gdiv);
           float wgt = 0.f;
@@ -906,8 +826,7 @@ int launch_prepare(const float* rois, const int* levels, int* ws, int batch, con
                    int aligned_height, int aligned_width, int sampling_ratio, int cap_px, hipStream_t stream) {
   const int max_rows_tile = kTileBins / aligned_width;
   roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
-      rois, levels, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile,
-      tuning().fwd_group, ws);
+      rois, levels, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile, ws);
   return check_launch("roi_align_prepare");
 }
 
@@ -949,11 +868,10 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   const int th = tuning().bwd_tile_rows;  // rows per tile (16; 8 and 32 measured slower): 32 * th lanes per workgroup
   const int g_ablate_p = tuning().ablate;
   // channels per workgroup: 32 accumulators per lane while the g block and T fit LDS comfortably, else 16
-  const int kc = (bins <= 64 && tuning().bwd_batch != 16) ? 32 : 16;   // MI_ROI_ALIGN_BWD_BATCH=16: tuning override
+  const int kc = (bins <= 64) ? 32 : 16;
   const int ah_pad = (aligned_height + 3) & ~3;
   const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);  // channel stride of the transposed g block: 4 * odd
-  const bool v2 = tuning().bwd_batch != 1;                   // MI_ROI_ALIGN_BWD_BATCH=1: the one-channel pass 1 (A/B)
-  const int g_words = v2 ? ((kc * bins + 63) & ~63) : kc * g_cs;
+  const int g_words = kc * g_cs;
   const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
   const size_t lds = (32 + (size_t)(((num_rois + 1) / 2 + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
   lv.tile_base[0] = 0;
@@ -962,20 +880,12 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   const int grid = lv.tile_base[lv.count] * (channels / kc);
 #define MI_LAUNCH_TILES_TH(SR, KC, TH)                                                                                \
   do {                                                                                                                \
-    if (lds > 64 * 1024) {                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC, TH, true>),               \
+    if (lds > 64 * 1024)                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC, TH>),                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC, TH, false>),              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    }                                                                                                                 \
-    if (v2)                                                                                                           \
-      roi_align_bwd_tiles<SR, KC, TH, true><<<grid, TH * 32, lds, stream>>>(                                         \
-          top_grad, lv, ws, num_rois, batch, channels, aligned_height, aligned_width,                                 \
-          (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs);                               \
-    else                                                                                                              \
-      roi_align_bwd_tiles<SR, KC, TH, false><<<grid, TH * 32, lds, stream>>>(                                        \
-          top_grad, lv, ws, num_rois, batch, channels, aligned_height, aligned_width,                                 \
-          (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs);                               \
+    roi_align_bwd_tiles<SR, KC, TH><<<grid, TH * 32, lds, stream>>>(                                                 \
+        top_grad, lv, ws, num_rois, batch, channels, aligned_height, aligned_width,                                   \
+        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs);                                 \
   } while (0)
 #define MI_LAUNCH_TILES(SR, KC)                                                                                       \
   do {                                                                                                                \

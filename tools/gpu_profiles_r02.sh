@@ -1,0 +1,47 @@
+#!/bin/bash
+# Round-2 profiles (run on the GPU box through gpurun; output gpurun_out/prof_r02/, copy what is judged into profiles/):
+#   1. the judged bench line (plain run: the tracer inflates launch-bound entries)
+#   2. rocprofv3 kernel-trace stats of the eagerly launched training step (bench.py --no-extras)
+#   3. one PMC pass over the same command for the MFMA utilisation of the convolution / GEMM kernels
+#   4. config-2-only kernel durations (run_one_kernel.py: prepare, fwd_records, fwd_nhwc, bwd_tiles) -> one CSV
+#   5. PMC passes (separate runs, --kernel-trace only beside --pmc) over the three config-2 RoIAlign calls
+#   6. FETCH_SIZE calibration for the 4 B / lane LDS-DMA pattern (tools/micro/fetch_calib.hip)
+TAG=r02; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+(cd $R && timeout 900 python bench.py 2> $O/bench_plain.err | grep '^{' | tail -1 > $O/bench_line.json)
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o t -f csv -- python $R/bench.py --no-extras --no-cpu-baseline --steps 10 --warmup 3 > $O/trace_stdout.log 2>&1
+cp $O/trace/*kernel_stats.csv $O/train_step_kernel_stats.csv 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES -d $O/pmc_mfma -o p -- python $R/bench.py --no-extras --no-cpu-baseline --steps 3 --warmup 2 > $O/pmc_mfma_stdout.log 2>&1
+python $R/tools/rocpd_mfma.py $(find $O/pmc_mfma -name '*.db') > $O/train_step_mfma_util.txt 2>&1
+echo "pass,kernel,calls,avg_ns,min_ns,max_ns" > $O/config2_kernel_durations.csv
+for pass in roi_align_fwd roi_align_bwd nhwc_fwd; do
+  if [ $pass = nhwc_fwd ]; then export MI_BENCH_NHWC=1; k=roi_align_fwd; else unset MI_BENCH_NHWC; k=$pass; fi
+  timeout 120 rocprofv3 --kernel-trace --stats -d $O/c2_$pass -o c -f csv -- python $R/tools/run_one_kernel.py $k 50 > $O/c2_$pass.log 2>&1
+  python - $O/c2_$pass $pass >> $O/config2_kernel_durations.csv <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "roi_align" in row["Name"]:
+            name = row["Name"].split("(")[0].replace("void mi::(anonymous namespace)::", "").replace("mi::(anonymous namespace)::", "")
+            print("%s,\"%s\",%s,%.1f,%s,%s" % (sys.argv[2], name, row["Calls"], float(row["AverageNs"]), row["MinNs"], row["MaxNs"]))
+PY
+done
+unset MI_BENCH_NHWC
+j=0
+for grp in "FETCH_SIZE" "WRITE_SIZE TCC_EA0_RDREQ_sum" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS"; do
+  j=$((j+1))
+  timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc$j -o p -- python $R/tools/run_one_kernel.py roi_align_fwd 5 > $O/pmc$j.log 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $O/pmcb$j -o p -- python $R/tools/run_one_kernel.py roi_align_bwd 5 > $O/pmcb$j.log 2>&1
+  MI_BENCH_NHWC=1 timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $O/pmcn$j -o p -- python $R/tools/run_one_kernel.py roi_align_fwd 5 > $O/pmcn$j.log 2>&1
+done
+python $R/tools/rocpd_pmc.py --json $O/pmc_fwd.json $(find $O/pmc[0-9]* -name '*.db') > $O/pmc_roi_align_fwd.txt
+python $R/tools/rocpd_pmc.py --json $O/pmc_bwd.json $(find $O/pmcb[0-9]* -name '*.db') > $O/pmc_roi_align_bwd.txt
+python $R/tools/rocpd_pmc.py --json $O/pmc_nhwc.json $(find $O/pmcn[0-9]* -name '*.db') > $O/pmc_roi_align_fwd_channels_last.txt
+python $R/tools/make_pmc_json.py $TAG $O/pmc_fwd.json $O/pmc_bwd.json $O/pmc_nhwc.json > $O/pmc_roi_align.json
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $O/fetch_calib $R/tools/micro/fetch_calib.hip > /dev/null 2>&1
+for m in 0 1; do
+  timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib$m -o p -- $O/fetch_calib $m > $O/calib$m.log 2>&1
+done
+python $R/tools/rocpd_pmc.py $(find $O/calib0 $O/calib1 -name '*.db') > $O/fetch_size_calibration.txt 2>&1
+rm -rf $O/trace $O/pmc_mfma $O/pmc[0-9]* $O/pmcb[0-9]* $O/pmcn[0-9]* $O/c2_*/ $O/calib[01] $O/fetch_calib
+cut -c1-600 $O/bench_line.json; echo; head -8 $O/train_step_kernel_stats.csv | cut -c1-160; head -12 $O/train_step_mfma_util.txt; cat $O/config2_kernel_durations.csv; cat $O/fetch_size_calibration.txt; grep hbm_bytes $O/pmc_roi_align.json
