@@ -295,11 +295,13 @@ __device__ __forceinline__ unsigned lds_addr_uniform(const void* p) {
 // roi_align_fwd_tile.hip; its per-RoI prologue (geometry, tables, window) is replaced by one scalar load of the
 // record, and workgroups are dispatched in sweep order.
 // -------------------------------------------------------------------------------------------------------------------
-template <int kSR, int kCap, int kCTt, int kHalves>
+// kA > 0: aligned_height == aligned_width == kA at compile time (7: box head, 14: mask / keypoint heads).
+template <int kSR, int kCap, int kCTt, int kHalves, int kA = 0>
 __global__ void __launch_bounds__(kCTt * 8 * kHalves)
 roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
-                      const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height,
-                      int aligned_width, int sampling_ratio, int ablate_arg) {
+                      const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height_arg,
+                      int aligned_width_arg, int sampling_ratio, int ablate_arg) {
+  const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   const int ablate = MI_ABLATE(ablate_arg);
   // kCTt channels per workgroup (32: half-waves own output columns; 16: quarter-waves do, twice as many workgroups
   // fit a CU -- the per-workgroup chain record load -> DMA -> landing -> arithmetic -> store drain is latency, and
@@ -545,12 +547,19 @@ struct BwdLds {
 
 // 16-row tiles with 32 channels: 84 VGPRs would cap a SIMD at 5 waves = two 8-wave workgroups per CU; pinning the
 // kernel to 6 waves per SIMD (<= 80 VGPRs) lets the third workgroup the LDS budget allows become resident.
-template <int kSR, int KC, int kTH>
+// kA > 0: aligned_height == aligned_width == kA at compile time (7 and 14, the sizes of the box / mask heads): the
+// per-lane index arithmetic of the g block (divisions by the channel stride and the padded height, once per workgroup
+// for eight DMA pieces per lane) and the loop bounds of pass 1 fold to constants.
+template <int kSR, int KC, int kTH, int kA = 0>
 __global__ void __launch_bounds__(kTH * 32)
     __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
 roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, const int* __restrict__ ws,
-                    int num_rois, int batch, int channels, int aligned_height, int aligned_width, int overwrite,
-                    int ablate_arg, int g_words, int ah_pad, int g_cs) {
+                    int num_rois, int batch, int channels, int aligned_height_arg, int aligned_width_arg, int overwrite,
+                    int ablate_arg, int g_words_arg, int ah_pad_arg, int g_cs_arg) {
+  const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
+  const int ah_pad = kA > 0 ? ((kA + 3) & ~3) : ah_pad_arg;
+  const int g_cs = kA > 0 ? 4 * ((kA * ((kA + 3) & ~3) / 4) | 1) : g_cs_arg;
+  const int g_words = kA > 0 ? KC * (4 * ((kA * ((kA + 3) & ~3) / 4) | 1)) : g_words_arg;
   const int ablate = MI_ABLATE(ablate_arg);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kTabDw = BwdLds<KC>::kTabDw;
@@ -778,21 +787,34 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
 }
 
 // RoIs the tile kernel does not cover: reference mapping, arithmetic and atomics (roi_align_kernel.cu:195-270).
+// They are rare (windows wider than kMaxWin, more than kMaxS samples per axis), so the grid is small: one workgroup per
+// (group of kSlowGroup ranks, channel tile) walks its ranks and leaves at once when none of them is flagged -- a launch
+// of num_rois x tiles workgroups that all return took 4.8 us at config 2.
+constexpr int kSlowGroup = 64;
 __global__ void __launch_bounds__(256)
 roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__ rois, const LevelTable lv,
                    const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height,
                    int aligned_width, int sampling_ratio, int nhwc) {
   const int tiles = channels / kCT;
-  const int pos = blockIdx.x / tiles;
-  const int c0 = (blockIdx.x - pos * tiles) * kCT;
+  const int group = blockIdx.x / tiles;
+  const int c0 = (blockIdx.x - group * tiles) * kCT;
+  const int bins = aligned_height * aligned_width;
+  const int tid = threadIdx.x;
+  // the flags of the group's ranks in one vector load (lane = rank), then only the flagged ranks are visited
+  unsigned long long todo;
+  {
+    const int p = group * kSlowGroup + (tid & 63);
+    const int f = p < num_rois ? ws[kCounterDwords + (long long)p * kRecDwords] : (int)kFlagZero;
+    todo = __ballot((f & (kFlagBwd | kFlagZero)) == 0);
+  }
+  while (todo != 0ull) {
+  const int pos = group * kSlowGroup + (int)__builtin_ctzll(todo);
+  todo &= todo - 1ull;
   const const_int_ptr rec = (const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)pos * kRecDwords);
-  const int flags = rec[0], r = rec[8], lvl = rec[11];
-  if (flags & (kFlagBwd | kFlagZero)) return;
+  const int r = rec[8], lvl = rec[11];
   float* __restrict__ bottom_grad = lv.grad[lvl];
   const int height = lv.height[lvl], width = lv.width[lvl];
   const float spatial_scale = lv.scale[lvl];
-  const int bins = aligned_height * aligned_width;
-  const int tid = threadIdx.x;
   const float* __restrict__ gsrc = top_grad + ((long long)r * channels + c0) * bins;
   const RoiGeom g = roi_geometry(rois + (long long)r * 5, spatial_scale, aligned_height, aligned_width, sampling_ratio);
   // element strides of (channel, pixel) in the gradient map: NCHW or channels-last
@@ -816,6 +838,7 @@ roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__
       }
     }
   }
+  }
 }
 
 size_t records_lds_bytes(int cap, int ct) {
@@ -837,14 +860,19 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
   int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio, kCap,
                           stream);
   if (rc != MI_OK) return rc;
-#define MI_LAUNCH_REC(SR)                                                                                             \
-  roi_align_fwd_records<SR, kCap, kCT, 1>                                                                             \
+#define MI_LAUNCH_REC(SR, A)                                                                                          \
+  roi_align_fwd_records<SR, kCap, kCT, 1, A>                                                                          \
       <<<num_rois * (channels / kCT), kCT * 8, records_lds_bytes(kCap, kCT), stream>>>(                               \
           lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, tuning().ablate)
-  if (sampling_ratio == 2)
-    MI_LAUNCH_REC(2);
+  const int a = aligned_height == aligned_width ? aligned_height : 0;
+  if (sampling_ratio == 2 && kCap == 336 && a == 7)
+    MI_LAUNCH_REC(2, (kCap == 336 ? 7 : 0));
+  else if (sampling_ratio == 2 && kCap == 336 && a == 14)
+    MI_LAUNCH_REC(2, (kCap == 336 ? 14 : 0));
+  else if (sampling_ratio == 2)
+    MI_LAUNCH_REC(2, 0);
   else
-    MI_LAUNCH_REC(0);
+    MI_LAUNCH_REC(0, 0);
 #undef MI_LAUNCH_REC
   return check_launch("roi_align_fwd_records");
 }
@@ -878,14 +906,23 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   for (int l = 0; l < lv.count; l++)
     lv.tile_base[l + 1] = lv.tile_base[l] + ((lv.width[l] + kTW - 1) / kTW) * ((lv.height[l] + th - 1) / th) * batch;
   const int grid = lv.tile_base[lv.count] * (channels / kc);
-#define MI_LAUNCH_TILES_TH(SR, KC, TH)                                                                                \
+#define MI_LAUNCH_TILES_A(SR, KC, TH, A)                                                                              \
   do {                                                                                                                \
     if (lds > 64 * 1024)                                                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC, TH>),                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC, TH, A>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    roi_align_bwd_tiles<SR, KC, TH><<<grid, TH * 32, lds, stream>>>(                                                 \
+    roi_align_bwd_tiles<SR, KC, TH, A><<<grid, TH * 32, lds, stream>>>(                                              \
         top_grad, lv, ws, num_rois, batch, channels, aligned_height, aligned_width,                                   \
         (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs);                                 \
+  } while (0)
+#define MI_LAUNCH_TILES_TH(SR, KC, TH)                                                                                \
+  do {                                                                                                                \
+    if (TH == 16 && KC == 32 && aligned_height == 7 && aligned_width == 7)                                            \
+      MI_LAUNCH_TILES_A(SR, KC, TH, (TH == 16 && KC == 32 ? 7 : 0));                                                  \
+    else if (TH == 16 && KC == 16 && aligned_height == 14 && aligned_width == 14)                                     \
+      MI_LAUNCH_TILES_A(SR, KC, TH, (TH == 16 && KC == 16 ? 14 : 0));                                                 \
+    else                                                                                                              \
+      MI_LAUNCH_TILES_A(SR, KC, TH, 0);                                                                               \
   } while (0)
 #define MI_LAUNCH_TILES(SR, KC)                                                                                       \
   do {                                                                                                                \
@@ -908,10 +945,11 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   }
 #undef MI_LAUNCH_TILES
 #undef MI_LAUNCH_TILES_TH
+#undef MI_LAUNCH_TILES_A
   int rc = check_launch("roi_align_bwd_tiles");
   if (rc != MI_OK) return rc;
   if (!(g_ablate_p & 16))
-    roi_align_bwd_slow<<<num_rois * (channels / kCT), 256, 0, stream>>>(top_grad, rois, lv, ws, num_rois, batch, channels,
+    roi_align_bwd_slow<<<((num_rois + kSlowGroup - 1) / kSlowGroup) * (channels / kCT), 256, 0, stream>>>(top_grad, rois, lv, ws, num_rois, batch, channels,
                                                                     aligned_height, aligned_width, sampling_ratio,
                                                                     nhwc ? 1 : 0);
   return check_launch("roi_align_bwd_slow");
