@@ -6,6 +6,8 @@ import torch
 import torch.nn as nn
 import torch.nn.init as init
 
+from ..affine_channel import affine_channel
+
 
 class AffineChannel2d(nn.Module):
     """Frozen-BN stand-in `x * w[c] + b[c]` (lib/nn/modules/affine.py:5-17).  Weight ~ U(0,1), bias 0, drawn in that
@@ -17,8 +19,10 @@ class AffineChannel2d(nn.Module):
         self.weight = nn.Parameter(torch.empty(num_features).uniform_())
         self.bias = nn.Parameter(torch.zeros(num_features))
 
-    def forward(self, x):
-        return x * self.weight.view(1, self.num_features, 1, 1) + self.bias.view(1, self.num_features, 1, 1)
+    def forward(self, x, residual=None, relu=False):
+        """`residual` / `relu`: what ResNet.py applies right after this layer (:270-286), folded into the same pass over
+        the activation (csrc/affine_channel.hip) when the tensors are float32 on the GPU."""
+        return affine_channel(x, self.weight, self.bias, residual, relu)
 
 
 def xavier_fill(tensor):

@@ -40,12 +40,17 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
         residual = x if self.downsample is None else self.downsample(x)
-        out += residual
-        return self.relu(out)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=residual, relu=True)     # out += residual; relu (ResNet.py:284-286)
+
+
+class Stem(nn.Sequential):
+    """conv1 -> affine -> relu -> maxpool with the reference's child names; the affine layer applies the ReLU itself."""
+
+    def forward(self, x):
+        return self.maxpool(self.bn1(self.conv1(x), relu=True))
 
 
 def make_stage(inplanes, outplanes, innerplanes, nblocks, cfg, dilation=1, stride_init=2):
@@ -74,7 +79,7 @@ class ResNetBody(nn.Module):
         self.block_counts = block_counts
         self.convX = len(block_counts) + 1
         self.freeze_at = cfg.RESNETS.FREEZE_AT
-        self.res1 = nn.Sequential(OrderedDict([                      # basic_bn_stem, ResNet.py:206-213
+        self.res1 = Stem(OrderedDict([                               # basic_bn_stem, ResNet.py:206-213
             ("conv1", nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)),
             ("bn1", AffineChannel2d(64)),
             ("relu", nn.ReLU(inplace=True)),

@@ -246,6 +246,25 @@ int mi_nms_batched(int num_problems, const float* const* dets, const int* n, flo
 int mi_bbox_overlaps(const float* boxes, int num_boxes, const float* query, int num_query,
                      float* overlaps, mi_stream_t stream);
 
+/* ---- frozen-BatchNorm chain of the ResNet bottleneck in one pass ---------------------------------------------------
+ * replaces, for float32 tensors, the element-wise sequence the reference builds from torch ops:
+ *   AffineChannel2d.forward (lib/nn/modules/affine.py:15-17)   x * weight[c] + bias[c]
+ *   followed by ReLU (lib/modeling/ResNet.py:270-277) or by "out += residual; relu" (:284-286), or by nothing (the
+ *   projection shortcut, :191-199).
+ * forward:  y = relu?(x * weight[c] + bias[c] (+ residual)), operations in that order, no FMA contraction: bit-identical
+ *           to the unfused chain.  residual may be NULL.  y may alias x.
+ * backward: grad_x = grad_y * [y > 0]? * weight[c]; grad_residual (may be NULL) = grad_y * [y > 0]?.  `y` (the forward
+ *           output) is only read when relu != 0.  weight / bias are frozen in every reference configuration
+ *           (ResNet.py:76-77): no gradient is produced for them.
+ * layout: MI_LAYOUT_NCHW (channel = (i / (H*W)) % C) or MI_LAYOUT_NHWC (channel = i % C, C % 4 == 0).
+ * All tensors dense and 16-byte aligned. */
+int mi_affine_channel_forward(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                              int batch, int channels, int height, int width, int relu, int layout,
+                              mi_stream_t stream);
+int mi_affine_channel_backward(const float* grad_y, const float* y, const float* weight, float* grad_x,
+                               float* grad_residual, int batch, int channels, int height, int width, int relu,
+                               int layout, mi_stream_t stream);
+
 /* ---- diagnostics (no reference counterpart) ---------------------------------------------------
  * Tuning aid used by tools/timeline.py: while a non-NULL device buffer of 8 int64 per forward workgroup is set,
  * the self-contained RoIAlign forward kernel stamps s_memtime at its phase boundaries into it. */

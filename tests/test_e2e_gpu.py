@@ -55,7 +55,10 @@ def rel_err(got, want):
     return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
 
 
-def test_training_post_conv_half_matches_the_reference(nets, golden):
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_training_post_conv_half_matches_the_reference(nets, golden, layout):
+    """`channels_last`: the pyramid is stored the way MIOpen's NHWC convolutions hand it over; the fused RoIAlign then runs
+    roi_align_fwd_nhwc and the tile backward writes channels-last gradients."""
     from detectron_pytorch_amd.rcnn import data as rdata
 
     cpu, gpu, cfg = nets
@@ -65,7 +68,8 @@ def test_training_post_conv_half_matches_the_reference(nets, golden):
     blobs = rdata.add_rpn_blobs(cfg, entries, [1.0, 1.0], np.random.RandomState(11))     # == roi_data/rpn.py (CPU test)
     d = dev()
     blobs_np, logits_np, deltas_np = synthetic_conv_outputs(seed=21, n=2)
-    blob_g = [torch.from_numpy(b).to(d).requires_grad_() for b in blobs_np]
+    fmt = torch.channels_last if layout == "channels_last" else torch.contiguous_format
+    blob_g = [torch.from_numpy(b).to(d).contiguous(memory_format=fmt).requires_grad_() for b in blobs_np]
     rpn_g = {}
     for i, lvl in enumerate(range(2, 7)):
         rpn_g["rpn_cls_logits_fpn%d" % lvl] = torch.from_numpy(logits_np[i]).to(d).requires_grad_()
@@ -136,7 +140,9 @@ def test_training_post_conv_half_matches_the_reference(nets, golden):
     # gradients w.r.t. the pyramid = the fused HIP RoIAlign backward over P2-P5 (box head 7x7 + mask head 14x14)
     roi_levels = blob_g[-4:]
     for i, f in enumerate(roi_levels):
-        g = np.zeros(f.numel(), np.float32) if f.grad is None else f.grad.detach().cpu().numpy().reshape(-1)
+        if f.grad is not None and layout == "channels_last":
+            assert f.grad.is_contiguous(memory_format=torch.channels_last)
+        g = np.zeros(f.numel(), np.float32) if f.grad is None else f.grad.detach().cpu().contiguous().numpy().reshape(-1)
         norm = float(golden["feat_grad_norm/%d" % i])
         assert abs(np.linalg.norm(g.astype(np.float64)) - norm) <= 2e-3 * norm + 1e-12, i
         idx = np.random.RandomState(i).randint(0, g.size, size=min(512, g.size))
