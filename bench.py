@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="headline only (no roofline / breakdown / inference objects)")
     ap.add_argument("--kernel-iters", type=int, default=200, help="back-to-back launches per roofline timing")
     ap.add_argument("--only-roofline", action="store_true", help="tuning aid: print only the roofline object")
+    ap.add_argument("--child-inference-graph", action="store_true",
+                    help="internal: measure the hipGraph form of the config-3 detection in this (child) process and print "
+                         "one JSON object -- a failed capture must not take the parent's bench line with it")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="harness self-test without a GPU (tests/): a toy model through the same rank / reducer / timing "
                          "/ JSON code on the gloo backend")
@@ -303,14 +306,9 @@ def inference_e2e(device, dtype, iters=10, warmup=3):
     """BASELINE config 3: e2e_faster_rcnn_R-50-FPN_1x test-time detection of one 1333x800 image ([1,3,800,1344] blob,
     TEST cfg of the yaml: 1000 pre-NMS / level, 1000 post-NMS, NMS 0.5, score 0.05, 100 detections), reference
     initialisers, seed 3; from the resident image blob to the final per-class detections."""
-    from detectron_pytorch_amd.rcnn import config, inference, model as rmodel
+    from detectron_pytorch_amd.rcnn import inference
 
-    cfg = config.faster_rcnn_r50_fpn()
-    torch.manual_seed(cfg.RNG_SEED)
-    net = rmodel.GeneralizedRCNN(cfg).to(device).eval()
-    rng = np.random.RandomState(0)
-    data = torch.from_numpy((rng.randn(1, 3, 800, 1344) * 50).astype(np.float32)).to(device)
-    im_info = torch.tensor([[800.0, 1344.0, 1.0]])
+    net, data, im_info = build_inference_job(device)
     autocast = torch.bfloat16 if dtype == "bf16" else None
     names, events = [], []
 
@@ -342,13 +340,72 @@ def inference_e2e(device, dtype, iters=10, warmup=3):
         for i in range(1, len(events)):
             acc[names[i]] = acc.get(names[i], 0.0) + events[i - 1].elapsed_time(events[i]) / 3
     net.mark = None
-    return {"workload": "e2e_faster_rcnn_R-50-FPN_1x inference, 1 image 1333x800 (blob 1x3x800x1344), synthetic, "
-                        "random-init weights (seed 3)", "images_per_s": round(1.0 / sec, 2),
-            "ms_per_image": round(sec * 1e3, 3), "detections": int(dets[0].numel()), "launch": "eager",
-            "breakdown_ms": {"backbone": round(acc.get("backbone", 0), 3), "rpn_convs": round(acc.get("rpn_convs", 0), 3),
-                             "proposals_nms_collect": round(acc.get("proposals", 0), 3),
-                             "roialign_box_head": round(acc.get("box_head", 0), 3),
-                             "bbox_decode_class_nms_top100": round(acc.get("postproc", 0), 3)}}
+    out = {"workload": "e2e_faster_rcnn_R-50-FPN_1x inference, 1 image 1333x800 (blob 1x3x800x1344), synthetic, "
+                       "random-init weights (seed 3)", "images_per_s": round(1.0 / sec, 2),
+           "ms_per_image": round(sec * 1e3, 3), "detections": int(dets[0].numel()), "launch": "eager",
+           "breakdown_ms": {"backbone": round(acc.get("backbone", 0), 3), "rpn_convs": round(acc.get("rpn_convs", 0), 3),
+                            "proposals_nms_collect": round(acc.get("proposals", 0), 3),
+                            "roialign_box_head": round(acc.get("box_head", 0), 3),
+                            "bbox_decode_class_nms_top100": round(acc.get("postproc", 0), 3)}}
+    del net, data
+    torch.cuda.empty_cache()
+    # the hipGraph form in a child process: a capture that goes wrong there cannot take this process down
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), "--child-inference-graph", "--dtype", dtype]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if res.returncode != 0 or not lines:
+            raise RuntimeError("child exit %d: %s" % (res.returncode, res.stderr[-300:]))
+        graph = json.loads(lines[-1])
+        out["eager"] = {"images_per_s": out["images_per_s"], "ms_per_image": out["ms_per_image"]}
+        out["hipgraph"] = graph
+        if graph.get("equals_eager_result"):
+            out.update(images_per_s=graph["images_per_s"], ms_per_image=graph["ms_per_image"], launch="hipgraph")
+    except Exception as exc:  # noqa: BLE001
+        out["hipgraph"] = {"error": repr(exc)[:400]}
+    return out
+
+
+def build_inference_job(device):
+    from detectron_pytorch_amd.rcnn import config, model as rmodel
+
+    cfg = config.faster_rcnn_r50_fpn()
+    torch.manual_seed(cfg.RNG_SEED)
+    net = rmodel.GeneralizedRCNN(cfg).to(device).eval()
+    rng = np.random.RandomState(0)
+    data = torch.from_numpy((rng.randn(1, 3, 800, 1344) * 50).astype(np.float32)).to(device)
+    return net, data, torch.tensor([[800.0, 1344.0, 1.0]])
+
+
+def inference_graph_child(device, dtype, iters=30):
+    """The same detection as `inference_e2e`, captured once as a hipGraph (rcnn.inference.DetectionGraph) and replayed per
+    image; each timed iteration copies the blob in, replays, and reads the result sizes back (the per-image host work of
+    a real test loop).  Checked against the eager result before it is timed."""
+    from detectron_pytorch_amd.rcnn import inference
+
+    net, data, im_info = build_inference_job(device)
+    autocast = torch.bfloat16 if dtype == "bf16" else None
+    want = inference.im_detect_all(net, data, im_info, autocast_dtype=autocast)
+    graph = inference.DetectionGraph(net, tuple(data.shape), device, autocast).capture(data, im_info)
+    got = graph(data, im_info)
+    same = bool(torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]))
+    for _ in range(3):
+        graph(data, im_info)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        got = graph(data, im_info)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / iters
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        graph.graph.replay()
+    stop.record()
+    torch.cuda.synchronize()
+    return {"images_per_s": round(1.0 / sec, 2), "ms_per_image": round(sec * 1e3, 3),
+            "gpu_ms_per_replay": round(start.elapsed_time(stop) / iters, 3), "detections": int(got[0].numel()),
+            "equals_eager_result": same, "host_syncs_per_image": 1}
 
 
 def cpu_baseline(images_per_rank):
@@ -498,6 +555,9 @@ def main():
     device = torch.device("cuda", local_rank)
     from tools import hot_path_bench as hp
 
+    if args.child_inference_graph:
+        print(json.dumps(inference_graph_child(device, args.dtype)), flush=True)
+        return
     if args.only_roofline:
         print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("MI_")},
                           "roofline": hp.roofline_roi_align_forward(device, args.kernel_iters)}), flush=True)

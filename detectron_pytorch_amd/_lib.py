@@ -40,6 +40,10 @@ SIGNATURES = {
     "mi_nms_batched_workspace_bytes": (_c_size_t, [_c_int, _c_void_p]),
     "mi_nms_batched": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t,
                                _c_void_p]),
+    "mi_nms_segmented_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "mi_nms_segmented": (_c_int, [_c_void_p, ctypes.c_longlong, ctypes.c_longlong, _c_void_p, ctypes.c_longlong,
+                                 ctypes.c_longlong, _c_int, _c_int, _c_float, _c_float, _c_void_p, _c_void_p, _c_void_p,
+                                 _c_size_t, _c_void_p]),
     "mi_roi_align_fpn_supported": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "mi_roi_align_forward_fpn": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                          _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),

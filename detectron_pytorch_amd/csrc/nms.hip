@@ -43,9 +43,9 @@ struct Workspace {
   size_t bytes;
 };
 
-inline size_t align16(size_t b) { return (b + 15) & ~size_t(15); }
+__host__ __device__ inline size_t align16(size_t b) { return (b + 15) & ~size_t(15); }
 
-Workspace carve(void* base, int n) {
+__host__ __device__ inline Workspace carve(void* base, int n) {
   Workspace w;
   const int col_blocks = (n + kTile - 1) / kTile;
   const size_t n_pad = (size_t)col_blocks * kTile;
@@ -73,38 +73,54 @@ Workspace carve(void* base, int n) {
 // word -> broadcast), the partial ranks meet in LDS.  n = 2000: 32 workgroups x 500 comparisons per lane
 // (the first version ranked 256 boxes per workgroup over the whole range: 8 workgroups on a 256-CU chip, 55 us).
 constexpr int kPrepChunk = 2048;
-template <bool kSort>
-__device__ __forceinline__ void prepare_body(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
+
+// Where the rows of one problem live.  mi_nms / mi_nms_batched: the packed [n,5] array (row stride 5, score at +4, no
+// threshold).  mi_nms_segmented: the caller's [R,4C] box and [R,C] score matrices read in place (row strides 4C and C),
+// with the rows at or below `thresh` dropped: they sort behind every live row and are not counted in *n_live.
+struct DetSource {
+  const float* box;
+  const float* score;
+  long long box_row, score_row;   // strides in floats
+  float thresh;                   // rows with score <= thresh (or NaN) take no part; -inf: every row takes part
+  __device__ __forceinline__ float score_at(int i) const {
+    const float v = score[(long long)i * score_row];
+    // a NaN score (a diverged network) must not break the rank sort: it compares as the lowest score, ties by index, so
+    // that the ranks stay a permutation and nothing downstream indexes with an uninitialised slot
+    return (v > thresh) ? v : -__builtin_inff();
+  }
+};
+
+template <bool kSort, bool kCount>
+__device__ __forceinline__ void prepare_body(const DetSource src, int n, float4* __restrict__ boxes,
                                              float* __restrict__ areas, int32_t* __restrict__ order,
-                                             int32_t* __restrict__ flags, int chunk) {
+                                             int32_t* __restrict__ flags, int chunk, int32_t* __restrict__ n_live) {
   __shared__ __attribute__((aligned(16))) float s_scores[kPrepChunk];
   __shared__ int s_rank[4][kTile];
+  __shared__ int s_live[4];
   const int tid = threadIdx.x, bi = tid & (kTile - 1), part = tid >> 6;
   const int i = chunk * kTile + bi;
   const bool live = i < n;
   float x1 = 0, y1 = 0, x2 = 0, y2 = 0, score = 0;
   if (live) {
-    const float* d = dets + (long long)i * 5;
+    const float* d = src.box + (long long)i * src.box_row;
     x1 = d[0];
     y1 = d[1];
     x2 = d[2];
     y2 = d[3];
-    score = d[4];
-    // a NaN score (a diverged network) must not break the rank sort: it compares as the lowest score, ties by index, so
-    // that the ranks stay a permutation and nothing downstream indexes with an uninitialised slot
-    if (!(score == score)) score = -__builtin_inff();
+    score = src.score_at(i);
   }
   int rank = i;
   if (kSort) {
-    int cnt = 0;
+    int cnt = 0, live_rows = 0;
     for (int base = 0; base < n; base += kPrepChunk) {
       const int lim = min(kPrepChunk, n - base);
       const int lim4 = (lim + 15) & ~15;  // padded with NaN (never greater, never equal): four scores per LDS read
       __syncthreads();
       for (int t = tid; t < lim4; t += 256)
         if (t < lim) {
-          const float v = dets[(long long)(base + t) * 5 + 4];
-          s_scores[t] = (v == v) ? v : -__builtin_inff();
+          const float v = src.score_at(base + t);
+          s_scores[t] = v;
+          if (kCount) live_rows += v > -__builtin_inff();
         } else {
           s_scores[t] = __builtin_nanf("");
         }
@@ -125,8 +141,14 @@ __device__ __forceinline__ void prepare_body(const float* __restrict__ dets, int
       }
     }
     s_rank[part][bi] = cnt;
+    if (kCount) {   // every workgroup of the problem sees all scores: the first one publishes the live-row count
+#pragma unroll
+      for (int d = kTile / 2; d > 0; d >>= 1) live_rows += __shfl_xor(live_rows, d, kTile);
+      if (bi == 0) s_live[part] = live_rows;
+    }
     __syncthreads();
     rank = s_rank[0][bi] + s_rank[1][bi] + s_rank[2][bi] + s_rank[3][bi];
+    if (kCount && chunk == 0 && tid == 0) *n_live = (s_live[0] + s_live[1]) + (s_live[2] + s_live[3]);
   }
   if (live && part == 0) {
     boxes[rank] = make_float4(x1, y1, x2, y2);
@@ -136,11 +158,15 @@ __device__ __forceinline__ void prepare_body(const float* __restrict__ dets, int
   }
 }
 
+__device__ __forceinline__ DetSource packed_source(const float* dets) {
+  return DetSource{dets, dets + 4, 5, 5, -__builtin_inff()};
+}
+
 template <bool kSort>
 __global__ void __launch_bounds__(256)
 nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
             float* __restrict__ areas, int32_t* __restrict__ order, int32_t* __restrict__ flags) {
-  prepare_body<kSort>(dets, n, boxes, areas, order, flags, blockIdx.x);
+  prepare_body<kSort, false>(packed_source(dets), n, boxes, areas, order, flags, blockIdx.x, nullptr);
 }
 
 // ---- 2. IoU bitmask tiles ---------------------------------------------------------------
@@ -382,7 +408,7 @@ __device__ __forceinline__ void reduce_regs_body(const uint64_t* __restrict__ ma
       count += __popcll(keepbits);
     }
   }
-  if (!kGE) {
+  if (!kGE || keep64 == nullptr) {   // GE without an index list: the caller wants the per-row kept flags only
     if (threadIdx.x == 0) *num_keep = count;
     return;
   }
@@ -442,8 +468,8 @@ template <bool kSort>
 __global__ void __launch_bounds__(256) nms_prepare_batched(const BatchTable t) {
   int p = 0;
   while (p + 1 < t.count && (int)blockIdx.x >= t.chunk_start[p + 1]) p++;
-  prepare_body<kSort>(t.dets[p], t.n[p], t.ws[p].boxes, t.ws[p].areas, t.ws[p].order, t.ws[p].flags,
-                      blockIdx.x - t.chunk_start[p]);
+  prepare_body<kSort, false>(packed_source(t.dets[p]), t.n[p], t.ws[p].boxes, t.ws[p].areas, t.ws[p].order, t.ws[p].flags,
+                             blockIdx.x - t.chunk_start[p], nullptr);
 }
 
 template <bool kGE>
@@ -465,6 +491,52 @@ __global__ void __launch_bounds__(256) nms_reduce_batched(const BatchTable t) {
   }
   reduce_regs_body<kGE>(t.ws[p].mask, t.ws[p].diag_t, t.n[p], t.ws[p].order, t.ws[p].flags,
                         static_cast<int32_t*>(t.keep[p]), static_cast<int64_t*>(t.keep[p]), t.num_keep[p]);
+}
+
+// ---- segmented entry point: the per-class NMS of the test-time post-processing (core/test.py:748-771) with the class
+// sizes never leaving the device.  Segment s = class s + 1: its candidate rows are ALL R RoIs, read in place from the
+// score / box matrices; the rows at or below the score threshold are dropped by the sort (they rank last) and the number
+// of live rows -- which only the device knows -- sizes the mask and the reduce of that segment. ----
+struct SegmentArgs {
+  const float* boxes;
+  const float* scores;
+  long long box_seg, box_row, score_seg, score_row;
+  int rows;
+  float score_thresh;
+  char* workspace;          // num_segments x seg_bytes, each carved like a single problem of `rows` boxes
+  size_t seg_bytes;
+  int32_t* n_live;          // [num_segments], in the workspace
+  int32_t* kept;            // [num_segments, rows] caller's flags
+  int32_t* num_keep;        // [num_segments]
+};
+
+__global__ void __launch_bounds__(256) nms_prepare_segmented(const SegmentArgs a) {
+  const int s = blockIdx.y;
+  const Workspace ws = carve(a.workspace + (size_t)s * a.seg_bytes, a.rows);
+  const DetSource src{a.boxes + s * a.box_seg, a.scores + s * a.score_seg, a.box_row, a.score_row, a.score_thresh};
+  prepare_body<true, true>(src, a.rows, ws.boxes, ws.areas, ws.order, a.kept + (long long)s * a.rows, blockIdx.x,
+                           a.n_live + s);
+}
+
+__global__ void __launch_bounds__(kTile) nms_mask_segmented(const SegmentArgs a, float thresh) {
+  const int s = blockIdx.z;
+  const int n = a.n_live[s];
+  const int col_blocks = (n + kTile - 1) / kTile;
+  if ((int)blockIdx.x >= col_blocks || (int)blockIdx.y >= col_blocks) return;
+  const Workspace ws = carve(a.workspace + (size_t)s * a.seg_bytes, a.rows);
+  mask_body<true>(ws.boxes, ws.areas, n, thresh, ws.mask, ws.diag_t, blockIdx.x, blockIdx.y, col_blocks);
+}
+
+__global__ void __launch_bounds__(256) nms_reduce_segmented(const SegmentArgs a) {
+  const int s = blockIdx.x;
+  const int n = a.n_live[s];
+  if (n == 0) {
+    if (threadIdx.x == 0) a.num_keep[s] = 0;
+    return;
+  }
+  const Workspace ws = carve(a.workspace + (size_t)s * a.seg_bytes, a.rows);
+  reduce_regs_body<true>(ws.mask, ws.diag_t, n, ws.order, a.kept + (long long)s * a.rows, nullptr, nullptr,
+                         a.num_keep + s);
 }
 
 // ---- 4. flags -> ascending original indices (n > 4096 path) -------------------------------------------------
@@ -675,6 +747,62 @@ extern "C" int mi_nms_batched(int num_problems, const float* const* dets, const 
     if ((rc = mi::check_launch("nms_reduce_batched")) != MI_OK) return rc;
   }
   return MI_OK;
+}
+
+extern "C" size_t mi_nms_segmented_workspace_bytes(int num_segments, int rows) {
+  if (num_segments <= 0 || rows <= 0) return 16;
+  return (size_t)num_segments * carve(nullptr, rows).bytes + align16((size_t)num_segments * sizeof(int32_t));
+}
+
+extern "C" int mi_nms_segmented(const float* boxes, long long box_segment_stride, long long box_row_stride,
+                                const float* scores, long long score_segment_stride, long long score_row_stride,
+                                int num_segments, int rows, float score_thresh, float nms_thresh, int32_t* kept,
+                                int32_t* num_keep, void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(num_segments >= 0 && rows >= 0, "nms_segmented: negative size");
+  if (num_segments == 0) return MI_OK;
+  MI_REQUIRE(num_keep != nullptr, "nms_segmented: null num_keep");
+  hipStream_t s = mi::as_stream(stream);
+  if (rows == 0) {
+    if (hipMemsetAsync(num_keep, 0, (size_t)num_segments * sizeof(int32_t), s) != hipSuccess)
+      return mi::check_launch("nms_segmented: zero fill");
+    return MI_OK;
+  }
+  MI_REQUIRE(boxes != nullptr && scores != nullptr && kept != nullptr && workspace != nullptr,
+             "nms_segmented: null pointer");
+  if (rows > kTile * kTile) {
+    mi::set_error("nms_segmented: %d rows per segment; the four-wave reduce takes at most %d", rows, kTile * kTile);
+    return MI_ERR_UNSUPPORTED;
+  }
+  MI_REQUIRE(num_segments <= 65535, "nms_segmented: at most 65535 segments");
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "nms_segmented: workspace must be 16-byte aligned");
+  const size_t need = mi_nms_segmented_workspace_bytes(num_segments, rows);
+  if (workspace_bytes < need) {
+    mi::set_error("nms_segmented: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return MI_ERR_WORKSPACE;
+  }
+  SegmentArgs a;
+  a.boxes = boxes;
+  a.scores = scores;
+  a.box_seg = box_segment_stride;
+  a.box_row = box_row_stride;
+  a.score_seg = score_segment_stride;
+  a.score_row = score_row_stride;
+  a.rows = rows;
+  a.score_thresh = score_thresh;
+  a.workspace = static_cast<char*>(workspace);
+  a.seg_bytes = carve(nullptr, rows).bytes;
+  a.n_live = reinterpret_cast<int32_t*>(a.workspace + (size_t)num_segments * a.seg_bytes);
+  a.kept = kept;
+  a.num_keep = num_keep;
+  const int cb = (rows + kTile - 1) / kTile;
+  int rc;
+  nms_prepare_segmented<<<dim3(cb, num_segments), 256, 0, s>>>(a);
+  if ((rc = mi::check_launch("nms_prepare_segmented")) != MI_OK) return rc;
+  nms_mask_segmented<<<dim3(cb, cb, num_segments), kTile, 0, s>>>(a, nms_thresh);
+  if ((rc = mi::check_launch("nms_mask_segmented")) != MI_OK) return rc;
+  nms_reduce_segmented<<<num_segments, 256, 0, s>>>(a);
+  return mi::check_launch("nms_reduce_segmented");
 }
 
 extern "C" int mi_bbox_overlaps(const float* boxes, int num_boxes, const float* query, int num_query,

@@ -3,9 +3,9 @@ site core/test.py:764; section 8f row 3).
 
 Mirrors `box_results_with_nms_and_limit` (lib/core/test.py:732-790): threshold the class scores, NMS (or Soft-NMS) per
 class, then keep the `detections_per_im` best over all classes.  The reference loops over the 80 classes on the host,
-one cython_nms call each; here the classes become the segments of ONE class-major detection array, `mi_nms_batched`
-(hard) or `mi_soft_nms_segmented` (soft) runs them side by side, and only two small count vectors cross to the host
-(the reference's return type -- one array per class -- needs the sizes there anyway).
+one cython_nms call each; here the classes are the segments of one call -- `mi_nms_segmented` (hard: reads the score and
+box blobs in place, class sizes stay on the device) or `mi_soft_nms_segmented` (soft) -- and run side by side; only the
+result sizes cross to the host (the reference's return type, one array per class, needs them there anyway).
 
 The reference reads its thresholds from the global cfg; here they are arguments with the reference's defaults
 (TEST.SCORE_THRESH 0.05, TEST.NMS 0.5, TEST.DETECTIONS_PER_IM 100, TEST.SOFT_NMS.* : core/config.py:222-227,358-368).
@@ -41,16 +41,74 @@ def class_major_detections(scores, boxes, score_thresh):
     return dets, cls, offsets
 
 
+TIE_SLACK = 28      # rows beyond DETECTIONS_PER_IM the static result can hold (scores tied with the 100th best)
+
+
+def box_results_static(scores, boxes, score_thresh=0.05, nms_thresh=0.5, detections_per_im=100, roi_valid=None):
+    """core/test.py:732-790 (hard NMS) with shapes fixed by the inputs' shapes and NO host synchronisation: what a
+    hipGraph of the whole detection step needs.  scores [R, C], boxes [R, 4C] device tensors; `roi_valid` [R] marks the
+    rows of a static-size RoI blob that are real proposals.  Returns a dict of device tensors:
+        dets [cap, 5], cls [cap] (class index, 1-based), valid [cap]   cap = detections_per_im + TIE_SLACK: the
+            detections class-major and RoI-ascending inside a class -- the reference's row order -- first `count` rows
+        count, total   int64 scalars: rows delivered, rows the reference returns (`total > cap` only when more than
+            TIE_SLACK scores tie with the detections_per_im-th best: the caller then takes the dynamic path)
+        class_counts   int64 [C - 1]."""
+    r, c = scores.shape
+    nseg = c - 1
+    if roi_valid is not None:
+        scores = torch.where(roi_valid.view(r, 1), scores, torch.full_like(scores, float("-inf")))
+    from .nms import nms_segmented
+    kept, _ = nms_segmented(scores, boxes, score_thresh, nms_thresh)
+    m = nseg * r
+    flat_scores = scores[:, 1:].t().reshape(m)                                # class-major, as `kept`
+    masked = torch.where(kept.view(m) != 0, flat_scores, torch.full_like(flat_scores, float("-inf")))
+    d = detections_per_im if detections_per_im > 0 else m
+    cap = min(m, d + TIE_SLACK)
+    vals, idx = torch.topk(masked, cap, sorted=True)
+    # image_thresh = the D-th best kept score (:781-784); everything >= it stays, ties included
+    thresh = vals[d - 1] if d <= cap else vals.new_full((), float("-inf"))
+    sel = (vals >= thresh) & (vals > float("-inf"))
+    total = ((masked >= thresh) & (masked > float("-inf"))).sum()
+    flat = torch.sort(torch.where(sel, idx, torch.full_like(idx, m))).values  # ascending flat index = class-major order
+    valid = flat < m
+    flat_c = torch.clamp_max(flat, m - 1)
+    cls0 = flat_c // r
+    roi = flat_c - cls0 * r
+    box4 = boxes.view(r, c, 4)[roi, cls0 + 1]
+    dets = torch.cat([box4, scores[roi, cls0 + 1].unsqueeze(1)], dim=1)
+    dets = torch.where(valid.view(cap, 1), dets, torch.zeros_like(dets))
+    class_counts = torch.zeros((nseg + 1,), dtype=torch.int64, device=scores.device)
+    class_counts.index_add_(0, torch.where(valid, cls0, torch.full_like(cls0, nseg)), torch.ones_like(cls0))
+    return {"dets": dets, "cls": (cls0 + 1) * valid, "valid": valid, "count": valid.sum(), "total": total,
+            "class_counts": class_counts[:nseg]}
+
+
+def _results_from_static(res, as_numpy):
+    """The reference's return type from the static result: ONE device-to-host copy (the sizes), then views."""
+    nseg = res["class_counts"].numel()
+    sizes = torch.cat([res["count"].view(1), res["total"].view(1), res["class_counts"]]).cpu().tolist()
+    count, total, counts = sizes[0], sizes[1], sizes[2:]
+    if total != count:
+        return None                                                           # more ties than TIE_SLACK holds
+    final = res["dets"][:count]
+    if as_numpy:
+        final_np = final.cpu().numpy()
+        per_class = np.split(final_np, np.cumsum(counts)[:-1]) if nseg else []
+        return final_np[:, 4], final_np[:, :4], [[]] + per_class
+    return final[:, 4], final[:, :4], [[]] + list(torch.split(final, counts))
+
+
 def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=0.5, detections_per_im=100,
                                    soft_nms=False, soft_nms_sigma=0.5, soft_nms_method="linear", device=None):
     """core/test.py:732-790.  scores [R, C], boxes [R, 4C] (numpy or tensors; class 0 = background).  Returns
     (scores [D], boxes [D,4], cls_boxes) with cls_boxes[j] a float32 [k_j, 5] array (cls_boxes[0] == []), numpy out for
     numpy in and device tensors out for tensors in -- the same rows in the same order as the reference.
 
-    Everything between the inputs and the final row selection works on the flat class-major array (a per-class Python
-    loop of 80 slice / gather / mask operations costs more than the NMS itself): the kept rows of all classes are one
-    boolean mask, the top-`detections_per_im` cut is one threshold, and the per-class results are views into the one
-    gathered result."""
+    Hard NMS (the default): `box_results_static` -- threshold, per-class NMS (`mi_nms_segmented`, all classes side by
+    side, class sizes never on the host), the detections_per_im cut and the final gather are one asynchronous sequence of
+    fixed shapes; the only device-to-host copy is the vector of result sizes the reference's return type needs.
+    Soft-NMS re-scores rows, so its candidates are compacted first (one more synchronisation for their number) and
+    `mi_soft_nms_segmented` runs the classes side by side."""
     as_numpy = isinstance(scores, np.ndarray)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if as_numpy else scores.device
@@ -59,8 +117,19 @@ def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=
     r, num_classes = scores_d.shape
     if boxes_d.shape != (r, 4 * num_classes):
         raise ValueError("boxes must be [R, 4 * num_classes]")
-    lib = _lib.lib()
     nseg = num_classes - 1
+    if r == 0 or nseg == 0:
+        empty = torch.zeros((0, 5), dtype=torch.float32, device=device)
+        if as_numpy:
+            e = empty.cpu().numpy()
+            return e[:, 4], e[:, :4], [[]] + [e] * nseg
+        return empty[:, 4], empty[:, :4], [[]] + [empty] * nseg
+    if not soft_nms and r <= 4096:
+        out = _results_from_static(box_results_static(scores_d, boxes_d, score_thresh, nms_thresh, detections_per_im),
+                                   as_numpy)
+        if out is not None:
+            return out
+    lib = _lib.lib()
     dets, seg, offsets = class_major_detections(scores_d, boxes_d, float(score_thresh))
     m = int(dets.size(0))
     stream = _lib.current_stream_handle(device)
@@ -86,7 +155,9 @@ def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=
         _lib.check(rc, "mi_soft_nms_segmented")
         kept_mask = slot < num_out[seg]                                    # each class's result is a prefix of its segment
     else:
-        off = offsets.cpu().numpy()                                        # the batched entry takes host-side sizes
+        # hard NMS beyond the static path's reach (more than 4096 RoIs, or a pile of tied scores at the cut): the
+        # compacted class-major array through mi_nms_batched, which takes host-side sizes
+        off = offsets.cpu().numpy()
         ns = np.diff(off)
         keep_all = torch.zeros((m,), dtype=torch.int64, device=device)
         num_all = torch.zeros((nseg,), dtype=torch.int32, device=device)

@@ -38,24 +38,36 @@ def bbox_transform(boxes, deltas, weights, clip):
 
 
 def clip_tiled_boxes(boxes, height, width):
-    """utils/boxes.py:138-153: clip every (x1,y1,x2,y2) group to the image."""
+    """utils/boxes.py:138-153: clip every (x1,y1,x2,y2) group to the image.  `height` / `width`: numbers, or 0-d device
+    tensors (the static path keeps the image size on the device)."""
     out = boxes.clone()
+    if torch.is_tensor(width):
+        zero = torch.zeros((), dtype=boxes.dtype, device=boxes.device)
+        out[:, 0::2] = torch.minimum(torch.maximum(out[:, 0::2], zero), (width - 1).to(boxes.dtype))
+        out[:, 1::2] = torch.minimum(torch.maximum(out[:, 1::2], zero), (height - 1).to(boxes.dtype))
+        return out
     out[:, 0::2] = out[:, 0::2].clamp(0, width - 1)
     out[:, 1::2] = out[:, 1::2].clamp(0, height - 1)
     return out
 
 
 @torch.no_grad()
-def im_detect_bbox(model, data, im_info, im_shape=None, autocast_dtype=None):
+def im_detect_bbox(model, data, im_info, im_shape=None, autocast_dtype=None, static=False):
     """test.py:127-190 for one image blob [1,3,H,W] already resident on the device; `im_shape` = (height, width) of the
-    ORIGINAL image (defaults to the blob's extent / scale).  Returns (scores [R,K], pred_boxes [R,4K], blob_conv)."""
+    ORIGINAL image (defaults to the blob's extent / scale).  Returns (scores [R,K], pred_boxes [R,4K], blob_conv).
+    `static`: `im_info` is a device tensor and stays there (scale and image size are read by the kernels, not by the
+    host), R = TEST.RPN_POST_NMS_TOP_N whatever the image; a fourth value `rois_valid` [R] is returned."""
     cfg = model.cfg
-    if autocast_dtype is not None:
-        with torch.autocast("cuda", dtype=autocast_dtype):
+    was_static, model.static_inference = model.static_inference, bool(static)
+    try:
+        if autocast_dtype is not None:
+            with torch.autocast("cuda", dtype=autocast_dtype):
+                ret = model(data, im_info)
+        else:
             ret = model(data, im_info)
-    else:
-        ret = model(data, im_info)
-    scale = float(im_info[0][2])
+    finally:
+        model.static_inference = was_static
+    scale = im_info[0, 2] if static else float(im_info[0][2])
     boxes = ret["rois"][:, 1:5] / scale
     scores = ret["cls_score"].float().reshape(-1, ret["cls_score"].shape[-1])
     deltas = ret["bbox_pred"].float().reshape(-1, ret["bbox_pred"].shape[-1])
@@ -63,10 +75,13 @@ def im_detect_bbox(model, data, im_info, im_shape=None, autocast_dtype=None):
         deltas = deltas[:, -4:]
     pred = bbox_transform(boxes, deltas, cfg.MODEL.BBOX_REG_WEIGHTS, cfg.BBOX_XFORM_CLIP)
     if im_shape is None:
-        im_shape = (float(im_info[0][0]) / scale, float(im_info[0][1]) / scale)
+        im_shape = (im_info[0, 0] / scale, im_info[0, 1] / scale) if static else \
+            (float(im_info[0][0]) / scale, float(im_info[0][1]) / scale)
     pred = clip_tiled_boxes(pred, im_shape[0], im_shape[1])
     if cfg.MODEL.CLS_AGNOSTIC_BBOX_REG:
         pred = pred.repeat(1, scores.shape[1])
+    if static:
+        return scores, pred, ret["blob_conv"], ret["rois_valid"]
     return scores, pred, ret["blob_conv"]
 
 
@@ -80,3 +95,62 @@ def im_detect_all(model, data, im_info, im_shape=None, autocast_dtype=None):
     return detection.box_results_with_nms_and_limit(
         scores, boxes, score_thresh=t.SCORE_THRESH, nms_thresh=t.NMS, detections_per_im=t.DETECTIONS_PER_IM,
         soft_nms=t.SOFT_NMS.ENABLED, soft_nms_sigma=t.SOFT_NMS.SIGMA, soft_nms_method=t.SOFT_NMS.METHOD)
+
+
+@torch.no_grad()
+def im_detect_all_static(model, data, im_info, autocast_dtype=None):
+    """`im_detect_all` as one asynchronous sequence of fixed shapes: image blob and `im_info` ([1,3] float32) are device
+    tensors, nothing is read back.  Returns detection.box_results_static's dict (hard NMS only)."""
+    cfg = model.cfg
+    if cfg.TEST.SOFT_NMS.ENABLED:
+        raise NotImplementedError("the static detection path runs hard NMS (Soft-NMS compacts its candidates first)")
+    scores, boxes, _, valid = im_detect_bbox(model, data, im_info, None, autocast_dtype, static=True)
+    t = cfg.TEST
+    return detection.box_results_static(scores, boxes, t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, roi_valid=valid)
+
+
+class DetectionGraph(object):
+    """One image's detection -- backbone, RPN, proposals, RoIAlign, box head, decode, per-class NMS, top-100 -- captured
+    once as a hipGraph and replayed per image: ~400 launches become one, and the host's only work per image is copying
+    the blob in and the result sizes out (the reference: five D2H copies, numpy and Cython between them,
+    SURVEY.md section 3.1).  One graph per blob shape (FPN pads blobs to multiples of 32: a handful of shapes per
+    dataset); `im_info` is a graph INPUT, so images of different scale share the graph of their blob shape."""
+
+    def __init__(self, model, blob_shape, device, autocast_dtype=None):
+        assert not model.training and blob_shape[0] == 1
+        self.model, self.autocast_dtype = model, autocast_dtype
+        self.data = torch.zeros(blob_shape, dtype=torch.float32, device=device)
+        self.im_info = torch.zeros((1, 3), dtype=torch.float32, device=device)
+        self.graph, self.out = None, None
+
+    def capture(self, data, im_info, warmup=3):
+        """`data`, `im_info`: a representative image (MIOpen picks its solvers during the eager warm-up runs)."""
+        self.data.copy_(data)
+        self.im_info.copy_(torch.as_tensor(im_info, dtype=torch.float32).view(1, 3))
+        side = torch.cuda.Stream(device=self.data.device)
+        side.wait_stream(torch.cuda.current_stream(self.data.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                im_detect_all_static(self.model, self.data, self.im_info, self.autocast_dtype)
+        torch.cuda.current_stream(self.data.device).wait_stream(side)
+        torch.cuda.synchronize(self.data.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.out = im_detect_all_static(self.model, self.data, self.im_info, self.autocast_dtype)
+        self.graph = graph
+        return self
+
+    def replay(self, data, im_info):
+        """Asynchronous: returns the static result dict (valid until the next replay)."""
+        self.data.copy_(data, non_blocking=True)
+        self.im_info.copy_(torch.as_tensor(im_info, dtype=torch.float32).view(1, 3), non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+    def __call__(self, data, im_info):
+        """(scores [D], boxes [D,4], cls_boxes) like `im_detect_all`; one device-to-host copy (the result sizes)."""
+        out = detection._results_from_static(self.replay(data, im_info), False)
+        if out is None:      # more tied scores at the detections_per_im cut than the static result holds
+            return im_detect_all(self.model, data, torch.as_tensor(im_info).cpu().view(1, 3), None, self.autocast_dtype)
+        # the views point into the graph's output buffer: hand out copies
+        return out[0].clone(), out[1].clone(), [[]] + [c.clone() for c in out[2][1:]]

@@ -68,6 +68,7 @@ class GeneralizedRCNN(nn.Module):
                 p.requires_grad = False
         self.iou_fn = nms.bbox_overlaps                 # mi_bbox_overlaps; tests on CPU tensors inject the oracle's
         self.mark = None                                # optional callable(label) invoked at stage boundaries (bench.py)
+        self.static_inference = False                   # eval forward with fixed shapes and no host sync (inference.py)
 
     def _mark(self, label):
         if self.mark is not None:
@@ -124,9 +125,19 @@ class GeneralizedRCNN(nn.Module):
         ret = {}
         if not self.training:
             with torch.no_grad():
-                rois = self.proposals(rpn_ret, im_info_d, static=False)
-                blobs = fpn_proposals.distribute(rois, cfg.FPN.ROI_MIN_LEVEL, cfg.FPN.ROI_MAX_LEVEL)
-                blobs["rois_levels"] = blobs["roi_levels"]
+                if self.static_inference:
+                    # always RPN_POST_NMS_TOP_N rows; the rows that are no proposals get image index -1 (the RoI operators
+                    # pool zeros for them) and are reported in `rois_valid`: no host synchronisation, capturable
+                    rois, valid = self.proposals(rpn_ret, im_info_d, static=True)
+                    rois = torch.cat([torch.where(valid, rois[:, 0], torch.full_like(rois[:, 0], -1.0)).view(-1, 1),
+                                      rois[:, 1:5]], dim=1)
+                    lvls = fpn_proposals.map_rois_to_fpn_levels(rois[:, 1:5], cfg.FPN.ROI_MIN_LEVEL, cfg.FPN.ROI_MAX_LEVEL)
+                    blobs = {"rois": rois, "rois_levels": lvls}
+                    ret["rois_valid"] = valid
+                else:
+                    rois = self.proposals(rpn_ret, im_info_d, static=False)
+                    blobs = fpn_proposals.distribute(rois, cfg.FPN.ROI_MIN_LEVEL, cfg.FPN.ROI_MAX_LEVEL)
+                    blobs["rois_levels"] = blobs["roi_levels"]
             self._mark("proposals")
             cls_score, bbox_pred = self.Box_Outs(self.Box_Head(roi_blobs, blobs))
             self._mark("box_head")

@@ -230,6 +230,23 @@ int mi_soft_nms_segmented(const float* dets, const int32_t* offsets, int num_seg
                           float overlap_thresh, float score_thresh, int method, float* out_dets, int64_t* out_inds,
                           int32_t* num_out, mi_stream_t stream);
 
+/* The per-class NMS of the test-time post-processing (the loop of core/test.py:748-771: `inds = np.where(scores[:, j] >
+ * TEST.SCORE_THRESH)`, `keep = box_utils.nms(dets_j, TEST.NMS)`) for all classes in one call, with nothing but the final
+ * flags coming back -- the class sizes exist on the device only.  Segment s (= class s + 1 at the call site) has `rows`
+ * candidate rows read IN PLACE:   box of row r   = boxes  + s * box_segment_stride   + r * box_row_stride   (4 floats)
+ *                                 score of row r = scores + s * score_segment_stride + r * score_row_stride
+ * (strides in floats; for the reference's scores [R,C] / boxes [R,4C] blobs: boxes + 4, strides 4 and 4C; scores + 1,
+ * strides 1 and C).  Rows with score <= score_thresh (or NaN) take no part.  cython_nms semantics (MI_NMS_GE_ORIG_ASC:
+ * suppress at IoU >= nms_thresh, equal scores: higher row first).  kept [num_segments, rows] int32: 1 where the row
+ * survives, 0 elsewhere (every element is written); num_keep [num_segments]: the survivors of each segment.
+ * rows <= 4096.  The kept rows of a segment in ascending row order are `dets_j[keep, :]` of the reference.
+ * workspace: mi_nms_segmented_workspace_bytes(num_segments, rows), 16-byte aligned, device. */
+size_t mi_nms_segmented_workspace_bytes(int num_segments, int rows);
+int mi_nms_segmented(const float* boxes, long long box_segment_stride, long long box_row_stride, const float* scores,
+                     long long score_segment_stride, long long score_row_stride, int num_segments, int rows,
+                     float score_thresh, float nms_thresh, int32_t* kept, int32_t* num_keep, void* workspace,
+                     size_t workspace_bytes, mi_stream_t stream);
+
 /* Independent NMS problems in one call (no reference counterpart: the reference runs one cython_nms per FPN level and
  * image on the host, modeling/generate_proposals.py:91-99,161).  `dets`, `n`, `keep`, `num_keep` are HOST arrays of
  * `num_problems` entries (device pointers / box counts); each problem follows the mi_nms contract, with at most 4096

@@ -368,6 +368,42 @@ def test_im_detect_all_on_device(nets):
         assert float(boxes[:, 1::2].min()) >= 0 and float(boxes[:, 1::2].max()) <= H - 1
 
 
+def test_detection_static_path_and_hipgraph_equal_the_dynamic_path(nets):
+    """The fixed-shape, synchronisation-free detection (static RoI blob with padding rows, mi_nms_segmented) and its
+    hipGraph replay return the detections of the dynamic path, bit for bit, for several images through one graph."""
+    from detectron_pytorch_amd.rcnn import inference
+
+    _, gpu, cfg = nets
+    gpu.eval()
+    saved = cfg.TEST.SCORE_THRESH
+    cfg.TEST.SCORE_THRESH = 0.012     # a randomly initialised classifier scores ~1/81 everywhere: let some rows through
+    try:
+        _check_static_detection(gpu, cfg, inference)
+    finally:
+        cfg.TEST.SCORE_THRESH = saved
+
+
+def _check_static_detection(gpu, cfg, inference):
+    graph, seen = None, 0
+    for seed, scale in ((2, 1.0), (5, 1.0), (7, 0.5)):
+        _, _, data_np = scenario(seed=seed)
+        blob = torch.from_numpy(data_np[:1]).to(dev())
+        im_info = torch.tensor([[float(H), float(W), scale]])
+        want = inference.im_detect_all(gpu, blob, im_info)
+        res = inference.im_detect_all_static(gpu, blob, im_info.to(dev()))
+        count = int(res["count"])
+        assert count == int(res["total"]) == want[0].numel()
+        assert torch.equal(res["dets"][:count, 4], want[0]) and torch.equal(res["dets"][:count, :4], want[1])
+        if graph is None:
+            graph = inference.DetectionGraph(gpu, tuple(blob.shape), dev()).capture(blob, im_info)
+        for _ in range(2):                                            # replays are repeatable
+            got = graph(blob, im_info)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+            assert [len(c) for c in got[2]] == [len(c) for c in want[2]]
+        seen += want[0].numel()
+    assert seen > 0, "the comparison never saw a detection"
+
+
 def test_non_finite_network_outputs_do_not_fault(nets):
     """A diverged network hands NaN / Inf logits and deltas to the post-convolution half.  The results are meaningless,
     but every HIP operator must stay inside its buffers (the rank sort of the NMS treats NaN scores as the lowest,

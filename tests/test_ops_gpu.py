@@ -573,6 +573,75 @@ def test_detection_postprocess_vs_oracle(oracle_mod, soft):
     assert s.shape == (0,) and b.shape == (0, 4) and all(x.shape == (0, 5) for x in c[1:])
 
 
+@pytest.mark.parametrize("rois,classes,seed", [(1000, 81, 3), (65, 4, 1), (1, 3, 2), (4096, 2, 5), (300, 21, 9)])
+def test_nms_segmented_matches_the_per_class_loop(oracle_mod, rois, classes, seed):
+    """mi_nms_segmented on the blobs in place == `np.where(scores[:, j] > thresh)` + cython NMS per class
+    (core/test.py:748-771): kept flags per (class, RoI), bit-exact, including tied and NaN scores and empty classes."""
+    from detectron_pytorch_amd import nms as mi_nms
+
+    scores, boxes = syn.detection_head_outputs(rois, classes, seed=seed)
+    if classes > 2:
+        scores[:, 2] = 0.0                                            # an empty class
+    if rois >= 64:
+        scores[5:25, 1] = scores[5, 1]                                # tied scores inside a class
+        scores[30, 1] = np.nan                                        # a diverged RoI takes no part
+    kept, num = mi_nms.nms_segmented(to_dev(scores), to_dev(boxes), 0.05, 0.5)
+    kept, num = kept.cpu().numpy(), num.cpu().numpy()
+    assert kept.shape == (classes - 1, rois) and set(np.unique(kept)) <= {0, 1}
+    for j in range(1, classes):
+        inds = np.where(scores[:, j] > 0.05)[0]
+        want = np.zeros(rois, np.int32)
+        if len(inds):
+            dets_j = np.hstack([boxes[inds, 4 * j:4 * j + 4], scores[inds, j:j + 1]]).astype(np.float32)
+            want[inds[oracle_mod.nms_cython(dets_j, 0.5)]] = 1
+        assert np.array_equal(kept[j - 1], want), "class %d" % j
+        assert num[j - 1] == want.sum()
+
+
+def test_nms_segmented_rejects_what_it_cannot_do():
+    from detectron_pytorch_amd import _lib
+
+    lib = _lib.lib()
+    x = torch.zeros(16, device=dev())
+    rc = lib.mi_nms_segmented(x.data_ptr(), 4, 8, x.data_ptr(), 1, 2, 1, 5000, 0.05, 0.5, x.data_ptr(), x.data_ptr(),
+                              x.data_ptr(), 1 << 30, None)
+    assert rc != 0 and b"4096" in lib.mi_last_error()
+    rc = lib.mi_nms_segmented(x.data_ptr(), 4, 8, x.data_ptr(), 1, 2, 1, 4, 0.05, 0.5, x.data_ptr(), x.data_ptr(),
+                              x.data_ptr(), 16, None)
+    assert rc != 0 and b"workspace" in lib.mi_last_error()
+
+
+def test_detection_static_result_and_tie_overflow(oracle_mod):
+    """box_results_static delivers the reference's rows without a host round trip; more ties at the top-100 cut than its
+    fixed-size result holds are detected (total > count) and the wrapper falls back to the compacting path."""
+    from detectron_pytorch_amd import detection
+    from oracle import postprocess
+
+    scores, boxes = syn.detection_head_outputs(600, 21, seed=4)
+    valid = np.ones(600, bool)
+    valid[500:] = False                                              # padding rows of a static RoI blob
+    res = detection.box_results_static(to_dev(scores), to_dev(boxes), 0.05, 0.5, 100, roi_valid=to_dev(valid))
+    want = postprocess.box_results_with_nms_and_limit(scores[:500], boxes[:500], detections_per_im=100)
+    count = int(res["count"])
+    assert count == int(res["total"]) == len(want[0])
+    assert np.array_equal(res["dets"][:count].cpu().numpy(), np.vstack([c for c in want[2][1:] if len(c)]))
+    assert np.array_equal(res["class_counts"].cpu().numpy(), [len(c) for c in want[2][1:]])
+    assert not bool(res["valid"][count:].any()) and float(res["dets"][count:].abs().sum()) == 0
+    # 200 far-apart boxes with one and the same score: the reference keeps all of them (scores >= image_thresh)
+    n = 200
+    scores = np.zeros((n, 3), np.float32)
+    scores[:, 1] = 0.5
+    scores[:7, 2] = np.linspace(0.9, 0.6, 7)
+    xy = (np.arange(n) * 40).astype(np.float32)
+    one = np.stack([xy, xy, xy + 10, xy + 10], axis=1)
+    boxes = np.tile(one, (1, 3)).astype(np.float32)
+    res = detection.box_results_static(to_dev(scores), to_dev(boxes), 0.05, 0.5, 100)
+    assert int(res["total"]) == 207 and int(res["count"]) == 100 + detection.TIE_SLACK
+    want = postprocess.box_results_with_nms_and_limit(scores, boxes, detections_per_im=100)
+    got = detection.box_results_with_nms_and_limit(scores, boxes, detections_per_im=100)
+    assert len(want[0]) == 207 and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
 def test_soft_nms_segmented_matches_single_calls(oracle_mod):
     from detectron_pytorch_amd import _lib
 

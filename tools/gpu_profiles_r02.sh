@@ -21,7 +21,7 @@ import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if "roi_align" in row["Name"]:
-            name = row["Name"].split("(")[0].replace("void mi::(anonymous namespace)::", "").replace("mi::(anonymous namespace)::", "")
+            name = row["Name"].replace("void ", "").replace("mi::(anonymous namespace)::", "").split("(")[0]
             print("%s,\"%s\",%s,%.1f,%s,%s" % (sys.argv[2], name, row["Calls"], float(row["AverageNs"]), row["MinNs"], row["MaxNs"]))
 PY
 done
