@@ -393,12 +393,16 @@ def _check_static_detection(gpu, cfg, inference):
         res = inference.im_detect_all_static(gpu, blob, im_info.to(dev()))
         count = int(res["count"])
         assert count == int(res["total"]) == want[0].numel()
-        assert torch.equal(res["dets"][:count, 4], want[0]) and torch.equal(res["dets"][:count, :4], want[1])
+        # the static RoI blob has more rows than the dynamic one: the box-head GEMMs run at another M and may round the
+        # last bit differently -- same detections, scores to 1e-6
+        stat = res["dets"][:count].clone()
+        assert torch.allclose(stat[:, 4], want[0], rtol=0, atol=1e-6) and torch.allclose(stat[:, :4], want[1], rtol=0, atol=1e-3)
+        assert torch.equal(res["class_counts"].cpu(), torch.tensor([len(c) for c in want[2][1:]]))
         if graph is None:
             graph = inference.DetectionGraph(gpu, tuple(blob.shape), dev()).capture(blob, im_info)
-        for _ in range(2):                                            # replays are repeatable
+        for _ in range(2):                        # the replay IS the static sequence: bit-identical to it, repeatably
             got = graph(blob, im_info)
-            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+            assert torch.equal(got[0], stat[:, 4]) and torch.equal(got[1], stat[:, :4])
             assert [len(c) for c in got[2]] == [len(c) for c in want[2]]
         seen += want[0].numel()
     assert seen > 0, "the comparison never saw a detection"

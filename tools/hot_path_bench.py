@@ -415,7 +415,7 @@ def inference_path(device, iters=10):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         pooled, res = run_static()
-    sizes = torch.cat([res["count"].view(1), res["total"].view(1), res["class_counts"]])
+        sizes = torch.cat([res["count"].view(1), res["total"].view(1), res["class_counts"]])
 
     def replay():
         graph.replay()
