@@ -508,6 +508,7 @@ struct SegmentArgs {
   int32_t* n_live;          // [num_segments], in the workspace
   int32_t* kept;            // [num_segments, rows] caller's flags
   int32_t* num_keep;        // [num_segments]
+  float* masked;            // [num_segments, rows] or nullptr: the score where the row survives, -inf elsewhere
 };
 
 __global__ void __launch_bounds__(256) nms_prepare_segmented(const SegmentArgs a) {
@@ -530,13 +531,84 @@ __global__ void __launch_bounds__(kTile) nms_mask_segmented(const SegmentArgs a,
 __global__ void __launch_bounds__(256) nms_reduce_segmented(const SegmentArgs a) {
   const int s = blockIdx.x;
   const int n = a.n_live[s];
+  int32_t* kept = a.kept + (long long)s * a.rows;
   if (n == 0) {
     if (threadIdx.x == 0) a.num_keep[s] = 0;
-    return;
+  } else {
+    const Workspace ws = carve(a.workspace + (size_t)s * a.seg_bytes, a.rows);
+    reduce_regs_body<true>(ws.mask, ws.diag_t, n, ws.order, kept, nullptr, nullptr, a.num_keep + s);
   }
-  const Workspace ws = carve(a.workspace + (size_t)s * a.seg_bytes, a.rows);
-  reduce_regs_body<true>(ws.mask, ws.diag_t, n, ws.order, a.kept + (long long)s * a.rows, nullptr, nullptr,
-                         a.num_keep + s);
+  if (a.masked == nullptr) return;
+  // the flags were written by wave 0 of this workgroup: workgroup-scope fence + barrier, then the whole workgroup writes
+  // the segment's row of the masked score matrix (what the detections_per_im cut of core/test.py:776-785 ranks)
+  __threadfence_block();
+  __syncthreads();
+  const float* score = a.scores + s * a.score_seg;
+  float* out = a.masked + (long long)s * a.rows;
+  for (int i = threadIdx.x; i < a.rows; i += 256)
+    out[i] = kept[i] != 0 ? score[(long long)i * a.score_row] : -__builtin_inff();
+}
+
+// ---- the detections_per_im cut and the final gather (core/test.py:776-790) in one workgroup.  Input: the masked score
+// matrix of mi_nms_segmented and its `cap` best entries in descending order (mi_topk_batched).  image_thresh = the
+// D-th best; every surviving row at or above it stays (ties included: `total` counts them all, `count` = how many of
+// them fit into the cap rows).  Output rows in the reference's order: class-major, RoI-ascending inside a class. ----
+constexpr int kSelectThreads = 1024;
+__global__ void __launch_bounds__(kSelectThreads)
+detection_select(const float* __restrict__ scores, const float* __restrict__ boxes, const float* __restrict__ masked,
+                 const float* __restrict__ top_vals, const long long* __restrict__ top_idx, int rows, int classes,
+                 int cap, int detections_per_im, float* __restrict__ dets, int32_t* __restrict__ cls,
+                 long long* __restrict__ sizes) {
+  __shared__ long long s_flat[kSelectThreads];
+  __shared__ int s_red[kSelectThreads / 64];
+  __shared__ int s_count;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nseg = classes - 1;
+  const long long m = (long long)nseg * rows;
+  const float ninf = -__builtin_inff();
+  const float thresh = (detections_per_im >= 1 && detections_per_im <= cap) ? top_vals[detections_per_im - 1] : ninf;
+  for (int j = tid; j < nseg; j += kSelectThreads) sizes[2 + j] = 0;
+  if (tid == 0) s_count = 0;
+  int mine = 0;
+  for (long long i = tid; i < m; i += kSelectThreads) {
+    const float v = masked[i];
+    mine += (v >= thresh) && (v > ninf);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+  if (lane == 0) s_red[wave] = mine;
+  const bool sel = tid < cap && top_vals[tid] >= thresh && top_vals[tid] > ninf;
+  const long long flat = sel ? top_idx[tid] : m + tid;   // unselected rows sort behind every real one, in input order
+  s_flat[tid] = tid < cap ? flat : m + tid;
+  __threadfence();                                       // the zeroed class counters, before the atomics below
+  __syncthreads();
+  if (tid == 0) {
+    int total = 0;
+    for (int w = 0; w < kSelectThreads / 64; w++) total += s_red[w];
+    sizes[1] = total;
+  }
+  if (tid < cap) {
+    int rank = 0;
+    for (int j = 0; j < cap; j++) rank += s_flat[j] < flat;
+    float* o = dets + (long long)rank * 5;
+    if (sel) {
+      const int c0 = (int)(flat / rows), roi = (int)(flat - (long long)c0 * rows);
+      const float* b = boxes + ((long long)roi * classes + c0 + 1) * 4;
+      o[0] = b[0];
+      o[1] = b[1];
+      o[2] = b[2];
+      o[3] = b[3];
+      o[4] = scores[(long long)roi * classes + c0 + 1];
+      cls[rank] = c0 + 1;
+      atomicAdd(reinterpret_cast<unsigned long long*>(&sizes[2 + c0]), 1ULL);
+      atomicAdd(&s_count, 1);
+    } else {
+      o[0] = o[1] = o[2] = o[3] = o[4] = 0.f;
+      cls[rank] = 0;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) sizes[0] = s_count;
 }
 
 // ---- 4. flags -> ascending original indices (n > 4096 path) -------------------------------------------------
@@ -757,7 +829,8 @@ extern "C" size_t mi_nms_segmented_workspace_bytes(int num_segments, int rows) {
 extern "C" int mi_nms_segmented(const float* boxes, long long box_segment_stride, long long box_row_stride,
                                 const float* scores, long long score_segment_stride, long long score_row_stride,
                                 int num_segments, int rows, float score_thresh, float nms_thresh, int32_t* kept,
-                                int32_t* num_keep, void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+                                int32_t* num_keep, float* masked_scores, void* workspace, size_t workspace_bytes,
+                                mi_stream_t stream) {
   mi::begin_call();
   MI_REQUIRE(num_segments >= 0 && rows >= 0, "nms_segmented: negative size");
   if (num_segments == 0) return MI_OK;
@@ -795,6 +868,7 @@ extern "C" int mi_nms_segmented(const float* boxes, long long box_segment_stride
   a.n_live = reinterpret_cast<int32_t*>(a.workspace + (size_t)num_segments * a.seg_bytes);
   a.kept = kept;
   a.num_keep = num_keep;
+  a.masked = masked_scores;
   const int cb = (rows + kTile - 1) / kTile;
   int rc;
   nms_prepare_segmented<<<dim3(cb, num_segments), 256, 0, s>>>(a);
@@ -803,6 +877,26 @@ extern "C" int mi_nms_segmented(const float* boxes, long long box_segment_stride
   if ((rc = mi::check_launch("nms_mask_segmented")) != MI_OK) return rc;
   nms_reduce_segmented<<<num_segments, 256, 0, s>>>(a);
   return mi::check_launch("nms_reduce_segmented");
+}
+
+extern "C" int mi_detection_select(const float* scores, const float* boxes, const float* masked_scores,
+                                   const float* top_values, const int64_t* top_indices, int rows, int num_classes,
+                                   int cap, int detections_per_im, float* dets, int32_t* cls, int64_t* sizes,
+                                   mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(rows > 0 && num_classes >= 2 && cap > 0, "detection_select: bad size");
+  if (cap > kSelectThreads) {
+    mi::set_error("detection_select: cap = %d rows; one workgroup ranks at most %d", cap, kSelectThreads);
+    return MI_ERR_UNSUPPORTED;
+  }
+  MI_REQUIRE((long long)(num_classes - 1) * rows >= cap, "detection_select: cap exceeds the number of candidates");
+  MI_REQUIRE(scores != nullptr && boxes != nullptr && masked_scores != nullptr && top_values != nullptr &&
+                 top_indices != nullptr && dets != nullptr && cls != nullptr && sizes != nullptr,
+             "detection_select: null pointer");
+  detection_select<<<1, kSelectThreads, 0, mi::as_stream(stream)>>>(
+      scores, boxes, masked_scores, top_values, reinterpret_cast<const long long*>(top_indices), rows, num_classes, cap,
+      detections_per_im, dets, cls, reinterpret_cast<long long*>(sizes));
+  return mi::check_launch("detection_select");
 }
 
 extern "C" int mi_bbox_overlaps(const float* boxes, int num_boxes, const float* query, int num_query,

@@ -67,7 +67,159 @@ rpn_decode_kernel(const float* __restrict__ bbox_pred, const float* __restrict__
   valid[t] = ok ? 1 : 0;
 }
 
+// ---- collect: steps 6-8 of proposals_for_one_image (generate_proposals.py:155-161) for every (level, image) problem
+// and the concatenation of collect_and_distribute_fpn_rpn_proposals.py:83-90, in one launch.  A problem's candidates
+// are its k decoded boxes in descending score order; a candidate is TAKEN when the NMS kept it, the size filter passed
+// it, and it is among the first post_nms_topN such boxes.  Every candidate gets a row of the flat arrays (its score, or
+// -inf when it is not taken; (image, x1, y1, x2, y2)), so the global top-k that follows has fixed shapes. ----
+constexpr int kMaxCollect = 16;
+constexpr int kCollectThreads = 1024;
+constexpr int kMaxCandidates = 4096;   // per problem == the NMS batch limit
+struct CollectProblem {
+  const float* dets;          // [k, 5]
+  const int* valid;           // [k]
+  const long long* keep;      // ascending kept positions (nullptr: no NMS ran, everything is kept)
+  const int* num_keep;
+  int k, image, offset;
+};
+struct CollectTable {
+  int count, post_nms_topn;
+  CollectProblem p[kMaxCollect];
+};
+
+__global__ void __launch_bounds__(kCollectThreads)
+rpn_collect_candidates(const CollectTable t, float* __restrict__ cand_scores, float* __restrict__ cand_rois) {
+  __shared__ int s_take[kMaxCandidates];
+  __shared__ int s_wave[kCollectThreads / 64];
+  const CollectProblem p = t.p[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < p.k; j += kCollectThreads) s_take[j] = p.keep == nullptr ? (p.valid[j] != 0) : 0;
+  __syncthreads();
+  if (p.keep != nullptr) {
+    const int nk = min(*p.num_keep, p.k);
+    for (int j = tid; j < nk; j += kCollectThreads) {
+      const long long pos = p.keep[j];
+      if (pos >= 0 && pos < p.k && p.valid[pos] != 0) s_take[pos] = 1;
+    }
+  }
+  __syncthreads();
+  // rank of every taken candidate in score order: contiguous chunks per thread, block-wide exclusive scan
+  const int per = (p.k + kCollectThreads - 1) / kCollectThreads;
+  const int begin = min(tid * per, p.k), end = min(begin + per, p.k);
+  int local = 0;
+  for (int j = begin; j < end; j++) local += s_take[j];
+  int incl = local;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int rank = incl - local;
+  for (int w = 0; w < wave; w++) rank += s_wave[w];
+  for (int j = begin; j < end; j++) {
+    bool taken = s_take[j] != 0;
+    if (taken) {
+      rank++;
+      taken = t.post_nms_topn <= 0 || rank <= t.post_nms_topn;
+    }
+    const float* d = p.dets + (long long)j * 5;
+    const long long row = p.offset + j;
+    cand_scores[row] = taken ? d[4] : -__builtin_inff();
+    float* o = cand_rois + row * 5;
+    o[0] = (float)p.image;
+    o[1] = d[0];
+    o[2] = d[1];
+    o[3] = d[2];
+    o[4] = d[3];
+  }
+}
+
+// The rows the global top-k picked, as the RoI blob the heads consume: (image, x1, y1, x2, y2), whether the row is a
+// proposal at all (fewer candidates than rows: score -inf), and its FPN level (utils/fpn.py:11-28, fp32 in the
+// reference's operation order: floor(lvl0 + log2(sqrt(area) / s0 + 1e-6)) clamped to [k_min, k_max]).
+__global__ void __launch_bounds__(256)
+rpn_collect_finish(const float* __restrict__ top_scores, const long long* __restrict__ top_idx,
+                   const float* __restrict__ cand_rois, int rows, int mark_invalid, int k_min, int k_max, float s0,
+                   float lvl0, float* __restrict__ rois, unsigned char* __restrict__ valid, int* __restrict__ levels) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* c = cand_rois + top_idx[r] * 5;
+  const bool ok = top_scores[r] > -__builtin_inff();
+  const float x1 = c[1], y1 = c[2], x2 = c[3], y2 = c[4];
+  float* o = rois + (long long)r * 5;
+  o[0] = (ok || !mark_invalid) ? c[0] : -1.f;
+  o[1] = x1;
+  o[2] = y1;
+  o[3] = x2;
+  o[4] = y2;
+  valid[r] = ok ? 1 : 0;
+  const float w = x2 - x1 + 1.f, h = y2 - y1 + 1.f;
+  float area = w * h;
+  area = area < 0.f ? 0.f : area;             // areas[neg_idx] = 0 (utils/boxes.py:113-121 via fpn.py:18)
+  const float s = sqrtf(area);
+  float lvl = floorf(lvl0 + log2f(s / s0 + 1e-6f));
+  lvl = fminf(fmaxf(lvl, (float)k_min), (float)k_max);
+  levels[r] = (int)lvl;
+}
+
 }  // namespace
+
+extern "C" int mi_rpn_collect_candidates(int num_problems, const float* const* dets, const int32_t* const* valid,
+                                         const int64_t* const* keep, const int32_t* const* num_keep, const int* k,
+                                         const int* image, int post_nms_topn, float* cand_scores, float* cand_rois,
+                                         mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(num_problems >= 0, "rpn_collect_candidates: negative problem count");
+  if (num_problems == 0) return MI_OK;
+  MI_REQUIRE(dets != nullptr && valid != nullptr && k != nullptr && image != nullptr && cand_scores != nullptr &&
+                 cand_rois != nullptr,
+             "rpn_collect_candidates: null pointer");
+  hipStream_t s = mi::as_stream(stream);
+  int offset = 0;
+  for (int first = 0; first < num_problems; first += kMaxCollect) {
+    CollectTable t;
+    t.count = num_problems - first < kMaxCollect ? num_problems - first : kMaxCollect;
+    t.post_nms_topn = post_nms_topn;
+    for (int q = 0; q < t.count; q++) {
+      const int i = first + q;
+      MI_REQUIRE(k[i] >= 0 && k[i] <= kMaxCandidates, "rpn_collect_candidates: problem %d has %d candidates (max %d)", i,
+                 k[i], kMaxCandidates);
+      MI_REQUIRE(k[i] == 0 || (dets[i] != nullptr && valid[i] != nullptr), "rpn_collect_candidates: null pointer");
+      const bool with_nms = keep != nullptr && keep[i] != nullptr;
+      MI_REQUIRE(!with_nms || (num_keep != nullptr && num_keep[i] != nullptr), "rpn_collect_candidates: null num_keep");
+      t.p[q].dets = dets[i];
+      t.p[q].valid = valid[i];
+      t.p[q].keep = with_nms ? reinterpret_cast<const long long*>(keep[i]) : nullptr;
+      t.p[q].num_keep = with_nms ? num_keep[i] : nullptr;
+      t.p[q].k = k[i];
+      t.p[q].image = image[i];
+      t.p[q].offset = offset;
+      offset += k[i];
+    }
+    rpn_collect_candidates<<<t.count, kCollectThreads, 0, s>>>(t, cand_scores, cand_rois);
+    int rc = mi::check_launch("rpn_collect_candidates");
+    if (rc != MI_OK) return rc;
+  }
+  return MI_OK;
+}
+
+extern "C" int mi_rpn_collect_finish(const float* top_scores, const int64_t* top_indices, const float* cand_rois,
+                                     int rows, int mark_invalid, int k_min, int k_max, float canonical_scale,
+                                     float canonical_level, float* rois, uint8_t* valid, int32_t* levels,
+                                     mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(rows >= 0 && k_min <= k_max, "rpn_collect_finish: bad size");
+  if (rows == 0) return MI_OK;
+  MI_REQUIRE(top_scores != nullptr && top_indices != nullptr && cand_rois != nullptr && rois != nullptr &&
+                 valid != nullptr && levels != nullptr,
+             "rpn_collect_finish: null pointer");
+  rpn_collect_finish<<<mi::ceil_div(rows, 256), 256, 0, mi::as_stream(stream)>>>(
+      top_scores, reinterpret_cast<const long long*>(top_indices), cand_rois, rows, mark_invalid, k_min, k_max,
+      canonical_scale, canonical_level, rois, valid, levels);
+  return mi::check_launch("rpn_collect_finish");
+}
 
 extern "C" int mi_rpn_decode_proposals(const float* bbox_pred, const float* topk_scores, const int64_t* topk_idx,
                                        const float* im_info, const double* base_anchors_host, int num_images,

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import topk as topk_mod
 from .nms import SOFT_NMS_METHODS
 
 
@@ -46,22 +47,48 @@ TIE_SLACK = 28      # rows beyond DETECTIONS_PER_IM the static result can hold (
 
 def box_results_static(scores, boxes, score_thresh=0.05, nms_thresh=0.5, detections_per_im=100, roi_valid=None):
     """core/test.py:732-790 (hard NMS) with shapes fixed by the inputs' shapes and NO host synchronisation: what a
-    hipGraph of the whole detection step needs.  scores [R, C], boxes [R, 4C] device tensors; `roi_valid` [R] marks the
-    rows of a static-size RoI blob that are real proposals.  Returns a dict of device tensors:
-        dets [cap, 5], cls [cap] (class index, 1-based), valid [cap]   cap = detections_per_im + TIE_SLACK: the
+    hipGraph of the whole detection step needs.  Three calls: mi_nms_segmented (threshold + per-class NMS on the blobs in
+    place, emitting the surviving scores), mi_topk_batched (their detections_per_im + TIE_SLACK best), mi_detection_select
+    (the image_thresh cut of :776-785, the gather, the per-class counts).  scores [R, C], boxes [R, 4C] device tensors;
+    `roi_valid` [R] marks the rows of a static-size RoI blob that are real proposals.  Returns a dict of device tensors:
+        dets [cap, 5], cls [cap] (class index, 1-based; 0 = unused row)   cap = detections_per_im + TIE_SLACK: the
             detections class-major and RoI-ascending inside a class -- the reference's row order -- first `count` rows
-        count, total   int64 scalars: rows delivered, rows the reference returns (`total > cap` only when more than
-            TIE_SLACK scores tie with the detections_per_im-th best: the caller then takes the dynamic path)
-        class_counts   int64 [C - 1]."""
+        sizes int64 [1 + C] = (count, total, detections of class 1 .. C-1); count: rows delivered, total: rows the
+            reference returns (`total > count` only when more than TIE_SLACK scores tie with the detections_per_im-th
+            best: the caller then takes the dynamic path).  `count`, `total`, `class_counts` are views of it."""
     r, c = scores.shape
     nseg = c - 1
     if roi_valid is not None:
         scores = torch.where(roi_valid.view(r, 1), scores, torch.full_like(scores, float("-inf")))
-    from .nms import nms_segmented
-    kept, _ = nms_segmented(scores, boxes, score_thresh, nms_thresh)
+    scores, boxes = scores.contiguous(), boxes.contiguous()
     m = nseg * r
-    flat_scores = scores[:, 1:].t().reshape(m)                                # class-major, as `kept`
-    masked = torch.where(kept.view(m) != 0, flat_scores, torch.full_like(flat_scores, float("-inf")))
+    d = detections_per_im if detections_per_im > 0 else m
+    cap = min(m, d + TIE_SLACK)
+    if cap > 1024 or not topk_mod.supported(m, cap):
+        return _box_results_static_torch(scores, boxes, score_thresh, nms_thresh, detections_per_im)
+    from .nms import nms_segmented
+    _, _, masked = nms_segmented(scores, boxes, score_thresh, nms_thresh, with_masked_scores=True)
+    vals, idx = topk_mod.topk(masked.view(m), cap)
+    dets = torch.empty((cap, 5), dtype=torch.float32, device=scores.device)
+    cls = torch.empty((cap,), dtype=torch.int32, device=scores.device)
+    sizes = torch.empty((2 + nseg,), dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        rc = _lib.lib().mi_detection_select(scores.data_ptr(), boxes.data_ptr(), masked.data_ptr(), vals.data_ptr(),
+                                            idx.data_ptr(), r, c, cap, int(detections_per_im), dets.data_ptr(),
+                                            cls.data_ptr(), sizes.data_ptr(), _lib.current_stream_handle(scores.device))
+    _lib.check(rc, "mi_detection_select")
+    return {"dets": dets, "cls": cls, "sizes": sizes, "count": sizes[0], "total": sizes[1], "class_counts": sizes[2:]}
+
+
+def _box_results_static_torch(scores, boxes, score_thresh, nms_thresh, detections_per_im):
+    """`box_results_static` for results beyond one workgroup's reach (no detections_per_im limit: up to R * (C - 1)
+    rows): the cut and the gather as tensor expressions, same outputs."""
+    r, c = scores.shape
+    nseg = c - 1
+    from .nms import nms_segmented
+    _, _, masked = nms_segmented(scores, boxes, score_thresh, nms_thresh, with_masked_scores=True)
+    m = nseg * r
+    masked = masked.view(m)
     d = detections_per_im if detections_per_im > 0 else m
     cap = min(m, d + TIE_SLACK)
     vals, idx = torch.topk(masked, cap, sorted=True)
@@ -79,14 +106,15 @@ def box_results_static(scores, boxes, score_thresh=0.05, nms_thresh=0.5, detecti
     dets = torch.where(valid.view(cap, 1), dets, torch.zeros_like(dets))
     class_counts = torch.zeros((nseg + 1,), dtype=torch.int64, device=scores.device)
     class_counts.index_add_(0, torch.where(valid, cls0, torch.full_like(cls0, nseg)), torch.ones_like(cls0))
-    return {"dets": dets, "cls": (cls0 + 1) * valid, "valid": valid, "count": valid.sum(), "total": total,
-            "class_counts": class_counts[:nseg]}
+    sizes = torch.cat([valid.sum().view(1), total.view(1), class_counts[:nseg]])
+    return {"dets": dets, "cls": ((cls0 + 1) * valid).to(torch.int32), "sizes": sizes, "count": sizes[0],
+            "total": sizes[1], "class_counts": sizes[2:]}
 
 
 def _results_from_static(res, as_numpy):
     """The reference's return type from the static result: ONE device-to-host copy (the sizes), then views."""
     nseg = res["class_counts"].numel()
-    sizes = torch.cat([res["count"].view(1), res["total"].view(1), res["class_counts"]]).cpu().tolist()
+    sizes = res["sizes"].cpu().tolist()
     count, total, counts = sizes[0], sizes[1], sizes[2:]
     if total != count:
         return None                                                           # more ties than TIE_SLACK holds

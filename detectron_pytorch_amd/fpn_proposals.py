@@ -14,9 +14,12 @@ sqrt, the division and the sum are correctly rounded on both sides, log2 is not 
 a RoI whose scale sits within an ulp of a power of two may land on the neighbouring level -- none does on the test
 sets, and the fixture from the reference's own utils/fpn.py is matched.
 """
+import ctypes
+
 import torch
 
 from . import _lib
+from . import topk as topk_mod
 from .nms import nms_device_many
 
 
@@ -59,14 +62,88 @@ def collect_and_distribute(rois_list, scores_list, post_nms_topN, k_min=2, k_max
     return distribute(collect(rois_list, scores_list, post_nms_topN), k_min, k_max)
 
 
-def generate_and_collect(ops, heads, im_info, post_nms_topN, static=False):
-    """GenerateProposals on every RPN level followed by `collect`, as ONE asynchronous pipeline: per level top-k + decode,
-    then a single batched NMS over all (level, image) problems, then one global top-k over the scores of the boxes that
-    survived (the others are masked to -inf) -- the per-level RoI lists of :83-95 are never materialised, and the only
-    host synchronisation is the final count.  `ops`: one generate_proposals.GenerateProposalsOp per level (same
-    nms_thresh); `heads`: the matching (rpn_cls_prob, rpn_bbox_pred) pairs.  Returns rois [R,5] in descending score
-    order, R <= post_nms_topN -- what `collect` returns for the reference's per-level outputs.  `static=True`: (rois
-    [k,5], valid [k]) with k = min(post_nms_topN, candidates) fixed by the shapes alone and no host synchronisation."""
+def _fused_supported(ops, heads, post_nms_topN):
+    if post_nms_topN <= 0 or post_nms_topN > topk_mod.MAX_K:
+        return False
+    for op, (sc, _) in zip(ops, heads):
+        total = sc[0].numel()
+        if sc.size(0) == 0 or not topk_mod.supported(total, op.num_candidates(total)):
+            return False
+    return True
+
+
+def generate_and_collect(ops, heads, im_info, post_nms_topN, static=False, with_levels=False, k_min=2, k_max=5):
+    """GenerateProposals on every RPN level followed by `collect`, as ONE asynchronous pipeline of a dozen launches:
+        mi_topk_batched            pre-NMS top-k of every (level, image) score map, all side by side
+        mi_rpn_decode_proposals    anchors + deltas -> boxes, clip, size filter                       (per level)
+        mi_nms_batched             all (level, image) problems side by side
+        mi_rpn_collect_candidates  kept & valid & first post_nms_topN of each problem -> one flat candidate array
+        mi_topk_batched            the post_nms_topN best of all levels and images (:83-98)
+        mi_rpn_collect_finish      the RoI blob, its validity mask and the FPN level of every RoI (:101-119)
+    The per-level RoI lists of :83-95 are never materialised and nothing is read back before the final count.
+    `ops`: one generate_proposals.GenerateProposalsOp per level (same nms_thresh); `heads`: the matching (rpn_cls_prob,
+    rpn_bbox_pred) pairs.  Returns rois [R,5] in descending score order, R <= post_nms_topN -- what `collect` returns
+    for the reference's per-level outputs.  `static=True`: (rois [k,5], valid [k]) with k = min(post_nms_topN,
+    candidates) fixed by the shapes alone and no host synchronisation at all; `with_levels=True` (static only): (rois,
+    valid, levels int32 [k]) where the rows that are no proposals carry image index -1."""
+    if not _fused_supported(ops, heads, post_nms_topN):
+        return _generate_and_collect_torch(ops, heads, im_info, post_nms_topN, static, with_levels, k_min, k_max)
+    lib = _lib.lib()
+    device = heads[0][0].device
+    # 1. one selection call for all (level, image) rows
+    rows, ks, shapes = [], [], []
+    for op, (sc, _) in zip(ops, heads):
+        n = sc.size(0)
+        flat = sc.detach().contiguous().view(n, -1)
+        k = op.num_candidates(flat.size(1))
+        rows += list(flat.unbind(0))
+        ks += [k] * n
+        shapes.append((n, k))
+    vals, idx, offs = topk_mod.topk_flat(rows, ks)
+    # 2. decode per level, 3. one batched NMS
+    decoded, first = [], 0
+    for op, (sc, dl), (n, k) in zip(ops, heads, shapes):
+        lo, hi = offs[first], offs[first + n]
+        decoded.append(op.decode(sc, dl, im_info, top=(vals[lo:hi].view(n, k), idx[lo:hi].view(n, k))))
+        first += n
+    thresh = ops[0].nms_thresh
+    problems = [(dets[i], valid[i], i) for dets, valid in decoded for i in range(dets.size(0))]
+    kept = nms_device_many([d for d, _, _ in problems], thresh, _lib.NMS_GE_ORIG_ASC) if thresh > 0 else None
+    # 4. candidates of all problems, flat
+    p = len(problems)
+    total = sum(int(d.size(0)) for d, _, _ in problems)
+    cand_scores = torch.empty((total,), dtype=torch.float32, device=device)
+    cand_rois = torch.empty((total, 5), dtype=torch.float32, device=device)
+    void_arr, int_arr = ctypes.c_void_p * p, ctypes.c_int * p
+    stream = _lib.current_stream_handle(device)
+    with torch.cuda.device(device):
+        rc = lib.mi_rpn_collect_candidates(
+            p, void_arr(*[d.data_ptr() for d, _, _ in problems]), void_arr(*[v.data_ptr() for _, v, _ in problems]),
+            void_arr(*[kp.data_ptr() for kp, _ in kept]) if kept is not None else None,
+            void_arr(*[nm.data_ptr() for _, nm in kept]) if kept is not None else None,
+            int_arr(*[int(d.size(0)) for d, _, _ in problems]), int_arr(*[i for _, _, i in problems]),
+            int(ops[0].post_nms_topN), cand_scores.data_ptr(), cand_rois.data_ptr(), stream)
+    _lib.check(rc, "mi_rpn_collect_candidates")
+    # 5. the best of all levels and images, 6. the RoI blob
+    k = min(int(post_nms_topN), total)
+    best, inds = topk_mod.topk(cand_scores, k)
+    rois = torch.empty((k, 5), dtype=torch.float32, device=device)
+    valid = torch.empty((k,), dtype=torch.bool, device=device)
+    levels = torch.empty((k,), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        rc = lib.mi_rpn_collect_finish(best.data_ptr(), inds.data_ptr(), cand_rois.data_ptr(), k,
+                                       1 if (static and with_levels) else 0, int(k_min), int(k_max), 224.0, 4.0,
+                                       rois.data_ptr(), valid.data_ptr(), levels.data_ptr(), stream)
+    _lib.check(rc, "mi_rpn_collect_finish")
+    if static:
+        return (rois, valid, levels) if with_levels else (rois, valid)
+    count = int(valid.sum().item())                                # the one synchronisation
+    return rois[:count]
+
+
+def _generate_and_collect_torch(ops, heads, im_info, post_nms_topN, static, with_levels, k_min, k_max):
+    """The same pipeline with torch.topk and tensor expressions for the selections: sizes beyond the fused kernels'
+    (more than 4096 candidates per problem or RoIs per batch -- no FPN configuration of the reference gets there)."""
     decoded = [op.decode(sc, dl, im_info) for op, (sc, dl) in zip(ops, heads)]
     thresh = ops[0].nms_thresh
     if thresh > 0:
@@ -84,7 +161,10 @@ def generate_and_collect(ops, heads, im_info, post_nms_topN, static=False):
     k = min(int(post_nms_topN), scores.numel()) if post_nms_topN > 0 else scores.numel()
     best, inds = torch.topk(scores, k, largest=True, sorted=True)
     if static:
-        # static-shape form for the training step: always k rows plus a validity mask, no host synchronisation at all
-        return boxes[inds], best > float("-inf")
+        rois, valid = boxes[inds], best > float("-inf")
+        if not with_levels:
+            return rois, valid
+        rois = torch.cat([torch.where(valid, rois[:, 0], torch.full_like(rois[:, 0], -1.0)).view(-1, 1), rois[:, 1:5]], 1)
+        return rois, valid, map_rois_to_fpn_levels(rois[:, 1:5], k_min, k_max)
     count = int((best > float("-inf")).sum().item())            # the one synchronisation
     return boxes[inds[:count]]

@@ -4,7 +4,7 @@ Mirrors `GenerateProposalsOp` (lib/modeling/generate_proposals.py:12-182) and `g
 (lib/modeling/generate_anchors.py:54-123).  The reference copies the RPN outputs to the host and runs numpy +
 cython_nms per image (:58-63, five levels x images per step); here, per level and for all images at once:
 
-    torch.topk over the [A*H*W] scores  ->  mi_rpn_decode_proposals (anchor + deltas -> box, clip, filter; one launch)
+    mi_topk_batched over the [A*H*W] scores  ->  mi_rpn_decode_proposals (anchor + deltas -> box, clip, filter; one launch)
     ->  mi_nms_batched (one problem per image, input already score-sorted)  ->  the first post_nms_topN kept and valid.
 
 No device-to-host copy before the final sizes are needed (the reference's return type is a concatenated array).
@@ -13,7 +13,7 @@ constructor arguments with the reference's defaults (core/config.py:132-149,936)
 
 Parity: the decode follows the arithmetic types numpy >= 2 gives the reference's expressions (fp32, with the
 width/height branch in fp64 -- see csrc/proposals.hip); boxes and kept sets equal the reference's on the fixtures.
-The order of tied scores is as undefined here (torch.topk) as there (np.argsort of the negated scores).
+The order of tied scores is undefined in the reference (np.argsort of the negated scores); here: lower index first.
 """
 import ctypes
 
@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import topk as topk_mod
 from .nms import nms_device_many
 
 BBOX_XFORM_CLIP = float(np.log(1000.0 / 16.0))  # core/config.py:936
@@ -57,9 +58,14 @@ class GenerateProposalsOp(object):
     def __call__(self, rpn_cls_prob, rpn_bbox_pred, im_info):
         return self.forward(rpn_cls_prob, rpn_bbox_pred, im_info)
 
-    def decode(self, rpn_cls_prob, rpn_bbox_pred, im_info):
+    def num_candidates(self, total):
+        """Pre-NMS candidates of one image of this level: min(pre_nms_topN, A*H*W) (:131-134)."""
+        return total if (self.pre_nms_topN <= 0 or self.pre_nms_topN >= total) else self.pre_nms_topN
+
+    def decode(self, rpn_cls_prob, rpn_bbox_pred, im_info, top=None):
         """Steps 1-5 (:113-153): top-k, decode, clip, filter.  Returns dets [N,k,5] (score-descending, rejected boxes
-        parked far away) and valid [N,k] int32; nothing is copied to the host."""
+        parked far away) and valid [N,k] int32; nothing is copied to the host.  `top`: (scores [N,k], flat indices [N,k])
+        when the caller has already selected (fpn_proposals does it for all levels in one call)."""
         _lib.require_cuda(rpn_cls_prob, "rpn_cls_prob")
         scores = rpn_cls_prob.detach().contiguous()
         deltas = rpn_bbox_pred.detach().contiguous()
@@ -72,8 +78,15 @@ class GenerateProposalsOp(object):
             raise ValueError("rpn_cls_prob [N,A,H,W] / rpn_bbox_pred [N,4A,H,W] float32 expected for %d anchors"
                              % self._num_anchors)
         total = a * h * w
-        k = total if (self.pre_nms_topN <= 0 or self.pre_nms_topN >= total) else self.pre_nms_topN
-        top_scores, top_idx = torch.topk(scores.view(n, total), k, dim=1, largest=True, sorted=True)     # :131-142
+        k = self.num_candidates(total)
+        if top is None:
+            if topk_mod.supported(total, k) and n > 0:
+                top_scores, top_idx = topk_mod.topk_rows(scores.view(n, total), k)
+            else:
+                top_scores, top_idx = torch.topk(scores.view(n, total), k, dim=1, largest=True, sorted=True)  # :131-142
+        else:
+            top_scores, top_idx = top                                          # [n, k] each, from one batched call
+        top_scores, top_idx = top_scores.contiguous(), top_idx.contiguous()
         dets = torch.empty((n, k, 5), dtype=torch.float32, device=device)
         valid = torch.empty((n, k), dtype=torch.int32, device=device)
         with torch.cuda.device(device):

@@ -102,11 +102,12 @@ def nms_device_many(dets_list, thresh, mode=_lib.NMS_GE_ORIG_ASC, max_streams=8)
     return outs
 
 
-def nms_segmented(scores, boxes, score_thresh, nms_thresh, first_class=1):
+def nms_segmented(scores, boxes, score_thresh, nms_thresh, first_class=1, with_masked_scores=False):
     """The per-class loop of core/test.py:748-771 as one asynchronous call on the blobs as the network leaves them:
     scores [R, C], boxes [R, 4C] float32 device tensors.  Class j >= first_class is a segment; its rows with
     score > score_thresh go through cython-semantics NMS.  Returns (kept int32 [C - first_class, R] 0/1 flags, num_keep
-    int32 [C - first_class]) -- device tensors, no host synchronisation, shapes fixed by the inputs' shapes alone."""
+    int32 [C - first_class]) -- device tensors, no host synchronisation, shapes fixed by the inputs' shapes alone;
+    `with_masked_scores`: a third tensor float32 [C - first_class, R], the score where the row survives, -inf elsewhere."""
     _lib.require_cuda(scores, "scores")
     if scores.dtype != torch.float32 or boxes.dtype != torch.float32 or scores.dim() != 2:
         raise TypeError("nms_segmented expects float32 scores [R, C] and boxes [R, 4C]")
@@ -118,17 +119,20 @@ def nms_segmented(scores, boxes, score_thresh, nms_thresh, first_class=1):
     dev = scores.device
     kept = torch.empty((max(nseg, 0), r), dtype=torch.int32, device=dev)
     num_keep = torch.empty((max(nseg, 0),), dtype=torch.int32, device=dev)
-    if nseg <= 0:
-        return kept, num_keep
+    masked = torch.empty((max(nseg, 0), r), dtype=torch.float32, device=dev) if with_masked_scores else None
+    if nseg <= 0 or r == 0:
+        num_keep.zero_()
+        return (kept, num_keep, masked) if with_masked_scores else (kept, num_keep)
     lib = _lib.lib()
     ws_bytes = lib.mi_nms_segmented_workspace_bytes(nseg, r)
     workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.mi_nms_segmented(boxes.data_ptr() + 16 * first_class, 4, 4 * c, scores.data_ptr() + 4 * first_class, 1, c,
                                   nseg, r, float(score_thresh), float(nms_thresh), kept.data_ptr(), num_keep.data_ptr(),
-                                  workspace.data_ptr(), ws_bytes, _lib.current_stream_handle(dev))
+                                  masked.data_ptr() if with_masked_scores else None, workspace.data_ptr(), ws_bytes,
+                                  _lib.current_stream_handle(dev))
     _lib.check(rc, "mi_nms_segmented")
-    return kept, num_keep
+    return (kept, num_keep, masked) if with_masked_scores else (kept, num_keep)
 
 
 def nms_gpu(dets, thresh):

@@ -81,7 +81,7 @@ class GeneralizedRCNN(nn.Module):
                                                sampling_ratio, self.cfg.FPN.ROI_MIN_LEVEL, self.cfg.FPN.ROI_MAX_LEVEL)
 
     # ---- proposals -----------------------------------------------------------------------------------------------------
-    def proposals(self, rpn_ret, im_info, static):
+    def proposals(self, rpn_ret, im_info, static, with_levels=False):
         """FPN.py:390-417 without leaving the device: sigmoid, GenerateProposals on every level, collect."""
         cfg = self.cfg
         heads_ = [(torch.sigmoid(rpn_ret["rpn_cls_logits_fpn%d" % lvl].detach().float()).contiguous(),
@@ -89,6 +89,10 @@ class GeneralizedRCNN(nn.Module):
                   for lvl in range(cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL + 1)]
         key = "TRAIN" if self.training else "TEST"
         post = int(cfg[key].RPN_POST_NMS_TOP_N * cfg.FPN.RPN_COLLECT_SCALE + 0.5)      # collect_and...py:74
+        if with_levels:
+            return fpn_proposals.generate_and_collect(self.RPN.proposal_ops(self.training), heads_, im_info, post,
+                                                      static=True, with_levels=True, k_min=cfg.FPN.ROI_MIN_LEVEL,
+                                                      k_max=cfg.FPN.ROI_MAX_LEVEL)
         return fpn_proposals.generate_and_collect(self.RPN.proposal_ops(self.training), heads_, im_info, post,
                                                   static=static)
 
@@ -128,10 +132,7 @@ class GeneralizedRCNN(nn.Module):
                 if self.static_inference:
                     # always RPN_POST_NMS_TOP_N rows; the rows that are no proposals get image index -1 (the RoI operators
                     # pool zeros for them) and are reported in `rois_valid`: no host synchronisation, capturable
-                    rois, valid = self.proposals(rpn_ret, im_info_d, static=True)
-                    rois = torch.cat([torch.where(valid, rois[:, 0], torch.full_like(rois[:, 0], -1.0)).view(-1, 1),
-                                      rois[:, 1:5]], dim=1)
-                    lvls = fpn_proposals.map_rois_to_fpn_levels(rois[:, 1:5], cfg.FPN.ROI_MIN_LEVEL, cfg.FPN.ROI_MAX_LEVEL)
+                    rois, valid, lvls = self.proposals(rpn_ret, im_info_d, static=True, with_levels=True)
                     blobs = {"rois": rois, "rois_levels": lvls}
                     ret["rois_valid"] = valid
                 else:

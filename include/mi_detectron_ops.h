@@ -244,8 +244,51 @@ int mi_soft_nms_segmented(const float* dets, const int32_t* offsets, int num_seg
 size_t mi_nms_segmented_workspace_bytes(int num_segments, int rows);
 int mi_nms_segmented(const float* boxes, long long box_segment_stride, long long box_row_stride, const float* scores,
                      long long score_segment_stride, long long score_row_stride, int num_segments, int rows,
-                     float score_thresh, float nms_thresh, int32_t* kept, int32_t* num_keep, void* workspace,
-                     size_t workspace_bytes, mi_stream_t stream);
+                     float score_thresh, float nms_thresh, int32_t* kept, int32_t* num_keep, float* masked_scores,
+                     void* workspace, size_t workspace_bytes, mi_stream_t stream);
+/* masked_scores (may be NULL) [num_segments, rows]: the score of every surviving row, -inf elsewhere -- the array the
+ * detections_per_im cut ranks (below). */
+
+/* The detections_per_im cut and the final gather of box_results_with_nms_and_limit (core/test.py:776-790) for hard NMS:
+ * `masked_scores` from mi_nms_segmented (segments = classes 1.., rows = RoIs); top_values / top_indices = its `cap`
+ * best entries in descending order (mi_topk_batched), cap <= 1024.  image_thresh = the detections_per_im-th best; every
+ * surviving row at or above it is a detection (ties included).  Writes, in the reference's row order (class-major,
+ * RoI-ascending inside a class): dets [cap,5] (x1,y1,x2,y2,score from boxes [rows, 4*num_classes] / scores [rows,
+ * num_classes]), cls [cap] (class index, 0 for unused rows), sizes [1 + num_classes] int64 = (rows delivered, rows the
+ * reference returns -- larger only when more than cap - detections_per_im scores tie at the cut --, then the detections
+ * of classes 1 .. num_classes-1).  Unused rows are zero. */
+int mi_detection_select(const float* scores, const float* boxes, const float* masked_scores, const float* top_values,
+                        const int64_t* top_indices, int rows, int num_classes, int cap, int detections_per_im,
+                        float* dets, int32_t* cls, int64_t* sizes, mi_stream_t stream);
+
+/* Sorted top-k of float32 arrays, independent problems side by side (one workgroup each): replaces np.argsort /
+ * np.argpartition of lib/modeling/generate_proposals.py:131-142 (pre-NMS top-k of a level's scores),
+ * collect_and_distribute_fpn_rpn_proposals.py:85-86 (post_nms_topN of the collected levels) and np.sort of
+ * core/test.py:781-784.  Problem p: values[p] [n[p]] -> out_values[p] [k[p]] descending, out_indices[p] [k[p]] int64;
+ * equal values: lower index first (the reference's order of ties is undefined); NaN ranks below -inf.
+ * 0 <= k <= n <= 2^24, k <= 4096.  The pointer / size arrays are HOST arrays. */
+int mi_topk_batched(int num_problems, const float* const* values, const int* n, const int* k, float* const* out_values,
+                    int64_t* const* out_indices, mi_stream_t stream);
+
+/* Steps 6-8 of GenerateProposalsOp.proposals_for_one_image (lib/modeling/generate_proposals.py:155-161) for all
+ * (level, image) problems and the concatenation of collect_and_distribute_fpn_rpn_proposals.py:83-90, one launch.
+ * Problem p (HOST arrays of num_problems entries): dets[p] [k[p],5] / valid[p] [k[p]] from mi_rpn_decode_proposals,
+ * keep[p] / num_keep[p] from mi_nms / mi_nms_batched in MI_NMS_GE_ORIG_ASC mode (keep == NULL or keep[p] == NULL: no
+ * NMS), image[p] = its batch index.  A candidate is taken when it was kept, is valid, and is among the first
+ * post_nms_topn (<= 0: all) such boxes of its problem.  Writes one row per candidate, problems back to back:
+ * cand_scores [sum k] (score, or -inf when not taken) and cand_rois [sum k, 5] (image, x1, y1, x2, y2). k[p] <= 4096. */
+int mi_rpn_collect_candidates(int num_problems, const float* const* dets, const int32_t* const* valid,
+                              const int64_t* const* keep, const int32_t* const* num_keep, const int* k, const int* image,
+                              int post_nms_topn, float* cand_scores, float* cand_rois, mi_stream_t stream);
+
+/* The RoI blob of the heads from the global top-k over cand_scores (mi_topk_batched): rois [rows,5] = cand_rois[
+ * top_indices], valid [rows] (uint8: the row is a proposal, i.e. its score is above -inf), levels [rows] int32 = the FPN
+ * level of utils/fpn.py:11-28 (floor(canonical_level + log2(sqrt(area) / canonical_scale + 1e-6)) in fp32, clamped to
+ * [k_min, k_max]).  mark_invalid != 0: rows that are no proposals get image index -1 (the RoI operators pool zeros for
+ * them).  Replaces collect (:91-98) and the level half of distribute (:101-119). */
+int mi_rpn_collect_finish(const float* top_scores, const int64_t* top_indices, const float* cand_rois, int rows,
+                          int mark_invalid, int k_min, int k_max, float canonical_scale, float canonical_level,
+                          float* rois, uint8_t* valid, int32_t* levels, mi_stream_t stream);
 
 /* Independent NMS problems in one call (no reference counterpart: the reference runs one cython_nms per FPN level and
  * image on the host, modeling/generate_proposals.py:91-99,161).  `dets`, `n`, `keep`, `num_keep` are HOST arrays of

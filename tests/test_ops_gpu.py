@@ -7,6 +7,8 @@ operation order with FMA contraction off, so they are checked bit-exactly too wh
 order is deterministic; backward ops use fp32 atomics (order unspecified in the reference as well)
 and are checked to 1e-4.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -626,7 +628,7 @@ def test_detection_static_result_and_tie_overflow(oracle_mod):
     assert count == int(res["total"]) == len(want[0])
     assert np.array_equal(res["dets"][:count].cpu().numpy(), np.vstack([c for c in want[2][1:] if len(c)]))
     assert np.array_equal(res["class_counts"].cpu().numpy(), [len(c) for c in want[2][1:]])
-    assert not bool(res["valid"][count:].any()) and float(res["dets"][count:].abs().sum()) == 0
+    assert not bool(res["cls"][count:].any()) and float(res["dets"][count:].abs().sum()) == 0
     # 200 far-apart boxes with one and the same score: the reference keeps all of them (scores >= image_thresh)
     n = 200
     scores = np.zeros((n, 3), np.float32)
@@ -737,6 +739,101 @@ def test_roi_align_fpn_fused_other_resolutions(oracle_mod, res, sr, channels, ch
                    oracle_mod.roi_align_forward(feats[k], rois[idx], res, res, scales[k], sr, threads=8), "fwd", exact=False)
         assert_close(dev_feats[k].grad, oracle_mod.roi_align_backward(gtop[idx], rois[idx], feats[k].shape, scales[k], sr,
                                                                       threads=8), "bwd")
+
+
+# ---- sorted top-k (the selections around the NMS kernels) ------------------------------------------------------------
+def _topk_reference(v, k):
+    """Descending values, ties by ascending index, NaN last: np.lexsort restatement of mi_topk_batched's contract."""
+    key = np.where(np.isnan(v), -np.inf, v).astype(np.float64)
+    key[np.isnan(v)] = -np.inf
+    nan_rank = np.isnan(v).astype(np.int64)                       # NaN below -inf
+    order = np.lexsort((np.arange(len(v)), -key, nan_rank))
+    return order[:k]
+
+
+@pytest.mark.parametrize("n,k,kind", [(201600, 2000, "sigmoid"), (201600, 1000, "concentrated"), (50400, 4096, "normal"),
+                                      (819, 819, "normal"), (1, 1, "normal"), (80000, 128, "masked"),
+                                      (5000, 1000, "ties"), (3000, 700, "nan"), (70000, 1000, "few_finite")])
+def test_topk_batched_matches_numpy(n, k, kind):
+    from detectron_pytorch_amd import topk
+
+    rng = np.random.RandomState(n % 97 + k)
+    if kind == "sigmoid":
+        v = (1 / (1 + np.exp(-rng.randn(n) * 3))).astype(np.float32)
+    elif kind == "concentrated":                                   # a fresh RPN: every score within 1e-3 of 0.5
+        v = (0.5 + rng.randn(n) * 1e-3).astype(np.float32)
+    elif kind == "masked":                                         # the detection cut: mostly -inf
+        v = np.full(n, -np.inf, np.float32)
+        live = rng.choice(n, 3000, replace=False)
+        v[live] = rng.rand(3000).astype(np.float32)
+    elif kind == "ties":                                           # 16 distinct values: the k-th is tied many times over
+        v = (rng.randint(0, 16, n) / 16).astype(np.float32)
+    elif kind == "nan":
+        v = rng.randn(n).astype(np.float32)
+        v[rng.rand(n) < 0.3] = np.nan
+        v[rng.rand(n) < 0.1] = -np.inf
+        v[rng.rand(n) < 0.05] = np.inf
+    elif kind == "few_finite":                                     # fewer live candidates than k: -inf rows fill up
+        v = np.full(n, -np.inf, np.float32)
+        v[rng.choice(n, 300, replace=False)] = rng.randn(300).astype(np.float32)
+    else:
+        v = rng.randn(n).astype(np.float32)
+    vals, idx = topk.topk(to_dev(v), k)
+    want = _topk_reference(v, k)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.array_equal(vals.cpu().numpy(), v[want], equal_nan=True)
+
+
+def test_topk_batched_many_problems_and_limits():
+    from detectron_pytorch_amd import _lib, topk
+
+    rng = np.random.RandomState(0)
+    rows = [rng.randn(n).astype(np.float32) for n in [10, 4000, 333, 64, 65, 100000] * 4]   # 24 problems: two launches
+    ks = [min(len(r), kk) for r, kk in zip(rows, [10, 1000, 1, 64, 33, 2000] * 4)]
+    out = topk.topk_many([to_dev(r) for r in rows], ks)
+    for r, k, (vals, idx) in zip(rows, ks, out):
+        want = _topk_reference(r, k)
+        assert np.array_equal(idx.cpu().numpy(), want) and np.array_equal(vals.cpu().numpy(), r[want])
+    x = to_dev(rng.randn(3, 5000).astype(np.float32))
+    vals, idx = topk.topk_rows(x, 50)
+    tv, ti = torch.topk(x, 50, dim=1)
+    assert torch.equal(vals, tv) and torch.equal(idx, ti)           # untied: identical to torch.topk
+    with pytest.raises(ValueError):
+        topk.topk(x[0].contiguous(), 4097)
+    lib = _lib.lib()
+    arr = (ctypes.c_void_p * 1)(x.data_ptr())
+    one = (ctypes.c_int * 1)(5000)
+    big = (ctypes.c_int * 1)(4097)
+    assert lib.mi_topk_batched(1, arr, one, big, arr, arr, None) != 0 and b"4096" in lib.mi_last_error()
+
+
+def test_rpn_collect_static_fused_equals_the_tensor_expression_path():
+    """generate_and_collect through the fused kernels (mi_topk_batched / mi_rpn_collect_candidates / _finish) == the same
+    pipeline written with torch.topk and tensor expressions, including the static form with padding rows and levels."""
+    from detectron_pytorch_amd import fpn_proposals, generate_proposals as gp
+
+    levels = [(2, 200, 336, 4, 32), (3, 100, 168, 8, 64), (4, 50, 84, 16, 128), (5, 25, 42, 32, 256), (6, 13, 21, 64, 512)]
+    im_info = to_dev(np.array([[800, 1344, 1.0], [760, 1200, 1.5]], np.float32))
+    for pre, post, thresh, min_size in ((1000, 1000, 0.7, 0), (2000, 2000, 0.7, 0), (600, 300, 0.0, 16)):
+        ops, heads = [], []
+        for lvl, h, w, stride, size in levels:
+            anchors = gp.generate_anchors(stride, (size,), (0.5, 1, 2))
+            sc, dl = syn.rpn_head_outputs(2, 3, h, w, seed=lvl)
+            ops.append(gp.GenerateProposalsOp(anchors, 1.0 / stride, pre, post, thresh, min_size, as_numpy=False))
+            heads.append((to_dev(sc), to_dev(dl)))
+        assert fpn_proposals._fused_supported(ops, heads, post)
+        got = fpn_proposals.generate_and_collect(ops, heads, im_info, post, static=True, with_levels=True)
+        want = fpn_proposals._generate_and_collect_torch(ops, heads, im_info, post, True, True, 2, 5)
+        n_valid = int(want[1].sum())
+        assert torch.equal(got[1], want[1]) and n_valid > 0
+        # rows that are proposals: same RoIs in the same order (scores are untied), same levels; padding rows: image -1
+        assert torch.equal(got[0][:n_valid], want[0][:n_valid]) and torch.equal(got[2][:n_valid], want[2][:n_valid])
+        assert bool((got[0][n_valid:, 0] == -1).all())
+        dyn = fpn_proposals.generate_and_collect(ops, heads, im_info, post)
+        assert torch.equal(dyn, got[0][:n_valid])
+    # an over-asked collect (post > candidates that survive): the tail is padding
+    got = fpn_proposals.generate_and_collect(ops, heads, im_info, 4000, static=True)
+    assert got[0].shape[0] == 4000 and int(got[1].sum()) < 4000
 
 
 # ---- RPN proposal generation on the device (generate_proposals.py:12-182) -----------------------------------------

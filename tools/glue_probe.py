@@ -25,9 +25,7 @@ cls, box = torch.from_numpy(cls_np).to(device), torch.from_numpy(box_np).to(devi
 part = sys.argv[2] if len(sys.argv) > 2 else "all"
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
     if part in ("all", "proposals"):
-        rois, valid = fpn_proposals.generate_and_collect(ops, heads, info, 1000, static=True)
-        rois = torch.cat([torch.where(valid, rois[:, 0], torch.full_like(rois[:, 0], -1.0)).view(-1, 1), rois[:, 1:5]], 1)
-        lv = fpn_proposals.map_rois_to_fpn_levels(rois[:, 1:5])
+        rois, valid, lv = fpn_proposals.generate_and_collect(ops, heads, info, 1000, static=True, with_levels=True)
         with torch.no_grad():
             pooled = roi_align_fpn(feats, scales, rois, 5 - lv, 7, 7, 2)
     if part in ("all", "detect"):

@@ -396,9 +396,7 @@ def inference_path(device, iters=10):
     def run_static():
         """The same work with fixed shapes and no host synchronisation (static RoI blob + validity mask, image index -1
         for the padding rows, mi_nms_segmented on the blobs in place): the form a hipGraph takes."""
-        rois, valid = fpn_proposals.generate_and_collect(ops, heads, info, 1000, static=True)
-        rois = torch.cat([torch.where(valid, rois[:, 0], torch.full_like(rois[:, 0], -1.0)).view(-1, 1), rois[:, 1:5]], 1)
-        lv = fpn_proposals.map_rois_to_fpn_levels(rois[:, 1:5])
+        rois, valid, lv = fpn_proposals.generate_and_collect(ops, heads, info, 1000, static=True, with_levels=True)
         with torch.no_grad():
             pooled = roi_align_fpn(feats, scales, rois, 5 - lv, 7, 7, 2)
         return pooled, detection.box_results_static(cls, box, roi_valid=valid)
@@ -415,7 +413,7 @@ def inference_path(device, iters=10):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         pooled, res = run_static()
-        sizes = torch.cat([res["count"].view(1), res["total"].view(1), res["class_counts"]])
+        sizes = res["sizes"]
 
     def replay():
         graph.replay()
