@@ -388,7 +388,9 @@ def inference_graph_child(device, dtype, iters=30):
     want = inference.im_detect_all(net, data, im_info, autocast_dtype=autocast)
     graph = inference.DetectionGraph(net, tuple(data.shape), device, autocast).capture(data, im_info)
     got = graph(data, im_info)
-    same = bool(torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]))
+    # same detections; scores to 1e-6 (hipBLASLt's split-K box-head GEMM accumulates with atomics: run-to-run last bits)
+    same = bool(got[0].shape == want[0].shape and torch.allclose(got[0], want[0], rtol=0, atol=1e-6)
+                and torch.allclose(got[1], want[1], rtol=0, atol=1e-3))
     for _ in range(3):
         graph(data, im_info)
     torch.cuda.synchronize()

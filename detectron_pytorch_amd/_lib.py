@@ -45,7 +45,8 @@ SIGNATURES = {
                                  ctypes.c_longlong, _c_int, _c_int, _c_float, _c_float, _c_void_p, _c_void_p, _c_void_p,
                                  _c_void_p, _c_size_t, _c_void_p]),
     "mi_detection_select": (_c_int, [_c_void_p] * 5 + [_c_int] * 4 + [_c_void_p] * 4),
-    "mi_topk_batched": (_c_int, [_c_int] + [_c_void_p] * 6),
+    "mi_topk_batched_workspace_bytes": (_c_size_t, [_c_int, _c_void_p, _c_void_p]),
+    "mi_topk_batched": (_c_int, [_c_int] + [_c_void_p] * 6 + [_c_size_t, _c_void_p]),
     "mi_rpn_collect_candidates": (_c_int, [_c_int] + [_c_void_p] * 6 + [_c_int, _c_void_p, _c_void_p, _c_void_p]),
     "mi_rpn_collect_finish": (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_float, _c_float] + [_c_void_p] * 4),
     "mi_roi_align_fpn_supported": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int]),

@@ -6,13 +6,17 @@
 // detections_per_im best class scores of an image (core/test.py:776-785, np.sort).  torch.topk answers each of them with a
 // dozen sort / merge launches (rocprofv3: ~320 us per test image for the six selections of the RPN path); here one
 // workgroup per problem does the whole selection out of LDS:
-//   1. radix select of the k-th largest key, 12 + 12 + 8 bits: three passes over the values (the array of the largest
-//      FPN level, 800 KB, stays in L2 after the first), LDS histogram, wave-aggregated atomics for the hot bins (RPN scores
-//      of a fresh network all share their leading bits: plain LDS atomics would serialise on one address);
-//   2. if the k-th key is tied with more elements than fit, two more passes select among the ties by index (lowest
-//      first), so the selected SET is unique and the result deterministic;
-//   3. one pass gathers the selected (key, index) pairs into LDS (slots from a wave-aggregated counter);
-//   4. bitonic sort of the <= 4096 pairs in LDS: descending value, ties by ascending index; NaN sorts last.
+//   1. radix select on the leading 24 bits of the k-th largest key, 12 + 12: two passes over the values (16 bytes per lane
+//      and load; the array of the largest FPN level, 800 KB, stays in L2 after the first), LDS histogram, wave-aggregated
+//      atomics for the hot bins (RPN scores of a fresh network all share their leading bits: plain LDS atomics would
+//      serialise on one address);
+//   2. one pass gathers every (key, index) pair at or above that 24-bit prefix into LDS (slots from a wave-aggregated
+//      counter) -- normally a few more than k;
+//   3. bitonic sort of the <= 4096 pairs in LDS: descending value, ties by ascending index; NaN sorts last; the first k
+//      are the answer.
+//   Only when more than 4096 values share the prefix (a flood of equal values: the -inf fill of a masked array) the last
+//   8 bits are selected too, and if the k-th value itself is tied, two more passes pick the lowest indices among the ties,
+//   so that the selected SET is unique and the result deterministic.
 // Latency-bound single-CU work per problem; the problems of a call run side by side.
 #include "common.h"
 
@@ -21,13 +25,18 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxK = 4096;
-constexpr int kMaxProblems = 16;
+constexpr int kMaxProblems = 64;
+constexpr int kSplitAbove = 32768;   // a problem with more values than this is cut into chunks of about kChunk ...
+constexpr int kChunk = 24576;        // ... one workgroup each, and a second launch merges the chunks' winners
+constexpr int kMaxChunks = 16;
 constexpr int kBins = 4096;
 
 struct Problem {
   const float* values;
   float* out_values;
   long long* out_indices;
+  const long long* remap;   // merge stage of a split problem: position -> original index (nullptr otherwise)
+  long long index_base;     // first stage of a split problem: index of values[0] in the whole array
   int n, k;
 };
 struct Table {
@@ -42,22 +51,19 @@ __device__ __forceinline__ uint32_t key_of(float v) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// histogram increment; the first two distinct bins of the wavefront are counted with one atomic each (a concentrated
-// distribution puts all 64 lanes on one LDS address, which the hardware serialises)
+// histogram increment; when every active lane of the wavefront hits the same bin (a concentrated distribution: the
+// hardware would serialise 64 atomics on one LDS address) the wavefront counts itself with one atomic
 __device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t bin, bool active, int lane) {
-  uint64_t todo = __ballot(active);
-#pragma unroll
-  for (int it = 0; it < 2; it++) {
-    if (todo == 0) break;
-    const int leader = __builtin_ctzll(todo);
-    const uint32_t b0 = __builtin_amdgcn_readlane(bin, leader);
-    const bool same = active && bin == b0;
-    const uint64_t m = __ballot(same);
-    if (lane == leader) atomicAdd(&hist[b0], (uint32_t)__popcll(m));
-    if (same) active = false;
-    todo &= ~m;
+  const uint64_t act = __ballot(active);
+  if (act == 0) return;
+  const int leader = __builtin_ctzll(act);
+  const uint32_t b0 = __builtin_amdgcn_readlane(bin, leader);
+  const uint64_t same = __ballot(active && bin == b0);
+  if (same == act) {
+    if (lane == leader) atomicAdd(&hist[b0], (uint32_t)__popcll(act));
+  } else if (active) {
+    atomicAdd(&hist[bin], 1u);
   }
-  if (active) atomicAdd(&hist[bin], 1u);
 }
 
 struct Found {
@@ -103,6 +109,35 @@ __device__ __forceinline__ Found find_bin(const uint32_t* hist, int bins, uint32
   return *s_found;
 }
 
+// Walk the values of one problem: every wavefront owns a contiguous range, a lane loads two float4 per trip (the pointer
+// is aligned down to 16 bytes; the up to three values in front of the array and behind it are masked out, they share a
+// 16-byte granule with real elements).  `body(i, v, live)` runs in wave-uniform control flow -- it may ballot.
+template <typename Body>
+__device__ __forceinline__ void for_each_value(const float* values, int n, Body body) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mis = (int)((reinterpret_cast<uintptr_t>(values) >> 2) & 3);
+  const float4* base = reinterpret_cast<const float4*>(values - mis);
+  const int total_vec = (n + mis + 3) >> 2;
+  const int per_wave = ((total_vec + kWaves - 1) / kWaves + 127) & ~127;
+  const int seg0 = min(wave * per_wave, total_vec), seg1 = min(seg0 + per_wave, total_vec);
+  for (int vb = seg0; vb < seg1; vb += 128) {
+    const int j0 = vb + lane, j1 = vb + 64 + lane;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (j0 < seg1) a = base[j0];
+    if (j1 < seg1) b = base[j1];
+    const int i0 = 4 * j0 - mis, i1 = 4 * j1 - mis;
+    const bool in0 = j0 < seg1, in1 = j1 < seg1;
+    body(i0 + 0, a.x, in0 && i0 + 0 >= 0 && i0 + 0 < n);
+    body(i0 + 1, a.y, in0 && i0 + 1 >= 0 && i0 + 1 < n);
+    body(i0 + 2, a.z, in0 && i0 + 2 >= 0 && i0 + 2 < n);
+    body(i0 + 3, a.w, in0 && i0 + 3 >= 0 && i0 + 3 < n);
+    body(i1 + 0, b.x, in1 && i1 + 0 >= 0 && i1 + 0 < n);
+    body(i1 + 1, b.y, in1 && i1 + 1 >= 0 && i1 + 1 < n);
+    body(i1 + 2, b.z, in1 && i1 + 2 >= 0 && i1 + 2 < n);
+    body(i1 + 3, b.w, in1 && i1 + 3 >= 0 && i1 + 3 < n);
+  }
+}
+
 __global__ void __launch_bounds__(kThreads) topk_select_sort(const Table t) {
   __shared__ uint32_t s_hist[kBins];
   __shared__ unsigned long long s_sel[kMaxK];
@@ -110,36 +145,21 @@ __global__ void __launch_bounds__(kThreads) topk_select_sort(const Table t) {
   __shared__ Found s_found;
   __shared__ uint32_t s_count;
   const Problem p = t.p[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int n = p.n, k = p.k;
   if (k <= 0) return;
-  // every wavefront walks a contiguous segment, 64 consecutive values per load instruction
-  const int per_wave = ((n + kWaves - 1) / kWaves + 63) & ~63;
-  const int seg0 = min(wave * per_wave, n), seg1 = min(seg0 + per_wave, n);
 
-  // ---- 1. radix select on the value keys --------------------------------------------------------------------------
+  // ---- 1. radix select on the value keys: 12 + 12 bits, and the last 8 only when they are needed -------------------
   uint32_t prefix = 0, mask = 0, kk = (uint32_t)k, ties = 0;
-  const int shifts[3] = {20, 8, 0};
-  const int widths[3] = {12, 12, 8};
-#pragma unroll
-  for (int pass = 0; pass < 3; pass++) {
-    const int shift = shifts[pass], bins = 1 << widths[pass];
+  uint32_t inv_floor = 0;       // ties are taken when (~index & 0xffffff) >= inv_floor
+  auto digit_pass = [&](int shift, int bins) {
     for (int b = tid; b < bins; b += kThreads) s_hist[b] = 0;
     __syncthreads();
-    for (int base = seg0; base < seg1; base += 256) {
-      float v[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = base + u * 64 + lane;
-        v[u] = i < seg1 ? p.values[i] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = base + u * 64 + lane;
-        const uint32_t key = key_of(v[u]);
-        hist_add(s_hist, (key >> shift) & (uint32_t)(bins - 1), i < seg1 && (key & mask) == prefix, lane);
-      }
-    }
+    const uint32_t pre = prefix, msk = mask;
+    for_each_value(p.values, n, [&](int, float v, bool live) {
+      const uint32_t key = key_of(v);
+      hist_add(s_hist, (key >> shift) & (uint32_t)(bins - 1), live && (key & msk) == pre, lane);
+    });
     __syncthreads();
     const Found f = find_bin(s_hist, bins, kk, s_wtot, &s_found);
     prefix |= f.bin << shift;
@@ -147,98 +167,156 @@ __global__ void __launch_bounds__(kThreads) topk_select_sort(const Table t) {
     kk -= f.above;
     ties = f.inside;
     __syncthreads();
-  }
-  const uint32_t kth = prefix;  // key of the k-th largest value; kk of its `ties` occurrences are wanted
-  // ---- 2. more ties than wanted: the kk lowest indices among them (select on the inverted index, 12 + 12 bits) ----
-  uint32_t inv_floor = 0;       // take a tie when (~index & 0xffffff) >= inv_floor
-  if (ties > kk) {
-    uint32_t iprefix = 0, imask = 0;
+  };
+  digit_pass(20, 1 << 12);
+  digit_pass(8, 1 << 12);
+  // after 24 bits: (k - kk) values lie above the prefix, `ties` share it.  If all of them fit into the LDS sort, the
+  // sort settles the rest (the common case); otherwise (a flood of equal values, e.g. the -inf fill of a masked array)
+  // the last 8 bits are selected too, and then -- if the k-th value itself is tied -- the lowest indices among the ties.
+  uint32_t floor_key = prefix;  // gather every value whose key is >= floor_key (and, for ties of it, passes inv_floor)
+  bool exact = false;           // floor_key is the full key of the k-th value
+  if ((uint32_t)k - kk + ties > (uint32_t)kMaxK) {
+    digit_pass(0, 1 << 8);
+    floor_key = prefix;
+    exact = true;
+    if (ties > kk) {
+      uint32_t iprefix = 0, imask = 0;
 #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      const int shift = pass == 0 ? 12 : 0;
-      for (int b = tid; b < kBins; b += kThreads) s_hist[b] = 0;
-      __syncthreads();
-      for (int base = seg0; base < seg1; base += 256) {
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = base + u * 64 + lane;
-          v[u] = i < seg1 ? p.values[i] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = base + u * 64 + lane;
+      for (int pass = 0; pass < 2; pass++) {
+        const int shift = pass == 0 ? 12 : 0;
+        for (int b = tid; b < kBins; b += kThreads) s_hist[b] = 0;
+        __syncthreads();
+        const uint32_t kth = prefix;
+        for_each_value(p.values, n, [&](int i, float v, bool live) {
           const uint32_t inv = ~(uint32_t)i & 0xffffffu;
-          hist_add(s_hist, (inv >> shift) & 0xfffu, i < seg1 && key_of(v[u]) == kth && (inv & imask) == iprefix, lane);
-        }
+          hist_add(s_hist, (inv >> shift) & 0xfffu, live && key_of(v) == kth && (inv & imask) == iprefix, lane);
+        });
+        __syncthreads();
+        const Found f = find_bin(s_hist, kBins, kk, s_wtot, &s_found);
+        iprefix |= f.bin << shift;
+        imask |= 0xfffu << shift;
+        kk -= f.above;
+        __syncthreads();
       }
-      __syncthreads();
-      const Found f = find_bin(s_hist, kBins, kk, s_wtot, &s_found);
-      iprefix |= f.bin << shift;
-      imask |= 0xfffu << shift;
-      kk -= f.above;
-      __syncthreads();
+      inv_floor = iprefix;
     }
-    inv_floor = iprefix;
   }
-  // ---- 3. gather the selected pairs into LDS ----------------------------------------------------------------------
+  const uint32_t cmp_mask = exact ? 0xffffffffu : 0xffffff00u;
+  const uint32_t gathered = exact ? (uint32_t)k : (uint32_t)k - kk + ties;   // how many pairs the gather finds
+  // ---- 2. gather the selected pairs into LDS ----------------------------------------------------------------------
   int m = 1;
-  while (m < k) m <<= 1;
+  while (m < (int)gathered) m <<= 1;
   for (int i = tid; i < m; i += kThreads) s_sel[i] = 0ULL;  // padding sorts last
   if (tid == 0) s_count = 0;
   __syncthreads();
-  for (int base = seg0; base < seg1; base += 256) {
-    float v[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = base + u * 64 + lane;
-      v[u] = i < seg1 ? p.values[i] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = base + u * 64 + lane;
-      const uint32_t key = key_of(v[u]);
-      const uint32_t inv = ~(uint32_t)i;
-      const bool take = i < seg1 && (key > kth || (key == kth && (inv & 0xffffffu) >= inv_floor));
-      const uint64_t mm = __ballot(take);
-      if (mm != 0) {
-        const int leader = __builtin_ctzll(mm);
-        uint32_t slot0 = 0;
-        if (lane == leader) slot0 = atomicAdd(&s_count, (uint32_t)__popcll(mm));
-        slot0 = __shfl(slot0, leader, 64);
-        if (take) {
-          const uint32_t slot = slot0 + (uint32_t)__popcll(mm & ((1ULL << lane) - 1ULL));
-          if (slot < (uint32_t)k) s_sel[slot] = ((unsigned long long)key << 32) | inv;
-        }
+  for_each_value(p.values, n, [&](int i, float v, bool live) {
+    const uint32_t key = key_of(v);
+    const uint32_t inv = ~(uint32_t)i;
+    const uint32_t hi = key & cmp_mask;
+    const bool take = live && (hi > floor_key || (hi == floor_key && (!exact || (inv & 0xffffffu) >= inv_floor)));
+    const uint64_t mm = __ballot(take);
+    if (mm != 0) {
+      const int leader = __builtin_ctzll(mm);
+      uint32_t slot0 = 0;
+      if (lane == leader) slot0 = atomicAdd(&s_count, (uint32_t)__popcll(mm));
+      slot0 = __shfl(slot0, leader, 64);
+      if (take) {
+        const uint32_t slot = slot0 + (uint32_t)__popcll(mm & ((1ULL << lane) - 1ULL));
+        if (slot < gathered) s_sel[slot] = ((unsigned long long)key << 32) | inv;
       }
     }
-  }
-  // ---- 4. bitonic sort, descending (value descending, index ascending) ----------------------------------------------
-  for (int size = 2; size <= m; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      for (int q = tid; q < (m >> 1); q += kThreads) {
-        const int i = ((q / stride) * stride << 1) + (q % stride), j = i + stride;
-        const bool desc = (i & size) == 0;
-        const unsigned long long a = s_sel[i], b = s_sel[j];
-        if ((a < b) == desc) {
-          s_sel[i] = b;
-          s_sel[j] = a;
-        }
-      }
+  });
+  // ---- 3. bitonic sort, descending (value descending, index ascending) ----------------------------------------------
+  // Sub-stages whose partner distance is below 128 stay inside a 128-element block; a wavefront owns whole blocks and
+  // runs those sub-stages back to back without workgroup barriers (LDS operations of one wavefront complete in order).
+  // Only the sub-stages with a distance of 128 and more -- 10 of the 66 of a 2048-element sort -- need the workgroup.
+  const int wave = tid >> 6;
+  const int block = m < 128 ? m : 128, half = block >> 1;
+  auto exchange = [&](int q, int stride, int size) {
+    const int i = ((q & ~(stride - 1)) << 1) | (q & (stride - 1)), j = i + stride;
+    const bool desc = (i & size) == 0;
+    const unsigned long long x = s_sel[i], y = s_sel[j];
+    if ((x < y) == desc) {
+      s_sel[i] = y;
+      s_sel[j] = x;
     }
+  };
   __syncthreads();
+  for (int size = 2; size <= m; size <<= 1) {
+    int stride = size >> 1;
+    for (; stride >= 128; stride >>= 1) {
+      for (int q = tid; q < (m >> 1); q += kThreads) exchange(q, stride, size);
+      __syncthreads();
+    }
+    for (int blk = wave; blk * block < m; blk += kWaves) {
+      const int q0 = blk * half;   // pairs [q0, q0 + half) live in elements [blk * block, (blk + 1) * block)
+      for (int st = stride; st > 0; st >>= 1) {
+        if (lane < half) exchange(q0 + lane, st, size);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+  }
   for (int r = tid; r < k; r += kThreads) {
     const uint32_t idx = ~(uint32_t)(s_sel[r] & 0xffffffffULL);
-    p.out_indices[r] = (long long)idx;
+    p.out_indices[r] = p.remap != nullptr ? p.remap[idx] : (long long)idx + p.index_base;
     p.out_values[r] = p.values[idx];
   }
 }
 
 }  // namespace
 
+namespace {
+
+// top-k is decomposable: top-k(whole) = top-k(union of the chunks' top-k).  One workgroup walks ~24k values in the time
+// the launch overhead costs anyway; the largest FPN level (201 600 scores) becomes 9 chunks side by side and a merge of
+// 9 k candidates.  Chunks are in index order and each chunk's winners are in (value desc, index asc) order, so "lower
+// position first" among the merge stage's ties is "lower index first" of the whole array.
+struct Split {
+  int chunks, chunk_n;
+};
+Split plan(int n, int k) {
+  Split s{1, n};
+  if (n <= kSplitAbove || k == 0) return s;
+  int chunks = (n + kChunk - 1) / kChunk;
+  if (chunks > kMaxChunks) chunks = kMaxChunks;
+  while (chunks > 1 && (long long)chunks * k > (1 << 24)) chunks--;
+  if (chunks < 2) return s;
+  s.chunks = chunks;
+  s.chunk_n = (((n + chunks - 1) / chunks) + 63) & ~63;
+  s.chunks = (n + s.chunk_n - 1) / s.chunk_n;
+  return s;
+}
+int chunk_k(const Split& sp, int n, int k, int c) {
+  const int len = (c + 1) * sp.chunk_n <= n ? sp.chunk_n : n - c * sp.chunk_n;
+  return k < len ? k : len;
+}
+size_t align16(size_t b) { return (b + 15) & ~size_t(15); }
+
+int launch_table(const Table& t, hipStream_t s) {
+  topk_select_sort<<<t.count, kThreads, 0, s>>>(t);
+  return mi::check_launch("topk_select_sort");
+}
+
+}  // namespace
+
+extern "C" size_t mi_topk_batched_workspace_bytes(int num_problems, const int* n, const int* k) {
+  size_t total = 16;
+  if (n == nullptr || k == nullptr) return total;
+  for (int q = 0; q < num_problems; q++) {
+    const Split sp = plan(n[q], k[q]);
+    if (sp.chunks < 2) continue;
+    size_t cand = 0;
+    for (int c = 0; c < sp.chunks; c++) cand += (size_t)chunk_k(sp, n[q], k[q], c);
+    total += align16(cand * sizeof(float)) + align16(cand * sizeof(long long));
+  }
+  return total;
+}
+
 extern "C" int mi_topk_batched(int num_problems, const float* const* values, const int* n, const int* k,
-                               float* const* out_values, int64_t* const* out_indices, mi_stream_t stream) {
+                               float* const* out_values, int64_t* const* out_indices, void* workspace,
+                               size_t workspace_bytes, mi_stream_t stream) {
   mi::begin_call();
   MI_REQUIRE(num_problems >= 0, "topk_batched: negative problem count");
   if (num_problems == 0) return MI_OK;
@@ -254,20 +332,65 @@ extern "C" int mi_topk_batched(int num_problems, const float* const* values, con
     MI_REQUIRE(k[q] == 0 || (values[q] != nullptr && out_values[q] != nullptr && out_indices[q] != nullptr),
                "topk_batched: null pointer in problem %d", q);
   }
-  hipStream_t s = mi::as_stream(stream);
-  for (int first = 0; first < num_problems; first += kMaxProblems) {
-    Table t;
-    t.count = num_problems - first < kMaxProblems ? num_problems - first : kMaxProblems;
-    for (int q = 0; q < t.count; q++) {
-      t.p[q].values = values[first + q];
-      t.p[q].out_values = out_values[first + q];
-      t.p[q].out_indices = reinterpret_cast<long long*>(out_indices[first + q]);
-      t.p[q].n = n[first + q];
-      t.p[q].k = k[first + q];
+  const size_t need = mi_topk_batched_workspace_bytes(num_problems, n, k);
+  if (need > 16) {
+    MI_REQUIRE(workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+               "topk_batched: a 16-byte aligned workspace is needed for problems of more than %d values", kSplitAbove);
+    if (workspace_bytes < need) {
+      mi::set_error("topk_batched: workspace %zu bytes < required %zu", workspace_bytes, need);
+      return MI_ERR_WORKSPACE;
     }
-    topk_select_sort<<<t.count, kThreads, 0, s>>>(t);
-    int rc = mi::check_launch("topk_select_sort");
-    if (rc != MI_OK) return rc;
   }
+  hipStream_t s = mi::as_stream(stream);
+  char* ws = static_cast<char*>(workspace);
+  Table first, merge;
+  first.count = merge.count = 0;
+  int rc;
+  auto push = [&](Table& t, const Problem& p) -> int {
+    t.p[t.count++] = p;
+    if (t.count == kMaxProblems) {
+      const int r = launch_table(t, s);
+      t.count = 0;
+      return r;
+    }
+    return MI_OK;
+  };
+  // first-stage tables are launched as they fill up, the merge problems after all of them (stream order)
+  for (int q = 0; q < num_problems; q++) {
+    if (k[q] == 0) continue;
+    const Split sp = plan(n[q], k[q]);
+    long long* out_idx = reinterpret_cast<long long*>(out_indices[q]);
+    if (sp.chunks < 2) {
+      if ((rc = push(first, Problem{values[q], out_values[q], out_idx, nullptr, 0, n[q], k[q]})) != MI_OK) return rc;
+      continue;
+    }
+    size_t cand = 0;
+    for (int c = 0; c < sp.chunks; c++) cand += (size_t)chunk_k(sp, n[q], k[q], c);
+    float* cand_vals = reinterpret_cast<float*>(ws);
+    ws += align16(cand * sizeof(float));
+    long long* cand_idx = reinterpret_cast<long long*>(ws);
+    ws += align16(cand * sizeof(long long));
+    size_t off = 0;
+    for (int c = 0; c < sp.chunks; c++) {
+      const int kc = chunk_k(sp, n[q], k[q], c);
+      const int len = (c + 1) * sp.chunk_n <= n[q] ? sp.chunk_n : n[q] - c * sp.chunk_n;
+      if ((rc = push(first, Problem{values[q] + (size_t)c * sp.chunk_n, cand_vals + off, cand_idx + off, nullptr,
+                                    (long long)c * sp.chunk_n, len, kc})) != MI_OK)
+        return rc;
+      off += kc;
+    }
+    // merges are collected and launched after every first-stage table of this call has been issued
+    if (merge.count == kMaxProblems) {
+      if (first.count > 0) {
+        if ((rc = launch_table(first, s)) != MI_OK) return rc;
+        first.count = 0;
+      }
+      if ((rc = launch_table(merge, s)) != MI_OK) return rc;
+      merge.count = 0;
+    }
+    merge.p[merge.count++] = Problem{cand_vals, out_values[q], out_idx, cand_idx, 0, (int)cand, k[q]};
+  }
+  if (first.count > 0 && (rc = launch_table(first, s)) != MI_OK) return rc;
+  if (merge.count > 0 && (rc = launch_table(merge, s)) != MI_OK) return rc;
   return MI_OK;
 }

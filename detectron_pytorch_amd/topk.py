@@ -42,8 +42,12 @@ def topk_flat(rows, ks):
     k_arr = (ctypes.c_int * p)(*[int(k) for k in ks])
     ov_arr = (ctypes.c_void_p * p)(*[vals.data_ptr() + 4 * offs[i] for i in range(p)])
     oi_arr = (ctypes.c_void_p * p)(*[idx.data_ptr() + 8 * offs[i] for i in range(p)])
+    lib = _lib.lib()
+    ws_bytes = lib.mi_topk_batched_workspace_bytes(p, n_arr, k_arr)
+    workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().mi_topk_batched(p, val_arr, n_arr, k_arr, ov_arr, oi_arr, _lib.current_stream_handle(dev))
+        rc = lib.mi_topk_batched(p, val_arr, n_arr, k_arr, ov_arr, oi_arr, workspace.data_ptr(), ws_bytes,
+                                 _lib.current_stream_handle(dev))
     _lib.check(rc, "mi_topk_batched")
     return vals, idx, offs
 

@@ -266,9 +266,12 @@ int mi_detection_select(const float* scores, const float* boxes, const float* ma
  * collect_and_distribute_fpn_rpn_proposals.py:85-86 (post_nms_topN of the collected levels) and np.sort of
  * core/test.py:781-784.  Problem p: values[p] [n[p]] -> out_values[p] [k[p]] descending, out_indices[p] [k[p]] int64;
  * equal values: lower index first (the reference's order of ties is undefined); NaN ranks below -inf.
- * 0 <= k <= n <= 2^24, k <= 4096.  The pointer / size arrays are HOST arrays. */
+ * 0 <= k <= n <= 2^24, k <= 4096.  The pointer / size arrays are HOST arrays.  A problem of more than 32768 values is
+ * cut into chunks that run side by side and a merge of their winners (second launch); their candidates live in
+ * `workspace` (device, 16-byte aligned, mi_topk_batched_workspace_bytes; may be NULL when no problem is that large). */
+size_t mi_topk_batched_workspace_bytes(int num_problems, const int* n, const int* k);
 int mi_topk_batched(int num_problems, const float* const* values, const int* n, const int* k, float* const* out_values,
-                    int64_t* const* out_indices, mi_stream_t stream);
+                    int64_t* const* out_indices, void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* Steps 6-8 of GenerateProposalsOp.proposals_for_one_image (lib/modeling/generate_proposals.py:155-161) for all
  * (level, image) problems and the concatenation of collect_and_distribute_fpn_rpn_proposals.py:83-90, one launch.

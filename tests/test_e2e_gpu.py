@@ -400,10 +400,12 @@ def _check_static_detection(gpu, cfg, inference):
         assert torch.equal(res["class_counts"].cpu(), torch.tensor([len(c) for c in want[2][1:]]))
         if graph is None:
             graph = inference.DetectionGraph(gpu, tuple(blob.shape), dev()).capture(blob, im_info)
-        for _ in range(2):                        # the replay IS the static sequence: bit-identical to it, repeatably
-            got = graph(blob, im_info)
-            assert torch.equal(got[0], stat[:, 4]) and torch.equal(got[1], stat[:, :4])
+        replays = [graph(blob, im_info) for _ in range(2)]
+        for got in replays:          # the replay is the static sequence (MIOpen / hipBLASLt may pick other kernels under
+            assert torch.allclose(got[0], stat[:, 4], rtol=0, atol=1e-6)      # capture: last-bit differences allowed)
+            assert torch.allclose(got[1], stat[:, :4], rtol=0, atol=1e-3)
             assert [len(c) for c in got[2]] == [len(c) for c in want[2]]
+        # (the box head's split-K GEMM accumulates with atomics: not even two replays agree to the last bit)
         seen += want[0].numel()
     assert seen > 0, "the comparison never saw a detection"
 

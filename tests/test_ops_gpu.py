@@ -804,7 +804,11 @@ def test_topk_batched_many_problems_and_limits():
     arr = (ctypes.c_void_p * 1)(x.data_ptr())
     one = (ctypes.c_int * 1)(5000)
     big = (ctypes.c_int * 1)(4097)
-    assert lib.mi_topk_batched(1, arr, one, big, arr, arr, None) != 0 and b"4096" in lib.mi_last_error()
+    assert lib.mi_topk_batched(1, arr, one, big, arr, arr, None, 0, None) != 0 and b"4096" in lib.mi_last_error()
+    wide = (ctypes.c_int * 1)(100000)
+    ten = (ctypes.c_int * 1)(10)
+    assert lib.mi_topk_batched_workspace_bytes(1, wide, ten) > 16 and lib.mi_topk_batched_workspace_bytes(1, one, ten) == 16
+    assert lib.mi_topk_batched(1, arr, wide, ten, arr, arr, None, 0, None) != 0 and b"workspace" in lib.mi_last_error()
 
 
 def test_rpn_collect_static_fused_equals_the_tensor_expression_path():
