@@ -77,21 +77,25 @@ constexpr int kPrepChunk = 2048;
 // Where the rows of one problem live.  mi_nms / mi_nms_batched: the packed [n,5] array (row stride 5, score at +4, no
 // threshold).  mi_nms_segmented: the caller's [R,4C] box and [R,C] score matrices read in place (row strides 4C and C),
 // with the rows at or below `thresh` dropped: they sort behind every live row and are not counted in *n_live.
+template <bool kPacked>
 struct DetSource {
   const float* box;
   const float* score;
-  long long box_row, score_row;   // strides in floats
-  float thresh;                   // rows with score <= thresh (or NaN) take no part; -inf: every row takes part
+  long long box_row_, score_row_;  // strides in floats (ignored when kPacked: the constant 5 keeps the address arithmetic
+  float thresh;                    // of the latency-critical single-problem path what it was)
+  // rows with score <= thresh (or NaN) take no part; thresh -inf: every row takes part
+  __device__ __forceinline__ long long box_row() const { return kPacked ? 5 : box_row_; }
+  __device__ __forceinline__ long long score_row() const { return kPacked ? 5 : score_row_; }
   __device__ __forceinline__ float score_at(int i) const {
-    const float v = score[(long long)i * score_row];
+    const float v = score[(long long)i * score_row()];
     // a NaN score (a diverged network) must not break the rank sort: it compares as the lowest score, ties by index, so
     // that the ranks stay a permutation and nothing downstream indexes with an uninitialised slot
     return (v > thresh) ? v : -__builtin_inff();
   }
 };
 
-template <bool kSort, bool kCount>
-__device__ __forceinline__ void prepare_body(const DetSource src, int n, float4* __restrict__ boxes,
+template <bool kSort, bool kCount, bool kPacked>
+__device__ __forceinline__ void prepare_body(const DetSource<kPacked> src, int n, float4* __restrict__ boxes,
                                              float* __restrict__ areas, int32_t* __restrict__ order,
                                              int32_t* __restrict__ flags, int chunk, int32_t* __restrict__ n_live) {
   __shared__ __attribute__((aligned(16))) float s_scores[kPrepChunk];
@@ -102,7 +106,7 @@ __device__ __forceinline__ void prepare_body(const DetSource src, int n, float4*
   const bool live = i < n;
   float x1 = 0, y1 = 0, x2 = 0, y2 = 0, score = 0;
   if (live) {
-    const float* d = src.box + (long long)i * src.box_row;
+    const float* d = src.box + (long long)i * src.box_row();
     x1 = d[0];
     y1 = d[1];
     x2 = d[2];
@@ -158,15 +162,15 @@ __device__ __forceinline__ void prepare_body(const DetSource src, int n, float4*
   }
 }
 
-__device__ __forceinline__ DetSource packed_source(const float* dets) {
-  return DetSource{dets, dets + 4, 5, 5, -__builtin_inff()};
+__device__ __forceinline__ DetSource<true> packed_source(const float* dets) {
+  return DetSource<true>{dets, dets + 4, 5, 5, -__builtin_inff()};
 }
 
 template <bool kSort>
 __global__ void __launch_bounds__(256)
 nms_prepare(const float* __restrict__ dets, int n, float4* __restrict__ boxes,
             float* __restrict__ areas, int32_t* __restrict__ order, int32_t* __restrict__ flags) {
-  prepare_body<kSort, false>(packed_source(dets), n, boxes, areas, order, flags, blockIdx.x, nullptr);
+  prepare_body<kSort, false, true>(packed_source(dets), n, boxes, areas, order, flags, blockIdx.x, nullptr);
 }
 
 // ---- 2. IoU bitmask tiles ---------------------------------------------------------------
@@ -468,7 +472,7 @@ template <bool kSort>
 __global__ void __launch_bounds__(256) nms_prepare_batched(const BatchTable t) {
   int p = 0;
   while (p + 1 < t.count && (int)blockIdx.x >= t.chunk_start[p + 1]) p++;
-  prepare_body<kSort, false>(packed_source(t.dets[p]), t.n[p], t.ws[p].boxes, t.ws[p].areas, t.ws[p].order, t.ws[p].flags,
+  prepare_body<kSort, false, true>(packed_source(t.dets[p]), t.n[p], t.ws[p].boxes, t.ws[p].areas, t.ws[p].order, t.ws[p].flags,
                              blockIdx.x - t.chunk_start[p], nullptr);
 }
 
@@ -514,8 +518,8 @@ struct SegmentArgs {
 __global__ void __launch_bounds__(256) nms_prepare_segmented(const SegmentArgs a) {
   const int s = blockIdx.y;
   const Workspace ws = carve(a.workspace + (size_t)s * a.seg_bytes, a.rows);
-  const DetSource src{a.boxes + s * a.box_seg, a.scores + s * a.score_seg, a.box_row, a.score_row, a.score_thresh};
-  prepare_body<true, true>(src, a.rows, ws.boxes, ws.areas, ws.order, a.kept + (long long)s * a.rows, blockIdx.x,
+  const DetSource<false> src{a.boxes + s * a.box_seg, a.scores + s * a.score_seg, a.box_row, a.score_row, a.score_thresh};
+  prepare_body<true, true, false>(src, a.rows, ws.boxes, ws.areas, ws.order, a.kept + (long long)s * a.rows, blockIdx.x,
                            a.n_live + s);
 }
 

@@ -606,10 +606,10 @@ def test_nms_segmented_rejects_what_it_cannot_do():
     lib = _lib.lib()
     x = torch.zeros(16, device=dev())
     rc = lib.mi_nms_segmented(x.data_ptr(), 4, 8, x.data_ptr(), 1, 2, 1, 5000, 0.05, 0.5, x.data_ptr(), x.data_ptr(),
-                              x.data_ptr(), 1 << 30, None)
+                              None, x.data_ptr(), 1 << 30, None)
     assert rc != 0 and b"4096" in lib.mi_last_error()
     rc = lib.mi_nms_segmented(x.data_ptr(), 4, 8, x.data_ptr(), 1, 2, 1, 4, 0.05, 0.5, x.data_ptr(), x.data_ptr(),
-                              x.data_ptr(), 16, None)
+                              None, x.data_ptr(), 16, None)
     assert rc != 0 and b"workspace" in lib.mi_last_error()
 
 
