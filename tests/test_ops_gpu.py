@@ -741,6 +741,48 @@ def test_roi_align_fpn_fused_other_resolutions(oracle_mod, res, sr, channels, ch
                                                                       threads=8), "bwd")
 
 
+# ---- the nn.Module wrappers of the reference (roi_xfrom/roi_align/modules/roi_align.py:6-45, model/roi_align/modules/
+# roi_align.py:6-42, model/roi_pooling/modules/roi_pool.py:5-14): same constructor arguments, forward + backward --------
+@pytest.mark.parametrize("cls_name", ["RoIAlign", "RoIAlignAvg", "RoIAlignMax", "LegacyRoIAlign", "LegacyRoIAlignAvg",
+                                      "LegacyRoIAlignMax", "_RoIPooling"])
+def test_reference_modules_forward_backward(oracle_mod, cls_name):
+    import torch.nn.functional as F
+
+    from detectron_pytorch_amd import roi_align as ra, roi_pool as rp
+
+    feat = syn.feature_map(2, 12, 25, 42, seed=3)
+    scale, res = 1.0 / 16, 7
+    rois = syn.rois_adversarial(40, 2, 25, 42, scale, seed=5)
+    plus = 1 if cls_name.endswith(("Avg", "Max")) else 0
+    if cls_name == "_RoIPooling":
+        mod = rp._RoIPooling(res, res, scale)
+        base, argmax = oracle_mod.roi_pool_forward(feat, rois, res, res, scale)
+    elif cls_name.startswith("Legacy"):
+        mod = getattr(ra, cls_name)(res, res, scale)
+        base = oracle_mod.roi_align_legacy_forward(feat, rois, res + plus, res + plus, scale)
+    else:
+        mod = getattr(ra, cls_name)(res, res, scale, 2)
+        base = oracle_mod.roi_align_forward(feat, rois, res + plus, res + plus, scale, 2)
+    # the pooling the reference's module applies on top (avg_pool2d / max_pool2d, kernel 2, stride 1), on the CPU
+    base_t = torch.from_numpy(base).requires_grad_(True)
+    want = F.avg_pool2d(base_t, 2, 1) if cls_name.endswith("Avg") else F.max_pool2d(base_t, 2, 1) if plus else base_t
+    f = to_dev(feat).requires_grad_(True)
+    out = mod(f, to_dev(rois))
+    assert out.shape == (40, 12, res, res)
+    assert_fwd(out, want.detach().numpy(), cls_name + " fwd", exact=False)
+    gtop = np.random.RandomState(1).randn(*out.shape).astype(np.float32)
+    out.backward(to_dev(gtop))
+    want.backward(torch.from_numpy(gtop))
+    g_base = base_t.grad.numpy()
+    if cls_name == "_RoIPooling":
+        ref_grad = oracle_mod.roi_pool_backward(g_base, rois, argmax, feat.shape, scale)
+    elif cls_name.startswith("Legacy"):
+        ref_grad = oracle_mod.roi_align_legacy_backward(g_base, rois, feat.shape, scale)
+    else:
+        ref_grad = oracle_mod.roi_align_backward(g_base, rois, feat.shape, scale, 2)
+    assert_close(f.grad, ref_grad, cls_name + " bwd")
+
+
 # ---- sorted top-k (the selections around the NMS kernels) ------------------------------------------------------------
 def _topk_reference(v, k):
     """Descending values, ties by ascending index, NaN last: np.lexsort restatement of mi_topk_batched's contract."""

@@ -173,6 +173,9 @@ def roofline_roi_align_forward(device, iters):
     info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
     if layout == _lib.LAYOUT_NCHW:
         info["channels_last"] = channels_last_variant(device, lib, stream, feat, rois, out, ws, alg_bytes, gtop, iters)
+    if layout == _lib.LAYOUT_NCHW:
+        info["cold_cache"] = cold_cache_variant(device, lib, stream, feat, rois, ws, ws_bytes, alg_bytes, r, c, h, w, res,
+                                                scale, sr, max(iters // 2, 20))
     copy_gbs = copy_ceiling(device)
     info["copy_ceiling"] = {"measured": round(copy_gbs, 1), "unit": "GB/s", "frac_of_copy": round(achieved / copy_gbs, 4),
                             "what": "torch device-to-device copy of 256 MiB, read + write bytes / time"}
@@ -207,6 +210,32 @@ def channels_last_variant(device, lib, stream, feat_nchw, rois, out, ws, alg_byt
     return {"kernel": "roi_align_prepare + roi_align_fwd_nhwc", "avg_launch_us": round(sec * 1e6, 2),
             "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "bwd_us": round(sec_bwd * 1e6, 2)}
+
+
+def cold_cache_variant(device, lib, stream, feat, rois, ws, ws_bytes, alg_bytes, r, c, h, w, res, scale, sr, iters):
+    """The headline call with the 256 MB Infinity Cache taken out of the picture: six distinct copies of the feature map
+    (6 x 68.8 MB = 413 MB) and six output buffers (6 x 25.7 MB) are visited round-robin, so that by the time a map comes
+    round again 567 MB of other traffic have passed through the MALL.  Same RoIs, same kernels, same timing method."""
+    from detectron_pytorch_amd import _lib
+
+    copies = 6
+    feats = [feat.clone() for _ in range(copies)]
+    outs = [torch.empty((r, c, res, res), device=device) for _ in range(copies)]
+    state = {"i": 0}
+
+    def launch():
+        i = state["i"] = (state["i"] + 1) % copies
+        rc = lib.mi_roi_align_forward_ws(feats[i].data_ptr(), rois.data_ptr(), outs[i].data_ptr(), 1, c, h, w, r, res, res,
+                                         scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, ws.data_ptr(), ws_bytes, stream)
+        assert rc == 0
+
+    sec = time_kernel(launch, iters)
+    gbs = alg_bytes / sec / 1e9
+    return {"avg_launch_us": round(sec * 1e6, 2), "achieved": round(gbs, 1), "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "distinct_feature_maps": copies,
+            "rotated_bytes": int(copies * (feat.numel() + outs[0].numel()) * 4),
+            "what": "same call over %d feature maps / outputs visited round-robin (> 256 MB between two visits of a map)"
+                    % copies}
 
 
 def copy_ceiling(device):
