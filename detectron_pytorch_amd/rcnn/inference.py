@@ -135,7 +135,7 @@ class DetectionGraph(object):
         torch.cuda.current_stream(self.data.device).wait_stream(side)
         torch.cuda.synchronize(self.data.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=side):     # the warm-up stream: one stream, a linear graph
             self.out = im_detect_all_static(self.model, self.data, self.im_info, self.autocast_dtype)
         self.graph = graph
         return self

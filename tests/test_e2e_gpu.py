@@ -277,7 +277,7 @@ def test_training_step_eager_and_hipgraph(nets):
     assert int(ret["blobs"]["num_rois"].sum()) > 0 and int(ret["blobs"]["num_fg"].min()) >= 8
     opt.zero_grad(set_to_none=True)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="relaxed"):
         ret = net(data, im_info, roidb=roidb, rpn_targets=rpn_t)
         loss = sum(ret["losses"].values())
         loss.backward()
@@ -337,7 +337,7 @@ def test_gradient_reducer_on_rccl_world_size_one(nets):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="relaxed"):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="relaxed"):
             red.begin_step()
             net(x).square().mean().backward()
         for _ in range(2):

@@ -23,7 +23,17 @@ def full():
     ret = net(data, im_info, roidb=roidb, rpn_targets=rpn_t)
     loss = sum(ret["losses"].values())
     loss.backward()
+    state["losses"] = {k: v.detach() for k, v in ret["losses"].items()}
+    state["n_fg"] = (ret["blobs"]["labels_int32"] > 0).sum()
+    state["n_valid"] = ret["collected_valid"].sum()
     return loss
+
+
+def checksums():
+    w = sum(float(p.detach().double().sum()) for p in net.parameters())
+    inp = float(data.double().sum()) + float(im_info.double().sum()) + sum(float(v.double().sum()) for v in roidb.values()) \
+        + sum(float(v.double().sum()) for v in rpn_t.values())
+    return "weights %.6f inputs %.6f" % (w, inp)
 
 
 def prep():
@@ -64,13 +74,15 @@ if piece == "optimizer":
     full()
 g = torch.cuda.CUDAGraph()
 try:
-    with torch.cuda.graph(g, capture_error_mode="relaxed"):
+    with torch.cuda.graph(g, stream=(side if os.environ.get("CAPTURE_STREAM", "side") == "side" else None), capture_error_mode="relaxed"):
         out = fn()
     for i in range(int(os.environ.get("REPLAYS", "1"))):
         g.replay()
         torch.cuda.synchronize()
         if piece in ("fwd_bwd", "full_step") and i % 5 == 0:
             print("replay", i, "loss", float(out[0] if isinstance(out, tuple) else out), flush=True)
+            print("   ", {k: round(float(v), 4) for k, v in state["losses"].items()}, "fg", int(state["n_fg"]), "valid",
+                  int(state["n_valid"]), checksums(), flush=True)
     print("CAPTURE_OK", piece, flush=True)
 except Exception as e:  # noqa: BLE001
     import traceback

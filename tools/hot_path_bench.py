@@ -75,7 +75,7 @@ def make_stepper(work, mode, device):
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="relaxed"):
             captured = work.step()
         eager = work.step()
         for t in captured[:4]:
@@ -440,7 +440,7 @@ def inference_path(device, iters=10):
     torch.cuda.current_stream(device).wait_stream(side)
     torch.cuda.synchronize(device)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=side):
         pooled, res = run_static()
         sizes = res["sizes"]
 
