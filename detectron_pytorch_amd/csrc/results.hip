@@ -1,0 +1,313 @@
+// results.hip -- the test-time result formats on the device, C-ABI mi_mask_paste_rle and
+// mi_keypoint_decode.
+//
+//   mi_mask_paste_rle    one detection of segm_results (lib/core/test.py:793-847): the M x M soft mask, zero-padded by one
+//       pixel, resized to the (expanded, truncated) reference box with cv2.resize's bilinear arithmetic, binarised, pasted
+//       into an im_h x im_w image and run-length encoded the way pycocotools does (column-major runs, zeros first).  The
+//       image is never materialised: a workgroup walks the box columns, evaluates the pasted bit of a pixel and of its
+//       predecessor in column-major order directly from the M x M mask in LDS, and emits the positions where they differ
+//       (ordered ballot compaction); run lengths are the differences of consecutive positions.  The reference resizes and
+//       pastes on the host with OpenCV and encodes with pycocotools, one detection at a time.
+//   mi_keypoint_decode   heatmaps_to_keypoints (lib/utils/keypoints.py:106-157): every heat map resized to the RoI with
+//       cv2.resize's bicubic arithmetic, arg-max (first maximum in row-major order), its logit and its softmax probability
+//       over the resized map (scores_to_probs, :214-222).  One workgroup per (RoI, keypoint); the resized map is never
+//       stored: each lane evaluates its pixels from the 56 x 56 map in LDS and keeps (max, arg-max, running sum of exp).
+//
+// Arithmetic: OpenCV's scalar code paths (modules/imgproc/src/resize.cpp: resizeGeneric_, HResizeLinear / VResizeLinear,
+// interpolateCubic, HResizeCubic / VResizeCubic), fp32 products and sums in their order, no FMA contraction (this library
+// is compiled with -ffp-contract=off); coordinates through double exactly as there.  OpenCV and pycocotools are absent
+// from the build environment: the CPU restatement these kernels are tested against (oracle/results.py) is unpinned.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxMask = 64;   // M + 2 <= 64 (the reference uses M = 28; 14 for the light-weight heads)
+
+// source index and weight of one destination coordinate of a bilinear axis (resizeGeneric_, ksize 2)
+struct Lin {
+  int s;
+  float w0, w1;
+};
+__device__ __forceinline__ Lin lin_axis_x(int d, double scale, int src) {   // horizontal: weights reset at the borders
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) {
+    f = 0.f;
+    s = 0;
+  }
+  if (s >= src - 1) {
+    f = 0.f;
+    s = src - 1;
+  }
+  return Lin{s, 1.f - f, f};
+}
+__device__ __forceinline__ Lin lin_axis_y(int d, double scale) {            // vertical: rows are clipped, weights kept
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  const int s = (int)floorf(f);
+  f -= (float)s;
+  return Lin{s, 1.f - f, f};
+}
+
+struct PasteGeom {
+  int bx0, by0, w, h;            // expanded integer box: origin, size
+  int x_0, x_1, y_0, y_1;        // its intersection with the image (columns / rows pasted)
+  double scale_x, scale_y;
+  int m2;                        // M + 2
+  float thresh;
+};
+
+// the pasted bit of image pixel (x, y); s_mask: padded [m2][m2] in LDS
+__device__ __forceinline__ int pasted_bit(const PasteGeom& g, const float* s_mask, int x, int y) {
+  if (x < g.x_0 || x >= g.x_1 || y < g.y_0 || y >= g.y_1) return 0;
+  const Lin ax = lin_axis_x(x - g.bx0, g.scale_x, g.m2);
+  const Lin ay = lin_axis_y(y - g.by0, g.scale_y);
+  const int sx1 = min(ax.s + 1, g.m2 - 1);
+  const int r0 = min(max(ay.s, 0), g.m2 - 1), r1 = min(max(ay.s + 1, 0), g.m2 - 1);
+  const float h0 = s_mask[r0 * g.m2 + ax.s] * ax.w0 + s_mask[r0 * g.m2 + sx1] * ax.w1;   // HResizeLinear
+  const float h1 = s_mask[r1 * g.m2 + ax.s] * ax.w0 + s_mask[r1 * g.m2 + sx1] * ax.w1;
+  const float v = h0 * ay.w0 + h1 * ay.w1;                                               // VResizeLinear
+  return v > g.thresh ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kThreads)
+mask_paste_rle(const float* __restrict__ masks, const int* __restrict__ boxes, int mask_size, int im_h, int im_w,
+               float thresh, int cap, unsigned* __restrict__ counts, int* __restrict__ num_counts) {
+  __shared__ float s_mask[kMaxMask * kMaxMask];
+  __shared__ int s_wave[kThreads / 64];
+  __shared__ int s_total;
+  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m2 = mask_size + 2;
+  for (int i = tid; i < m2 * m2; i += kThreads) {
+    const int r = i / m2, c = i - r * m2;
+    s_mask[i] = (r == 0 || c == 0 || r == m2 - 1 || c == m2 - 1)
+                    ? 0.f
+                    : masks[((long long)d * mask_size + (r - 1)) * mask_size + (c - 1)];
+  }
+  if (tid == 0) s_total = 0;
+  const int* b = boxes + (long long)d * 4;
+  PasteGeom g;
+  g.bx0 = b[0];
+  g.by0 = b[1];
+  g.w = max(b[2] - b[0] + 1, 1);       // lib/core/test.py:817-820
+  g.h = max(b[3] - b[1] + 1, 1);
+  g.x_0 = max(b[0], 0);                // :826-829
+  g.x_1 = min(b[2] + 1, im_w);
+  g.y_0 = max(b[1], 0);
+  g.y_1 = min(b[3] + 1, im_h);
+  g.scale_x = 1.0 / ((double)g.w / (double)m2);
+  g.scale_y = 1.0 / ((double)g.h / (double)m2);
+  g.m2 = m2;
+  g.thresh = thresh;
+  __syncthreads();
+  unsigned* out = counts + (long long)d * cap;
+  const long long total = (long long)im_h * im_w;
+  const int rh = g.y_1 - g.y_0, ncols = g.x_1 - g.x_0;
+  if (rh > 0 && ncols > 0) {
+    // candidates of a column: its rh pasted pixels and the pixel right after them (where a run of ones must end), unless
+    // that pixel is itself a pasted pixel of the next column (full-height paste) or lies behind the image
+    const long long per_col = rh + 1, ncand = per_col * ncols;
+    for (long long base = 0; base < ncand; base += kThreads) {
+      const long long t = base + tid;
+      bool change = false;
+      long long gpos = 0;
+      if (t < ncand) {
+        const int ci = (int)(t / per_col), yy = (int)(t - (long long)ci * per_col);
+        const int x = g.x_0 + ci;
+        int y = g.y_0 + yy, xx = x;
+        bool real = true;
+        if (yy == rh) {                       // the pixel after the column's pasted rows
+          if (y == im_h) {                    // ... is the first pixel of the next column
+            y = 0;
+            xx = x + 1;
+            real = xx < im_w && !(g.y_0 == 0 && xx < g.x_1);
+          }
+        }
+        if (real) {
+          gpos = (long long)xx * im_h + y;
+          const int cur = pasted_bit(g, s_mask, xx, y);
+          int prev = 0;
+          if (gpos > 0) {
+            const int py = y > 0 ? y - 1 : im_h - 1, px = y > 0 ? xx : xx - 1;
+            prev = pasted_bit(g, s_mask, px, py);
+          }
+          change = cur != prev;
+        }
+      }
+      const unsigned long long mm = __ballot(change);
+      if (lane == 0) s_wave[wave] = __popcll(mm);
+      __syncthreads();
+      int off = s_total;
+      for (int w = 0; w < wave; w++) off += s_wave[w];
+      if (change) {
+        const int k = off + __popcll(mm & ((1ull << lane) - 1ull));
+        if (k < cap) out[k] = (unsigned)gpos;            // positions first; run lengths below
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int add = 0;
+        for (int w = 0; w < kThreads / 64; w++) add += s_wave[w];
+        s_total += add;
+      }
+      __syncthreads();
+    }
+  }
+  // positions p_0 < p_1 < ... -> run lengths: p_0, p_1 - p_0, ..., total - p_last  (rleEncode; p_0 == 0: first run empty)
+  const int npos = s_total;
+  if (tid == 0) num_counts[d] = npos + 1;
+  if (npos + 1 > cap) return;                             // the caller sees the size it needs and calls again
+  __threadfence_block();
+  __syncthreads();
+  // in place, chunk by chunk from the TOP: a chunk reads the last position of the chunk below it, which must still be a
+  // position; inside a chunk every read precedes every write
+  for (int base = (npos / kThreads) * kThreads; base >= 0; base -= kThreads) {
+    const int k = base + tid;
+    unsigned lo = 0, hi = 0;
+    const bool live = k <= npos;
+    if (live) {
+      lo = k > 0 ? out[k - 1] : 0u;
+      hi = k < npos ? out[k] : (unsigned)total;
+    }
+    __syncthreads();
+    if (live) out[k] = hi - lo;
+    __syncthreads();
+  }
+}
+
+// ---- keypoints -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_coeffs(float x, float* c) {            // resize.cpp interpolateCubic
+  const float a = -0.75f;
+  c[0] = ((a * (x + 1.f) - 5.f * a) * (x + 1.f) + 8.f * a) * (x + 1.f) - 4.f * a;
+  c[1] = ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+  c[2] = ((a + 2.f) * (1.f - x) - (a + 3.f)) * (1.f - x) * (1.f - x) + 1.f;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+constexpr int kMaxHeat = 64;   // HEATMAP_SIZE <= 64 (the reference uses 56)
+
+__global__ void __launch_bounds__(kThreads)
+keypoint_decode(const float* __restrict__ maps, const float* __restrict__ rois, int num_keypoints, int heat, int min_size,
+                float* __restrict__ xy_preds) {
+  __shared__ float s_map[kMaxHeat * kMaxHeat];
+  __shared__ float s_max[kThreads / 64], s_sum[kThreads / 64];
+  __shared__ long long s_arg[kThreads / 64];
+  const int r = blockIdx.x / num_keypoints, k = blockIdx.x - r * num_keypoints;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = maps + ((long long)r * num_keypoints + k) * heat * heat;
+  for (int i = tid; i < heat * heat; i += kThreads) s_map[i] = src[i];
+  const float* roi = rois + (long long)r * 4;
+  const float offset_x = roi[0], offset_y = roi[1];                          // lib/utils/keypoints.py:116-124
+  const float width = fmaxf(roi[2] - roi[0], 1.f), height = fmaxf(roi[3] - roi[1], 1.f);
+  int map_w = (int)ceilf(width), map_h = (int)ceilf(height);
+  if (min_size > 0) {                                                       // :131-136
+    map_w = max(map_w, min_size);
+    map_h = max(map_h, min_size);
+  }
+  const float width_correction = width / (float)map_w, height_correction = height / (float)map_h;
+  const double scale_x = 1.0 / ((double)map_w / (double)heat), scale_y = 1.0 / ((double)map_h / (double)heat);
+  __syncthreads();
+  // lane-private running state over its pixels (row-major order within the lane is ascending, so "first maximum" holds)
+  float best = -__builtin_inff(), run_max = -__builtin_inff(), run_sum = 0.f;
+  long long best_pos = 0x7fffffffffffffffLL;
+  const long long npix = (long long)map_w * map_h;
+  for (long long p = tid; p < npix; p += kThreads) {
+    const int y = (int)(p / map_w), x = (int)(p - (long long)y * map_w);
+    float fx = (float)(((double)x + 0.5) * scale_x - 0.5), fy = (float)(((double)y + 0.5) * scale_y - 0.5);
+    const int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= (float)sx;
+    fy -= (float)sy;
+    float cx[4], cy[4];
+    cubic_coeffs(fx, cx);
+    cubic_coeffs(fy, cy);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                                            // VResizeCubic over the four clipped rows
+      const int row = min(max(sy - 1 + j, 0), heat - 1);
+      float hsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {                                          // HResizeCubic, replicated border
+        const int col = min(max(sx - 1 + i, 0), heat - 1);
+        hsum = hsum + s_map[row * heat + col] * cx[i];
+      }
+      v = v + hsum * cy[j];
+    }
+    if (v > best) {
+      best = v;
+      best_pos = p;
+    }
+    if (v > run_max) {                                                       // online softmax denominator
+      run_sum = run_sum * __expf(run_max - v) + 1.f;
+      run_max = v;
+    } else {
+      run_sum += __expf(v - run_max);
+    }
+  }
+  // block reduction: maximum (ties: lowest position), then the sum rescaled to it
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const float ob = __shfl_xor(best, d, 64);
+    const long long op = __shfl_xor(best_pos, d, 64);
+    if (ob > best || (ob == best && op < best_pos)) {
+      best = ob;
+      best_pos = op;
+    }
+  }
+  if (lane == 0) {
+    s_max[wave] = best;
+    s_arg[wave] = best_pos;
+  }
+  __syncthreads();
+  float gmax = s_max[0];
+  long long garg = s_arg[0];
+  for (int w = 1; w < kThreads / 64; w++)
+    if (s_max[w] > gmax || (s_max[w] == gmax && s_arg[w] < garg)) {
+      gmax = s_max[w];
+      garg = s_arg[w];
+    }
+  float part = run_max > -__builtin_inff() ? run_sum * expf(run_max - gmax) : 0.f;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+  if (lane == 0) s_sum[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    float denom = 0.f;
+    for (int w = 0; w < kThreads / 64; w++) denom += s_sum[w];
+    const int x_int = (int)(garg % map_w), y_int = (int)(garg / map_w);
+    // :150-155; (x_int + 0.5) is float64 in the reference (np.int64 + python float), the products follow
+    float* o = xy_preds + (long long)r * 4 * num_keypoints + k;
+    o[0 * num_keypoints] = (float)(((double)x_int + 0.5) * (double)width_correction + (double)offset_x);
+    o[1 * num_keypoints] = (float)(((double)y_int + 0.5) * (double)height_correction + (double)offset_y);
+    o[2 * num_keypoints] = gmax;
+    o[3 * num_keypoints] = 1.f / denom;                                      // exp(max - max) / sum
+  }
+}
+
+}  // namespace
+
+extern "C" int mi_mask_paste_rle(const float* masks, const int32_t* boxes, int num_masks, int mask_size, int im_height,
+                                 int im_width, float thresh, int capacity, uint32_t* counts, int32_t* num_counts,
+                                 mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(num_masks >= 0 && mask_size > 0 && im_height > 0 && im_width > 0 && capacity > 0, "mask_paste_rle: bad size");
+  MI_REQUIRE(mask_size + 2 <= kMaxMask, "mask_paste_rle: masks of at most %d x %d are supported", kMaxMask - 2, kMaxMask - 2);
+  MI_REQUIRE((long long)im_height * im_width < (1LL << 32), "mask_paste_rle: image too large for 32-bit run lengths");
+  if (num_masks == 0) return MI_OK;
+  MI_REQUIRE(masks != nullptr && boxes != nullptr && counts != nullptr && num_counts != nullptr,
+             "mask_paste_rle: null pointer");
+  mask_paste_rle<<<num_masks, kThreads, 0, mi::as_stream(stream)>>>(masks, boxes, mask_size, im_height, im_width, thresh,
+                                                                   capacity, counts, num_counts);
+  return mi::check_launch("mask_paste_rle");
+}
+
+extern "C" int mi_keypoint_decode(const float* heatmaps, const float* rois, int num_rois, int num_keypoints,
+                                  int heatmap_size, int min_size, float* xy_preds, mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(num_rois >= 0 && num_keypoints > 0 && heatmap_size > 0, "keypoint_decode: bad size");
+  MI_REQUIRE(heatmap_size <= kMaxHeat, "keypoint_decode: heat maps of at most %d x %d are supported", kMaxHeat, kMaxHeat);
+  if (num_rois == 0) return MI_OK;
+  MI_REQUIRE(heatmaps != nullptr && rois != nullptr && xy_preds != nullptr, "keypoint_decode: null pointer");
+  keypoint_decode<<<num_rois * num_keypoints, kThreads, 0, mi::as_stream(stream)>>>(heatmaps, rois, num_keypoints,
+                                                                                   heatmap_size, min_size, xy_preds);
+  return mi::check_launch("keypoint_decode");
+}

@@ -59,12 +59,12 @@ def _defaults():
     c.MRCNN = Node(                                           # config.py:731-775
         ROI_MASK_HEAD="", RESOLUTION=14, ROI_XFORM_METHOD="RoIAlign", ROI_XFORM_RESOLUTION=7,
         ROI_XFORM_SAMPLING_RATIO=0, DIM_REDUCED=256, DILATION=2, UPSAMPLE_RATIO=1, USE_FC_OUTPUT=False,
-        CONV_INIT="GaussianFill", CLS_SPECIFIC_MASK=True, WEIGHT_LOSS_MASK=1.0)
+        CONV_INIT="GaussianFill", CLS_SPECIFIC_MASK=True, WEIGHT_LOSS_MASK=1.0, THRESH_BINARIZE=0.5)
     c.KRCNN = Node(                                           # config.py:780-860
         ROI_KEYPOINTS_HEAD="", HEATMAP_SIZE=-1, UP_SCALE=-1, USE_DECONV=False, DECONV_DIM=256, USE_DECONV_OUTPUT=False,
         DILATION=1, DECONV_KERNEL=4, NUM_KEYPOINTS=-1, NUM_STACKED_CONVS=8, CONV_HEAD_DIM=256, CONV_HEAD_KERNEL=3,
         CONV_INIT="GaussianFill", ROI_XFORM_METHOD="RoIAlign", ROI_XFORM_RESOLUTION=7, ROI_XFORM_SAMPLING_RATIO=0,
-        LOSS_WEIGHT=1.0, NORMALIZE_BY_VISIBLE_KEYPOINTS=True)
+        LOSS_WEIGHT=1.0, NORMALIZE_BY_VISIBLE_KEYPOINTS=True, NMS_OKS=False, INFERENCE_MIN_SIZE=0)
     c.RESNETS = Node(                                         # config.py:870-900
         NUM_GROUPS=1, WIDTH_PER_GROUP=64, STRIDE_1X1=True, TRANS_FUNC="bottleneck_transformation",
         STEM_FUNC="basic_bn_stem", SHORTCUT_FUNC="basic_bn_shortcut", RES5_DILATION=1, FREEZE_AT=2,

@@ -7,7 +7,8 @@ ends in `detection.box_results_with_nms_and_limit` (one batched HIP NMS over all
 """
 import torch
 
-from .. import detection
+from .. import detection, fpn_proposals
+from . import results
 
 
 def bbox_transform(boxes, deltas, weights, clip):
@@ -95,6 +96,65 @@ def im_detect_all(model, data, im_info, im_shape=None, autocast_dtype=None):
     return detection.box_results_with_nms_and_limit(
         scores, boxes, score_thresh=t.SCORE_THRESH, nms_thresh=t.NMS, detections_per_im=t.DETECTIONS_PER_IM,
         soft_nms=t.SOFT_NMS.ENABLED, soft_nms_sigma=t.SOFT_NMS.SIGMA, soft_nms_method=t.SOFT_NMS.METHOD)
+
+
+def _rois_blob(boxes, im_scale, cfg, name):
+    """test.py:869-920 `_get_rois_blob` + `_add_multilevel_rois_for_test` for ONE image on the device: [R, 5] RoIs in
+    blob coordinates (batch index 0) and their FPN levels (the fused RoIAlign takes the level vector; the per-level
+    blobs and the restore permutation of the reference are not needed)."""
+    rois = torch.cat([torch.zeros((boxes.size(0), 1), dtype=torch.float32, device=boxes.device),
+                      boxes.float() * im_scale], dim=1)
+    lvls = fpn_proposals.map_rois_to_fpn_levels(rois[:, 1:5], cfg.FPN.ROI_MIN_LEVEL, cfg.FPN.ROI_MAX_LEVEL)
+    return {name: rois, name + "_levels": lvls}
+
+
+@torch.no_grad()
+def im_detect_mask(model, im_scale, boxes, blob_conv):
+    """test.py:365-401: class-specific soft masks [R, K, M, M] (probabilities) of the detected `boxes` [R, 4] (image
+    coordinates, device tensor), from the backbone features `blob_conv` of the same image."""
+    cfg = model.cfg
+    m = cfg.MRCNN.RESOLUTION
+    k = cfg.MODEL.NUM_CLASSES if cfg.MRCNN.CLS_SPECIFIC_MASK else 1
+    if boxes.size(0) == 0:
+        return torch.zeros((0, k, m, m), dtype=torch.float32, device=boxes.device)
+    pred = model.mask_net(blob_conv, _rois_blob(boxes, im_scale, cfg, "mask_rois"))
+    return pred.float().reshape(-1, k, m, m)
+
+
+@torch.no_grad()
+def im_detect_keypoints(model, im_scale, boxes, blob_conv):
+    """test.py:528-563: keypoint heat-map logits [R, J, H, H] of the detected `boxes`."""
+    cfg = model.cfg
+    h = cfg.KRCNN.HEATMAP_SIZE
+    if boxes.size(0) == 0:
+        return torch.zeros((0, cfg.KRCNN.NUM_KEYPOINTS, h, h), dtype=torch.float32, device=boxes.device)
+    pred = model.keypoint_net(blob_conv, _rois_blob(boxes, im_scale, cfg, "keypoint_rois"))
+    return pred.float().reshape(-1, cfg.KRCNN.NUM_KEYPOINTS, h, h)
+
+
+@torch.no_grad()
+def im_detect_all_results(model, data, im_info, im_shape=None, autocast_dtype=None):
+    """test.py:50-112 for one image blob (no test-time augmentation): boxes, then masks and keypoints of the detected
+    boxes, in the reference's result formats: (cls_boxes, cls_segms, cls_keyps).  cls_boxes[j] [k_j, 5] device tensors;
+    cls_segms[j] a list of COCO RLE dicts (None when MODEL.MASK_ON is off); cls_keyps[j] a list of [4, K] tensors (None
+    when MODEL.KEYPOINTS_ON is off)."""
+    cfg = model.cfg
+    scale = float(im_info[0][2])
+    if im_shape is None:
+        im_shape = (int(round(float(im_info[0][0]) / scale)), int(round(float(im_info[0][1]) / scale)))
+    scores, boxes, blob_conv = im_detect_bbox(model, data, im_info, im_shape, autocast_dtype)
+    t = cfg.TEST
+    _, boxes_out, cls_boxes = detection.box_results_with_nms_and_limit(
+        scores, boxes, score_thresh=t.SCORE_THRESH, nms_thresh=t.NMS, detections_per_im=t.DETECTIONS_PER_IM,
+        soft_nms=t.SOFT_NMS.ENABLED, soft_nms_sigma=t.SOFT_NMS.SIGMA, soft_nms_method=t.SOFT_NMS.METHOD)
+    cls_segms = cls_keyps = None
+    if cfg.MODEL.MASK_ON:
+        masks = im_detect_mask(model, scale, boxes_out, blob_conv)
+        cls_segms = results.segm_results(cls_boxes, masks, boxes_out, im_shape[0], im_shape[1], cfg)
+    if cfg.MODEL.KEYPOINTS_ON:
+        heatmaps = im_detect_keypoints(model, scale, boxes_out, blob_conv)
+        cls_keyps = results.keypoint_results(cls_boxes, heatmaps, boxes_out, cfg)
+    return cls_boxes, cls_segms, cls_keyps
 
 
 @torch.no_grad()

@@ -1,0 +1,126 @@
+"""Test-time result formats on the device: instance masks pasted into the image and
+run-length encoded, keypoints decoded from heat maps.
+
+Reference: lib/core/test.py:793-847 `segm_results` (per detection: zero-pad the M x M mask, cv2.resize to the expanded
+box, binarise, paste, pycocotools.mask.encode) and :850-866 `keypoint_results` / lib/utils/keypoints.py:106-157
+`heatmaps_to_keypoints` (per RoI: cv2.resize INTER_CUBIC of 17 heat maps, arg-max, softmax probability).  Both run on
+the host there, one detection at a time, through OpenCV and pycocotools.  Here `mi_mask_paste_rle` produces the run
+lengths of all detections in one launch without materialising any image, `mi_keypoint_decode` reduces every (RoI,
+keypoint) map in one launch without storing the resized map; the host only turns the run lengths (a few hundred
+integers per mask) into COCO's string form.
+
+OpenCV and pycocotools are not part of this repository's environment: the kernels follow their published algorithms
+(csrc/results.hip) and are tested against a CPU restatement of the same (oracle/results.py, parity unpinned).
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def expand_boxes(boxes, scale):
+    """lib/utils/boxes.py:233-249 for float32 boxes [R, 4] (device)."""
+    w_half = (boxes[:, 2] - boxes[:, 0]) * .5
+    h_half = (boxes[:, 3] - boxes[:, 1]) * .5
+    x_c = (boxes[:, 2] + boxes[:, 0]) * .5
+    y_c = (boxes[:, 3] + boxes[:, 1]) * .5
+    w_half = w_half * scale
+    h_half = h_half * scale
+    return torch.stack([x_c - w_half, y_c - h_half, x_c + w_half, y_c + h_half], dim=1)
+
+
+def rle_to_string(counts):
+    """maskApi.c rleToString: run lengths (1-D integer array) -> COCO's compressed ASCII form.  Vectorised over the runs:
+    each run is written as 5-bit groups, least significant first, bit 5 = "more groups follow", + 48."""
+    x = np.asarray(counts, dtype=np.int64).copy()
+    if x.size > 3:
+        x[3:] -= np.asarray(counts, dtype=np.int64)[1:-2]
+    n = x.size
+    chars = np.zeros((n, 14), np.uint8)
+    used = np.zeros((n, 14), bool)
+    alive = np.ones(n, bool)
+    level = 0
+    while alive.any():
+        c = x & 0x1f
+        x = x >> 5                                              # arithmetic shift, as of a signed long
+        more = np.where((c & 0x10) != 0, x != -1, x != 0)
+        chars[:, level] = np.where(alive, (c | (more.astype(np.int64) << 5)) + 48, 0)
+        used[:, level] = alive
+        alive = alive & more
+        level += 1
+    return chars[used].tobytes().decode("ascii")                # row-major: run by run, group by group
+
+
+def mask_rle_counts(masks, boxes_int, im_h, im_w, thresh=0.5, capacity=1024):
+    """`mi_mask_paste_rle`: masks [D, M, M] float32, boxes_int [D, 4] int32 (device).  Returns (counts [D, cap] uint32 as
+    int64 on the host, num_counts [D]).  One launch; repeated with a larger capacity only when a mask has more runs than
+    `capacity` (the kernel reports the true number)."""
+    _lib.require_cuda(masks, "masks")
+    masks = masks.contiguous().float()
+    boxes_int = boxes_int.contiguous().to(torch.int32)
+    d, m = masks.size(0), masks.size(-1)
+    dev = masks.device
+    while True:
+        counts = torch.empty((d, capacity), dtype=torch.int32, device=dev)   # uint32 run lengths
+        num = torch.empty((d,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().mi_mask_paste_rle(masks.data_ptr(), boxes_int.data_ptr(), d, m, int(im_h), int(im_w),
+                                              float(thresh), int(capacity), counts.data_ptr(), num.data_ptr(),
+                                              _lib.current_stream_handle(dev))
+        _lib.check(rc, "mi_mask_paste_rle")
+        num_h = num.cpu().numpy()
+        need = int(num_h.max()) if d else 0
+        if need <= capacity:
+            return counts.cpu().numpy().view(np.uint32).astype(np.int64), num_h
+        capacity = 1 << int(np.ceil(np.log2(need)))
+
+
+def segm_results(cls_boxes, masks, ref_boxes, im_h, im_w, cfg):
+    """lib/core/test.py:793-847.  cls_boxes: per class [k_j, 5] (only the lengths are used, as there); masks [R, K, M, M]
+    device tensor in the class-major row order of cls_boxes; ref_boxes [R, 4] device tensor.  Returns cls_segms: per class
+    a list of {'size': [h, w], 'counts': str}."""
+    num_classes = cfg.MODEL.NUM_CLASSES
+    cls_segms = [[] for _ in range(num_classes)]
+    lengths = [0] + [int(len(cls_boxes[j])) for j in range(1, num_classes)]
+    r = sum(lengths)
+    assert r == masks.size(0), "masks and cls_boxes disagree (test.py:846)"
+    if r == 0:
+        return cls_segms
+    m = cfg.MRCNN.RESOLUTION
+    cls_of_row = torch.repeat_interleave(torch.arange(num_classes), torch.tensor(lengths)).to(masks.device)
+    rows = torch.arange(r, device=masks.device)
+    sel = masks[rows, cls_of_row] if cfg.MRCNN.CLS_SPECIFIC_MASK else masks[:, 0]
+    boxes_int = expand_boxes(ref_boxes.float(), (m + 2.0) / m).to(torch.int32)        # :803-805 (truncation)
+    counts, num = mask_rle_counts(sel, boxes_int, im_h, im_w, cfg.MRCNN.THRESH_BINARIZE)
+    ind = 0
+    for j in range(1, num_classes):
+        for _ in range(lengths[j]):
+            cls_segms[j].append({"size": [int(im_h), int(im_w)], "counts": rle_to_string(counts[ind, :num[ind]])})
+            ind += 1
+    return cls_segms
+
+
+def heatmaps_to_keypoints(maps, rois, min_size=0):
+    """lib/utils/keypoints.py:106-157 on the device: maps [R, K, H, H] float32 logits, rois [R, 4] -> xy_preds [R, 4, K]
+    (x, y, logit, probability)."""
+    _lib.require_cuda(maps, "maps")
+    maps = maps.contiguous().float()
+    rois = rois.contiguous().float()
+    r, k, h, _ = maps.shape
+    out = torch.empty((r, 4, k), dtype=torch.float32, device=maps.device)
+    with torch.cuda.device(maps.device):
+        rc = _lib.lib().mi_keypoint_decode(maps.data_ptr(), rois.data_ptr(), r, k, h, int(min_size), out.data_ptr(),
+                                           _lib.current_stream_handle(maps.device))
+    _lib.check(rc, "mi_keypoint_decode")
+    return out
+
+
+def keypoint_results(cls_boxes, pred_heatmaps, ref_boxes, cfg, person_idx=1):
+    """lib/core/test.py:850-866 (`person_idx`: datasets' 'person' class, 1 for COCO).  Returns cls_keyps: per class a list
+    of [4, K] arrays (device tensors)."""
+    if cfg.KRCNN.NMS_OKS:
+        raise NotImplementedError("KRCNN.NMS_OKS (utils/keypoints.py:225-266) is off in every shipped yaml and not built")
+    cls_keyps = [[] for _ in range(cfg.MODEL.NUM_CLASSES)]
+    xy_preds = heatmaps_to_keypoints(pred_heatmaps, ref_boxes, cfg.KRCNN.INFERENCE_MIN_SIZE)
+    cls_keyps[person_idx] = [xy_preds[i] for i in range(xy_preds.size(0))]
+    return cls_keyps

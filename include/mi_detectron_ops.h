@@ -328,6 +328,27 @@ int mi_affine_channel_backward(const float* grad_y, const float* y, const float*
                                float* grad_residual, int batch, int channels, int height, int width, int relu,
                                int layout, mi_stream_t stream);
 
+/* ---- test-time result formats -------------------------------------------------------
+ * mi_mask_paste_rle: one call = the per-detection body of segm_results (lib/core/test.py:807-844) for `num_masks`
+ * detections: masks [num_masks, M, M] float32 (the class channel already selected, :813-816), boxes [num_masks, 4] int32
+ * = `expand_boxes(ref_boxes, (M + 2) / M).astype(np.int32)` (:803-805).  Each mask is zero-padded by one pixel, resized to
+ * the box with cv2.resize's INTER_LINEAR arithmetic for float32, binarised with `> thresh` (cfg.MRCNN.THRESH_BINARIZE),
+ * pasted into an im_height x im_width image and run-length encoded like pycocotools.mask.encode (column-major runs, the
+ * first run counts zeros).  counts [num_masks, capacity] uint32 receives the run lengths of detection d at row d,
+ * num_counts [num_masks] their number -- ALWAYS the true number: when it exceeds `capacity` the row is unspecified and the
+ * caller repeats the call with a larger capacity.  The string form (maskApi.c rleToString) is host work on a few hundred
+ * integers.  M + 2 <= 64.
+ * mi_keypoint_decode: heatmaps_to_keypoints (lib/utils/keypoints.py:106-157): heatmaps [num_rois, K, H, H] float32 logits,
+ * rois [num_rois, 4]; every map is resized to (ceil(width), ceil(height)) of its RoI (at least min_size when > 0) with
+ * cv2.resize's INTER_CUBIC arithmetic and reduced to xy_preds [num_rois, 4, K] = (x, y, logit, softmax probability over
+ * the resized map) of its first maximum.  H <= 64.
+ * OpenCV / pycocotools are third-party packages of the reference; their published algorithms are restated
+ * (csrc/results.hip, oracle/results.py). */
+int mi_mask_paste_rle(const float* masks, const int32_t* boxes, int num_masks, int mask_size, int im_height, int im_width,
+                      float thresh, int capacity, uint32_t* counts, int32_t* num_counts, mi_stream_t stream);
+int mi_keypoint_decode(const float* heatmaps, const float* rois, int num_rois, int num_keypoints, int heatmap_size,
+                       int min_size, float* xy_preds, mi_stream_t stream);
+
 /* ---- diagnostics (no reference counterpart) ---------------------------------------------------
  * Tuning aid used by tools/timeline.py: while a non-NULL device buffer of 8 int64 per forward workgroup is set,
  * the self-contained RoIAlign forward kernel stamps s_memtime at its phase boundaries into it. */

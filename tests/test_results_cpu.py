@@ -1,0 +1,85 @@
+"""The restatement of the result formats (oracle/results.py: cv2.resize linear / cubic for float32, pycocotools RLE) checked
+for internal consistency, and the package's host-side string encoder against it.  OpenCV / pycocotools are absent here, so
+these are properties and hand-computed vectors, not comparisons with the packages (parity unpinned, see the oracle)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import results as R  # noqa: E402
+
+
+def test_rle_hand_vectors_and_round_trip():
+    m = np.zeros((5, 4), np.uint8)
+    m[1:3, 1] = 1                                          # column-major: 6 zeros, 2 ones, 12 zeros
+    assert R.rle_counts(m) == [6, 2, 12]
+    assert R.rle_to_string([6, 2, 12]) == "62<"            # one 5-bit group each: chr(v + 48)
+    full = np.ones((3, 2), np.uint8)
+    assert R.rle_counts(full) == [0, 6]                    # the first run counts zeros, even when there are none
+    assert R.rle_counts(np.zeros((3, 2), np.uint8)) == [6]
+    # 40 = 0b01000 + (1 << 5): low group 8 with the continuation bit (|0x20 -> 40 + 48 = 'X'), then 1 -> '1'
+    assert R.rle_to_string([40]) == "X1"
+    # from the fourth run on the difference to the run two back is stored: [5, 3, 7, 3] -> 5, 3, 7, 0
+    assert R.rle_to_string([5, 3, 7, 3]) == "5370"
+    # a negative difference needs the sign bit of the last group: [1, 9, 1, 2] -> 1, 9, 1, -7 = ...11001 -> 0x19 + 48
+    assert R.rle_to_string([1, 9, 1, 2]) == "191" + chr(0x19 + 48)
+    rng = np.random.RandomState(0)
+    for h, w, p in ((37, 53, 0.4), (800, 1333, 0.001), (1, 1, 0.5), (64, 1, 0.5)):
+        mask = (rng.rand(h, w) < p).astype(np.uint8)
+        counts = R.rle_counts(mask)
+        assert sum(counts) == h * w
+        s = R.rle_to_string(counts)
+        assert R.rle_from_string(s) == counts
+        assert np.array_equal(R.rle_decode(counts, h, w), mask)
+
+
+def test_package_string_encoder_equals_the_restatement():
+    from detectron_pytorch_amd.rcnn import results
+
+    rng = np.random.RandomState(1)
+    for n in (1, 2, 3, 4, 7, 500):
+        c = rng.randint(0, 2_000_000, n)
+        c[rng.rand(n) < 0.3] = rng.randint(0, 40, int((rng.rand(n) < 0.3).sum()) or 1)[0]
+        assert results.rle_to_string(c) == R.rle_to_string(c.tolist())
+
+
+def test_resize_restatement_properties():
+    rng = np.random.RandomState(2)
+    a = rng.rand(30, 30).astype(np.float32)
+    assert np.array_equal(R.cv2_resize_linear(a, 30, 30), a)                     # identity at scale 1
+    assert np.array_equal(R.cv2_resize_cubic(a, 30, 30), a)
+    const = np.full((30, 30), 0.7, np.float32)
+    assert np.allclose(R.cv2_resize_linear(const, 77, 13), 0.7, atol=1e-6)      # partition of unity
+    assert np.allclose(R.cv2_resize_cubic(const, 77, 13), 0.7, atol=1e-6)
+    up = R.cv2_resize_linear(a, 91, 64)
+    assert up.shape == (64, 91) and up.min() >= a.min() - 1e-6 and up.max() <= a.max() + 1e-6
+    # exact 2x up-scale of a ramp: destination centres fall at quarter positions ((dx + .5) / 2 - .5)
+    ramp = np.arange(8, dtype=np.float32)[None, :].repeat(4, 0)
+    got = R.cv2_resize_linear(ramp, 16, 4)[0]
+    want = np.clip((np.arange(16) + 0.5) / 2 - 0.5, 0, 7).astype(np.float32)
+    assert np.allclose(got, want, atol=1e-6)
+    # three channels resize independently
+    b = rng.rand(12, 9, 3).astype(np.float32)
+    c3 = R.cv2_resize_cubic(b, 20, 31)
+    for ch in range(3):
+        assert np.array_equal(c3[:, :, ch], R.cv2_resize_cubic(b[:, :, ch], 20, 31))
+
+
+def test_paste_and_segm_results_shapes():
+    rng = np.random.RandomState(3)
+    masks = rng.rand(3, 4, 28, 28).astype(np.float32)
+    ref = np.array([[10, 20, 100, 90], [-20, -5, 40, 30], [600, 400, 700, 520]], np.float32)
+    cls_boxes = [[], np.zeros((2, 5)), np.zeros((0, 5)), np.zeros((1, 5))]
+    segms = R.segm_results(cls_boxes, masks, ref, 480, 640)
+    assert [len(s) for s in segms] == [0, 2, 0, 1]
+    for rles in segms:
+        for rle in rles:
+            counts = R.rle_from_string(rle["counts"])
+            assert rle["size"] == [480, 640] and sum(counts) == 480 * 640
+    # the pasted mask is confined to the expanded box and the image
+    box = R.expand_boxes(ref, 30.0 / 28).astype(np.int32)[2]
+    im = R.paste_mask(masks[2, 3], box, 480, 640)
+    ys, xs = np.nonzero(im)
+    assert xs.size == 0 or (xs.min() >= max(box[0], 0) and xs.max() <= min(box[2], 639) and ys.max() <= 479)
