@@ -493,6 +493,20 @@ def cpu_baseline(images_per_rank):
         extra["generate_proposals_P2_2img_top2000_ms"] = round((time.perf_counter() - t) * 1e3, 3)
     except Exception as e:  # pragma: no cover
         extra["generate_proposals_error"] = str(e)
+    try:  # the result formats of one image (beside nms.result_formats): bounded to 10 masks / 2 persons, scaled up
+        from oracle import results as oresults
+
+        masks_np, boxes_np, maps_np, person_np = syn.result_format_inputs()
+        bi = oresults.expand_boxes(boxes_np, 30.0 / 28).astype(np.int32)
+        t = time.perf_counter()
+        for i in range(10):
+            oresults.mask_encode(oresults.paste_mask(masks_np[i], bi[i], 800, 1333))
+        extra["segm_100_masks_800x1333_ms"] = round((time.perf_counter() - t) * 10 * 1e3, 1)
+        t = time.perf_counter()
+        oresults.heatmaps_to_keypoints(maps_np[:2], person_np[:2])
+        extra["keypoint_decode_20x17_ms"] = round((time.perf_counter() - t) * 10 * 1e3, 1)
+    except Exception as e:  # pragma: no cover
+        extra["result_formats_error"] = str(e)
     return {"value": round(images / total, 3), "unit": "images/s (hot path only)", "cores": threads, "kind": "port",
             "sample": "%d x the hot-path step of one image: RoIAlign fwd+bwd 512x256x7x7 and 128x256x14x14 on "
                       "1x256x200x336 (OpenMP, %d threads) + 5 x cython-semantics NMS n=2000 thr=0.7 (1 thread); "

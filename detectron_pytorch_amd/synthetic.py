@@ -153,6 +153,30 @@ def detection_head_outputs(num_rois=300, num_classes=21, seed=0, im_h=IM_H, im_w
     return scores, boxes.reshape(num_rois, 4 * num_classes).astype(np.float32)
 
 
+def result_format_inputs(num_dets=100, num_person=20, mask_size=28, heat=56, seed=0, im_h=800, im_w=1333):
+    """Inputs of the test-time result formats (core/test.py:793-866): blob-like soft masks [D, M, M] with their detection
+    boxes (COCO-like sizes, some over the image border), and peaked keypoint heat maps [P, 17, H, H] with person boxes."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:mask_size, 0:mask_size].astype(np.float32)
+    masks = np.zeros((num_dets, mask_size, mask_size), np.float32)
+    for i in range(num_dets):
+        cx, cy = rng.uniform(0.3, 0.7, 2) * mask_size
+        s = rng.uniform(0.2, 0.5) * mask_size
+        masks[i] = 1 / (1 + np.exp(-(1.5 - ((xx - cx) ** 2 + (yy - cy) ** 2) / s ** 2 + rng.randn(mask_size, mask_size) * 0.3)))
+    w, h = rng.uniform(16, 500, num_dets), rng.uniform(16, 400, num_dets)
+    x1, y1 = rng.uniform(-20, im_w - 30, num_dets), rng.uniform(-20, im_h - 30, num_dets)
+    boxes = np.stack([x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    maps = rng.randn(num_person, 17, heat, heat).astype(np.float32)
+    for i in range(num_person):
+        for k in range(17):
+            py, px = rng.randint(4, heat - 4, 2)
+            maps[i, k, py - 2:py + 3, px - 2:px + 3] += 5.0
+    pw, ph = rng.uniform(40, 300, num_person), rng.uniform(80, 600, num_person)
+    px1, py1 = rng.uniform(0, im_w - 310, num_person), rng.uniform(0, im_h - 610, num_person).clip(0)
+    person = np.stack([px1, py1, px1 + pw, py1 + ph], 1).astype(np.float32)
+    return masks, boxes, maps, person
+
+
 def roi_align_touched_pixels(rois, batch, height, width, aligned_height, aligned_width, spatial_scale, sampling_ratio):
     """U of the algorithmic-bytes formula: the number of distinct feature pixels (n, y, x) that
     any sample of any RoI references with a non-zero weight.  float32 sampling arithmetic of roi_align_kernel.cu:74-110

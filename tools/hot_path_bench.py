@@ -3,6 +3,7 @@ bench.py as sub-objects of its JSON line: the roofline object of the RoIAlign fo
 the other RoIAlign shapes of a step, NMS latencies, the post-convolution inference glue.  No oracle import here: the CPU
 baseline lives in bench.py."""
 import json
+import time
 import os
 import sys
 
@@ -13,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from detectron_pytorch_amd import synthetic as syn  # noqa: E402
+from detectron_pytorch_amd import _lib as _lib_mod, synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
@@ -388,6 +389,37 @@ def nms_latency(device, iters):
     op = gp.GenerateProposalsOp(anchors, 0.25, 2000, 2000, 0.7, 0, as_numpy=False)
     sec = time_kernel(lambda: op(sc, dl, info), 10, warmup=3)
     out["generate_proposals_P2_2img_top2000"] = {"ms": round(sec * 1e3, 3)}
+    # the result formats of one image (core/test.py:793-866): 100 masks pasted + run-length encoded, 20 persons' keypoints
+    from detectron_pytorch_amd.rcnn import results
+
+    masks_np, boxes_np, maps_np, person_np = syn.result_format_inputs()
+    masks, maps = torch.from_numpy(masks_np).to(device), torch.from_numpy(maps_np).to(device)
+    boxes_int = results.expand_boxes(torch.from_numpy(boxes_np).to(device), 30.0 / 28).to(torch.int32)
+    person = torch.from_numpy(person_np).to(device)
+
+    def segm():
+        counts, num = results.mask_rle_counts(masks, boxes_int, 800, 1333)
+        return [results.rle_to_string(counts[i, :num[i]]) for i in range(len(num))]
+
+    t0 = time.perf_counter()
+    for _ in range(5):
+        segm()
+    host_sec = (time.perf_counter() - t0) / 5
+    counts = torch.empty((100, 1024), dtype=torch.int32, device=device)
+    num = torch.empty((100,), dtype=torch.int32, device=device)
+    lib = _lib_mod.lib()
+
+    def paste_kernel():
+        assert lib.mi_mask_paste_rle(masks.data_ptr(), boxes_int.data_ptr(), 100, 28, 800, 1333, 0.5, 1024, counts.data_ptr(),
+                                     num.data_ptr(), _lib_mod.current_stream_handle(device)) == 0
+
+    out["result_formats"] = {
+        "segm_100_masks_800x1333_ms": round(host_sec * 1e3, 3),
+        "mask_paste_rle_kernel_us": round(time_kernel(paste_kernel, 20, warmup=3) * 1e6, 1),
+        "keypoint_decode_20x17_us": round(time_kernel(lambda: results.heatmaps_to_keypoints(maps, person), 20, warmup=3) * 1e6, 1),
+        "what": "segm = mi_mask_paste_rle for 100 detections + one D2H copy of the run lengths + COCO string encoding on "
+                "the host; keypoints = mi_keypoint_decode for 20 person boxes x 17 heat maps (bicubic resize to the box, "
+                "arg-max, softmax probability)"}
     return out
 
 
