@@ -124,3 +124,38 @@ def keypoint_results(cls_boxes, pred_heatmaps, ref_boxes, cfg, person_idx=1):
     xy_preds = heatmaps_to_keypoints(pred_heatmaps, ref_boxes, cfg.KRCNN.INFERENCE_MIN_SIZE)
     cls_keyps[person_idx] = [xy_preds[i] for i in range(xy_preds.size(0))]
     return cls_keyps
+
+
+# ---- detections.pkl (lib/core/test_engine.py:300-313, :369-397) ------------------------------------------------------
+def empty_results(num_classes, num_images):
+    """test_engine.py:369-388: all_boxes[cls][image] = [N, 5]; all_segms[cls][image] = list of COCO RLEs; all_keyps[cls]
+    [image] = list of [4, K] arrays -- each in 1:1 correspondence with the boxes."""
+    def make():
+        return [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    return make(), make(), make()
+
+
+def extend_results(index, all_res, im_res):
+    """test_engine.py:391-397: file one image's per-class results (background skipped)."""
+    for cls_idx in range(1, len(im_res)):
+        all_res[cls_idx][index] = im_res[cls_idx]
+
+
+def _to_host(x):
+    if torch.is_tensor(x):
+        return x.detach().cpu().numpy()
+    if isinstance(x, (list, tuple)):
+        return [_to_host(v) for v in x]
+    return x
+
+
+def save_detections(path, all_boxes, all_segms, all_keyps, cfg_yaml=""):
+    """The `detections.pkl` of test_engine.py:300-313: {'all_boxes', 'all_segms', 'all_keyps', 'cfg'} pickled with the
+    highest protocol (utils/io.py:39-43).  Device tensors are brought to the host as numpy arrays (what the reference's
+    numpy pipeline holds at this point); `cfg_yaml` is the yaml dump of the configuration."""
+    import pickle
+
+    obj = dict(all_boxes=_to_host(all_boxes), all_segms=_to_host(all_segms), all_keyps=_to_host(all_keyps), cfg=cfg_yaml)
+    with open(path, "wb") as fp:
+        pickle.dump(obj, fp, pickle.HIGHEST_PROTOCOL)
+    return path

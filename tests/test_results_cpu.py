@@ -83,3 +83,26 @@ def test_paste_and_segm_results_shapes():
     im = R.paste_mask(masks[2, 3], box, 480, 640)
     ys, xs = np.nonzero(im)
     assert xs.size == 0 or (xs.min() >= max(box[0], 0) and xs.max() <= min(box[2], 639) and ys.max() <= 479)
+
+
+def test_detections_pkl_layout(tmp_path):
+    """test_engine.py:300-313, :369-397: the pickle a reference evaluation run would read."""
+    import pickle
+
+    import torch
+
+    from detectron_pytorch_amd.rcnn import results
+
+    all_boxes, all_segms, all_keyps = results.empty_results(3, 2)
+    assert len(all_boxes) == 3 and len(all_boxes[0]) == 2 and all_boxes[1][0] is not all_boxes[1][1]
+    cls_boxes = [[], torch.tensor([[1.0, 2, 3, 4, 0.9]]), torch.zeros((0, 5))]
+    cls_segms = [[], [{"size": [4, 5], "counts": "62<"}], []]
+    cls_keyps = [[], [torch.ones(4, 17)], []]
+    results.extend_results(1, all_boxes, cls_boxes)
+    results.extend_results(1, all_segms, cls_segms)
+    results.extend_results(1, all_keyps, cls_keyps)
+    path = results.save_detections(str(tmp_path / "detections.pkl"), all_boxes, all_segms, all_keyps, "MODEL: {}")
+    got = pickle.load(open(path, "rb"))
+    assert sorted(got) == ["all_boxes", "all_keyps", "all_segms", "cfg"] and got["cfg"] == "MODEL: {}"
+    assert got["all_boxes"][1][0] == [] and got["all_boxes"][1][1].shape == (1, 5)
+    assert got["all_segms"][1][1] == cls_segms[1] and got["all_keyps"][1][1][0].shape == (4, 17)
