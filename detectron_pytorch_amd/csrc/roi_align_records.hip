@@ -860,10 +860,17 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
   int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio, kCap,
                           stream);
   if (rc != MI_OK) return rc;
+  // the LDS images of MI_ROI_ALIGN_CAP >= 448 exceed the 64 KB a kernel may ask for without opting in
 #define MI_LAUNCH_REC(SR, A)                                                                                          \
-  roi_align_fwd_records<SR, kCap, kCT, 1, A>                                                                          \
-      <<<num_rois * (channels / kCT), kCT * 8, records_lds_bytes(kCap, kCT), stream>>>(                               \
-          lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, tuning().ablate)
+  do {                                                                                                                \
+    if (records_lds_bytes(kCap, kCT) > 64 * 1024)                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_records<SR, kCap, kCT, 1, A>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)records_lds_bytes(kCap, kCT));       \
+    roi_align_fwd_records<SR, kCap, kCT, 1, A>                                                                        \
+        <<<num_rois * (channels / kCT), kCT * 8, records_lds_bytes(kCap, kCT), stream>>>(                             \
+            lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio,           \
+            tuning().ablate);                                                                                         \
+  } while (0)
   const int a = aligned_height == aligned_width ? aligned_height : 0;
   if (sampling_ratio == 2 && kCap == 336 && a == 7)
     MI_LAUNCH_REC(2, (kCap == 336 ? 7 : 0));

@@ -237,6 +237,34 @@ def test_roi_align_empty_and_autograd_contract():
         RoIAlignFunction(7, 7, 0.25, 2)(f, torch.zeros(3, 4, device=dev()))
 
 
+def test_roi_align_fpn_without_rois_gives_zero_gradients():
+    """An empty RoI set (no foreground RoI for the mask head) must hand back zero-filled gradients for every level, not
+    the uninitialised memory an OVERWRITE-mode backward would otherwise leave (mi_roi_align_backward_fpn, R == 0)."""
+    from detectron_pytorch_amd.roi_align import roi_align_fpn
+
+    scales = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4]
+    feats = [torch.randn(2, 8, int(np.ceil(256 * s)), int(np.ceil(320 * s)), device=dev(), requires_grad=True) for s in scales]
+    poison = [torch.full_like(f, float("nan")) for f in feats for _ in range(4)]      # dirty the allocator's free blocks
+    del poison
+    out = roi_align_fpn(feats, scales, torch.zeros((0, 5), device=dev()), torch.zeros((0,), dtype=torch.int32, device=dev()),
+                        7, 7, 2)
+    assert out.shape == (0, 8, 7, 7)
+    out.sum().backward()
+    for f in feats:
+        assert f.grad is not None and float(f.grad.abs().sum()) == 0.0
+
+
+def test_roi_align_forward_large_lds_caps(oracle_mod, tuning_env):
+    """MI_ROI_ALIGN_CAP = 448 / 640 ask for more than 64 KB of dynamic LDS: the launcher opts in (it used to fail)."""
+    feat = syn.feature_map(1, 32, 100, 168, seed=2)
+    rois = syn.rois_canonical(64, 1, seed=3, im_h=800, im_w=1344)
+    want = oracle_mod.roi_align_forward(feat, rois, 7, 7, 0.125, 2, threads=8)
+    for cap in ("448", "640"):
+        tuning_env(MI_ROI_ALIGN_CAP=cap)
+        out, _ = _roi_align_gpu(feat, rois, 7, 0.125, 2)
+        assert_fwd(out, want, "cap " + cap, exact=False)
+
+
 # ---- RoIAlign (legacy) ----------------------------------------------------------------------------
 def test_roi_align_legacy_golden_and_oracle(oracle_mod):
     from detectron_pytorch_amd.roi_align import LegacyRoIAlignFunction
