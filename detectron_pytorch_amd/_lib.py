@@ -65,7 +65,7 @@ SIGNATURES = {
     "mi_affine_channel_forward": (_c_int, [_c_void_p] * 5 + [_c_int] * 6 + [_c_void_p]),
     "mi_affine_channel_backward": (_c_int, [_c_void_p] * 5 + [_c_int] * 6 + [_c_void_p]),
     "mi_mask_paste_rle": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void_p,
-                                  _c_void_p, _c_void_p]),
+                                  _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "mi_keypoint_decode": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "mi_dbg_roi_align_timeline": (None, [_c_void_p]),
     "mi_dbg_reload_tuning": (None, []),

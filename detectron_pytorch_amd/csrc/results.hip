@@ -73,7 +73,8 @@ __device__ __forceinline__ int pasted_bit(const PasteGeom& g, const float* s_mas
 
 __global__ void __launch_bounds__(kThreads)
 mask_paste_rle(const float* __restrict__ masks, const int* __restrict__ boxes, int mask_size, int im_h, int im_w,
-               float thresh, int cap, unsigned* __restrict__ counts, int* __restrict__ num_counts) {
+               float thresh, int cap, unsigned* __restrict__ counts, int* __restrict__ num_counts, int str_cap,
+               unsigned char* __restrict__ strings, int* __restrict__ num_bytes) {
   __shared__ float s_mask[kMaxMask * kMaxMask];
   __shared__ int s_wave[kThreads / 64];
   __shared__ int s_total;
@@ -110,30 +111,37 @@ mask_paste_rle(const float* __restrict__ masks, const int* __restrict__ boxes, i
     const long long per_col = rh + 1, ncand = per_col * ncols;
     for (long long base = 0; base < ncand; base += kThreads) {
       const long long t = base + tid;
-      bool change = false;
+      bool change = false, real = false;
       long long gpos = 0;
+      int yy = 0, xx = 0, y = 0, cur = 0;
       if (t < ncand) {
-        const int ci = (int)(t / per_col), yy = (int)(t - (long long)ci * per_col);
-        const int x = g.x_0 + ci;
-        int y = g.y_0 + yy, xx = x;
-        bool real = true;
-        if (yy == rh) {                       // the pixel after the column's pasted rows
-          if (y == im_h) {                    // ... is the first pixel of the next column
-            y = 0;
-            xx = x + 1;
-            real = xx < im_w && !(g.y_0 == 0 && xx < g.x_1);
-          }
+        const int ci = (int)(t / per_col);
+        yy = (int)(t - (long long)ci * per_col);
+        xx = g.x_0 + ci;
+        y = g.y_0 + yy;
+        real = true;
+        if (yy == rh && y == im_h) {          // the pixel after a full-height column is the first pixel of the next column
+          y = 0;
+          xx += 1;
+          real = xx < im_w && !(g.y_0 == 0 && xx < g.x_1);
         }
         if (real) {
           gpos = (long long)xx * im_h + y;
-          const int cur = pasted_bit(g, s_mask, xx, y);
-          int prev = 0;
-          if (gpos > 0) {
-            const int py = y > 0 ? y - 1 : im_h - 1, px = y > 0 ? xx : xx - 1;
-            prev = pasted_bit(g, s_mask, px, py);
-          }
-          change = cur != prev;
+          cur = pasted_bit(g, s_mask, xx, y);
         }
+      }
+      // the column-major predecessor of a candidate with yy >= 1 is the candidate before it (a pasted pixel of the same
+      // column): its bit sits in the neighbouring lane
+      const int from_left = __shfl_up(cur, 1, 64);
+      if (real) {
+        int prev = 0;
+        if (yy >= 1 && lane > 0) {
+          prev = from_left;
+        } else if (gpos > 0) {
+          const int py = y > 0 ? y - 1 : im_h - 1, px = y > 0 ? xx : xx - 1;
+          prev = pasted_bit(g, s_mask, px, py);
+        }
+        change = cur != prev;
       }
       const unsigned long long mm = __ballot(change);
       if (lane == 0) s_wave[wave] = __popcll(mm);
@@ -156,7 +164,10 @@ mask_paste_rle(const float* __restrict__ masks, const int* __restrict__ boxes, i
   // positions p_0 < p_1 < ... -> run lengths: p_0, p_1 - p_0, ..., total - p_last  (rleEncode; p_0 == 0: first run empty)
   const int npos = s_total;
   if (tid == 0) num_counts[d] = npos + 1;
-  if (npos + 1 > cap) return;                             // the caller sees the size it needs and calls again
+  if (npos + 1 > cap) {                                   // the caller sees the size it needs and calls again
+    if (tid == 0 && num_bytes != nullptr) num_bytes[d] = 0x7fffffff;
+    return;
+  }
   __threadfence_block();
   __syncthreads();
   // in place, chunk by chunk from the TOP: a chunk reads the last position of the chunk below it, which must still be a
@@ -173,6 +184,50 @@ mask_paste_rle(const float* __restrict__ masks, const int* __restrict__ boxes, i
     if (live) out[k] = hi - lo;
     __syncthreads();
   }
+  if (strings == nullptr) return;
+  // ---- maskApi.c rleToString: run k is written as the difference to run k - 2 (from the fourth run on) in 5-bit groups,
+  // least significant first, bit 5 = "more groups follow", + 48.  Byte offsets: ordered block scan of the group counts.
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  unsigned char* str = strings + (long long)d * str_cap;
+  for (int base = 0; base <= npos; base += kThreads) {
+    const int k = base + tid;
+    unsigned char ch[8];
+    int n = 0;
+    if (k <= npos) {
+      long long x = (long long)out[k] - (k > 2 ? (long long)out[k - 2] : 0LL);
+      bool more = true;
+      while (more && n < 8) {
+        int c = (int)(x & 0x1f);
+        x >>= 5;                                            // arithmetic shift of a signed long
+        more = (c & 0x10) ? x != -1 : x != 0;
+        if (more) c |= 0x20;
+        ch[n++] = (unsigned char)(c + 48);
+      }
+    }
+    int incl = n;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int up = __shfl_up(incl, dd, 64);
+      if (lane >= dd) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int off = s_total + incl - n;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    for (int j = 0; j < n; j++)
+      if (off + j < str_cap) str[off + j] = ch[j];
+    __syncthreads();
+    if (tid == 0) {
+      int add = 0;
+      for (int w = 0; w < kThreads / 64; w++) add += s_wave[w];
+      s_total += add;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) num_bytes[d] = s_total;
 }
 
 // ---- keypoints -------------------------------------------------------------------------------------------------------
@@ -287,7 +342,7 @@ keypoint_decode(const float* __restrict__ maps, const float* __restrict__ rois, 
 
 extern "C" int mi_mask_paste_rle(const float* masks, const int32_t* boxes, int num_masks, int mask_size, int im_height,
                                  int im_width, float thresh, int capacity, uint32_t* counts, int32_t* num_counts,
-                                 mi_stream_t stream) {
+                                 int string_capacity, uint8_t* strings, int32_t* num_bytes, mi_stream_t stream) {
   mi::begin_call();
   MI_REQUIRE(num_masks >= 0 && mask_size > 0 && im_height > 0 && im_width > 0 && capacity > 0, "mask_paste_rle: bad size");
   MI_REQUIRE(mask_size + 2 <= kMaxMask, "mask_paste_rle: masks of at most %d x %d are supported", kMaxMask - 2, kMaxMask - 2);
@@ -295,8 +350,10 @@ extern "C" int mi_mask_paste_rle(const float* masks, const int32_t* boxes, int n
   if (num_masks == 0) return MI_OK;
   MI_REQUIRE(masks != nullptr && boxes != nullptr && counts != nullptr && num_counts != nullptr,
              "mask_paste_rle: null pointer");
+  MI_REQUIRE(strings == nullptr || (num_bytes != nullptr && string_capacity > 0), "mask_paste_rle: strings without a size");
   mask_paste_rle<<<num_masks, kThreads, 0, mi::as_stream(stream)>>>(masks, boxes, mask_size, im_height, im_width, thresh,
-                                                                   capacity, counts, num_counts);
+                                                                   capacity, counts, num_counts, string_capacity, strings,
+                                                                   num_bytes);
   return mi::check_launch("mask_paste_rle");
 }
 

@@ -6,8 +6,8 @@ box, binarise, paste, pycocotools.mask.encode) and :850-866 `keypoint_results` /
 `heatmaps_to_keypoints` (per RoI: cv2.resize INTER_CUBIC of 17 heat maps, arg-max, softmax probability).  Both run on
 the host there, one detection at a time, through OpenCV and pycocotools.  Here `mi_mask_paste_rle` produces the run
 lengths of all detections in one launch without materialising any image, `mi_keypoint_decode` reduces every (RoI,
-keypoint) map in one launch without storing the resized map; the host only turns the run lengths (a few hundred
-integers per mask) into COCO's string form.
+keypoint) map in one launch without storing the resized map; COCO's string form of the run lengths is written by the
+same kernel (`rle_to_string` below is the host restatement of it, kept for callers that hold run lengths).
 
 OpenCV and pycocotools are not part of this repository's environment: the kernels follow their published algorithms
 (csrc/results.hip) and are tested against a CPU restatement of the same (oracle/results.py, parity unpinned).
@@ -51,28 +51,48 @@ def rle_to_string(counts):
     return chars[used].tobytes().decode("ascii")                # row-major: run by run, group by group
 
 
-def mask_rle_counts(masks, boxes_int, im_h, im_w, thresh=0.5, capacity=1024):
-    """`mi_mask_paste_rle`: masks [D, M, M] float32, boxes_int [D, 4] int32 (device).  Returns (counts [D, cap] uint32 as
-    int64 on the host, num_counts [D]).  One launch; repeated with a larger capacity only when a mask has more runs than
-    `capacity` (the kernel reports the true number)."""
+def mask_rle(masks, boxes_int, im_h, im_w, thresh=0.5, capacity=1024, with_strings=True):
+    """`mi_mask_paste_rle`: masks [D, M, M] float32, boxes_int [D, 4] int32 (device).  Returns (counts [D, cap] int64 on the
+    host, num_counts [D], strings): strings[d] is COCO's compressed ASCII form of row d (None when `with_strings` is
+    off).  One launch and one device-to-host copy; repeated with larger buffers only when a mask has more runs than
+    `capacity` (the kernel reports the true sizes)."""
     _lib.require_cuda(masks, "masks")
     masks = masks.contiguous().float()
     boxes_int = boxes_int.contiguous().to(torch.int32)
     d, m = masks.size(0), masks.size(-1)
     dev = masks.device
+    str_cap = 4 * capacity
     while True:
         counts = torch.empty((d, capacity), dtype=torch.int32, device=dev)   # uint32 run lengths
-        num = torch.empty((d,), dtype=torch.int32, device=dev)
+        sizes = torch.empty((2, d), dtype=torch.int32, device=dev)           # number of runs, number of string bytes
+        strings = torch.empty((d, str_cap), dtype=torch.uint8, device=dev) if with_strings else None
         with torch.cuda.device(dev):
             rc = _lib.lib().mi_mask_paste_rle(masks.data_ptr(), boxes_int.data_ptr(), d, m, int(im_h), int(im_w),
-                                              float(thresh), int(capacity), counts.data_ptr(), num.data_ptr(),
+                                              float(thresh), int(capacity), counts.data_ptr(), sizes[0].data_ptr(),
+                                              int(str_cap), strings.data_ptr() if with_strings else None,
+                                              sizes[1].data_ptr() if with_strings else None,
                                               _lib.current_stream_handle(dev))
         _lib.check(rc, "mi_mask_paste_rle")
-        num_h = num.cpu().numpy()
-        need = int(num_h.max()) if d else 0
-        if need <= capacity:
-            return counts.cpu().numpy().view(np.uint32).astype(np.int64), num_h
-        capacity = 1 << int(np.ceil(np.log2(need)))
+        sizes_h = sizes.cpu().numpy()
+        need = int(sizes_h[0].max()) if d else 0
+        need_bytes = int(sizes_h[1].max()) if (d and with_strings and need <= capacity) else 0
+        if need <= capacity and need_bytes <= str_cap:
+            out_strings = None
+            if with_strings:
+                raw = strings.cpu().numpy()
+                out_strings = [raw[i, :sizes_h[1, i]].tobytes().decode("ascii") for i in range(d)]
+            return counts.cpu().numpy().view(np.uint32).astype(np.int64), sizes_h[0], out_strings
+        if need > capacity:
+            capacity = 1 << int(np.ceil(np.log2(need)))
+            str_cap = max(str_cap, 4 * capacity)
+        else:
+            str_cap = 1 << int(np.ceil(np.log2(need_bytes)))
+
+
+def mask_rle_counts(masks, boxes_int, im_h, im_w, thresh=0.5, capacity=1024):
+    """Run lengths only: (counts [D, cap], num_counts [D])."""
+    counts, num, _ = mask_rle(masks, boxes_int, im_h, im_w, thresh, capacity, with_strings=False)
+    return counts, num
 
 
 def segm_results(cls_boxes, masks, ref_boxes, im_h, im_w, cfg):
@@ -91,11 +111,11 @@ def segm_results(cls_boxes, masks, ref_boxes, im_h, im_w, cfg):
     rows = torch.arange(r, device=masks.device)
     sel = masks[rows, cls_of_row] if cfg.MRCNN.CLS_SPECIFIC_MASK else masks[:, 0]
     boxes_int = expand_boxes(ref_boxes.float(), (m + 2.0) / m).to(torch.int32)        # :803-805 (truncation)
-    counts, num = mask_rle_counts(sel, boxes_int, im_h, im_w, cfg.MRCNN.THRESH_BINARIZE)
+    _, _, strings = mask_rle(sel, boxes_int, im_h, im_w, cfg.MRCNN.THRESH_BINARIZE)
     ind = 0
     for j in range(1, num_classes):
         for _ in range(lengths[j]):
-            cls_segms[j].append({"size": [int(im_h), int(im_w)], "counts": rle_to_string(counts[ind, :num[ind]])})
+            cls_segms[j].append({"size": [int(im_h), int(im_w)], "counts": strings[ind]})
             ind += 1
     return cls_segms
 

@@ -336,8 +336,9 @@ int mi_affine_channel_backward(const float* grad_y, const float* y, const float*
  * pasted into an im_height x im_width image and run-length encoded like pycocotools.mask.encode (column-major runs, the
  * first run counts zeros).  counts [num_masks, capacity] uint32 receives the run lengths of detection d at row d,
  * num_counts [num_masks] their number -- ALWAYS the true number: when it exceeds `capacity` the row is unspecified and the
- * caller repeats the call with a larger capacity.  The string form (maskApi.c rleToString) is host work on a few hundred
- * integers.  M + 2 <= 64.
+ * caller repeats the call with a larger capacity.  strings (may be NULL) [num_masks, string_capacity] receives COCO's
+ * compressed ASCII form of the run lengths (maskApi.c rleToString), num_bytes [num_masks] its true length (larger than
+ * string_capacity: repeat with more room; a row whose run lengths did not fit reports INT32_MAX).  M + 2 <= 64.
  * mi_keypoint_decode: heatmaps_to_keypoints (lib/utils/keypoints.py:106-157): heatmaps [num_rois, K, H, H] float32 logits,
  * rois [num_rois, 4]; every map is resized to (ceil(width), ceil(height)) of its RoI (at least min_size when > 0) with
  * cv2.resize's INTER_CUBIC arithmetic and reduced to xy_preds [num_rois, 4, K] = (x, y, logit, softmax probability over
@@ -345,7 +346,8 @@ int mi_affine_channel_backward(const float* grad_y, const float* y, const float*
  * OpenCV / pycocotools are third-party packages of the reference; their published algorithms are restated
  * (csrc/results.hip, oracle/results.py). */
 int mi_mask_paste_rle(const float* masks, const int32_t* boxes, int num_masks, int mask_size, int im_height, int im_width,
-                      float thresh, int capacity, uint32_t* counts, int32_t* num_counts, mi_stream_t stream);
+                      float thresh, int capacity, uint32_t* counts, int32_t* num_counts, int string_capacity,
+                      uint8_t* strings, int32_t* num_bytes, mi_stream_t stream);
 int mi_keypoint_decode(const float* heatmaps, const float* rois, int num_rois, int num_keypoints, int heatmap_size,
                        int min_size, float* xy_preds, mi_stream_t stream);
 

@@ -49,12 +49,12 @@ def test_mask_paste_rle_matches_the_restatement(m):
     im_h, im_w = 800, 1333
     masks = soft_masks(len(BOXES), m, seed=m)
     masks[5] = 0.9                                                     # the one-pixel box pastes a one
-    counts, num = results.mask_rle_counts(torch.from_numpy(masks).to(dev()), torch.from_numpy(BOXES).to(dev()), im_h, im_w)
+    counts, num, strings = results.mask_rle(torch.from_numpy(masks).to(dev()), torch.from_numpy(BOXES).to(dev()), im_h, im_w)
     for i, box in enumerate(BOXES):
         want = R.rle_counts(R.paste_mask(masks[i], box, im_h, im_w))
         assert num[i] == len(want), "detection %d: %d runs, want %d" % (i, num[i], len(want))
         assert counts[i, :num[i]].tolist() == want, "detection %d" % i
-        assert results.rle_to_string(counts[i, :num[i]]) == R.rle_to_string(want)
+        assert results.rle_to_string(counts[i, :num[i]]) == R.rle_to_string(want) == strings[i]
 
 
 def test_mask_paste_rle_grows_its_capacity_and_handles_noise():
@@ -65,12 +65,14 @@ def test_mask_paste_rle_grows_its_capacity_and_handles_noise():
     rng = np.random.RandomState(5)
     masks = rng.rand(2, 28, 28).astype(np.float32)
     boxes = np.array([[50, 60, 400, 380], [5, 5, 60, 40]], np.int32)
-    counts, num = results.mask_rle_counts(torch.from_numpy(masks).to(dev()), torch.from_numpy(boxes).to(dev()), 480, 640,
-                                          capacity=64)
+    counts, num, strings = results.mask_rle(torch.from_numpy(masks).to(dev()), torch.from_numpy(boxes).to(dev()), 480, 640,
+                                            capacity=64)
     for i in range(2):
         want = R.rle_counts(R.paste_mask(masks[i], boxes[i], 480, 640))
         assert len(want) > 64 or i == 1
-        assert counts[i, :num[i]].tolist() == want
+        assert counts[i, :num[i]].tolist() == want and strings[i] == R.rle_to_string(want)
+    only_counts = results.mask_rle_counts(torch.from_numpy(masks).to(dev()), torch.from_numpy(boxes).to(dev()), 480, 640)
+    assert only_counts[0][0, :only_counts[1][0]].tolist() == R.rle_counts(R.paste_mask(masks[0], boxes[0], 480, 640))
 
 
 def test_segm_results_end_to_end():

@@ -398,27 +398,27 @@ def nms_latency(device, iters):
     person = torch.from_numpy(person_np).to(device)
 
     def segm():
-        counts, num = results.mask_rle_counts(masks, boxes_int, 800, 1333)
-        return [results.rle_to_string(counts[i, :num[i]]) for i in range(len(num))]
+        return results.mask_rle(masks, boxes_int, 800, 1333)[2]
 
     t0 = time.perf_counter()
     for _ in range(5):
         segm()
     host_sec = (time.perf_counter() - t0) / 5
     counts = torch.empty((100, 1024), dtype=torch.int32, device=device)
-    num = torch.empty((100,), dtype=torch.int32, device=device)
+    strs = torch.empty((100, 4096), dtype=torch.uint8, device=device)
+    num = torch.empty((2, 100), dtype=torch.int32, device=device)
     lib = _lib_mod.lib()
 
     def paste_kernel():
         assert lib.mi_mask_paste_rle(masks.data_ptr(), boxes_int.data_ptr(), 100, 28, 800, 1333, 0.5, 1024, counts.data_ptr(),
-                                     num.data_ptr(), _lib_mod.current_stream_handle(device)) == 0
+                                     num[0].data_ptr(), 4096, strs.data_ptr(), num[1].data_ptr(),
+                                     _lib_mod.current_stream_handle(device)) == 0
 
     out["result_formats"] = {
         "segm_100_masks_800x1333_ms": round(host_sec * 1e3, 3),
         "mask_paste_rle_kernel_us": round(time_kernel(paste_kernel, 20, warmup=3) * 1e6, 1),
         "keypoint_decode_20x17_us": round(time_kernel(lambda: results.heatmaps_to_keypoints(maps, person), 20, warmup=3) * 1e6, 1),
-        "what": "segm = mi_mask_paste_rle for 100 detections + one D2H copy of the run lengths + COCO string encoding on "
-                "the host; keypoints = mi_keypoint_decode for 20 person boxes x 17 heat maps (bicubic resize to the box, "
+        "what": "segm = mi_mask_paste_rle for 100 detections (run lengths and COCO strings) + one D2H copy; keypoints = mi_keypoint_decode for 20 person boxes x 17 heat maps (bicubic resize to the box, "
                 "arg-max, softmax probability)"}
     return out
 
