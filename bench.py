@@ -58,6 +58,9 @@ def parse_args():
                          "optimizer) are captured once in a hipGraph and replayed -- the training step is static-shaped "
                          "and sync-free by construction; with N > 1 the all-reduces run between the backward graph and the "
                          "optimizer graph")
+    ap.add_argument("--layout", default="nchw", choices=["nchw", "channels_last"],
+                    help="memory format of the model and the image blob of the training step (the RoI operators take "
+                         "both; MIOpen picks other fp32 solvers for channels_last)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no roofline / breakdown / inference objects)")
     ap.add_argument("--kernel-iters", type=int, default=200, help="back-to-back launches per roofline timing")
@@ -118,7 +121,7 @@ class TrainHarness:
     """One rank of the data-parallel job: model, resident minibatch, optimizer, gradient reducer, and the step in its
     two launch forms."""
 
-    def __init__(self, device, rank, world, dtype, launch, cfg=None, images_per_rank=IMAGES_PER_RANK):
+    def __init__(self, device, rank, world, dtype, launch, cfg=None, images_per_rank=IMAGES_PER_RANK, layout="nchw"):
         from detectron_pytorch_amd import parallel
         from detectron_pytorch_amd.rcnn import config, data as rdata, model as rmodel, train as rtrain
 
@@ -130,10 +133,14 @@ class TrainHarness:
         self.cfg = cfg
         torch.manual_seed(cfg.RNG_SEED)                   # every rank starts from the same weights (a replica)
         self.net = rmodel.GeneralizedRCNN(cfg).to(device)
+        self.layout = layout
+        if layout == "channels_last":
+            self.net = self.net.to(memory_format=torch.channels_last)
         self.net.train()
         self.autocast = torch.bfloat16 if dtype == "bf16" else None
         batch = rdata.synthetic_minibatch(cfg, images_per_rank, seed=rank)      # per-rank images (weak scaling)
-        self.data, self.im_info, self.roidb, self.rpn_targets = rdata.to_device(batch, device)
+        self.data, self.im_info, self.roidb, self.rpn_targets = rdata.to_device(batch, device,
+                                                                                channels_last=layout == "channels_last")
         # the reference's learning-rate rule: the yaml's BASE_LR is for NUM_GPUS x IMS_PER_BATCH = 16 images and is
         # rescaled linearly to the actual batch (tools/train_net_step.py:166-201); first iteration of the warm-up
         # (SOLVER.WARM_UP_FACTOR = 1/3, config.py:560)
@@ -421,6 +428,33 @@ def inference_graph_child(device, dtype, iters=30):
             "equals_eager_result": same, "host_syncs_per_image": 1}
 
 
+def mask_inference(device, iters=8, warmup=3):
+    """e2e_mask_rcnn_R-50-FPN test-time detection of one image INCLUDING the result formats (core/test.py:50-112): boxes,
+    100 masks through the mask head, pasted and run-length encoded (COCO RLE strings on the host at the end).  The
+    randomly initialised classifier scores ~1/81 everywhere, so TEST.SCORE_THRESH is lowered until 100 detections pass
+    -- the amount of mask work of a trained model on a crowded image."""
+    from detectron_pytorch_amd.rcnn import config, inference, model as rmodel
+
+    cfg = config.mask_rcnn_r50_fpn()
+    cfg.TEST.SCORE_THRESH = 0.0
+    torch.manual_seed(cfg.RNG_SEED)
+    net = rmodel.GeneralizedRCNN(cfg).to(device).eval()
+    rng = np.random.RandomState(0)
+    data = torch.from_numpy((rng.randn(1, 3, 800, 1344) * 50).astype(np.float32)).to(device)
+    im_info = torch.tensor([[800.0, 1344.0, 1.0]])
+    for _ in range(warmup):
+        out = inference.im_detect_all_results(net, data, im_info)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = inference.im_detect_all_results(net, data, im_info)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / iters
+    return {"workload": "e2e_mask_rcnn_R-50-FPN inference with result formats, 1 image 1333x800, eager",
+            "ms_per_image": round(sec * 1e3, 3), "images_per_s": round(1.0 / sec, 2),
+            "detections": int(sum(len(c) for c in out[0][1:])), "masks_encoded": int(sum(len(c) for c in out[1][1:]))}
+
+
 def cpu_baseline(images_per_rank):
     """The oracle (a C port of the reference kernels, kind="port") on the host cores of this box, on a bounded sample of
     the same workload: the hot-path step of ONE image (512-RoI 7x7 and 128-RoI 14x14 RoIAlign fwd+bwd on a 1x256x200x336
@@ -589,7 +623,7 @@ def main():
         print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("MI_")},
                           "roofline": hp.roofline_roi_align_forward(device, args.kernel_iters)}), flush=True)
         return
-    work = TrainHarness(device, rank, world, args.dtype, args.launch)
+    work = TrainHarness(device, rank, world, args.dtype, args.launch, layout=args.layout)
     if args.launch == "graph":
         work.capture()
     else:
@@ -611,7 +645,7 @@ def main():
                                    "512 RoIs/image, <=128 mask RoIs/image, 8 gt boxes/image, random-init weights (seed 3)"
                                    % IMAGES_PER_RANK,
                        "global_batch": IMAGES_PER_RANK * world, "images_per_rank": IMAGES_PER_RANK,
-                       "parallelism": "dp%d" % world, "launch": work.mode,
+                       "parallelism": "dp%d" % world, "launch": work.mode, "layout": work.layout,
                        "trainable_params": work.params, "gradient_payload_bytes": work.params * 4,
                        "loss_first": round(first_loss, 4), "loss_last": round(last_loss, 4)},
         }
@@ -637,6 +671,10 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as exc:  # noqa: BLE001
                     line["bf16_autocast"] = {"error": repr(exc)}
+            try:
+                line["mask_inference"] = mask_inference(device)
+            except Exception as exc:  # noqa: BLE001
+                line["mask_inference"] = {"error": repr(exc)[:300]}
             line["config5_x101_mask_keypoint"] = config5(device, rank, args)
             line["nms"] = hp.nms_latency(device, args.kernel_iters)
             line["inference_path"] = hp.inference_path(device)
