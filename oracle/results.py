@@ -12,9 +12,11 @@ cannot be fetched (no network), so this file restates their PUBLISHED algorithms
     special-cased.)
   * pycocotools 2.0 (`pycocotools.mask.encode`, lib/core/test.py:838): common/maskApi.c rleEncode (column-major run
     lengths, first run counts zeros) and rleToString (differences to the run two back, 5 bits per character + 48).
-What IS anchored on the reference: the call sites and everything around the two packages -- `segm_results`
+What IS pinned to the reference: the call sites and everything around the two packages -- `segm_results`
 (lib/core/test.py:793-847), `expand_boxes` (lib/utils/boxes.py:233-249), `heatmaps_to_keypoints` / `scores_to_probs`
-(lib/utils/keypoints.py:106-157, :214-222) -- restated line by line below.
+(lib/utils/keypoints.py:106-157, :214-222) -- restated line by line below and checked, in tests/test_results_cpu.py,
+against the reference's OWN source text of those functions executed with only `cv2.resize` and `mask_util.encode` bound
+to the restatements of this file (exact equality of every RLE string and every keypoint value).
 """
 import numpy as np
 

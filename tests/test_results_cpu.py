@@ -106,3 +106,77 @@ def test_detections_pkl_layout(tmp_path):
     assert sorted(got) == ["all_boxes", "all_keyps", "all_segms", "cfg"] and got["cfg"] == "MODEL: {}"
     assert got["all_boxes"][1][0] == [] and got["all_boxes"][1][1].shape == (1, 5)
     assert got["all_segms"][1][1] == cls_segms[1] and got["all_keyps"][1][1][0].shape == (4, 17)
+
+
+REFERENCE = "/root/reference/lib"
+
+
+def _reference_functions():
+    """segm_results (core/test.py), heatmaps_to_keypoints / scores_to_probs (utils/keypoints.py) and expand_boxes
+    (utils/boxes.py) executed from the reference's OWN source text; only the two absent third-party packages are stubbed,
+    by the restatements under test: cv2.resize -> oracle.results.cv2_resize_*, pycocotools.mask.encode -> the restated RLE."""
+    import re
+    import types
+
+    def fn(path, name):
+        src = open(os.path.join(REFERENCE, path)).read()
+        return re.search(r"^def %s\(.*?(?=^def |\Z)" % name, src, re.S | re.M).group(0)
+
+    cv2 = types.SimpleNamespace(INTER_CUBIC=2, INTER_LINEAR=1)
+
+    def resize(src, dsize, interpolation=1):
+        f = R.cv2_resize_cubic if interpolation == cv2.INTER_CUBIC else R.cv2_resize_linear
+        return f(src, int(dsize[0]), int(dsize[1]))
+
+    cv2.resize = resize
+
+    def encode(fortran_masks):
+        return [{"size": list(fortran_masks.shape[:2]),
+                 "counts": R.rle_to_string(R.rle_counts(fortran_masks[:, :, i])).encode("ascii")}
+                for i in range(fortran_masks.shape[2])]
+
+    def make(cfg):
+        box_utils = types.ModuleType("box_utils")
+        box_utils.np = np
+        exec(compile(fn("utils/boxes.py", "expand_boxes"), "utils/boxes.py", "exec"), box_utils.__dict__)
+        ns = {"np": np, "cv2": cv2, "cfg": cfg, "box_utils": box_utils, "mask_util": types.SimpleNamespace(encode=encode)}
+        exec(compile(fn("core/test.py", "segm_results"), "core/test.py", "exec"), ns)
+        exec(compile(fn("utils/keypoints.py", "scores_to_probs") + fn("utils/keypoints.py", "heatmaps_to_keypoints"),
+                     "utils/keypoints.py", "exec"), ns)
+        return ns
+
+    return make, types
+
+
+def test_reference_call_sites_run_on_the_restated_packages():
+    """Pins everything AROUND the two absent packages to the reference: its own segm_results / heatmaps_to_keypoints text
+    gives exactly what oracle/results.py's restatement of them gives (box expansion and truncation, padding, paste
+    offsets, class order, the float64 coordinate arithmetic of the keypoints)."""
+    import pytest
+
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference tree is not present on this machine")
+    make, types = _reference_functions()
+    rng = np.random.RandomState(5)
+    for m, cls_specific in ((28, True), (14, False)):
+        cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=5),
+                                    MRCNN=types.SimpleNamespace(RESOLUTION=m, CLS_SPECIFIC_MASK=cls_specific, THRESH_BINARIZE=0.5),
+                                    KRCNN=types.SimpleNamespace(INFERENCE_MIN_SIZE=0, NUM_KEYPOINTS=17))
+        ns = make(cfg)
+        lengths = [0, 2, 0, 3, 1]
+        r = sum(lengths)
+        masks = rng.rand(r, 5 if cls_specific else 1, m, m).astype(np.float32)
+        x1, y1 = rng.uniform(-30, 500, r), rng.uniform(-30, 300, r)
+        ref_boxes = np.stack([x1, y1, x1 + rng.uniform(2, 250, r), y1 + rng.uniform(2, 200, r)], 1).astype(np.float32)
+        cls_boxes = [np.zeros((n, 5), np.float32) for n in lengths]
+        want = ns["segm_results"](cls_boxes, masks, ref_boxes, 427, 640)
+        got = R.segm_results(cls_boxes, masks, ref_boxes, 427, 640, cls_specific=cls_specific)
+        assert got == want
+    for min_size in (0, 48):
+        cfg.KRCNN.INFERENCE_MIN_SIZE = min_size
+        ns = make(cfg)
+        maps = rng.randn(4, 17, 56, 56).astype(np.float32)
+        rois = np.array([[10, 20, 110, 220], [0, 0, 30.5, 15.2], [5, 5, 5.5, 5.2], [100.3, 50.7, 320.9, 410.1]], np.float32)
+        want = ns["heatmaps_to_keypoints"](maps.copy(), rois)
+        got = R.heatmaps_to_keypoints(maps, rois, min_size)
+        assert want.dtype == got.dtype == np.float32 and np.array_equal(want, got)
