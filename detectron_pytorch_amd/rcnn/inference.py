@@ -157,16 +157,37 @@ def im_detect_all_results(model, data, im_info, im_shape=None, autocast_dtype=No
     return cls_boxes, cls_segms, cls_keyps
 
 
+RLE_CAPACITY, RLE_STRING_CAPACITY = 1024, 4096      # per mask, static path (a noisier mask sends the image to the eager path)
+
+
 @torch.no_grad()
-def im_detect_all_static(model, data, im_info, autocast_dtype=None):
+def im_detect_all_static(model, data, im_info, autocast_dtype=None, mask_im_shape=None):
     """`im_detect_all` as one asynchronous sequence of fixed shapes: image blob and `im_info` ([1,3] float32) are device
-    tensors, nothing is read back.  Returns detection.box_results_static's dict (hard NMS only)."""
+    tensors, nothing is read back.  Returns detection.box_results_static's dict (hard NMS only).
+    `mask_im_shape` = (height, width) of the original image: the mask branch runs too (model with MODEL.MASK_ON) -- the
+    fixed-size detection rows go through the mask head (unused rows carry image index -1 and pool zeros) and
+    `mi_mask_paste_rle`; the dict gains 'rle_counts', 'rle_sizes', 'rle_strings' (results.mask_rle_static)."""
     cfg = model.cfg
     if cfg.TEST.SOFT_NMS.ENABLED:
         raise NotImplementedError("the static detection path runs hard NMS (Soft-NMS compacts its candidates first)")
-    scores, boxes, _, valid = im_detect_bbox(model, data, im_info, None, autocast_dtype, static=True)
+    scores, boxes, blob_conv, valid = im_detect_bbox(model, data, im_info, None, autocast_dtype, static=True)
     t = cfg.TEST
-    return detection.box_results_static(scores, boxes, t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, roi_valid=valid)
+    res = detection.box_results_static(scores, boxes, t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, roi_valid=valid)
+    if mask_im_shape is not None:
+        m = cfg.MRCNN.RESOLUTION
+        det_boxes, cls = res["dets"][:, :4], res["cls"].long()
+        rows = cls > 0
+        rois = torch.cat([torch.where(rows, torch.zeros_like(det_boxes[:, 0]), torch.full_like(det_boxes[:, 0], -1.0)).view(-1, 1),
+                          det_boxes * im_info[0, 2]], dim=1)
+        lvls = fpn_proposals.map_rois_to_fpn_levels(rois[:, 1:5], cfg.FPN.ROI_MIN_LEVEL, cfg.FPN.ROI_MAX_LEVEL)
+        masks = model.mask_net(blob_conv, {"mask_rois": rois, "mask_rois_levels": lvls}).float()
+        k = cfg.MODEL.NUM_CLASSES if cfg.MRCNN.CLS_SPECIFIC_MASK else 1
+        masks = masks.reshape(-1, k, m, m)
+        sel = masks[torch.arange(masks.size(0), device=masks.device), cls] if cfg.MRCNN.CLS_SPECIFIC_MASK else masks[:, 0]
+        boxes_int = results.expand_boxes(det_boxes, (m + 2.0) / m).to(torch.int32)
+        res["rle_counts"], res["rle_sizes"], res["rle_strings"] = results.mask_rle_static(
+            sel, boxes_int, mask_im_shape[0], mask_im_shape[1], cfg.MRCNN.THRESH_BINARIZE, RLE_CAPACITY, RLE_STRING_CAPACITY)
+    return res
 
 
 class DetectionGraph(object):
@@ -176,9 +197,13 @@ class DetectionGraph(object):
     SURVEY.md section 3.1).  One graph per blob shape (FPN pads blobs to multiples of 32: a handful of shapes per
     dataset); `im_info` is a graph INPUT, so images of different scale share the graph of their blob shape."""
 
-    def __init__(self, model, blob_shape, device, autocast_dtype=None):
+    def __init__(self, model, blob_shape, device, autocast_dtype=None, mask_im_shape=None):
+        """`mask_im_shape` = (height, width) of the original images this graph serves: boxes AND masks in the reference's
+        result formats (`__call__` then returns (cls_boxes, cls_segms)); the image size is baked into the captured mask
+        kernel, so such a graph serves one image size."""
         assert not model.training and blob_shape[0] == 1
-        self.model, self.autocast_dtype = model, autocast_dtype
+        assert mask_im_shape is None or model.cfg.MODEL.MASK_ON
+        self.model, self.autocast_dtype, self.mask_im_shape = model, autocast_dtype, mask_im_shape
         self.data = torch.zeros(blob_shape, dtype=torch.float32, device=device)
         self.im_info = torch.zeros((1, 3), dtype=torch.float32, device=device)
         self.graph, self.out = None, None
@@ -191,12 +216,12 @@ class DetectionGraph(object):
         side.wait_stream(torch.cuda.current_stream(self.data.device))
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                im_detect_all_static(self.model, self.data, self.im_info, self.autocast_dtype)
+                im_detect_all_static(self.model, self.data, self.im_info, self.autocast_dtype, self.mask_im_shape)
         torch.cuda.current_stream(self.data.device).wait_stream(side)
         torch.cuda.synchronize(self.data.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):     # the warm-up stream: one stream, a linear graph
-            self.out = im_detect_all_static(self.model, self.data, self.im_info, self.autocast_dtype)
+            self.out = im_detect_all_static(self.model, self.data, self.im_info, self.autocast_dtype, self.mask_im_shape)
         self.graph = graph
         return self
 
@@ -208,9 +233,32 @@ class DetectionGraph(object):
         return self.out
 
     def __call__(self, data, im_info):
-        """(scores [D], boxes [D,4], cls_boxes) like `im_detect_all`; one device-to-host copy (the result sizes)."""
+        """(scores [D], boxes [D,4], cls_boxes) like `im_detect_all`; one device-to-host copy (the result sizes).  With
+        `mask_im_shape`: (cls_boxes, cls_segms) like `im_detect_all_results`."""
+        if self.mask_im_shape is not None:
+            return self._call_with_masks(data, im_info)
         out = detection._results_from_static(self.replay(data, im_info), False)
         if out is None:      # more tied scores at the detections_per_im cut than the static result holds
             return im_detect_all(self.model, data, torch.as_tensor(im_info).cpu().view(1, 3), None, self.autocast_dtype)
         # the views point into the graph's output buffer: hand out copies
         return out[0].clone(), out[1].clone(), [[]] + [c.clone() for c in out[2][1:]]
+
+    def _call_with_masks(self, data, im_info):
+        res = self.replay(data, im_info)
+        out = detection._results_from_static(res, False)
+        sizes = res["rle_sizes"].cpu().numpy()
+        count = 0 if out is None else int(out[0].numel())
+        if out is None or (count and (sizes[0, :count].max() > RLE_CAPACITY or sizes[1, :count].max() > RLE_STRING_CAPACITY)):
+            # ties beyond the static result, or a mask with more runs than the static buffers hold: the eager path
+            cls_boxes, cls_segms, _ = im_detect_all_results(self.model, data, torch.as_tensor(im_info).cpu().view(1, 3),
+                                                            self.mask_im_shape, self.autocast_dtype)
+            return cls_boxes, cls_segms
+        cls_boxes = [[]] + [c.clone() for c in out[2][1:]]
+        raw = res["rle_strings"][:count].cpu().numpy()
+        h, w = int(self.mask_im_shape[0]), int(self.mask_im_shape[1])
+        cls_segms, ind = [[] for _ in cls_boxes], 0
+        for j in range(1, len(cls_boxes)):
+            for _ in range(len(cls_boxes[j])):
+                cls_segms[j].append({"size": [h, w], "counts": raw[ind, :sizes[1, ind]].tobytes().decode("ascii")})
+                ind += 1
+        return cls_boxes, cls_segms

@@ -51,6 +51,26 @@ def rle_to_string(counts):
     return chars[used].tobytes().decode("ascii")                # row-major: run by run, group by group
 
 
+def mask_rle_static(masks, boxes_int, im_h, im_w, thresh=0.5, capacity=1024, str_cap=4096):
+    """One asynchronous `mi_mask_paste_rle` launch with fixed buffer sizes (what a hipGraph captures): returns device
+    tensors (counts int32 [D, capacity], sizes int32 [2, D] = (number of runs, number of string bytes), strings uint8
+    [D, str_cap]).  A row whose sizes exceed the capacities is incomplete; the caller checks `sizes` on the host."""
+    _lib.require_cuda(masks, "masks")
+    masks = masks.contiguous().float()
+    boxes_int = boxes_int.contiguous().to(torch.int32)
+    d, m = masks.size(0), masks.size(-1)
+    dev = masks.device
+    counts = torch.empty((d, capacity), dtype=torch.int32, device=dev)
+    sizes = torch.empty((2, d), dtype=torch.int32, device=dev)
+    strings = torch.empty((d, str_cap), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mi_mask_paste_rle(masks.data_ptr(), boxes_int.data_ptr(), d, m, int(im_h), int(im_w), float(thresh),
+                                          int(capacity), counts.data_ptr(), sizes[0].data_ptr(), int(str_cap),
+                                          strings.data_ptr(), sizes[1].data_ptr(), _lib.current_stream_handle(dev))
+    _lib.check(rc, "mi_mask_paste_rle")
+    return counts, sizes, strings
+
+
 def mask_rle(masks, boxes_int, im_h, im_w, thresh=0.5, capacity=1024, with_strings=True):
     """`mi_mask_paste_rle`: masks [D, M, M] float32, boxes_int [D, 4] int32 (device).  Returns (counts [D, cap] int64 on the
     host, num_counts [D], strings): strings[d] is COCO's compressed ASCII form of row d (None when `with_strings` is
