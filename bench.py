@@ -65,7 +65,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="headline only (no roofline / breakdown / inference objects)")
     ap.add_argument("--kernel-iters", type=int, default=200, help="back-to-back launches per roofline timing")
     ap.add_argument("--only-roofline", action="store_true", help="tuning aid: print only the roofline object")
-    ap.add_argument("--child-inference-graph", action="store_true",
+    ap.add_argument("--child-inference-graph", nargs="?", const="box", default=None, choices=["box", "mask"],
                     help="internal: measure the hipGraph form of the config-3 detection in this (child) process and print "
                          "one JSON object -- a failed capture must not take the parent's bench line with it")
     ap.add_argument("--selftest-cpu", action="store_true",
@@ -428,12 +428,8 @@ def inference_graph_child(device, dtype, iters=30):
             "equals_eager_result": same, "host_syncs_per_image": 1}
 
 
-def mask_inference(device, iters=12, warmup=3):
-    """e2e_mask_rcnn_R-50-FPN test-time detection of one image INCLUDING the result formats (core/test.py:50-112): boxes,
-    100 masks through the mask head, pasted and run-length encoded (COCO RLE strings on the host at the end).  The
-    randomly initialised classifier scores ~1/81 everywhere, so TEST.SCORE_THRESH is lowered until 100 detections pass
-    -- the amount of mask work of a trained model on a crowded image."""
-    from detectron_pytorch_amd.rcnn import config, inference, model as rmodel
+def build_mask_inference_job(device):
+    from detectron_pytorch_amd.rcnn import config, model as rmodel
 
     cfg = config.mask_rcnn_r50_fpn()
     cfg.TEST.SCORE_THRESH = 0.0
@@ -441,7 +437,41 @@ def mask_inference(device, iters=12, warmup=3):
     net = rmodel.GeneralizedRCNN(cfg).to(device).eval()
     rng = np.random.RandomState(0)
     data = torch.from_numpy((rng.randn(1, 3, 800, 1344) * 50).astype(np.float32)).to(device)
-    im_info = torch.tensor([[800.0, 1344.0, 1.0]])
+    return net, data, torch.tensor([[800.0, 1344.0, 1.0]])
+
+
+def mask_graph_child(device, iters=20):
+    """`mask_inference` as one replayed hipGraph (DetectionGraph with the mask branch), in a child process; checked against
+    the eager result formats (same detections; masks may differ in the few pixels at the 0.5 threshold)."""
+    from detectron_pytorch_amd.rcnn import inference
+
+    net, data, im_info = build_mask_inference_job(device)
+    want_boxes, want_segms, _ = inference.im_detect_all_results(net, data, im_info, (800, 1344))
+    graph = inference.DetectionGraph(net, tuple(data.shape), device, mask_im_shape=(800, 1344)).capture(data, im_info)
+    got_boxes, got_segms = graph(data, im_info)
+    same = [len(c) for c in got_boxes] == [len(c) for c in want_boxes]
+    identical = sum(g["counts"] == w["counts"] for gs, ws in zip(got_segms, want_segms) for g, w in zip(gs, ws))
+    for _ in range(3):
+        graph(data, im_info)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        got_boxes, got_segms = graph(data, im_info)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / iters
+    return {"images_per_s": round(1.0 / sec, 2), "ms_per_image": round(sec * 1e3, 3), "same_detections_as_eager": bool(same),
+            "rle_strings_identical_to_eager": "%d of %d" % (identical, sum(len(c) for c in want_segms)),
+            "masks_encoded": int(sum(len(c) for c in got_segms))}
+
+
+def mask_inference(device, iters=12, warmup=3):
+    """e2e_mask_rcnn_R-50-FPN test-time detection of one image INCLUDING the result formats (core/test.py:50-112): boxes,
+    100 masks through the mask head, pasted and run-length encoded (COCO RLE strings on the host at the end).  The
+    randomly initialised classifier scores ~1/81 everywhere, so TEST.SCORE_THRESH is lowered until 100 detections pass
+    -- the amount of mask work of a trained model on a crowded image."""
+    from detectron_pytorch_amd.rcnn import inference
+
+    net, data, im_info = build_mask_inference_job(device)
     for _ in range(warmup):
         out = inference.im_detect_all_results(net, data, im_info)
     ts = []
@@ -452,7 +482,19 @@ def mask_inference(device, iters=12, warmup=3):
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     med, mean = float(np.median(ts)), float(np.mean(ts))
-    return {"workload": "e2e_mask_rcnn_R-50-FPN inference with result formats, 1 image 1333x800, eager",
+    hipgraph = {}
+    del net, data
+    torch.cuda.empty_cache()
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-inference-graph", "mask"],
+                             capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if res.returncode != 0 or not lines:
+            raise RuntimeError("child exit %d: %s" % (res.returncode, res.stderr[-300:]))
+        hipgraph = json.loads(lines[-1])
+    except Exception as exc:  # noqa: BLE001
+        hipgraph = {"error": repr(exc)[:300]}
+    return {"workload": "e2e_mask_rcnn_R-50-FPN inference with result formats, 1 image 1333x800, eager", "hipgraph": hipgraph,
             "ms_per_image": round(med * 1e3, 3), "images_per_s": round(1.0 / med, 2),
             "ms_per_image_mean": round(mean * 1e3, 3), "ms_per_image_max": round(max(ts) * 1e3, 3),
             "detections": int(sum(len(c) for c in out[0][1:])), "masks_encoded": int(sum(len(c) for c in out[1][1:])),
@@ -622,8 +664,11 @@ def main():
     device = torch.device("cuda", local_rank)
     from tools import hot_path_bench as hp
 
-    if args.child_inference_graph:
+    if args.child_inference_graph == "box":
         print(json.dumps(inference_graph_child(device, args.dtype)), flush=True)
+        return
+    if args.child_inference_graph == "mask":
+        print(json.dumps(mask_graph_child(device)), flush=True)
         return
     if args.only_roofline:
         print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("MI_")},
