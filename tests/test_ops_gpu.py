@@ -259,10 +259,17 @@ def test_roi_align_forward_large_lds_caps(oracle_mod, tuning_env):
     feat = syn.feature_map(1, 32, 100, 168, seed=2)
     rois = syn.rois_canonical(64, 1, seed=3, im_h=800, im_w=1344)
     want = oracle_mod.roi_align_forward(feat, rois, 7, 7, 0.125, 2, threads=8)
-    for cap in ("448", "640"):
+    for cap in ("448", "640", "256", "192"):
         tuning_env(MI_ROI_ALIGN_CAP=cap)
         out, _ = _roi_align_gpu(feat, rois, 7, 0.125, 2)
         assert_fwd(out, want, "cap " + cap, exact=False)
+    feat14 = syn.feature_map(2, 64, 50, 84, seed=4)
+    rois14 = syn.rois_canonical(48, 2, seed=5, im_h=800, im_w=1344)
+    want14 = oracle_mod.roi_align_forward(feat14, rois14, 14, 14, 1.0 / 16, 2, threads=8)
+    for cap in ("256", "448"):
+        tuning_env(MI_ROI_ALIGN_CAP=cap)
+        out, _ = _roi_align_gpu(feat14, rois14, 14, 1.0 / 16, 2)
+        assert_fwd(out, want14, "14x14 cap " + cap, exact=False)
 
 
 # ---- RoIAlign (legacy) ----------------------------------------------------------------------------
