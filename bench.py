@@ -498,9 +498,10 @@ def mask_inference(device, iters=12, warmup=3):
             "ms_per_image": round(med * 1e3, 3), "images_per_s": round(1.0 / med, 2),
             "ms_per_image_mean": round(mean * 1e3, 3), "ms_per_image_max": round(max(ts) * 1e3, 3),
             "detections": int(sum(len(c) for c in out[0][1:])), "masks_encoded": int(sum(len(c) for c in out[1][1:])),
-            "what": "median over %d images; about one image in four or five stalls ~60 ms on the host inside torch.conv2d "
-                    "(MIOpen immediate mode; cProfile: the RPN head's convolutions) once the mask head's shapes are in "
-                    "the mix -- the mean and the maximum show it" % iters}
+            "what": "median over %d images; every third or fourth image stalls 60-80 ms on the host inside torch.conv2d "
+                    "(cProfile: the RPN head's convolutions) once the mask head's shapes are in the mix -- independent "
+                    "of the caching allocator's settings and of Python's garbage collector (gc.freeze), absent from the "
+                    "hipGraph form; the mean and the maximum show it" % iters}
 
 
 def cpu_baseline(images_per_rank):

@@ -19,6 +19,13 @@ data = torch.from_numpy((np.random.RandomState(0).randn(1, 3, 800, 1344) * 50).a
 im_info = torch.tensor([[800.0, 1344.0, 1.0]])
 
 
+if os.environ.get("GC_FREEZE"):
+    import gc
+
+    gc.collect()
+    gc.freeze()
+
+
 def timed(fn):
     torch.cuda.synchronize()
     t = time.perf_counter()
