@@ -43,7 +43,7 @@ def main():
                "MIOpen layout / im2col helpers" if ("transpose" in n or "Im2d2Col" in n or "Col2Im" in n or "SubTensor" in n) else
                "PyTorch element-wise / reduce / index")
         groups[key] += t
-    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:120]:
         print("%6.2f%% %9.1f %11.1f %11.1f  %s" % (100.0 * t / busy, c / steps, t / steps / 1e3, t / c / 1e3, n[:140]))
     print("\ngroups (share of kernel time):")
     for k, t in sorted(groups.items(), key=lambda kv: -kv[1]):
