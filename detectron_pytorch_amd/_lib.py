@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_detectron_ops.so")
 
 MI_OK = 0
+ABI_VERSION = 2  # MI_ABI_VERSION of include/mi_detectron_ops.h this binding was written against
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 ROI_ALIGN_CAFFE2, ROI_ALIGN_LEGACY = 0, 1
 NMS_GE_ORIG_ASC, NMS_GT_SORTED_POS = 0, 1
@@ -50,6 +51,7 @@ SIGNATURES = {
     "mi_rpn_collect_candidates": (_c_int, [_c_int] + [_c_void_p] * 6 + [_c_int, _c_void_p, _c_void_p, _c_void_p]),
     "mi_rpn_collect_finish": (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_float, _c_float] + [_c_void_p] * 4),
     "mi_roi_align_fpn_supported": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int]),
+    "mi_roi_align_forward_fpn_writes_records": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "mi_roi_align_forward_fpn": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                          _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "mi_roi_align_backward_fpn": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
@@ -106,8 +108,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.mi_abi_version() != 1:
-            raise MiOpsError("ABI version mismatch: library %d, binding 1" % handle.mi_abi_version())
+        if handle.mi_abi_version() != ABI_VERSION:
+            raise MiOpsError("ABI version mismatch: library %d, binding %d -- rebuild with "
+                             "`python -m detectron_pytorch_amd.build --force`" % (handle.mi_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -261,6 +261,11 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
     return mi::check_launch("roi_align_legacy_fwd");
   }
   const int cap = ring_words();
+  // NCHW: the tile-centric kernel -- one launch, no scratch, no records (roi_align_fwd_tiles.hip)
+  if (layout == MI_LAYOUT_NCHW && !force_direct() && !mi::tuning().use_records &&
+      mi::roi_align_fwd_tiles_supported(channels, height, width, aligned_height, aligned_width))
+    return mi::launch_roi_align_fwd_tiles(features, rois, output, batch, channels, height, width, num_rois,
+                                          aligned_height, aligned_width, spatial_scale, sampling_ratio, s);
   if (workspace != nullptr) {
     MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
@@ -403,6 +408,25 @@ bool to_level_table(const mi_fpn_levels* in, int batch, bool forward, mi::LevelT
 }
 }  // namespace
 
+namespace {
+// NCHW maps go through the tile-centric forward, which leaves no records in the workspace
+bool fpn_forward_uses_tiles(const mi::LevelTable& lv, int channels, int aligned_height, int aligned_width, int layout) {
+  if (layout != MI_LAYOUT_NCHW || force_direct() || mi::tuning().use_records) return false;
+  for (int l = 0; l < lv.count; l++)
+    if (!mi::roi_align_fwd_tiles_supported(channels, lv.height[l], lv.width[l], aligned_height, aligned_width))
+      return false;
+  return true;
+}
+}  // namespace
+
+extern "C" int mi_roi_align_forward_fpn_writes_records(const mi_fpn_levels* levels, int channels, int num_rois,
+                                                       int aligned_height, int aligned_width, int layout) {
+  mi::LevelTable lv;
+  if (!to_level_table(levels, 1, true, &lv)) return 0;
+  if (mi_roi_align_fpn_supported(levels, channels, num_rois, aligned_height, aligned_width, layout) != 1) return 0;
+  return fpn_forward_uses_tiles(lv, channels, aligned_height, aligned_width, layout) ? 0 : 1;
+}
+
 extern "C" int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
                                           int aligned_width, int layout) {
   if (levels == nullptr || levels->num_levels < 1 || levels->num_levels > mi::kMaxLevels || force_direct() ||
@@ -438,6 +462,9 @@ extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float
              mi::roi_align_records_workspace_bytes(num_rois));
   MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align_fpn: workspace must be 16-byte aligned");
   const int cap = ring_words();
+  if (fpn_forward_uses_tiles(lv, channels, aligned_height, aligned_width, layout))
+    return mi::launch_roi_align_fwd_tiles_levels(lv, rois, roi_levels, output, batch, channels, num_rois,
+                                                 aligned_height, aligned_width, sampling_ratio, mi::as_stream(stream));
   if (layout == MI_LAYOUT_NHWC) {
     int rc = mi::launch_roi_align_prepare_levels(lv, rois, roi_levels, workspace, batch, num_rois, aligned_height,
                                                  aligned_width, sampling_ratio, mi::as_stream(stream));
@@ -486,6 +513,9 @@ extern "C" int mi_roi_align_forward_writes_records(int channels, int height, int
                                                    int aligned_height, int aligned_width, int variant, int layout) {
   if (variant != MI_ROI_ALIGN_CAFFE2 || force_direct() || no_ws() || num_rois <= 0)
     return 0;
+  if (layout == MI_LAYOUT_NCHW && !mi::tuning().use_records &&
+      mi::roi_align_fwd_tiles_supported(channels, height, width, aligned_height, aligned_width))
+    return 0;  // the tile-centric forward needs no records; the backward writes its own
   if (layout == MI_LAYOUT_NCHW)
     return mi::roi_align_fwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width) ? 1 : 0;
   if (layout == MI_LAYOUT_NHWC)

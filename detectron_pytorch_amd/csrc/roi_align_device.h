@@ -111,6 +111,14 @@ int launch_roi_align_fwd_tile(const float* features, const float* rois, float* o
                               int height, int width, int num_rois, int aligned_height, int aligned_width,
                               float spatial_scale, int sampling_ratio, int ring_words, hipStream_t stream);
 void roi_align_fwd_tile_set_timeline(long long* device_buffer);
+// tile-centric forward, one launch, no scratch (roi_align_fwd_tiles.hip)
+bool roi_align_fwd_tiles_supported(int channels, int height, int width, int aligned_height, int aligned_width);
+int launch_roi_align_fwd_tiles(const float* features, const float* rois, float* output, int batch, int channels,
+                               int height, int width, int num_rois, int aligned_height, int aligned_width,
+                               float spatial_scale, int sampling_ratio, hipStream_t stream);
+int launch_roi_align_fwd_tiles_levels(LevelTable lv, const float* rois, const int* levels, float* output, int batch,
+                                      int channels, int num_rois, int aligned_height, int aligned_width,
+                                      int sampling_ratio, hipStream_t stream);
 // two-launch forward fast path with caller scratch (roi_align_records.hip)
 size_t roi_align_records_workspace_bytes(int num_rois);
 bool roi_align_fwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,

@@ -25,6 +25,7 @@
 // operation order, bit-exact).
 #include "common.h"
 #include "roi_align_device.h"
+#include "lds_dma.h"
 #include "roi_align_record_layout.h"
 
 #include <type_traits>
@@ -245,9 +246,6 @@ struct TabEntry {
   int lo;
 };
 
-using lds_ptr_t = __attribute__((address_space(3))) void*;
-using lds_cfloat_t = __attribute__((address_space(3))) const float*;
-using const_int_ptr = const __attribute__((address_space(4))) int*;
 
 __device__ __forceinline__ unsigned lds_addr_opaque(const void* p) {
   unsigned a = (unsigned)(uintptr_t)(lds_cfloat_t)p;
@@ -261,33 +259,6 @@ __device__ __forceinline__ void lds_pair(unsigned a, float& v0, float& v1) {
 }
 __device__ __forceinline__ const float* lds_at(const float* base, int byte_off) {
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// One LDS-DMA piece: LDS[lds_base + lane * 4] = buffer[voff + soff] for the active lanes (buffer_load_dword ... lds).
-// Issued through inline asm ON PURPOSE: hipcc orders every later LDS read of the kernel behind an LDS-DMA it can see
-// (vmcnt(0) before the first ds_read, it cannot tell which part of the LDS image a piece lands in), which would
-// serialise the prefetch of the next window with the arithmetic on the current one.  The kernel waits for its DMA
-// explicitly (s_waitcnt vmcnt(0) in front of the barrier that publishes a window); nothing reads a window before.
-using srd_t = __attribute__((ext_vector_type(4))) unsigned;
-__device__ __forceinline__ srd_t make_srd(const void* base, unsigned num_bytes) {
-  const uintptr_t b = reinterpret_cast<uintptr_t>(base);
-  srd_t r;
-  r.x = (unsigned)uniform((int)(b & 0xffffffffu));
-  r.y = (unsigned)uniform((int)(b >> 32)) & 0xffffu;  // stride 0
-  r.z = (unsigned)uniform((int)num_bytes);
-  r.w = 0x00020000u;
-  return r;
-}
-__device__ __forceinline__ void dma_dword(srd_t srd, unsigned lds_base, unsigned voff, unsigned soff) {
-  lds_base = (unsigned)uniform((int)lds_base);  // the "s" constraint alone does not move a VGPR-resident value
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-               :
-               : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff)
-               : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr_uniform(const void* p) {
-  return (unsigned)uniform((int)(unsigned)(uintptr_t)(lds_cfloat_t)p);
 }
 
 // -------------------------------------------------------------------------------------------------------------------

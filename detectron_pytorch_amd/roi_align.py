@@ -52,8 +52,9 @@ def _check_inputs(features, rois):
 
 def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_scale, sampling_ratio,
                       variant=_lib.ROI_ALIGN_CAFFE2, return_workspace=False):
-    """Raw forward (no autograd): returns a new [R, C, ah, aw] tensor (and, on request, the device scratch holding
-    the per-RoI records, which a backward over the same rois can reuse)."""
+    """Raw forward (no autograd): returns a new [R, C, ah, aw] tensor and, on request, the device scratch holding the
+    per-RoI records a backward over the same rois can reuse -- None when the forward wrote none (NCHW features: the
+    tile-centric kernel needs no scratch at all)."""
     _check_inputs(features, rois)
     features, layout = _layout_of(features)
     if variant == _lib.ROI_ALIGN_LEGACY and layout != _lib.LAYOUT_NCHW:
@@ -64,15 +65,24 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
     # every element is written by the kernel: no zero fill (the reference's .zero_() at :23 is redundant)
     output = torch.empty((r, c, aligned_height, aligned_width), dtype=features.dtype, device=features.device)
     lib = _lib.lib()
-    # device scratch of the two-launch fast path (per-RoI records); the caching allocator makes this a free-list pop
-    ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
-    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=features.device)
+    records = variant == _lib.ROI_ALIGN_CAFFE2 and bool(lib.mi_roi_align_forward_writes_records(
+        c, h, w, r, int(aligned_height), int(aligned_width), int(variant), layout))
+    workspace = None
     with torch.cuda.device(features.device):
-        rc = lib.mi_roi_align_forward_ws(
-            features.data_ptr(), rois.data_ptr(), output.data_ptr(), n, c, h, w, r,
-            int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
-            int(variant), layout, workspace.data_ptr(), ws_bytes, _lib.current_stream_handle(features.device))
-    _lib.check(rc, "mi_roi_align_forward_ws")
+        if records:
+            # device scratch of the two-launch channels-last path (per-RoI records); a free-list pop of the allocator
+            ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+            workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=features.device)
+            rc = lib.mi_roi_align_forward_ws(
+                features.data_ptr(), rois.data_ptr(), output.data_ptr(), n, c, h, w, r,
+                int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
+                int(variant), layout, workspace.data_ptr(), ws_bytes, _lib.current_stream_handle(features.device))
+        else:
+            rc = lib.mi_roi_align_forward(
+                features.data_ptr(), rois.data_ptr(), output.data_ptr(), n, c, h, w, r,
+                int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
+                int(variant), layout, _lib.current_stream_handle(features.device))
+    _lib.check(rc, "mi_roi_align_forward")
     return (output, workspace) if return_workspace else output
 
 
@@ -120,14 +130,9 @@ class _RoIAlign(Function):
         ctx.feature_size = tuple(features.shape)
         ctx.channels_last = (features.dim() == 4 and not features.is_contiguous()
                              and features.is_contiguous(memory_format=torch.channels_last))
+        # records a forward left in its scratch (channels-last features) serve the backward over the same rois
         output, workspace = roi_align_forward(features, rois, *ctx.cfg, return_workspace=True)
-        # the records the forward left in the workspace serve the backward over the same rois (both layouts run
-        # roi_align_prepare); whether they were written is the library's business: the flag is only a promise that
-        # nothing else touched the buffer
-        reuse = variant == _lib.ROI_ALIGN_CAFFE2 and _lib.lib().mi_roi_align_forward_writes_records(
-            features.size(1), features.size(2), features.size(3), rois.size(0), ctx.cfg[0], ctx.cfg[1],
-            int(variant), _lib.LAYOUT_NHWC if ctx.channels_last else _lib.LAYOUT_NCHW)
-        ctx.save_for_backward(rois, workspace if reuse else rois.new_empty(0))
+        ctx.save_for_backward(rois, workspace if workspace is not None else rois.new_empty(0))
         return output
 
     @staticmethod
@@ -200,6 +205,9 @@ class _RoIAlignFPN(Function):
                                               int(sampling_ratio), layout, workspace.data_ptr(), ws_bytes,
                                               _lib.current_stream_handle(rois.device))
         _lib.check(rc, "mi_roi_align_forward_fpn")
+        # NCHW maps: the tile-centric forward leaves no records, the backward writes its own
+        ctx.records_ready = bool(lib.mi_roi_align_forward_fpn_writes_records(
+            ctypes.byref(table), c, r, int(aligned_height), int(aligned_width), layout))
         ctx.cfg = (int(aligned_height), int(aligned_width), int(sampling_ratio), tuple(float(s) for s in scales))
         ctx.shapes = [tuple(f.shape) for f in features]
         ctx.layout = layout
@@ -221,7 +229,8 @@ class _RoIAlignFPN(Function):
             rc = lib.mi_roi_align_backward_fpn(ctypes.byref(table), grad_output.data_ptr(), rois.data_ptr(),
                                                roi_levels.data_ptr(), n, c, rois.size(0), ah, aw, sr, ctx.layout,
                                                workspace.data_ptr(), workspace.numel(),
-                                               _lib.ROI_ALIGN_RECORDS_READY | _lib.ROI_ALIGN_OVERWRITE,
+                                               (_lib.ROI_ALIGN_RECORDS_READY if ctx.records_ready else 0)
+                                               | _lib.ROI_ALIGN_OVERWRITE,
                                                _lib.current_stream_handle(grad_output.device))
         _lib.check(rc, "mi_roi_align_backward_fpn")
         return (None, None, None, None, None, None) + tuple(grads)

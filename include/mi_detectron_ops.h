@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+/* 2: round-2/3 entry points (top-k, segmented NMS, RPN collect, affine, result formats, FPN-fused RoIAlign), RoIs of a
+ * non-existent image pool zeros, tile-centric NCHW forward (no records). */
+#define MI_ABI_VERSION 2
 
 typedef void* mi_stream_t; /* hipStream_t */
 
@@ -78,9 +80,10 @@ int mi_roi_align_forward(const float* features, const float* rois, float* output
                          int aligned_height, int aligned_width, float spatial_scale,
                          int sampling_ratio, int variant, int layout, mi_stream_t stream);
 
-/* Same operation with caller-provided device scratch (the fast paths: roi_align_fwd_records on NCHW features,
- * roi_align_fwd_nhwc on channels-last ones): a first launch condenses each RoI into a record in `workspace` (window,
- * tap tables, LDS stages) at its rank along a sweep of the image, a second launch consumes the records.
+/* Same operation with caller-provided device scratch.  NCHW features are pooled by the tile-centric kernel
+ * (roi_align_fwd_tiles: one launch, the scratch is not touched -- mi_roi_align_forward_writes_records() == 0); on
+ * channels-last features (roi_align_fwd_nhwc) a first launch condenses each RoI into a record in `workspace` (tap
+ * tables) at its rank along a sweep of the image, a second launch consumes the records.
  * `workspace` must hold mi_roi_align_forward_workspace_bytes(num_rois) bytes, 16-byte aligned; its contents are
  * scratch (no initialisation needed, overwritten by every call; two calls that may run concurrently on different
  * streams need distinct workspaces).  workspace == NULL behaves exactly like mi_roi_align_forward. */
@@ -142,6 +145,11 @@ typedef struct mi_fpn_levels {
 } mi_fpn_levels;
 int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
                                int aligned_width, int layout);
+/* 1 when mi_roi_align_forward_fpn with these arguments leaves the records of its rois in the workspace (channels-last
+ * maps); 0 when it does not (NCHW maps: the tile-centric forward needs none) -- the backward must then be called
+ * without MI_ROI_ALIGN_RECORDS_READY and writes its own. */
+int mi_roi_align_forward_fpn_writes_records(const mi_fpn_levels* levels, int channels, int num_rois,
+                                            int aligned_height, int aligned_width, int layout);
 int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels, float* output,
                              int batch, int channels, int num_rois, int aligned_height, int aligned_width,
                              int sampling_ratio, int layout, void* workspace, size_t workspace_bytes,

@@ -37,7 +37,7 @@ def test_library_loads_and_binding_matches_header(hip_lib_path):
     from detectron_pytorch_amd import _lib
 
     handle = _lib.lib()
-    assert handle.mi_abi_version() == 1
+    assert handle.mi_abi_version() == _lib.ABI_VERSION
     assert set(_lib.SIGNATURES) == set(declared_symbols())
     assert handle.mi_nms_workspace_bytes(0) >= 16
     # workspace grows with n * ceil(n/64) mask words

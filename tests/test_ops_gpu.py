@@ -69,18 +69,25 @@ def tuning_env(monkeypatch):
     _lib.lib().mi_dbg_reload_tuning()
 
 
-@pytest.fixture(params=["stream", "direct"])
+@pytest.fixture(params=["stream", "records", "direct"])
 def roi_align_impl(request, tuning_env):
-    """Run a test against both RoIAlign implementations behind mi_roi_align_*: the record-driven fast paths (default)
-    and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
-    tuning_env(MI_ROI_ALIGN_IMPL="direct" if request.param == "direct" else None)
+    """Run a test against the RoIAlign implementations behind mi_roi_align_*: the default fast paths ("stream": the
+    tile-centric NCHW forward, the record-driven channels-last forward and backward), the per-RoI record forward
+    (MI_ROI_ALIGN_IMPL=records) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
+    tuning_env(MI_ROI_ALIGN_IMPL=None if request.param == "stream" else request.param)
     return request.param
+
+
+def _fwd_is_exact(impl, channels):
+    """The direct kernels keep the reference's operation order; the fast paths (FMA, separable) decline channel counts
+    that are no multiple of their channel tile and fall back to them."""
+    return impl == "direct" or channels % (16 if impl == "stream" else 32) != 0
 
 
 def test_extension_is_loaded_not_a_fallback(hip_lib_path):
     from detectron_pytorch_amd import _lib
 
-    assert _lib.lib().mi_abi_version() == 1
+    assert _lib.lib().mi_abi_version() == _lib.ABI_VERSION
     maps = open("/proc/self/maps").read()
     assert "libmi_detectron_ops.so" in maps
 
@@ -123,7 +130,7 @@ def test_roi_align_vs_oracle_adversarial_rois(oracle_mod, roi_align_impl, shape,
     gtop = np.random.RandomState(7).randn(nrois, c, res, res).astype(np.float32)
     out, grad = _roi_align_gpu(feat, rois, res, scale, sr, gtop)
     ref_out = oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=8)
-    assert_fwd(out, ref_out, "fwd", exact=(roi_align_impl == "direct" or c % 32 != 0))
+    assert_fwd(out, ref_out, "fwd", exact=_fwd_is_exact(roi_align_impl, c))
     assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, sr, threads=8), "bwd")
 
 

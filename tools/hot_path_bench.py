@@ -142,13 +142,15 @@ def roofline_roi_align_forward(device, iters):
         assert rc == 0
 
     seconds = time_kernel(launch, iters)
+    ready_fwd = bool(lib.mi_roi_align_forward_writes_records(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, layout))
     touched = touched_pixels(rois_np, 1, h, w, res, res, scale, sr)
     alg_bytes = 4 * r * c * res * res + 4 * c * touched + 20 * r
     achieved = alg_bytes / seconds / 1e9
     traffic, traffic_src = pmc_traffic("forward")
     info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
+            "kernel": ("roi_align_prepare + roi_align_fwd_records" if ready_fwd else "roi_align_fwd_tiles")
+            + " (one mi_roi_align_forward_ws call)",
             "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
             "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
     # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
@@ -156,9 +158,11 @@ def roofline_roi_align_forward(device, iters):
     gin = torch.zeros(1, c, h, w, device=device)
 
     overwrite = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
-    bwd_flags = _lib.ROI_ALIGN_RECORDS_READY | (_lib.ROI_ALIGN_OVERWRITE if overwrite else 0)
+    # the NCHW forward (tile-centric) leaves no records: the backward call then includes its own records launch
+    ready = bool(lib.mi_roi_align_forward_writes_records(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, layout))
+    bwd_flags = (_lib.ROI_ALIGN_RECORDS_READY if ready else 0) | (_lib.ROI_ALIGN_OVERWRITE if overwrite else 0)
 
-    def launch_bwd():  # records of the forward above are still in `ws`; zero fill only where the path accumulates
+    def launch_bwd():  # zero fill only where the path accumulates
         if not overwrite:
             gin.zero_()
         rc = lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
@@ -264,7 +268,8 @@ def other_shapes(device, lib, stream, iters):
         ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         over = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
-        flags = _lib.ROI_ALIGN_RECORDS_READY | (_lib.ROI_ALIGN_OVERWRITE if over else 0)
+        ready = bool(lib.mi_roi_align_forward_writes_records(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
+        flags = (_lib.ROI_ALIGN_RECORDS_READY if ready else 0) | (_lib.ROI_ALIGN_OVERWRITE if over else 0)
 
         def fwd():
             assert lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), o.data_ptr(), n, c, h, w, r, res, res, scale,
