@@ -33,6 +33,7 @@ __device__ __forceinline__ srd_t make_srd(const void* base, unsigned num_bytes) 
 // (s_waitcnt vmcnt(0) in front of the barrier that publishes an image); nothing reads an image before.
 __device__ __forceinline__ void dma_dword(srd_t srd, unsigned lds_base, unsigned voff, unsigned soff) {
   lds_base = (unsigned)uniform((int)lds_base);  // the "s" constraint alone does not move a VGPR-resident value
+  soff = (unsigned)uniform((int)soff);
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds"
                :
                : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff)

@@ -238,6 +238,7 @@ int check_common(const void* a, const void* rois, const void* b, int batch, int 
 // (tools/timeline.py); nullptr switches the stamps off.
 extern "C" void mi_dbg_roi_align_timeline(long long* device_buffer) {
   mi::roi_align_fwd_tile_set_timeline(device_buffer);
+  mi::roi_align_fwd_tiles_set_timeline(device_buffer);
   mi::roi_align_fwd_nhwc_set_timeline(device_buffer);
 }
 

@@ -112,6 +112,7 @@ int launch_roi_align_fwd_tile(const float* features, const float* rois, float* o
                               float spatial_scale, int sampling_ratio, int ring_words, hipStream_t stream);
 void roi_align_fwd_tile_set_timeline(long long* device_buffer);
 // tile-centric forward, one launch, no scratch (roi_align_fwd_tiles.hip)
+void roi_align_fwd_tiles_set_timeline(long long* device_buffer);
 bool roi_align_fwd_tiles_supported(int channels, int height, int width, int aligned_height, int aligned_width);
 int launch_roi_align_fwd_tiles(const float* features, const float* rois, float* output, int batch, int channels,
                                int height, int width, int num_rois, int aligned_height, int aligned_width,
