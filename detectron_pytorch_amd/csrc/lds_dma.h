@@ -40,6 +40,17 @@ __device__ __forceinline__ void dma_dword(srd_t srd, unsigned lds_base, unsigned
                : "memory");
 }
 
+// The 16-byte form: LDS[lds_base + lane * 16 .. + 15] = buffer[voff + soff .. + 15].  The LDS side needs no more than
+// dword alignment (LDS-DMA writes are not subject to the alignment replay of ds_write_b128).
+__device__ __forceinline__ void dma_dwordx4(srd_t srd, unsigned lds_base, unsigned voff, unsigned soff) {
+  lds_base = (unsigned)uniform((int)lds_base);
+  soff = (unsigned)uniform((int)soff);
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff)
+               : "memory");
+}
+
 __device__ __forceinline__ unsigned lds_addr_uniform(const void* p) {
   return (unsigned)uniform((int)(unsigned)(uintptr_t)(lds_cfloat_t)p);
 }

@@ -61,13 +61,9 @@ struct TabEnt {  // one axis sample: LDS byte offset of its lower tap (clamped i
   float hw, lw;
   int lo_rel;
 };
-struct Ent {  // one scan survivor
-  float start[2], bin[2];
-  int g[2], pa[2], pb[2];
-  int r, flags, unit_base, nunits, slow, pad;
-};
-struct Unit {  // one (RoI, bin row)
-  int e, ph, r, pw;  // pw = pwa | pwb << 8
+struct AxEnt {  // one scan survivor, one axis (32 bytes)
+  float start, bin;
+  int g, flags, pa, pb, r, pad;
 };
 enum : int { kEntNotFast = 1, kEntZero = 2 };
 
@@ -78,15 +74,12 @@ struct TileCfg {
   static constexpr int kPlane = kPx | 1;  // odd: 32 planes -> 32 banks
   static constexpr int kPieces = (kPx + 63) / 64;
   static constexpr int S = (kA > 0 && kSR > 0) ? kA * kSR : kMaxSamples;  // table entries per axis and RoI
-  static constexpr int EB = S <= 16 ? 16 : 8;                            // RoIs per batch
-  static constexpr int PB = kA > 0 ? kA : kMaxSamples;                    // bins per axis the lane mappings provide for
-  static constexpr int kMaxUnits = EB * PB;
+  static constexpr int EB = 16;                                           // RoIs per batch (the prefix lives in 16 lanes)
+  static constexpr int PB = kA > 0 ? kA : kMaxSamples;                    // bins per axis
   static constexpr size_t kImgBytes = (size_t)kCt * kPlane * 4;
-  static constexpr size_t kTabBytes = (size_t)EB * S * 2 * sizeof(TabEnt);
-  static constexpr size_t kLdsBytes =
-      kImgBytes + kTabBytes + kCandCap * sizeof(Cand) + EB * sizeof(Ent) + kMaxUnits * sizeof(Unit) + 64 * 4;
+  static constexpr size_t kTabBytes = (size_t)2 * EB * S * sizeof(TabEnt);
+  static constexpr size_t kLdsBytes = kImgBytes + kTabBytes + 2 * kCandCap * sizeof(Cand) + 2 * EB * sizeof(AxEnt) + 64 * 4;
   static_assert(kPitch + 1 < 256, "ds_read2_b32 offsets");
-  static_assert(EB * 2 * S <= kThreads && EB * 2 * PB <= kThreads && EB * PB <= kThreads, "one pass per phase");
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -104,13 +97,24 @@ __device__ __forceinline__ v2f lds_rows(unsigned byte_addr) {
   return r;
 }
 __device__ __forceinline__ v2f splat(float w) { return (v2f){w, w}; }
+// LDS traffic of ONE wavefront is processed in order: between two phases of a wave that communicate through LDS only the
+// compiler has to be kept from reordering them
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // kSR > 0 and kA > 0: sampling_ratio == kSR, aligned_height == aligned_width == kA at compile time.
+//
+// Roles: wave 0 builds everything that depends on the y axis, wave 1 everything that depends on the x axis (each scans
+// the RoIs itself: no cross-wave communication before the one barrier), waves 2-7 issue the image DMA.
 template <int kSR, int kA, int TH, int TW>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))  // two workgroups per CU
 roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const int* __restrict__ levels,
                     float* __restrict__ out, int num_rois, int batch, int channels, int ah_arg, int aw_arg,
-                    int sr_arg, int ntiles, long long* __restrict__ timeline) {
+                    int sr_arg, int ntiles, long long* __restrict__ timeline, int ablate_arg) {
+  const int ablate = MI_ABLATE(ablate_arg);  // tuning builds only: 1 no image DMA, 2 no tap reads / arithmetic, 4 no stores
   // tuning aid (tools/timeline_tiles.py): clock stamps of lane 0 of every workgroup, null in normal operation
   const auto stamp = [&](int k) {
     if (timeline != nullptr && threadIdx.x == 0) timeline[(long long)blockIdx.x * 8 + k] = (long long)clock64();
@@ -122,12 +126,10 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
   const int sr = kSR > 0 ? kSR : sr_arg;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* img = reinterpret_cast<float*>(smem);
-  TabEnt* ytab = reinterpret_cast<TabEnt*>(smem + Cfg::kImgBytes);  // [EB][S]
-  TabEnt* xtab = ytab + EB * S;                                     // [EB][S]
-  Cand* cand = reinterpret_cast<Cand*>(xtab + EB * S);
-  Ent* ents = reinterpret_cast<Ent*>(cand + kCandCap);
-  Unit* units = reinterpret_cast<Unit*>(ents + EB);
-  int* misc = reinterpret_cast<int*>(units + Cfg::kMaxUnits);  // [0..7] wave counts, [8] units of the batch
+  TabEnt* tabs = reinterpret_cast<TabEnt*>(smem + Cfg::kImgBytes);  // [axis][EB][S]
+  Cand* cands = reinterpret_cast<Cand*>(tabs + 2 * EB * S);         // [axis][kCandCap]: each axis wave keeps its own copy
+  AxEnt* axes = reinterpret_cast<AxEnt*>(cands + 2 * kCandCap);     // [axis][EB]
+  int* misc = reinterpret_cast<int*>(axes + 2 * EB);                // [0] RoIs of the batch, [1] more batches follow
 
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   // ---- this workgroup's tile ----
@@ -151,50 +153,6 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
   const int bins = ah * aw;
   const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
 
-  // ---- the RoIs this lane will test first: fetched in front of the DMA ----
-  float pre[kPreload][5];
-  int prel[kPreload];
-#pragma unroll
-  for (int k = 0; k < kPreload; k++) {
-    const int i = tid + k * kThreads;
-    prel[k] = 0;
-#pragma unroll
-    for (int j = 0; j < 5; j++) pre[k][j] = 0.f;
-    if (i < num_rois) {
-#pragma unroll
-      for (int j = 0; j < 5; j++) pre[k][j] = rois[(long long)i * 5 + j];
-      if (levels != nullptr) prel[k] = levels[i];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < kPreload; k++) {  // the values must have arrived before the DMA is issued (in-order vmcnt)
-#pragma unroll
-    for (int j = 0; j < 5; j++) asm volatile("" ::"v"(pre[k][j]));
-    asm volatile("" ::"v"(prel[k]));
-  }
-  stamp(1);
-
-  // ---- tile image: [channel][row][kPitch] by LDS-DMA, lanes flattened over (row, column), clamped to the map ----
-  {
-    const float* slab = feat + ((long long)n * channels + c0) * height * width;
-    const srd_t srd = make_srd(slab, (unsigned)kCt * plane_bytes);  // the range check includes the scalar offset
-    const unsigned img_lds = lds_addr_uniform(img);
-    for (int k = wave; k < Cfg::kPieces; k += kNWaves) {
-      const int p = k * 64 + lane;
-      const int row = p / kPitch, col = p - row * kPitch;
-      const unsigned voff = (unsigned)(min(y0 + row, height - 1) * width + min(x0 + col, width - 1)) * 4u;
-      if (p < Cfg::kPx) {
-#pragma unroll
-        for (int c = 0; c < kCt; c++)
-          dma_dword(srd, img_lds + (unsigned)(c * kPlane + k * 64) * 4u, voff, (unsigned)c * plane_bytes);
-      }
-    }
-  }
-  stamp(2);
-
-  const int grp = tid >> 5, cl = tid & 31;
-  const unsigned img_c = (unsigned)(uintptr_t)(lds_cfloat_t)(img + cl * kPlane);  // LDS byte address of this lane's plane
-
   // one RoI against this tile, multiplications and compares only: true for every RoI that has a bin here or that this
   // tile owns (a superset; the tables decide).  A bin's anchor is the lower tap of its first sample, whose coordinate
   // lies in [start, start + length]; taps are clamped to the map.
@@ -212,202 +170,365 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
     return ya < tile_y_hi && yb >= tile_y_lo && xa < tile_x_hi && xb >= tile_x_lo;
   };
 
-  // ---- scan: survivors with ordinal in [win_lo, win_lo + kCandCap) go to LDS (ordinals follow the RoI index);
-  // returns the number of survivors of the tile ----
-  // (first: the RoIs fetched in front of the DMA are used; later passes -- tiles with more than kCandCap survivors --
-  // read them again, so that the registers are free while the units run)
-  const auto scan = [&](int win_lo, auto first_pass) -> int {
-    constexpr bool kFirst = decltype(first_pass)::value;
-    int total = 0;
-    for (int base = 0; base < num_rois; base += kThreads) {
-      const int i = base + tid;
-      float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f;
-      int rl = 0;
-      if (kFirst && base == 0) {
-        r0 = pre[0][0], r1 = pre[0][1], r2 = pre[0][2], r3 = pre[0][3], r4 = pre[0][4], rl = prel[0];
-      } else if (kFirst && kPreload > 1 && base == kThreads) {
-        r0 = pre[kPreload - 1][0], r1 = pre[kPreload - 1][1], r2 = pre[kPreload - 1][2], r3 = pre[kPreload - 1][3],
-        r4 = pre[kPreload - 1][4], rl = prel[kPreload - 1];
-      } else if (i < num_rois) {
-        const float* q = rois + (long long)i * 5;
-        r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
-        if (levels != nullptr) rl = levels[i];
-      }
-      const bool hit = i < num_rois && test(i, r0, r1, r2, r3, r4, rl);
-      const unsigned long long m = __ballot(hit);
-      if (lane == 0) misc[wave] = __popcll(m);
-      __syncthreads();
-      int off = total, all = 0;
+  const int axis = wave;  // meaningful in waves 0 (y) and 1 (x)
+  Cand* mycand = cands + (wave & 1) * kCandCap;
+  AxEnt* myax = axes + (wave & 1) * EB;
+  TabEnt* mytab = tabs + (wave & 1) * EB * S;
+
+  // ---- scan (one wave): survivors with ordinal in [win_lo, win_lo + kCandCap) go to LDS (ordinals follow the RoI
+  // index); returns the number of survivors of the tile.  Eight RoIs per lane are fetched together. ----
+  const auto scan = [&](int win_lo) -> int {
+    int count = 0;
+    constexpr int kPer = 8;
+    for (int base = 0; base < num_rois; base += 64 * kPer) {
+      float rv[kPer][5];
+      int rl[kPer];
 #pragma unroll
-      for (int w = 0; w < kNWaves; w++) {
-        const int cnt = misc[w];
-        off += w < wave ? cnt : 0;
-        all += cnt;
+      for (int k = 0; k < kPer; k++) {
+        const int i = base + k * 64 + lane;
+        rl[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) rv[k][j] = 0.f;
+        if (i < num_rois) {
+#pragma unroll
+          for (int j = 0; j < 5; j++) rv[k][j] = rois[(long long)i * 5 + j];
+          if (levels != nullptr) rl[k] = levels[i];
+        }
       }
-      const int ord = off + __popcll(m & ((1ull << lane) - 1ull)) - win_lo;
-      if (hit && ord >= 0 && ord < kCandCap) {
-        Cand cr;
-        cr.b = r0, cr.x1 = r1, cr.y1 = r2, cr.x2 = r3, cr.y2 = r4, cr.id = i, cr.pad0 = 0, cr.pad1 = 0;
-        cand[ord] = cr;
+#pragma unroll
+      for (int k = 0; k < kPer; k++) {
+        const int i = base + k * 64 + lane;
+        const bool hit = i < num_rois && test(i, rv[k][0], rv[k][1], rv[k][2], rv[k][3], rv[k][4], rl[k]);
+        const unsigned long long m = __ballot(hit);
+        const int ord = count + __popcll(m & ((1ull << lane) - 1ull)) - win_lo;
+        if (hit && ord >= 0 && ord < kCandCap) {
+          Cand cr;
+          cr.b = rv[k][0], cr.x1 = rv[k][1], cr.y1 = rv[k][2], cr.x2 = rv[k][3], cr.y2 = rv[k][4], cr.id = i, cr.pad0 = 0,
+          cr.pad1 = 0;
+          mycand[ord] = cr;
+        }
+        count += __popcll(m);
       }
-      total += all;
-      __syncthreads();
     }
-    return total;
+    return count;
   };
-  int total = scan(0, std::true_type());
-  stamp(3);
-  if (timeline != nullptr && tid == 0) timeline[(long long)blockIdx.x * 8 + 7] = total;
 
-  bool image_ready = false;
-  for (int win_lo = 0;; win_lo += kCandCap) {
-    if (win_lo > 0) total = scan(win_lo, std::false_type());
-    const int ncand = min(total - win_lo, kCandCap);
-
-    for (int b0 = 0; b0 < ncand; b0 += EB) {
-      const int ne = min(EB, ncand - b0);
-      // ---- geometry: one lane per RoI (roi_align_kernel.cu:76-98) ----
-      if (tid < ne) {
-        const Cand cr = cand[b0 + tid];
+  // ---- one batch of <= EB survivors, one axis (one wave) ----
+  const auto build = [&](int b0, int ne) {
+    const int aligned = axis == 0 ? ah : aw, size = axis == 0 ? height : width, origin = axis == 0 ? y0 : x0;
+    if constexpr (kSR == 2 && kA > 0) {
+      // compile-time 2 x 2 grid: one pass.  lane = (RoI, sample); the two samples of a bin sit in neighbouring lanes, so
+      // the footprint of a bin and its tile come from a lane exchange instead of a second pass over LDS.
+      if (lane < ne) {
+        const Cand cr = mycand[b0 + lane];
         const int b = (int)cr.b;
-        Ent en;
-        en.start[0] = cr.y1 * spatial_scale;
-        en.start[1] = cr.x1 * spatial_scale;
-        const float len_h = fmaxf(cr.y2 * spatial_scale - en.start[0], 1.f);
-        const float len_w = fmaxf(cr.x2 * spatial_scale - en.start[1], 1.f);
-        en.bin[0] = len_h / (float)ah;
-        en.bin[1] = len_w / (float)aw;
-        en.g[0] = sr > 0 ? sr : (int)ceilf(len_h / (float)ah);
-        en.g[1] = sr > 0 ? sr : (int)ceilf(len_w / (float)aw);
-        en.pa[0] = en.pa[1] = 0x7fff;
-        en.pb[0] = en.pb[1] = 0;
-        en.r = cr.id;
+        AxEnt en;
+        en.start = en.bin = 0.f;
+        en.g = 2;
         en.flags = (b < 0 || b >= batch) ? kEntZero : 0;
-        // sampling grids the tables cannot hold (only possible with an adaptive grid) make the RoI a slow one
-        if (!(en.g[0] >= 1 && en.g[0] <= S && ah * en.g[0] <= S && en.g[1] >= 1 && en.g[1] <= S && aw * en.g[1] <= S))
-          en.flags |= kEntNotFast;
-        en.unit_base = en.nunits = en.slow = en.pad = 0;
-        ents[tid] = en;
+        en.pa = 0x7fff;
+        en.pb = 0;
+        en.r = cr.id;
+        en.pad = 0;
+        myax[lane] = en;
       }
-      __syncthreads();
-      // ---- tables: lane = (RoI, axis, sample); axis 0 = y ----
-      {
-        const int e = tid / (2 * S), rem = tid - e * (2 * S);
-        const int axis = rem / S, s = rem - axis * S;
-        if (e < ne) {
-          const Ent& en = ents[e];
-          const int g = en.g[axis], aligned = axis == 0 ? ah : aw, size = axis == 0 ? height : width;
-          const bool g_ok = !(en.flags & kEntNotFast);
-          const int gs = g_ok ? g : 1;          // a slow RoI still gets its first entry: the owner test reads it
-          const int ns = g_ok ? aligned * g : 1;
-          if (s < ns) {
-            const int p = s / gs, i = s - p * gs;
-            // roi_align_kernel.cu:106-110
-            float v = en.start[axis] + (float)p * en.bin[axis] + ((float)i + .5f) * en.bin[axis] / (float)g;
-            if (v < -1.0f || v > (float)size) atomicOr(&ents[e].flags, (int)kEntNotFast);
-            // roi_align_kernel.cu:27-52
-            if (v <= 0) v = 0;
-            int lo = (int)v;
-            float lw, hw;
-            if (lo >= size - 1) {
-              lo = size - 1;  // the reference's upper tap is the same pixel; here it is the copy one row / column on
-              lw = 0.f;
-              hw = 1.f;
-            } else {
-              lw = v - (float)lo;
-              hw = 1.f - lw;
-            }
-            // the entries of bins that belong to other tiles are never used for a result: their offset is clamped into
-            // the image so that the units can compute whole rows with fixed indices
-            TabEnt t;
-            if (axis == 0) {
-              const float count = (float)en.g[0] * (float)en.g[1];
-              t.lo_rel = lo - y0;
-              t.off = min(max(t.lo_rel, 0), Cfg::kRows - 2) * kPitch * 4;
-              t.hw = hw / count;
-              t.lw = lw / count;
-              ytab[e * S + s] = t;
-            } else {
-              t.lo_rel = lo - x0;
-              t.off = min(max(t.lo_rel, 0), kPitch - 2) * 4;
-              t.hw = hw;
-              t.lw = lw;
-              xtab[e * S + s] = t;
-            }
+      wave_sync();
+      for (int t = lane; t < ne * S; t += 64) {
+        const int e = t / S, s = t - e * S;
+        const Cand cr = mycand[b0 + e];
+        const float lo_c = axis == 0 ? cr.y1 : cr.x1, hi_c = axis == 0 ? cr.y2 : cr.x2;
+        // roi_align_kernel.cu:79-88, 106-110
+        const float start = lo_c * spatial_scale;
+        const float len = fmaxf(hi_c * spatial_scale - start, 1.f);
+        const float bin = len / (float)kA;
+        const int p = s >> 1, i = s & 1;
+        float v = start + (float)p * bin + ((float)i + .5f) * bin / 2.f;
+        int flag = (v < -1.0f || v > (float)size) ? (int)kEntNotFast : 0;
+        // roi_align_kernel.cu:27-52
+        if (v <= 0) v = 0;
+        int lo = (int)v;
+        float lw, hw;
+        if (lo >= size - 1) {
+          lo = size - 1;  // the reference's upper tap is the same pixel; here it is the copy one row / column on
+          lw = 0.f;
+          hw = 1.f;
+        } else {
+          lw = v - (float)lo;
+          hw = 1.f - lw;
+        }
+        TabEnt te;
+        te.lo_rel = lo - origin;
+        if (axis == 0) {
+          te.off = min(max(te.lo_rel, 0), Cfg::kRows - 2) * kPitch * 4;
+          te.hw = hw / 4.f;  // count = 2 * 2 (roi_align_kernel.cu:101)
+          te.lw = lw / 4.f;
+        } else {
+          te.off = min(max(te.lo_rel, 0), kPitch - 2) * 4;
+          te.hw = hw;
+          te.lw = lw;
+        }
+        mytab[e * S + s] = te;
+        const int other = __shfl_xor(te.lo_rel, 1);  // the bin's second sample (S and 64 are even: same pass)
+        if (i == 0) {
+          if (other + 1 - te.lo_rel > kHalo) flag |= kEntNotFast;
+          if (te.lo_rel >= 0 && te.lo_rel < (axis == 0 ? TH : TW)) {
+            atomicMin(&myax[e].pa, p);
+            atomicMax(&myax[e].pb, p + 1);
           }
         }
+        if (flag) atomicOr(&myax[e].flags, flag);
       }
-      __syncthreads();
-      // ---- bins: lane = (RoI, axis, bin): footprint within the halo?  which bins belong to this tile? ----
-      {
-        const int e = tid / (2 * PB), rem = tid - e * (2 * PB);
-        const int axis = rem / PB, p = rem - axis * PB;
-        if (e < ne && p < (axis == 0 ? ah : aw) && !(ents[e].flags & kEntNotFast)) {
-          const int g = ents[e].g[axis];
-          const TabEnt* tab = axis == 0 ? ytab : xtab;
-          const int lo_rel = tab[e * S + p * g].lo_rel, hi_rel = tab[e * S + p * g + g - 1].lo_rel + 1;
-          if (hi_rel - lo_rel > kHalo) atomicOr(&ents[e].flags, (int)kEntNotFast);
-          if (lo_rel >= 0 && lo_rel < (axis == 0 ? TH : TW)) {
-            atomicMin(&ents[e].pa[axis], p);
-            atomicMax(&ents[e].pb[axis], p + 1);
-          }
+      if (b0 == 0) stamp(2);
+      return;
+    }
+    // geometry: one lane per RoI (roi_align_kernel.cu:76-98)
+    float count_f = 1.f;
+    if (lane < ne) {
+      const Cand cr = mycand[b0 + lane];
+      const int b = (int)cr.b;
+      const float lo_c = axis == 0 ? cr.y1 : cr.x1, hi_c = axis == 0 ? cr.y2 : cr.x2;
+      const float lo_o = axis == 0 ? cr.x1 : cr.y1, hi_o = axis == 0 ? cr.x2 : cr.y2;
+      AxEnt en;
+      en.start = lo_c * spatial_scale;
+      const float len = fmaxf(hi_c * spatial_scale - en.start, 1.f);
+      en.bin = len / (float)aligned;
+      en.g = sr > 0 ? sr : (int)ceilf(len / (float)aligned);
+      const float start_o = lo_o * spatial_scale;
+      const float len_o = fmaxf(hi_o * spatial_scale - start_o, 1.f);
+      const int aligned_o = axis == 0 ? aw : ah;
+      const int g_o = sr > 0 ? sr : (int)ceilf(len_o / (float)aligned_o);
+      en.flags = (b < 0 || b >= batch) ? kEntZero : 0;
+      // sampling grids the tables cannot hold (only possible with an adaptive grid) make the RoI a slow one
+      if (!(en.g >= 1 && en.g <= S && aligned * en.g <= S)) en.flags |= kEntNotFast;
+      en.pa = 0x7fff;
+      en.pb = 0;
+      en.r = cr.id;
+      en.pad = __float_as_int((float)en.g * (float)g_o);  // count (roi_align_kernel.cu:101)
+      myax[lane] = en;
+    }
+    wave_sync();
+    // tables: lane = (RoI, sample)
+    for (int t = lane; t < ne * S; t += 64) {
+      const int e = t / S, s = t - e * S;
+      const AxEnt en = myax[e];
+      const bool g_ok = !(en.flags & kEntNotFast);
+      const int gs = g_ok ? en.g : 1;          // a slow RoI still gets its first entry: the owner test reads it
+      const int ns = g_ok ? aligned * en.g : 1;
+      if (s < ns) {
+        const int p = s / gs, i = s - p * gs;
+        // roi_align_kernel.cu:106-110
+        float v = en.start + (float)p * en.bin + ((float)i + .5f) * en.bin / (float)en.g;
+        if (v < -1.0f || v > (float)size) atomicOr(&myax[e].flags, (int)kEntNotFast);
+        // roi_align_kernel.cu:27-52
+        if (v <= 0) v = 0;
+        int lo = (int)v;
+        float lw, hw;
+        if (lo >= size - 1) {
+          lo = size - 1;  // the reference's upper tap is the same pixel; here it is the copy one row / column on
+          lw = 0.f;
+          hw = 1.f;
+        } else {
+          lw = v - (float)lo;
+          hw = 1.f - lw;
+        }
+        // the entries of bins that belong to other tiles are never used for a result: their offset is clamped into the
+        // image so that the units can compute whole rows with fixed indices
+        TabEnt te;
+        te.lo_rel = lo - origin;
+        if (axis == 0) {
+          const float count = __int_as_float(en.pad);
+          te.off = min(max(te.lo_rel, 0), Cfg::kRows - 2) * kPitch * 4;
+          te.hw = hw / count;
+          te.lw = lw / count;
+        } else {
+          te.off = min(max(te.lo_rel, 0), kPitch - 2) * 4;
+          te.hw = hw;
+          te.lw = lw;
+        }
+        mytab[e * S + s] = te;
+      }
+    }
+    wave_sync();
+    if (b0 == 0) stamp(2);
+    // bins: lane = (RoI, bin): footprint within the halo?  which bins belong to this tile?
+    for (int t = lane; t < ne * PB; t += 64) {
+      const int e = t / PB, p = t - e * PB;
+      const AxEnt en = myax[e];
+      if (p < aligned && !(en.flags & kEntNotFast)) {
+        const int lo_rel = mytab[e * S + p * en.g].lo_rel, hi_rel = mytab[e * S + p * en.g + en.g - 1].lo_rel + 1;
+        if (hi_rel - lo_rel > kHalo) atomicOr(&myax[e].flags, (int)kEntNotFast);
+        if (lo_rel >= 0 && lo_rel < (axis == 0 ? TH : TW)) {
+          atomicMin(&myax[e].pa, p);
+          atomicMax(&myax[e].pb, p + 1);
         }
       }
-      __syncthreads();
-      // ---- units per RoI, prefix ----
-      if (tid < 64) {
-        int nun = 0;
-        if (tid < ne) {
-          const Ent& en = ents[tid];
-          if (!(en.flags & (kEntNotFast | kEntZero))) {
-            if (en.pb[0] > en.pa[0] && en.pb[1] > en.pa[1]) nun = en.pb[0] - en.pa[0];
-          } else if (en.flags & kEntZero) {
-            ents[tid].slow = 1;
-          } else {
-            // the tile that holds the first anchor computes the whole RoI
-            const int ly = ytab[tid * S].lo_rel, lx = xtab[tid * S].lo_rel;
-            ents[tid].slow = (ly >= 0 && ly < TH && lx >= 0 && lx < TW) ? 1 : 0;
-          }
-        }
-        int incl = nun;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int o = __shfl_up(incl, d);
-          if (lane >= d) incl += o;
-        }
-        if (tid < ne) {
-          ents[tid].nunits = nun;
-          ents[tid].unit_base = incl - nun;
-        }
-        if (tid == 63) misc[8] = incl;
-      }
-      __syncthreads();
-      {
-        // unit descriptors: lane = (RoI, row of the RoI inside this tile)
-        const int ue = tid / PB, uk = tid - ue * PB;
-        if (ue < ne) {
-          const Ent& en = ents[ue];
-          if (uk < en.nunits) {
-            Unit u;
-            u.e = ue, u.ph = en.pa[0] + uk, u.r = en.r, u.pw = en.pa[1] | (en.pb[1] << 8);
-            units[en.unit_base + uk] = u;
-          }
-        }
-      }
-      if (!image_ready) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        image_ready = true;
-      }
-      __syncthreads();
+    }
+    (void)count_f;
+  };
 
-      // ---- units: 32 lanes = 32 channels per (RoI, bin row) ----
-      const int nunits = misc[8];
-      if (win_lo == 0 && b0 == 0) stamp(4);
-      for (int u = grp; u < nunits; u += kGroups) {
-        const Unit un = units[u];
-        const int e = un.e, ph = un.ph;
-        const int pwa = un.pw & 0xff, pwb = un.pw >> 8;
-        float* __restrict__ dst = out + (((long long)un.r * channels + c0 + cl) * ah + ph) * aw;
+  const int grp = tid >> 5, cl = tid & 31;
+  const unsigned img_c = (unsigned)(uintptr_t)(lds_cfloat_t)(img + cl * kPlane);  // LDS byte address of this lane's plane
+  const TabEnt* ytab = tabs;
+  const TabEnt* xtab = tabs + EB * S;
+
+  // ---- fast scan (the two axis waves, half of the RoIs each, fetched together): survivors are appended to both axis
+  // lists through an LDS counter.  The order of the list is arbitrary; it only matters when the list overflows, and then
+  // the axis waves rescan in RoI order.
+  if (tid == 0) {
+    misc[2] = 0;  // survivors
+    misc[3] = 0;  // axis waves that have finished the scan
+  }
+  __syncthreads();
+  if (wave < 2) {
+    constexpr int kPer = 4;
+    for (int base = 0; base < num_rois; base += 128 * kPer) {
+      float rv[kPer][5];
+      int rl[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; k++) {
+        const int i = base + k * 128 + tid;
+        rl[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) rv[k][j] = 0.f;
+        if (i < num_rois) {
+#pragma unroll
+          for (int j = 0; j < 5; j++) rv[k][j] = rois[(long long)i * 5 + j];
+          if (levels != nullptr) rl[k] = levels[i];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kPer; k++) {
+        const int i = base + k * 128 + tid;
+        const bool hit = i < num_rois && test(i, rv[k][0], rv[k][1], rv[k][2], rv[k][3], rv[k][4], rl[k]);
+        const unsigned long long m = __ballot(hit);
+        if (m != 0ull) {
+          int slot = 0;
+          if (lane == 0) slot = atomicAdd(&misc[2], __popcll(m));
+          slot = __builtin_amdgcn_readfirstlane(slot) + __popcll(m & ((1ull << lane) - 1ull));
+          if (hit && slot < kCandCap) {
+            Cand cr;
+            cr.b = rv[k][0], cr.x1 = rv[k][1], cr.y1 = rv[k][2], cr.x2 = rv[k][3], cr.y2 = rv[k][4], cr.id = i, cr.pad0 = 0,
+            cr.pad1 = 0;
+            cands[slot] = cr;
+            cands[kCandCap + slot] = cr;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(&misc[3], 1);
+  }
+  stamp(1);
+
+  int win_lo = 0, b0 = 0, total = 0, ncand = 0;  // waves 0 and 1
+  for (bool first = true;; first = false) {
+    if (wave < 2) {
+      if (first) {
+        while (__atomic_load_n(&misc[3], __ATOMIC_RELAXED) < 2) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        total = __atomic_load_n(&misc[2], __ATOMIC_RELAXED);
+        if (total > kCandCap) total = scan(0);  // overflow: windows of the list in RoI order
+        ncand = min(total, kCandCap);
+      } else {
+        b0 += EB;
+        if (b0 >= ncand) {
+          win_lo += kCandCap;
+          total = scan(win_lo);
+          ncand = min(total - win_lo, kCandCap);
+          b0 = 0;
+        }
+      }
+      const int ne = min(EB, ncand - b0);
+      build(b0, ne);
+      if (tid == 0) {
+        misc[0] = ne;
+        misc[1] = (b0 + EB < ncand || win_lo + kCandCap < total) ? 1 : 0;
+        if (first && timeline != nullptr) timeline[(long long)blockIdx.x * 8 + 7] = total;
+      }
+      if (first) stamp(3);
+    } else if (first) {
+      // ---- tile image: [channel][row][kPitch] by LDS-DMA, lanes flattened over (row, column), clamped to the map:
+      // rows / columns past it repeat the last row / column ----
+      const float* slab = feat + ((long long)n * channels + c0) * height * width;
+      const srd_t srd = make_srd(slab, (unsigned)kCt * plane_bytes);  // the range check includes the scalar offset
+      const unsigned img_lds = lds_addr_uniform(img);
+      // instruction j = (piece, channel): the six DMA waves take j = wave - 2, wave + 4, ...
+      // Interior tiles of maps with 16-byte aligned rows move 16 bytes per lane (a quarter of the requests); a tile that
+      // reaches past the last column needs the per-pixel clamp of the dword form.
+      const bool vec4 = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && x0 + kPitch <= width &&
+                        (kPitch & 3) == 0 && (TW & 3) == 0;
+      if (vec4) {
+        constexpr int kCPR = kPitch / 4, kChunks = Cfg::kRows * kCPR, kP4 = (kChunks + 63) / 64;
+        for (int k = 0; k < ((ablate & 1) ? 0 : kP4); k++) {
+          const int q = k * 64 + lane;
+          const int row = q / kCPR, j = q - row * kCPR;
+          const unsigned voff = (unsigned)(min(y0 + row, height - 1) * width + x0 + 4 * j) * 4u;
+          if (q < kChunks) {
+            for (int c = (wave - 2 + (kNWaves - 2) * 64 - k * kCt) % (kNWaves - 2); c < kCt; c += kNWaves - 2)
+              dma_dwordx4(srd, img_lds + (unsigned)(c * kPlane + k * 256) * 4u, voff, (unsigned)c * plane_bytes);
+          }
+        }
+      } else {
+        for (int k = 0; k < ((ablate & 1) ? 0 : Cfg::kPieces); k++) {
+          const int p = k * 64 + lane;
+          const int row = p / kPitch, col = p - row * kPitch;
+          const unsigned voff = (unsigned)(min(y0 + row, height - 1) * width + min(x0 + col, width - 1)) * 4u;
+          if (p < Cfg::kPx) {
+            for (int c = (wave - 2 + (kNWaves - 2) * 64 - k * kCt) % (kNWaves - 2); c < kCt; c += kNWaves - 2)
+              dma_dword(srd, img_lds + (unsigned)(c * kPlane + k * 64) * 4u, voff, (unsigned)c * plane_bytes);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();  // tables built, image landed
+    if (first) stamp(4);
+    const int ne = misc[0];
+    const bool more = misc[1] != 0;
+
+    // ---- every wave: per-RoI state in lanes 0..15, prefix of the unit counts ----
+    int e_r = 0, e_pa0 = 0, e_pw = 0, e_flags = 0, e_slow = 0, incl = 0;
+    {
+      int nun = 0;
+      if (lane < ne) {
+        const AxEnt ey = axes[lane], ex = axes[EB + lane];
+        e_flags = ey.flags | ex.flags;
+        e_r = ey.r;
+        e_pa0 = ey.pa;
+        e_pw = (ex.pa & 0xff) | (ex.pb << 8);
+        if (!(e_flags & (kEntNotFast | kEntZero))) {
+          if (ey.pb > ey.pa && ex.pb > ex.pa) nun = ey.pb - ey.pa;
+        } else if (e_flags & kEntZero) {
+          e_slow = 1;
+        } else {
+          // the tile that holds the first anchor computes the whole RoI
+          const int ly = ytab[lane * S].lo_rel, lx = xtab[lane * S].lo_rel;
+          e_slow = (ly >= 0 && ly < TH && lx >= 0 && lx < TW) ? 1 : 0;
+        }
+      }
+      incl = nun;
+#pragma unroll
+      for (int d = 1; d < EB; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+      }
+    }
+    const int nunits = __builtin_amdgcn_readlane(incl, EB - 1);
+    const unsigned long long slow_mask = __ballot(e_slow != 0);
+
+    // ---- units: 32 lanes = 32 channels per (RoI, bin row) ----
+    for (int ub = 0; ub < nunits; ub += kGroups) {
+      const int u_lo = ub + 2 * wave, u_hi = u_lo + 1;  // the units of this wave's two halves
+      // the RoI of a unit = number of RoIs whose units all come before it
+      const int e_lo = __popcll(__ballot(lane < EB && incl <= u_lo)), e_hi = __popcll(__ballot(lane < EB && incl <= u_hi));
+      const int u = lane < 32 ? u_lo : u_hi;
+      const int e = min(lane < 32 ? e_lo : e_hi, EB - 1);
+      const int r = __shfl(e_r, e), pa0 = __shfl(e_pa0, e), pw = __shfl(e_pw, e);
+      const int before = __shfl(incl, max(e - 1, 0));
+      if (u < nunits) {
+        const int ph = pa0 + (u - (e > 0 ? before : 0));
+        const int pwa = pw & 0xff, pwb = pw >> 8;
+        float* __restrict__ dst = out + (((long long)r * channels + c0 + cl) * ah + ph) * aw;
         if constexpr (kA > 0) {
           static_assert(kSR == 2, "the unrolled path is written for 2 x 2 samples");
           const TabEnt ya = ytab[e * S + ph * 2], yb = ytab[e * S + ph * 2 + 1];
@@ -415,22 +536,40 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
           const v2f wya = {ya.hw, ya.lw}, wyb = {yb.hw, yb.lw};
           const TabEnt* xe = xtab + e * S;
           float acc[kA];
+          if (ablate & 2) {
 #pragma unroll
-          for (int pw0 = 0; pw0 < kA; pw0 += 2) {
-            constexpr int kNB = 2;
-            const int nb = kA - pw0 < kNB ? kA - pw0 : kNB;
-            if (pw0 < pwb && pw0 + nb > pwa) {
+            for (int j = 0; j < kA; j++) acc[j] = 0.f;
+          } else {
+            // two bins at a time; the x entries of the next pair are fetched before the taps of this pair are used, so a
+            // row costs one LDS latency per pair instead of two.  Bins of the row that belong to another tile are computed
+            // too (their table entries point into the image) and dropped by the stores.
+            constexpr int kNB = 2, kBatches = (kA + kNB - 1) / kNB;
+            int xo[2][2 * kNB];
+            float hx[2][2 * kNB], lx[2][2 * kNB];
+            const auto fetch_x = [&](int bi, int buf) {
+#pragma unroll
+              for (int q = 0; q < 2 * kNB; q++) {
+                if (bi * 2 * kNB + q < 2 * kA) {
+                  const TabEnt x = xe[bi * 2 * kNB + q];
+                  xo[buf][q] = x.off;
+                  hx[buf][q] = x.hw;
+                  lx[buf][q] = x.lw;
+                }
+              }
+            };
+            fetch_x(0, 0);
+#pragma unroll
+            for (int bi = 0; bi < kBatches; bi++) {
+              const int buf = bi & 1;
+              const int nb = kA - bi * kNB < kNB ? kA - bi * kNB : kNB;
+              const bool mine = bi * kNB < pwb && bi * kNB + nb > pwa;  // a pair with no bin of this tile costs nothing
               v2f t[kNB][2][2][2];  // [bin][iy][ix][x tap] = {row y, row y + 1}
-              float hx[kNB][2], lx[kNB][2];
 #pragma unroll
               for (int j = 0; j < kNB; j++) {
-                if (j < nb) {
+                if (j < nb && mine) {
 #pragma unroll
                   for (int ix = 0; ix < 2; ix++) {
-                    const TabEnt x = xe[(pw0 + j) * 2 + ix];
-                    hx[j][ix] = x.hw;
-                    lx[j][ix] = x.lw;
-                    const unsigned aa = row_a + (unsigned)x.off, ab = row_b + (unsigned)x.off;
+                    const unsigned aa = row_a + (unsigned)xo[buf][j * 2 + ix], ab = row_b + (unsigned)xo[buf][j * 2 + ix];
                     t[j][0][ix][0] = lds_rows<kPitch, 0>(aa);
                     t[j][0][ix][1] = lds_rows<kPitch, 1>(aa);
                     t[j][1][ix][0] = lds_rows<kPitch, 0>(ab);
@@ -438,29 +577,29 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
                   }
                 }
               }
+              if (bi + 1 < kBatches) fetch_x(bi + 1, buf ^ 1);
 #pragma unroll
               for (int j = 0; j < kNB; j++) {
-                if (j < nb) {
-                  v2f sa = t[j][0][0][0] * hx[j][0];
-                  sa = __builtin_elementwise_fma(t[j][0][0][1], splat(lx[j][0]), sa);
-                  sa = __builtin_elementwise_fma(t[j][0][1][0], splat(hx[j][1]), sa);
-                  sa = __builtin_elementwise_fma(t[j][0][1][1], splat(lx[j][1]), sa);
-                  v2f sb = t[j][1][0][0] * hx[j][0];
-                  sb = __builtin_elementwise_fma(t[j][1][0][1], splat(lx[j][0]), sb);
-                  sb = __builtin_elementwise_fma(t[j][1][1][0], splat(hx[j][1]), sb);
-                  sb = __builtin_elementwise_fma(t[j][1][1][1], splat(lx[j][1]), sb);
+                if (j < nb) acc[bi * kNB + j] = 0.f;
+                if (j < nb && mine) {
+                  const int q = j * 2;
+                  v2f sa = t[j][0][0][0] * hx[buf][q];
+                  sa = __builtin_elementwise_fma(t[j][0][0][1], splat(lx[buf][q]), sa);
+                  sa = __builtin_elementwise_fma(t[j][0][1][0], splat(hx[buf][q + 1]), sa);
+                  sa = __builtin_elementwise_fma(t[j][0][1][1], splat(lx[buf][q + 1]), sa);
+                  v2f sb = t[j][1][0][0] * hx[buf][q];
+                  sb = __builtin_elementwise_fma(t[j][1][0][1], splat(lx[buf][q]), sb);
+                  sb = __builtin_elementwise_fma(t[j][1][1][0], splat(hx[buf][q + 1]), sb);
+                  sb = __builtin_elementwise_fma(t[j][1][1][1], splat(lx[buf][q + 1]), sb);
                   v2f a2 = sa * wya;
                   a2 = __builtin_elementwise_fma(sb, wyb, a2);
-                  acc[pw0 + j] = a2.x + a2.y;
+                  acc[bi * kNB + j] = a2.x + a2.y;
                 }
               }
-            } else {
-#pragma unroll
-              for (int j = 0; j < kNB; j++)
-                if (j < nb) acc[pw0 + j] = 0.f;
             }
           }
-          if (pwa == 0 && pwb == kA) {
+          if (ablate & 4) {
+          } else if (pwa == 0 && pwb == kA) {
             if constexpr (kA == 7) {
               *reinterpret_cast<f4u*>(dst) = f4u{acc[0], acc[1], acc[2], acc[3]};
               *reinterpret_cast<f3u*>(dst + 4) = f3u{acc[4], acc[5], acc[6]};
@@ -480,66 +619,65 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
           }
         } else {
           // any pooled size / sampling grid: bin by bin
-          const int gh = ents[e].g[0], gw = ents[e].g[1];
-          for (int pw = pwa; pw < pwb; pw++) {
+          const int gh = axes[e].g, gw = axes[EB + e].g;
+          for (int pwi = pwa; pwi < pwb; pwi++) {
             v2f a2 = {0.f, 0.f};
             for (int iy = 0; iy < gh; iy++) {
               const TabEnt y = ytab[e * S + ph * gh + iy];
               v2f sy = {0.f, 0.f};
               for (int ix = 0; ix < gw; ix++) {
-                const TabEnt x = xtab[e * S + pw * gw + ix];
+                const TabEnt x = xtab[e * S + pwi * gw + ix];
                 const unsigned a = img_c + (unsigned)y.off + (unsigned)x.off;
                 sy = __builtin_elementwise_fma(lds_rows<kPitch, 0>(a), splat(x.hw), sy);
                 sy = __builtin_elementwise_fma(lds_rows<kPitch, 1>(a), splat(x.lw), sy);
               }
               a2 = __builtin_elementwise_fma(sy, (v2f){y.hw, y.lw}, a2);
             }
-            dst[pw] = a2.x + a2.y;
+            dst[pwi] = a2.x + a2.y;
           }
         }
       }
-      if (win_lo == 0 && b0 == 0) stamp(5);
-
-      // ---- RoIs this tile owns that the tables cannot describe: reference operation order from global memory ----
-      for (int e = 0; e < ne; e++) {
-        if (!ents[e].slow) continue;
-        const int r = ents[e].r;
-        float* __restrict__ dst = out + ((long long)r * channels + c0) * bins;
-        if (ents[e].flags & kEntZero) {
-          for (int i = tid; i < kCt * bins; i += kThreads) dst[i] = 0.f;
-          continue;
-        }
-        const RoiGeom g = roi_geometry(rois + (long long)r * 5, spatial_scale, ah, aw, sr);
-        const float* src = feat + ((long long)g.batch_ind * channels + c0) * height * width;
-        for (int i = tid; i < kCt * bins; i += kThreads) {
-          const int c = i / bins, bin = i - c * bins;
-          const int ph = bin / aw, pw = bin - ph * aw;
-          const float* plane = src + (long long)c * height * width;
-          float output_val = 0.f;
-          for (int iy = 0; iy < g.grid_h; iy++) {
-            const float y = sample_y(g, ph, iy);
-            for (int ix = 0; ix < g.grid_w; ix++) {
-              const float x = sample_x(g, pw, ix);
-              const Taps t = sample_taps(height, width, y, x);
-              float val = 0.f;
-              if (t.y_low >= 0) {
-                const float v1 = plane[t.y_low * width + t.x_low], v2 = plane[t.y_low * width + t.x_high];
-                const float v3 = plane[t.y_high * width + t.x_low], v4 = plane[t.y_high * width + t.x_high];
-                val = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t.w1, v1), __fmul_rn(t.w2, v2)), __fmul_rn(t.w3, v3)),
-                                __fmul_rn(t.w4, v4));
-              }
-              output_val = __fadd_rn(output_val, val);
-            }
-          }
-          dst[i] = output_val / g.count;
-        }
-      }
-      __syncthreads();  // tables and entries are reused by the next batch
     }
-    if (win_lo + kCandCap >= total) break;
+    if (first) stamp(5);
+
+    // ---- RoIs this tile owns that the tables cannot describe: reference operation order from global memory ----
+    for (unsigned long long todo = slow_mask; todo != 0ull; todo &= todo - 1ull) {
+      const int e = (int)__builtin_ctzll(todo);
+      const int r = __builtin_amdgcn_readlane(e_r, e);
+      const int fl = __builtin_amdgcn_readlane(e_flags, e);
+      float* __restrict__ dst = out + ((long long)r * channels + c0) * bins;
+      if (fl & kEntZero) {
+        for (int i = tid; i < kCt * bins; i += kThreads) dst[i] = 0.f;
+        continue;
+      }
+      const RoiGeom g = roi_geometry(rois + (long long)r * 5, spatial_scale, ah, aw, sr);
+      const float* src = feat + ((long long)g.batch_ind * channels + c0) * height * width;
+      for (int i = tid; i < kCt * bins; i += kThreads) {
+        const int c = i / bins, bin = i - c * bins;
+        const int ph = bin / aw, pw = bin - ph * aw;
+        const float* plane = src + (long long)c * height * width;
+        float output_val = 0.f;
+        for (int iy = 0; iy < g.grid_h; iy++) {
+          const float y = sample_y(g, ph, iy);
+          for (int ix = 0; ix < g.grid_w; ix++) {
+            const float x = sample_x(g, pw, ix);
+            const Taps t = sample_taps(height, width, y, x);
+            float val = 0.f;
+            if (t.y_low >= 0) {
+              const float v1 = plane[t.y_low * width + t.x_low], v2 = plane[t.y_low * width + t.x_high];
+              const float v3 = plane[t.y_high * width + t.x_low], v4 = plane[t.y_high * width + t.x_high];
+              val = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t.w1, v1), __fmul_rn(t.w2, v2)), __fmul_rn(t.w3, v3)),
+                              __fmul_rn(t.w4, v4));
+            }
+            output_val = __fadd_rn(output_val, val);
+          }
+        }
+        dst[i] = output_val / g.count;
+      }
+    }
+    if (!more) break;
+    __syncthreads();  // tables and entries are reused by the next batch
   }
-  // a workgroup without a single survivor must not retire while its DMA is still writing LDS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stamp(6);
 }
 
@@ -556,7 +694,7 @@ int launch_one(const LevelTable& lv, const float* rois, const int* levels, float
   }();
   (void)attr;
   roi_align_fwd_tiles<kSR, kA, kTH, kTW><<<ntiles * (channels / kCt), kThreads, Cfg::kLdsBytes, stream>>>(
-      lv, rois, levels, out, num_rois, batch, channels, ah, aw, sr, ntiles, g_tiles_timeline);
+      lv, rois, levels, out, num_rois, batch, channels, ah, aw, sr, ntiles, g_tiles_timeline, tuning().ablate);
   return check_launch("roi_align_fwd_tiles");
 }
 

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Iteration aid: HIP-event time of the config-2 RoIAlign forward call (200 launches), nothing else."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from detectron_pytorch_amd import _lib, synthetic as syn  # noqa: E402
+from tools.hot_path_bench import time_kernel  # noqa: E402
+
+dev = torch.device("cuda", 0)
+lib = _lib.lib()
+stream = _lib.current_stream_handle(dev)
+h, w, scale = syn.FPN_LEVELS[2]
+c, r, res, sr = syn.FPN_DIM, int(os.environ.get("R", 512)), int(os.environ.get("RES", 7)), 2
+feat = torch.from_numpy(syn.feature_map(1, c, h, w, seed=0)).to(dev)
+rois = torch.from_numpy(syn.rois_canonical(r, 1, seed=0)).to(dev)
+out = torch.empty((r, c, res, res), device=dev)
+
+
+def launch():
+    assert lib.mi_roi_align_forward(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, scale, sr,
+                                    0, 0, stream) == 0
+
+
+print("fwd %.2f us" % (time_kernel(launch, 200) * 1e6))

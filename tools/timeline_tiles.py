@@ -41,7 +41,7 @@ print("workgroups stamped", len(t), " hits per tile: mean %.1f max %d" % (t[:, 7
 hits = t[:, 7].copy()
 busy = t[:, 4] != 0
 t0 = t[:, 0].min()
-names = ["roi fetch", "dma issue", "scan", "tables + image landed", "units (batch 0)", "rest (slow, more batches)"]
+names = ["scan (all waves)", "spin + tables", "tail of build", "barrier (image landed)", "units (batch 0)", "rest (slow, more batches)"]
 tb = t[busy]
 for k in range(6):
     d = (tb[:, k + 1] - tb[:, k]) * 0.01
