@@ -264,9 +264,10 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
   const int cap = ring_words();
   // NCHW: the tile-centric kernel -- one launch, no scratch, no records (roi_align_fwd_tiles.hip)
   if (layout == MI_LAYOUT_NCHW && !force_direct() && !mi::tuning().use_records &&
-      mi::roi_align_fwd_tiles_supported(channels, height, width, aligned_height, aligned_width))
+      mi::roi_align_fwd_tiles_supported(channels, height, width, aligned_height, aligned_width))  // any workspace size
     return mi::launch_roi_align_fwd_tiles(features, rois, output, batch, channels, height, width, num_rois,
-                                          aligned_height, aligned_width, spatial_scale, sampling_ratio, s);
+                                          aligned_height, aligned_width, spatial_scale, sampling_ratio, workspace,
+                                          workspace_bytes, s);
   if (workspace != nullptr) {
     MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
@@ -420,6 +421,22 @@ bool fpn_forward_uses_tiles(const mi::LevelTable& lv, int channels, int aligned_
 }
 }  // namespace
 
+extern "C" size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels* levels, int batch, int aligned_height,
+                                                             int aligned_width, int sampling_ratio) {
+  mi::LevelTable lv;
+  if (batch <= 0 || aligned_height <= 0 || aligned_width <= 0 || levels == nullptr || levels->num_levels < 1 ||
+      levels->num_levels > mi::kMaxLevels)
+    return 0;
+  lv = {};
+  lv.count = levels->num_levels;
+  for (int l = 0; l < lv.count; l++) {
+    if (levels->height[l] <= 0 || levels->width[l] <= 0) return 0;
+    lv.height[l] = levels->height[l];
+    lv.width[l] = levels->width[l];
+  }
+  return mi::roi_align_fwd_tiles_workspace_bytes(lv, batch, aligned_height, aligned_width, sampling_ratio);
+}
+
 extern "C" int mi_roi_align_forward_fpn_writes_records(const mi_fpn_levels* levels, int channels, int num_rois,
                                                        int aligned_height, int aligned_width, int layout) {
   mi::LevelTable lv;
@@ -454,18 +471,19 @@ extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float
   if (num_rois == 0) return MI_OK;
   mi::LevelTable lv;
   MI_REQUIRE(to_level_table(levels, batch, true, &lv), "roi_align_fpn: malformed level table");
-  MI_REQUIRE(rois != nullptr && roi_levels != nullptr && output != nullptr && workspace != nullptr,
-             "roi_align_fpn: null pointer");
+  MI_REQUIRE(rois != nullptr && roi_levels != nullptr && output != nullptr, "roi_align_fpn: null pointer");
   MI_REQUIRE(mi_roi_align_fpn_supported(levels, channels, num_rois, aligned_height, aligned_width, layout) == 1,
              "roi_align_fpn: shapes not served by the fused path (mi_roi_align_fpn_supported() == 0)");
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align_fpn: workspace must be 16-byte aligned");
+  const int cap = ring_words();
+  if (fpn_forward_uses_tiles(lv, channels, aligned_height, aligned_width, layout))  // any workspace size, also none
+    return mi::launch_roi_align_fwd_tiles_levels(lv, rois, roi_levels, output, batch, channels, num_rois,
+                                                 aligned_height, aligned_width, sampling_ratio, workspace,
+                                                 workspace_bytes, mi::as_stream(stream));
+  MI_REQUIRE(workspace != nullptr, "roi_align_fpn: null pointer");
   MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
              "roi_align_fpn: workspace of %zu bytes, %zu needed", workspace_bytes,
              mi::roi_align_records_workspace_bytes(num_rois));
-  MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align_fpn: workspace must be 16-byte aligned");
-  const int cap = ring_words();
-  if (fpn_forward_uses_tiles(lv, channels, aligned_height, aligned_width, layout))
-    return mi::launch_roi_align_fwd_tiles_levels(lv, rois, roi_levels, output, batch, channels, num_rois,
-                                                 aligned_height, aligned_width, sampling_ratio, mi::as_stream(stream));
   if (layout == MI_LAYOUT_NHWC) {
     int rc = mi::launch_roi_align_prepare_levels(lv, rois, roi_levels, workspace, batch, num_rois, aligned_height,
                                                  aligned_width, sampling_ratio, mi::as_stream(stream));

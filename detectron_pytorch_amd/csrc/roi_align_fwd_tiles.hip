@@ -9,6 +9,11 @@
 // tile -- whichever RoI it belongs to.  Every feature byte is fetched once per channel group (+ halo), neighbouring
 // tiles run side by side, and nothing has to be sorted, ranked or prepared.
 //
+// Two ways to get the per-tile tables:
+//   * no scratch (mi_roi_align_forward): every workgroup scans the RoIs and builds the tables of its tile itself;
+//   * with scratch (mi_roi_align_forward_ws): roi_align_tiles_prepare, one small workgroup per TILE, does that once and
+//     leaves "descriptor blocks" in the workspace; the eight channel groups of a tile just DMA the block beside the image.
+//
 //   workgroup = (tile, 32-channel group), 512 lanes.  blockIdx % ncg = channel group: with round-robin dispatch an
 //       XCD's L2 only ever sees "its" channel slabs.
 //   1. every lane fetches the RoIs it will test (lane = RoI), THEN the tile DMA is issued (the loads are ordered in
@@ -50,7 +55,6 @@ constexpr int kGroups = kThreads / 32;  // units in flight
 constexpr int kHalo = 4;        // rows below / columns right of the tile that a bin's taps may reach
 constexpr int kCandCap = 64;    // scan survivors held in LDS per pass
 constexpr int kMaxSamples = 32; // samples per axis the generic tables hold
-constexpr int kPreload = 2;     // RoIs per lane fetched in front of the DMA
 
 struct Cand {  // 32 bytes
   float b, x1, y1, x2, y2;
@@ -66,6 +70,16 @@ struct AxEnt {  // one scan survivor, one axis (32 bytes)
   int g, flags, pa, pb, r, pad;
 };
 enum : int { kEntNotFast = 1, kEntZero = 2 };
+constexpr int kEB = 16;       // RoIs per batch (the unit prefix lives in 16 lanes)
+constexpr int kPreBlocks = 2; // descriptor blocks roi_align_tiles_prepare leaves per tile (survivors 0..31)
+
+// Everything the units need to know about one batch of <= kEB RoIs of a tile; the same bytes in LDS and in the workspace.
+template <int S>
+struct DescBlock {
+  TabEnt tabs[2][kEB][S];  // [axis][RoI][sample]; axis 0 = y
+  AxEnt axes[2][kEB];
+  int misc[16];            // [0] RoIs of the batch, [1] more batches follow, [2] scan survivors of the tile
+};
 
 template <int kSR, int kA, int TH, int TW>
 struct TileCfg {
@@ -74,12 +88,13 @@ struct TileCfg {
   static constexpr int kPlane = kPx | 1;  // odd: 32 planes -> 32 banks
   static constexpr int kPieces = (kPx + 63) / 64;
   static constexpr int S = (kA > 0 && kSR > 0) ? kA * kSR : kMaxSamples;  // table entries per axis and RoI
-  static constexpr int EB = 16;                                           // RoIs per batch (the prefix lives in 16 lanes)
   static constexpr int PB = kA > 0 ? kA : kMaxSamples;                    // bins per axis
+  using Block = DescBlock<S>;
   static constexpr size_t kImgBytes = (size_t)kCt * kPlane * 4;
-  static constexpr size_t kTabBytes = (size_t)2 * EB * S * sizeof(TabEnt);
-  static constexpr size_t kLdsBytes = kImgBytes + kTabBytes + 2 * kCandCap * sizeof(Cand) + 2 * EB * sizeof(AxEnt) + 64 * 4;
+  static constexpr size_t kLdsBytes = kImgBytes + sizeof(Block) + 2 * kCandCap * sizeof(Cand) + 64;
+  static constexpr size_t kPrepLdsBytes = sizeof(Block) + kPreBlocks * kEB * sizeof(Cand) + 64;
   static_assert(kPitch + 1 < 256, "ds_read2_b32 offsets");
+  static_assert(sizeof(Block) % 16 == 0 && kImgBytes % 4 == 0, "16-byte DMA pieces");
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -105,117 +120,120 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// kSR > 0 and kA > 0: sampling_ratio == kSR, aligned_height == aligned_width == kA at compile time.
-//
-// Roles: wave 0 builds everything that depends on the y axis, wave 1 everything that depends on the x axis (each scans
-// the RoIs itself: no cross-wave communication before the one barrier), waves 2-7 issue the image DMA.
-template <int kSR, int kA, int TH, int TW>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))  // two workgroups per CU
-roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const int* __restrict__ levels,
-                    float* __restrict__ out, int num_rois, int batch, int channels, int ah_arg, int aw_arg,
-                    int sr_arg, int ntiles, long long* __restrict__ timeline, int ablate_arg) {
-  const int ablate = MI_ABLATE(ablate_arg);  // tuning builds only: 1 no image DMA, 2 no tap reads / arithmetic, 4 no stores
-  // tuning aid (tools/timeline_tiles.py): clock stamps of lane 0 of every workgroup, null in normal operation
-  const auto stamp = [&](int k) {
-    if (timeline != nullptr && threadIdx.x == 0) timeline[(long long)blockIdx.x * 8 + k] = (long long)clock64();
-  };
-  stamp(0);
-  using Cfg = TileCfg<kSR, kA, TH, TW>;
-  constexpr int kPitch = Cfg::kPitch, kPlane = Cfg::kPlane, S = Cfg::S, EB = Cfg::EB, PB = Cfg::PB;
-  const int ah = kA > 0 ? kA : ah_arg, aw = kA > 0 ? kA : aw_arg;
-  const int sr = kSR > 0 ? kSR : sr_arg;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* img = reinterpret_cast<float*>(smem);
-  TabEnt* tabs = reinterpret_cast<TabEnt*>(smem + Cfg::kImgBytes);  // [axis][EB][S]
-  Cand* cands = reinterpret_cast<Cand*>(tabs + 2 * EB * S);         // [axis][kCandCap]: each axis wave keeps its own copy
-  AxEnt* axes = reinterpret_cast<AxEnt*>(cands + 2 * kCandCap);     // [axis][EB]
-  int* misc = reinterpret_cast<int*>(axes + 2 * EB);                // [0] RoIs of the batch, [1] more batches follow
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-  // ---- this workgroup's tile ----
-  // (integer divisions run on the vector unit: readfirstlane brings the wave-uniform results back to SGPRs, otherwise
-  // everything derived from them occupies vector registers)
-  const int ncg = channels / kCt;
-  const int tile_global = uniform((int)blockIdx.x / ncg);
-  const int cg = (int)blockIdx.x - tile_global * ncg;
-  int tile = tile_global, lvl = 0;
-  while (lvl + 1 < lv.count && tile >= lv.tile_base[lvl + 1]) lvl++;
-  tile -= lv.tile_base[lvl];
-  const float* __restrict__ feat = lv.feat[lvl];
-  const int height = lv.height[lvl], width = lv.width[lvl];
-  const float spatial_scale = lv.scale[lvl];
-  const int tiles_x = (width + TW - 1) / TW, tiles_y = (height + TH - 1) / TH;
-  const int n = uniform(tile / (tiles_x * tiles_y));
-  const int trem = tile - n * tiles_x * tiles_y;
+// ---- one tile -------------------------------------------------------------------------------------------------------
+struct TileCtx {
+  int tile_global, lvl, n, x0, y0, height, width;
+  float scale;
+  const float* feat;
+};
+// (integer divisions run on the vector unit: readfirstlane brings the wave-uniform results back to SGPRs, otherwise
+// everything derived from them occupies vector registers)
+template <int TH, int TW>
+__device__ __forceinline__ TileCtx decode_tile(const LevelTable& lv, int tile_global) {
+  // The level table is only ever indexed with compile-time constants: a run-time index into a kernel argument turns
+  // into a chain of dependent scalar loads (one K$ miss each, ~2 us before the first useful instruction); this way the
+  // whole table arrives with the first loads and the level is picked by selects.
+  TileCtx tc;
+  tc.tile_global = tile_global;
+  int lvl = 0, base = 0;
+  tc.height = lv.height[0];
+  tc.width = lv.width[0];
+  tc.scale = lv.scale[0];
+  tc.feat = lv.feat[0];
+#pragma unroll
+  for (int l = 1; l < kMaxLevels; l++) {
+    if (l < lv.count && tile_global >= lv.tile_base[l]) {
+      lvl = l;
+      base = lv.tile_base[l];
+      tc.height = lv.height[l];
+      tc.width = lv.width[l];
+      tc.scale = lv.scale[l];
+      tc.feat = lv.feat[l];
+    }
+  }
+  const int tile = tile_global - base;
+  tc.lvl = lvl;
+  const int tiles_x = (tc.width + TW - 1) / TW, tiles_y = (tc.height + TH - 1) / TH;
+  tc.n = uniform(tile / (tiles_x * tiles_y));
+  const int trem = tile - tc.n * tiles_x * tiles_y;
   const int tyi = uniform(trem / tiles_x), txi = trem - tyi * tiles_x;
-  const int x0 = txi * TW, y0 = tyi * TH;
-  const int c0 = cg * kCt;
-  const int bins = ah * aw;
-  const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
+  tc.x0 = txi * TW;
+  tc.y0 = tyi * TH;
+  return tc;
+}
 
-  // one RoI against this tile, multiplications and compares only: true for every RoI that has a bin here or that this
-  // tile owns (a superset; the tables decide).  A bin's anchor is the lower tap of its first sample, whose coordinate
-  // lies in [start, start + length]; taps are clamped to the map.
-  const float tile_y_lo = (float)y0, tile_y_hi = (float)(y0 + TH), tile_x_lo = (float)x0, tile_x_hi = (float)(x0 + TW);
-  const float h_max = (float)(height - 1), w_max = (float)(width - 1);
-  const auto test = [&](int i, float rb, float rx1, float ry1, float rx2, float ry2, int rl) -> bool {
-    const int b = (int)rb;
-    if (b < 0 || b >= batch) return (i % ntiles) == tile_global;  // zeros, written by tile (i mod tiles)
-    const int l = min(max(rl, 0), lv.count - 1);
-    if (l != lvl || b != n) return false;
-    const float sy = ry1 * spatial_scale, sx = rx1 * spatial_scale;
-    const float ey = sy + fmaxf(ry2 * spatial_scale - sy, 1.f), ex = sx + fmaxf(rx2 * spatial_scale - sx, 1.f);
-    const float ya = fminf(fmaxf(sy, 0.f), h_max) - 1.f, yb = fminf(fmaxf(ey, 0.f), h_max) + 1.f;
-    const float xa = fminf(fmaxf(sx, 0.f), w_max) - 1.f, xb = fminf(fmaxf(ex, 0.f), w_max) + 1.f;
-    return ya < tile_y_hi && yb >= tile_y_lo && xa < tile_x_hi && xb >= tile_x_lo;
-  };
+// One RoI against a tile, multiplications and compares only: true for every RoI that has a bin there or that the tile
+// owns (a superset; the tables decide).  A bin's anchor is the lower tap of its first sample, whose coordinate lies in
+// [start, start + length]; taps are clamped to the map.
+template <int TH, int TW>
+__device__ __forceinline__ bool tile_test(const TileCtx& tc, int levels_count, int batch, int ntiles, int i, float rb,
+                                          float rx1, float ry1, float rx2, float ry2, int rl) {
+  const int b = (int)rb;
+  if (b < 0 || b >= batch) return (i % ntiles) == tc.tile_global;  // zeros, written by tile (i mod tiles)
+  const int l = min(max(rl, 0), levels_count - 1);
+  if (l != tc.lvl || b != tc.n) return false;
+  const float h_max = (float)(tc.height - 1), w_max = (float)(tc.width - 1);
+  const float sy = ry1 * tc.scale, sx = rx1 * tc.scale;
+  const float ey = sy + fmaxf(ry2 * tc.scale - sy, 1.f), ex = sx + fmaxf(rx2 * tc.scale - sx, 1.f);
+  const float ya = fminf(fmaxf(sy, 0.f), h_max) - 1.f, yb = fminf(fmaxf(ey, 0.f), h_max) + 1.f;
+  const float xa = fminf(fmaxf(sx, 0.f), w_max) - 1.f, xb = fminf(fmaxf(ex, 0.f), w_max) + 1.f;
+  return ya < (float)(tc.y0 + TH) && yb >= (float)tc.y0 && xa < (float)(tc.x0 + TW) && xb >= (float)tc.x0;
+}
 
-  const int axis = wave;  // meaningful in waves 0 (y) and 1 (x)
-  Cand* mycand = cands + (wave & 1) * kCandCap;
-  AxEnt* myax = axes + (wave & 1) * EB;
-  TabEnt* mytab = tabs + (wave & 1) * EB * S;
-
-  // ---- scan (one wave): survivors with ordinal in [win_lo, win_lo + kCandCap) go to LDS (ordinals follow the RoI
-  // index); returns the number of survivors of the tile.  Eight RoIs per lane are fetched together. ----
-  const auto scan = [&](int win_lo) -> int {
-    int count = 0;
-    constexpr int kPer = 8;
-    for (int base = 0; base < num_rois; base += 64 * kPer) {
-      float rv[kPer][5];
-      int rl[kPer];
+// Scan by ONE wave in RoI order: survivors with ordinal in [win_lo, win_lo + cap) go to list[0 .. cap) (and to a second
+// copy `list2` when given); returns the number of survivors of the tile.  Eight RoIs per lane are fetched together.
+template <int TH, int TW>
+__device__ __forceinline__ int scan_ordered(const TileCtx& tc, int levels_count, int batch, int ntiles,
+                                            const float* __restrict__ rois, const int* __restrict__ levels,
+                                            int num_rois, int win_lo, int cap, Cand* list, Cand* list2) {
+  const int lane = threadIdx.x & 63;
+  int count = 0;
+  constexpr int kPer = 8;
+  for (int base = 0; base < num_rois; base += 64 * kPer) {
+    float rv[kPer][5];
+    int rl[kPer];
 #pragma unroll
-      for (int k = 0; k < kPer; k++) {
-        const int i = base + k * 64 + lane;
-        rl[k] = 0;
+    for (int k = 0; k < kPer; k++) {
+      const int i = base + k * 64 + lane;
+      rl[k] = 0;
 #pragma unroll
-        for (int j = 0; j < 5; j++) rv[k][j] = 0.f;
-        if (i < num_rois) {
+      for (int j = 0; j < 5; j++) rv[k][j] = 0.f;
+      if (i < num_rois) {
 #pragma unroll
-          for (int j = 0; j < 5; j++) rv[k][j] = rois[(long long)i * 5 + j];
-          if (levels != nullptr) rl[k] = levels[i];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kPer; k++) {
-        const int i = base + k * 64 + lane;
-        const bool hit = i < num_rois && test(i, rv[k][0], rv[k][1], rv[k][2], rv[k][3], rv[k][4], rl[k]);
-        const unsigned long long m = __ballot(hit);
-        const int ord = count + __popcll(m & ((1ull << lane) - 1ull)) - win_lo;
-        if (hit && ord >= 0 && ord < kCandCap) {
-          Cand cr;
-          cr.b = rv[k][0], cr.x1 = rv[k][1], cr.y1 = rv[k][2], cr.x2 = rv[k][3], cr.y2 = rv[k][4], cr.id = i, cr.pad0 = 0,
-          cr.pad1 = 0;
-          mycand[ord] = cr;
-        }
-        count += __popcll(m);
+        for (int j = 0; j < 5; j++) rv[k][j] = rois[(long long)i * 5 + j];
+        if (levels != nullptr) rl[k] = levels[i];
       }
     }
-    return count;
-  };
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int i = base + k * 64 + lane;
+      const bool hit = i < num_rois && tile_test<TH, TW>(tc, levels_count, batch, ntiles, i, rv[k][0], rv[k][1], rv[k][2],
+                                                          rv[k][3], rv[k][4], rl[k]);
+      const unsigned long long m = __ballot(hit);
+      const int ord = count + __popcll(m & ((1ull << lane) - 1ull)) - win_lo;
+      if (hit && ord >= 0 && ord < cap) {
+        Cand cr;
+        cr.b = rv[k][0], cr.x1 = rv[k][1], cr.y1 = rv[k][2], cr.x2 = rv[k][3], cr.y2 = rv[k][4], cr.id = i, cr.pad0 = 0,
+        cr.pad1 = 0;
+        list[ord] = cr;
+        if (list2 != nullptr) list2[ord] = cr;
+      }
+      count += __popcll(m);
+    }
+  }
+  return count;
+}
 
-  // ---- one batch of <= EB survivors, one axis (one wave) ----
-  const auto build = [&](int b0, int ne) {
-    const int aligned = axis == 0 ? ah : aw, size = axis == 0 ? height : width, origin = axis == 0 ? y0 : x0;
+// One batch of <= kEB survivors, ONE axis, by ONE wave: axis entries, sample tables (the reference's fp32 operations,
+// roi_align_kernel.cu:74-110, 16-52), and per bin the footprint check and the range [pa, pb) of bins whose anchor lies in
+// the tile.  mycand: the wave's survivor list; myax / mytab: axis `axis` of the descriptor block.
+template <int kSR, int kA, int TH, int TW>
+__device__ __forceinline__ void build_axis(const TileCtx& tc, int axis, int batch, int ah, int aw, int sr,
+                                           const Cand* mycand, AxEnt* myax, TabEnt* mytab, int b0, int ne) {
+  using Cfg = TileCfg<kSR, kA, TH, TW>;
+  constexpr int kPitch = Cfg::kPitch, S = Cfg::S, PB = Cfg::PB;
+  const int lane = threadIdx.x & 63;
+  const int aligned = axis == 0 ? ah : aw, size = axis == 0 ? tc.height : tc.width, origin = axis == 0 ? tc.y0 : tc.x0;
     if constexpr (kSR == 2 && kA > 0) {
       // compile-time 2 x 2 grid: one pass.  lane = (RoI, sample); the two samples of a bin sit in neighbouring lanes, so
       // the footprint of a bin and its tile come from a lane exchange instead of a second pass over LDS.
@@ -238,8 +256,8 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
         const Cand cr = mycand[b0 + e];
         const float lo_c = axis == 0 ? cr.y1 : cr.x1, hi_c = axis == 0 ? cr.y2 : cr.x2;
         // roi_align_kernel.cu:79-88, 106-110
-        const float start = lo_c * spatial_scale;
-        const float len = fmaxf(hi_c * spatial_scale - start, 1.f);
+        const float start = lo_c * tc.scale;
+        const float len = fmaxf(hi_c * tc.scale - start, 1.f);
         const float bin = len / (float)kA;
         const int p = s >> 1, i = s & 1;
         float v = start + (float)p * bin + ((float)i + .5f) * bin / 2.f;
@@ -278,23 +296,21 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
         }
         if (flag) atomicOr(&myax[e].flags, flag);
       }
-      if (b0 == 0) stamp(2);
-      return;
+            return;
     }
     // geometry: one lane per RoI (roi_align_kernel.cu:76-98)
-    float count_f = 1.f;
     if (lane < ne) {
       const Cand cr = mycand[b0 + lane];
       const int b = (int)cr.b;
       const float lo_c = axis == 0 ? cr.y1 : cr.x1, hi_c = axis == 0 ? cr.y2 : cr.x2;
       const float lo_o = axis == 0 ? cr.x1 : cr.y1, hi_o = axis == 0 ? cr.x2 : cr.y2;
       AxEnt en;
-      en.start = lo_c * spatial_scale;
-      const float len = fmaxf(hi_c * spatial_scale - en.start, 1.f);
+      en.start = lo_c * tc.scale;
+      const float len = fmaxf(hi_c * tc.scale - en.start, 1.f);
       en.bin = len / (float)aligned;
       en.g = sr > 0 ? sr : (int)ceilf(len / (float)aligned);
-      const float start_o = lo_o * spatial_scale;
-      const float len_o = fmaxf(hi_o * spatial_scale - start_o, 1.f);
+      const float start_o = lo_o * tc.scale;
+      const float len_o = fmaxf(hi_o * tc.scale - start_o, 1.f);
       const int aligned_o = axis == 0 ? aw : ah;
       const int g_o = sr > 0 ? sr : (int)ceilf(len_o / (float)aligned_o);
       en.flags = (b < 0 || b >= batch) ? kEntZero : 0;
@@ -349,8 +365,7 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
       }
     }
     wave_sync();
-    if (b0 == 0) stamp(2);
-    // bins: lane = (RoI, bin): footprint within the halo?  which bins belong to this tile?
+        // bins: lane = (RoI, bin): footprint within the halo?  which bins belong to this tile?
     for (int t = lane; t < ne * PB; t += 64) {
       const int e = t / PB, p = t - e * PB;
       const AxEnt en = myax[e];
@@ -363,30 +378,138 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
         }
       }
     }
-    (void)count_f;
-  };
+}
 
-  const int grp = tid >> 5, cl = tid & 31;
-  const unsigned img_c = (unsigned)(uintptr_t)(lds_cfloat_t)(img + cl * kPlane);  // LDS byte address of this lane's plane
-  const TabEnt* ytab = tabs;
-  const TabEnt* xtab = tabs + EB * S;
+// ---- roi_align_tiles_prepare: one 256-lane workgroup per TILE; leaves the descriptor blocks of the tile's first
+// kPreBlocks * kEB scan survivors (in RoI order) in the workspace ------------------------------------------------------
+constexpr int kPrepThreads = 256;
+template <int kSR, int kA, int TH, int TW>
+__global__ void __launch_bounds__(kPrepThreads)
+roi_align_tiles_prepare(const LevelTable lv, const float* __restrict__ rois, const int* __restrict__ levels, int num_rois,
+                        int batch, int ah_arg, int aw_arg, int sr_arg, int ntiles, unsigned char* __restrict__ desc) {
+  using Cfg = TileCfg<kSR, kA, TH, TW>;
+  using Block = typename Cfg::Block;
+  const int ah = kA > 0 ? kA : ah_arg, aw = kA > 0 ? kA : aw_arg;
+  const int sr = kSR > 0 ? kSR : sr_arg;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Block* blk = reinterpret_cast<Block*>(smem);
+  Cand* cand = reinterpret_cast<Cand*>(smem + sizeof(Block));  // [kPreBlocks * kEB]
+  int* wcount = reinterpret_cast<int*>(cand + kPreBlocks * kEB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const TileCtx tc = decode_tile<TH, TW>(lv, (int)blockIdx.x);
+  constexpr int kCap = kPreBlocks * kEB, kW = kPrepThreads / 64;
 
-  // ---- fast scan (the two axis waves, half of the RoIs each, fetched together): survivors are appended to both axis
-  // lists through an LDS counter.  The order of the list is arbitrary; it only matters when the list overflows, and then
-  // the axis waves rescan in RoI order.
-  if (tid == 0) {
-    misc[2] = 0;  // survivors
-    misc[3] = 0;  // axis waves that have finished the scan
+  // scan, lane = RoI; ordinals follow the RoI index
+  int total = 0;
+  for (int base = 0; base < num_rois; base += kPrepThreads) {
+    const int i = base + tid;
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f;
+    int rl = 0;
+    if (i < num_rois) {
+      const float* q = rois + (long long)i * 5;
+      r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
+      if (levels != nullptr) rl = levels[i];
+    }
+    const bool hit = i < num_rois && tile_test<TH, TW>(tc, lv.count, batch, ntiles, i, r0, r1, r2, r3, r4, rl);
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    int off = total, all = 0;
+#pragma unroll
+    for (int w = 0; w < kW; w++) {
+      const int cnt = wcount[w];
+      off += w < wave ? cnt : 0;
+      all += cnt;
+    }
+    const int ord = off + __popcll(m & ((1ull << lane) - 1ull));
+    if (hit && ord < kCap) {
+      Cand cr;
+      cr.b = r0, cr.x1 = r1, cr.y1 = r2, cr.x2 = r3, cr.y2 = r4, cr.id = i, cr.pad0 = 0, cr.pad1 = 0;
+      cand[ord] = cr;
+    }
+    total += all;
+    __syncthreads();
   }
-  __syncthreads();
-  if (wave < 2) {
-    constexpr int kPer = 4;
-    for (int base = 0; base < num_rois; base += 128 * kPer) {
+  for (int k = 0; k < kPreBlocks; k++) {
+    const int ne = min(max(total - k * kEB, 0), kEB);
+    if (k > 0 && ne == 0) break;  // the main kernel reads block k only when block k - 1 says "more"
+    if (wave < 2) build_axis<kSR, kA, TH, TW>(tc, wave, batch, ah, aw, sr, cand, blk->axes[wave], &blk->tabs[wave][0][0], k * kEB, ne);
+    if (tid == 0) {
+      blk->misc[0] = ne;
+      blk->misc[1] = total > (k + 1) * kEB ? 1 : 0;
+      blk->misc[2] = total;
+    }
+    __syncthreads();
+    const int4* src = reinterpret_cast<const int4*>(blk);
+    int4* dst = reinterpret_cast<int4*>(desc + ((size_t)blockIdx.x * kPreBlocks + k) * sizeof(Block));
+    for (int i = tid; i < (int)(sizeof(Block) / 16); i += kPrepThreads) dst[i] = src[i];
+    __syncthreads();
+  }
+}
+
+// kSR > 0 and kA > 0: sampling_ratio == kSR, aligned_height == aligned_width == kA at compile time.
+//
+// Roles: waves 2-7 issue the image DMA.  With `desc` wave 0 DMA's the tile's descriptor block beside it; without, wave 0
+// builds everything that depends on the y axis and wave 1 everything that depends on the x axis.
+template <int kSR, int kA, int TH, int TW>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))  // two workgroups per CU
+roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const int* __restrict__ levels,
+                    float* __restrict__ out, int num_rois, int batch, int channels, int ah_arg, int aw_arg,
+                    int sr_arg, int ntiles, const unsigned char* __restrict__ desc, long long* __restrict__ timeline,
+                    int ablate_arg) {
+  const int ablate = MI_ABLATE(ablate_arg);  // tuning builds only: 1 no image DMA, 2 no tap reads / arithmetic, 4 no stores
+  // tuning aid (tools/timeline_tiles.py): clock stamps of lane 0 of every workgroup, null in normal operation
+  const auto stamp = [&](int k) {
+    if (timeline != nullptr && threadIdx.x == 0) timeline[(long long)blockIdx.x * 8 + k] = (long long)clock64();
+  };
+  stamp(0);
+  if (ablate & 8) return;  // tuning builds: launch and dispatch only
+  using Cfg = TileCfg<kSR, kA, TH, TW>;
+  using Block = typename Cfg::Block;
+  constexpr int kPitch = Cfg::kPitch, kPlane = Cfg::kPlane, S = Cfg::S, EB = kEB;
+  const int ah = kA > 0 ? kA : ah_arg, aw = kA > 0 ? kA : aw_arg;
+  const int sr = kSR > 0 ? kSR : sr_arg;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* img = reinterpret_cast<float*>(smem);
+  Block* blk = reinterpret_cast<Block*>(smem + Cfg::kImgBytes);
+  Cand* cands = reinterpret_cast<Cand*>(smem + Cfg::kImgBytes + sizeof(Block));  // [axis][kCandCap]: a copy per axis wave
+  int* ctr = reinterpret_cast<int*>(cands + 2 * kCandCap);                       // [0] survivors, [1] waves done scanning
+  int* misc = blk->misc;
+  TabEnt* tabs = &blk->tabs[0][0][0];
+  AxEnt* axes = &blk->axes[0][0];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int ncg = channels / kCt;
+  const int tile_global = uniform((int)blockIdx.x / ncg);
+  const int cg = (int)blockIdx.x - tile_global * ncg;
+  const TileCtx tc = decode_tile<TH, TW>(lv, tile_global);
+  const float* __restrict__ feat = tc.feat;
+  const int height = tc.height, width = tc.width, n = tc.n, x0 = tc.x0, y0 = tc.y0;
+  const float spatial_scale = tc.scale;
+  const int c0 = cg * kCt;
+  const int bins = ah * aw;
+  const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
+  const bool pre = desc != nullptr;
+
+  const int axis = wave & 1;  // meaningful in waves 0 (y) and 1 (x)
+  Cand* mycand = cands + axis * kCandCap;
+
+  if (!pre) {
+    // ---- fast scan: every lane tests the RoIs tid, tid + 512, ... (fetched together, BEFORE the DMA is issued: waiting
+    // for them must not wait for the image) and appends its survivors to both axis lists through an LDS counter.  The
+    // order of the list is arbitrary; it only matters when the list overflows, and then the axis waves rescan in order.
+    if (tid == 0) {
+      ctr[0] = 0;
+      ctr[1] = 0;
+    }
+    __syncthreads();
+    constexpr int kPer = 2;
+    for (int base = 0; base < num_rois; base += kThreads * kPer) {
       float rv[kPer][5];
       int rl[kPer];
 #pragma unroll
       for (int k = 0; k < kPer; k++) {
-        const int i = base + k * 128 + tid;
+        const int i = base + k * kThreads + tid;
         rl[k] = 0;
 #pragma unroll
         for (int j = 0; j < 5; j++) rv[k][j] = 0.f;
@@ -398,12 +521,13 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
       }
 #pragma unroll
       for (int k = 0; k < kPer; k++) {
-        const int i = base + k * 128 + tid;
-        const bool hit = i < num_rois && test(i, rv[k][0], rv[k][1], rv[k][2], rv[k][3], rv[k][4], rl[k]);
+        const int i = base + k * kThreads + tid;
+        const bool hit = i < num_rois && tile_test<TH, TW>(tc, lv.count, batch, ntiles, i, rv[k][0], rv[k][1], rv[k][2],
+                                                            rv[k][3], rv[k][4], rl[k]);
         const unsigned long long m = __ballot(hit);
         if (m != 0ull) {
           int slot = 0;
-          if (lane == 0) slot = atomicAdd(&misc[2], __popcll(m));
+          if (lane == 0) slot = atomicAdd(&ctr[0], __popcll(m));
           slot = __builtin_amdgcn_readfirstlane(slot) + __popcll(m & ((1ull << lane) - 1ull));
           if (hit && slot < kCandCap) {
             Cand cr;
@@ -416,39 +540,67 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) atomicAdd(&misc[3], 1);
+    if (lane == 0) atomicAdd(&ctr[1], 1);
   }
   stamp(1);
 
-  int win_lo = 0, b0 = 0, total = 0, ncand = 0;  // waves 0 and 1
+  const int grp = tid >> 5, cl = tid & 31;
+  const unsigned img_c = (unsigned)(uintptr_t)(lds_cfloat_t)(img + cl * kPlane);  // LDS byte address of this lane's plane
+  const TabEnt* ytab = tabs;
+  const TabEnt* xtab = tabs + EB * S;
+  (void)grp;
+
+  // Batches of <= 16 survivors.  With descriptors: blocks 0 .. kPreBlocks-1 come from the workspace; survivors past them
+  // (a tile under a pile of RoIs) are scanned and built here, in RoI order, like everything without descriptors.
+  int win_lo = 0, b0 = 0, total = 0, ncand = 0, nblk = 0;  // waves 0 and 1
   for (bool first = true;; first = false) {
     if (wave < 2) {
-      if (first) {
-        while (__atomic_load_n(&misc[3], __ATOMIC_RELAXED) < 2) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        total = __atomic_load_n(&misc[2], __ATOMIC_RELAXED);
-        if (total > kCandCap) total = scan(0);  // overflow: windows of the list in RoI order
-        ncand = min(total, kCandCap);
-      } else {
-        b0 += EB;
-        if (b0 >= ncand) {
-          win_lo += kCandCap;
-          total = scan(win_lo);
-          ncand = min(total - win_lo, kCandCap);
+      if (pre && nblk < kPreBlocks) {
+        if (wave == 0) {
+          const unsigned char* src = desc + ((size_t)tile_global * kPreBlocks + nblk) * sizeof(Block);
+          const srd_t bsrd = make_srd(src, (unsigned)sizeof(Block));
+          const unsigned dst_lds = lds_addr_uniform(blk);
+          for (int k = 0; k * 1024 < (int)sizeof(Block); k++)
+            if (k * 1024 + lane * 16 < (int)sizeof(Block)) dma_dwordx4(bsrd, dst_lds + (unsigned)k * 1024u, (unsigned)(k * 1024 + lane * 16), 0u);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        nblk++;
+        if (nblk == kPreBlocks) {  // what follows the blocks starts at survivor kPreBlocks * kEB
+          win_lo = kPreBlocks * EB - kCandCap;
+          ncand = 0;
           b0 = 0;
         }
-      }
-      const int ne = min(EB, ncand - b0);
-      build(b0, ne);
-      if (tid == 0) {
-        misc[0] = ne;
-        misc[1] = (b0 + EB < ncand || win_lo + kCandCap < total) ? 1 : 0;
-        if (first && timeline != nullptr) timeline[(long long)blockIdx.x * 8 + 7] = total;
+      } else {
+        if (pre && total == 0) total = misc[2];  // (set by the last block; > kPreBlocks * kEB or we would not be here)
+        if (!pre && first) {
+          while (__atomic_load_n(&ctr[1], __ATOMIC_RELAXED) < kNWaves) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          total = __atomic_load_n(&ctr[0], __ATOMIC_RELAXED);
+          if (total > kCandCap)  // overflow: windows of the list in RoI order
+            total = scan_ordered<TH, TW>(tc, lv.count, batch, ntiles, rois, levels, num_rois, 0, kCandCap, mycand, nullptr);
+          ncand = min(total, kCandCap);
+        } else {
+          b0 += EB;
+          if (b0 >= ncand) {
+            win_lo += kCandCap;
+            total = scan_ordered<TH, TW>(tc, lv.count, batch, ntiles, rois, levels, num_rois, win_lo, kCandCap, mycand, nullptr);
+            ncand = min(total - win_lo, kCandCap);
+            b0 = 0;
+          }
+        }
+        const int ne = min(EB, ncand - b0);
+        build_axis<kSR, kA, TH, TW>(tc, axis, batch, ah, aw, sr, mycand, axes + axis * EB, tabs + axis * EB * S, b0, ne);
+        if (tid == 0) {
+          misc[0] = ne;
+          misc[1] = (b0 + EB < ncand || win_lo + kCandCap < total) ? 1 : 0;
+          misc[2] = total;
+        }
       }
       if (first) stamp(3);
     } else if (first) {
       // ---- tile image: [channel][row][kPitch] by LDS-DMA, lanes flattened over (row, column), clamped to the map:
-      // rows / columns past it repeat the last row / column ----
+      // rows / columns past it repeat the last row / column, so that "upper tap = lower tap + 1" holds for a sample
+      // clamped to the border too (the reference reads the border pixel twice, weights 1 and 0) ----
       const float* slab = feat + ((long long)n * channels + c0) * height * width;
       const srd_t srd = make_srd(slab, (unsigned)kCt * plane_bytes);  // the range check includes the scalar offset
       const unsigned img_lds = lds_addr_uniform(img);
@@ -481,10 +633,12 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();  // tables built, image landed
+    __syncthreads();  // tables built / fetched, image landed
     if (first) stamp(4);
+    if (ablate & 16) break;  // tuning builds: nothing after the barrier
     const int ne = misc[0];
     const bool more = misc[1] != 0;
+    if (first && timeline != nullptr && tid == 0) timeline[(long long)blockIdx.x * 8 + 7] = misc[2];
 
     // ---- every wave: per-RoI state in lanes 0..15, prefix of the unit counts ----
     int e_r = 0, e_pa0 = 0, e_pw = 0, e_flags = 0, e_slow = 0, incl = 0;
@@ -686,16 +840,36 @@ long long* g_tiles_timeline = nullptr;
 
 template <int kSR, int kA>
 int launch_one(const LevelTable& lv, const float* rois, const int* levels, float* out, int num_rois, int batch,
-               int channels, int ah, int aw, int sr, int ntiles, hipStream_t stream) {
+               int channels, int ah, int aw, int sr, int ntiles, unsigned char* desc, hipStream_t stream) {
   using Cfg = TileCfg<kSR, kA, kTH, kTW>;
   static const bool attr = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_tiles<kSR, kA, kTH, kTW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::kLdsBytes) == hipSuccess;
   }();
   (void)attr;
+  if (desc != nullptr) {
+    roi_align_tiles_prepare<kSR, kA, kTH, kTW><<<ntiles, kPrepThreads, Cfg::kPrepLdsBytes, stream>>>(
+        lv, rois, levels, num_rois, batch, ah, aw, sr, ntiles, desc);
+    const int rc = check_launch("roi_align_tiles_prepare");
+    if (rc != MI_OK) return rc;
+  }
   roi_align_fwd_tiles<kSR, kA, kTH, kTW><<<ntiles * (channels / kCt), kThreads, Cfg::kLdsBytes, stream>>>(
-      lv, rois, levels, out, num_rois, batch, channels, ah, aw, sr, ntiles, g_tiles_timeline, tuning().ablate);
+      lv, rois, levels, out, num_rois, batch, channels, ah, aw, sr, ntiles, desc, g_tiles_timeline, tuning().ablate);
   return check_launch("roi_align_fwd_tiles");
+}
+
+int count_tiles(LevelTable& lv, int batch) {
+  lv.tile_base[0] = 0;
+  for (int l = 0; l < lv.count; l++)
+    lv.tile_base[l + 1] =
+        lv.tile_base[l] + ((lv.width[l] + kTW - 1) / kTW) * ((lv.height[l] + kTH - 1) / kTH) * batch;
+  return lv.tile_base[lv.count];
+}
+
+size_t block_bytes(int aligned_height, int aligned_width, int sampling_ratio) {
+  if (sampling_ratio == 2 && aligned_height == 7 && aligned_width == 7) return sizeof(DescBlock<14>);
+  if (sampling_ratio == 2 && aligned_height == 14 && aligned_width == 14) return sizeof(DescBlock<28>);
+  return sizeof(DescBlock<kMaxSamples>);
 }
 
 }  // namespace
@@ -708,32 +882,40 @@ bool roi_align_fwd_tiles_supported(int channels, int height, int width, int alig
          (long long)kCt * height * width * 4 < (1LL << 31);
 }
 
+// bytes of scratch with which the forward runs as roi_align_tiles_prepare + roi_align_fwd_tiles
+size_t roi_align_fwd_tiles_workspace_bytes(LevelTable lv, int batch, int aligned_height, int aligned_width,
+                                           int sampling_ratio) {
+  return (size_t)count_tiles(lv, batch) * kPreBlocks * block_bytes(aligned_height, aligned_width, sampling_ratio);
+}
+
+// workspace: nullptr (or too small) = one launch, every workgroup builds its own tables
 int launch_roi_align_fwd_tiles_levels(LevelTable lv, const float* rois, const int* levels, float* output, int batch,
                                       int channels, int num_rois, int aligned_height, int aligned_width,
-                                      int sampling_ratio, hipStream_t stream) {
-  lv.tile_base[0] = 0;
-  for (int l = 0; l < lv.count; l++)
-    lv.tile_base[l + 1] =
-        lv.tile_base[l] + ((lv.width[l] + kTW - 1) / kTW) * ((lv.height[l] + kTH - 1) / kTH) * batch;
-  const int ntiles = lv.tile_base[lv.count];
+                                      int sampling_ratio, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const int ntiles = count_tiles(lv, batch);
   if ((long long)ntiles * (channels / kCt) >= (1LL << 31)) {
     set_error("roi_align_fwd_tiles: grid too large");
     return MI_ERR_BAD_ARGUMENT;
   }
+  unsigned char* desc = static_cast<unsigned char*>(workspace);
+  if (desc != nullptr && (workspace_bytes < (size_t)ntiles * kPreBlocks * block_bytes(aligned_height, aligned_width, sampling_ratio) ||
+                          (reinterpret_cast<uintptr_t>(desc) & 15) != 0 || tuning().no_ws))
+    desc = nullptr;
   if (sampling_ratio == 2 && aligned_height == 7 && aligned_width == 7)
-    return launch_one<2, 7>(lv, rois, levels, output, num_rois, batch, channels, 7, 7, 2, ntiles, stream);
+    return launch_one<2, 7>(lv, rois, levels, output, num_rois, batch, channels, 7, 7, 2, ntiles, desc, stream);
   if (sampling_ratio == 2 && aligned_height == 14 && aligned_width == 14)
-    return launch_one<2, 14>(lv, rois, levels, output, num_rois, batch, channels, 14, 14, 2, ntiles, stream);
+    return launch_one<2, 14>(lv, rois, levels, output, num_rois, batch, channels, 14, 14, 2, ntiles, desc, stream);
   return launch_one<0, 0>(lv, rois, levels, output, num_rois, batch, channels, aligned_height, aligned_width,
-                          sampling_ratio, ntiles, stream);
+                          sampling_ratio, ntiles, desc, stream);
 }
 
 int launch_roi_align_fwd_tiles(const float* features, const float* rois, float* output, int batch, int channels,
                                int height, int width, int num_rois, int aligned_height, int aligned_width,
-                               float spatial_scale, int sampling_ratio, hipStream_t stream) {
+                               float spatial_scale, int sampling_ratio, void* workspace, size_t workspace_bytes,
+                               hipStream_t stream) {
   return launch_roi_align_fwd_tiles_levels(single_level(features, nullptr, batch, height, width, spatial_scale), rois,
                                            nullptr, output, batch, channels, num_rois, aligned_height, aligned_width,
-                                           sampling_ratio, stream);
+                                           sampling_ratio, workspace, workspace_bytes, stream);
 }
 
 }  // namespace mi

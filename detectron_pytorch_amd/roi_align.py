@@ -67,23 +67,29 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
     lib = _lib.lib()
     records = variant == _lib.ROI_ALIGN_CAFFE2 and bool(lib.mi_roi_align_forward_writes_records(
         c, h, w, r, int(aligned_height), int(aligned_width), int(variant), layout))
-    workspace = None
+    # device scratch (a free-list pop of the caching allocator): per-RoI records of the channels-last path, or the per-tile
+    # descriptors with which the NCHW tile kernel does not rebuild its tables per channel group
+    ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+    if layout == _lib.LAYOUT_NCHW and variant == _lib.ROI_ALIGN_CAFFE2:
+        ws_bytes = max(ws_bytes, _tiles_workspace_bytes([(h, w)], n, aligned_height, aligned_width, sampling_ratio))
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=features.device)
     with torch.cuda.device(features.device):
-        if records:
-            # device scratch of the two-launch channels-last path (per-RoI records); a free-list pop of the allocator
-            ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
-            workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=features.device)
-            rc = lib.mi_roi_align_forward_ws(
-                features.data_ptr(), rois.data_ptr(), output.data_ptr(), n, c, h, w, r,
-                int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
-                int(variant), layout, workspace.data_ptr(), ws_bytes, _lib.current_stream_handle(features.device))
-        else:
-            rc = lib.mi_roi_align_forward(
-                features.data_ptr(), rois.data_ptr(), output.data_ptr(), n, c, h, w, r,
-                int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
-                int(variant), layout, _lib.current_stream_handle(features.device))
-    _lib.check(rc, "mi_roi_align_forward")
-    return (output, workspace) if return_workspace else output
+        rc = lib.mi_roi_align_forward_ws(
+            features.data_ptr(), rois.data_ptr(), output.data_ptr(), n, c, h, w, r,
+            int(aligned_height), int(aligned_width), float(spatial_scale), int(sampling_ratio),
+            int(variant), layout, workspace.data_ptr(), ws_bytes, _lib.current_stream_handle(features.device))
+    _lib.check(rc, "mi_roi_align_forward_ws")
+    return (output, workspace if records else None) if return_workspace else output
+
+
+def _tiles_workspace_bytes(sizes, batch, aligned_height, aligned_width, sampling_ratio):
+    """mi_roi_align_forward_tiles_workspace_bytes for maps of the given (height, width)s."""
+    t = _lib.FpnLevels()
+    t.num_levels = len(sizes)
+    for i, (h, w) in enumerate(sizes):
+        t.height[i], t.width[i] = int(h), int(w)
+    return int(_lib.lib().mi_roi_align_forward_tiles_workspace_bytes(
+        ctypes.byref(t), int(batch), int(aligned_height), int(aligned_width), int(sampling_ratio)))
 
 
 def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_width, spatial_scale,
@@ -193,7 +199,9 @@ class _RoIAlignFPN(Function):
         n, c = features[0].size(0), features[0].size(1)
         r = rois.size(0)
         output = torch.empty((r, c, aligned_height, aligned_width), dtype=torch.float32, device=rois.device)
-        ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+        ws_bytes = max(lib.mi_roi_align_forward_workspace_bytes(r),
+                       _tiles_workspace_bytes([(f.size(2), f.size(3)) for f in features], n, aligned_height,
+                                              aligned_width, sampling_ratio))
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=rois.device)
         table = _fpn_table(features, scales)
         layout = _common_layout(features)

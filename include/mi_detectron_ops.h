@@ -145,6 +145,13 @@ typedef struct mi_fpn_levels {
 } mi_fpn_levels;
 int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
                                int aligned_width, int layout);
+/* Scratch with which the NCHW forward (tile-centric) runs as two launches: a per-TILE pre-kernel builds the tap tables of
+ * every tile once, the pooling kernel's workgroups (one per tile and 32 channels) fetch them instead of rebuilding them
+ * per channel group.  Pass max(this, mi_roi_align_forward_workspace_bytes(num_rois)) bytes to the _ws / _fpn entry points
+ * to cover both layouts; with a smaller workspace (or none) NCHW features are pooled by ONE launch, ~1.6x slower at the
+ * config-2 shape.  Only height[] / width[] / num_levels of `levels` are read (one level for the single-map entries). */
+size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels* levels, int batch, int aligned_height,
+                                                  int aligned_width, int sampling_ratio);
 /* 1 when mi_roi_align_forward_fpn with these arguments leaves the records of its rois in the workspace (channels-last
  * maps); 0 when it does not (NCHW maps: the tile-centric forward needs none) -- the backward must then be called
  * without MI_ROI_ALIGN_RECORDS_READY and writes its own. */

@@ -25,4 +25,18 @@ def launch():
                                     0, 0, stream) == 0
 
 
-print("fwd %.2f us" % (time_kernel(launch, 200) * 1e6))
+print("fwd (one launch, no scratch) %.2f us" % (time_kernel(launch, 200) * 1e6))
+import ctypes  # noqa: E402
+
+lv = _lib.FpnLevels()
+lv.num_levels, lv.height[0], lv.width[0] = 1, h, w
+wsb = max(lib.mi_roi_align_forward_tiles_workspace_bytes(ctypes.byref(lv), 1, res, res, sr), lib.mi_roi_align_forward_workspace_bytes(r))
+ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+
+
+def launch_ws():
+    assert lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, scale, sr,
+                                       0, 0, ws.data_ptr(), wsb, stream) == 0
+
+
+print("fwd (tile descriptors, two launches, %d KB scratch) %.2f us" % (wsb // 1024, time_kernel(launch_ws, 200) * 1e6))
