@@ -181,14 +181,14 @@ __device__ __forceinline__ bool tile_test(const TileCtx& tc, int levels_count, i
 }
 
 // Scan by ONE wave in RoI order: survivors with ordinal in [win_lo, win_lo + cap) go to list[0 .. cap) (and to a second
-// copy `list2` when given); returns the number of survivors of the tile.  Eight RoIs per lane are fetched together.
+// copy `list2` when given); returns the number of survivors of the tile.  Four RoIs per lane are fetched together.
 template <int TH, int TW>
 __device__ __forceinline__ int scan_ordered(const TileCtx& tc, int levels_count, int batch, int ntiles,
                                             const float* __restrict__ rois, const int* __restrict__ levels,
                                             int num_rois, int win_lo, int cap, Cand* list, Cand* list2) {
   const int lane = threadIdx.x & 63;
   int count = 0;
-  constexpr int kPer = 8;
+  constexpr int kPer = 4;
   for (int base = 0; base < num_rois; base += 64 * kPer) {
     float rv[kPer][5];
     int rl[kPer];
@@ -251,7 +251,11 @@ __device__ __forceinline__ void build_axis(const TileCtx& tc, int axis, int batc
         myax[lane] = en;
       }
       wave_sync();
-      for (int t = lane; t < ne * S; t += 64) {
+      constexpr int kPasses = (kEB * S + 63) / 64;
+#pragma unroll 1
+      for (int pass = 0; pass < kPasses; pass++) {  // (unrolling the passes was measured: slower, 49 us against 40)
+        const int t = pass * 64 + lane;
+        if (t >= ne * S) continue;
         const int e = t / S, s = t - e * S;
         const Cand cr = mycand[b0 + e];
         const float lo_c = axis == 0 ? cr.y1 : cr.x1, hi_c = axis == 0 ? cr.y2 : cr.x2;
@@ -380,6 +384,196 @@ __device__ __forceinline__ void build_axis(const TileCtx& tc, int axis, int batc
     }
 }
 
+// ---- one batch of a tile, all waves of the workgroup: every (RoI, bin row) unit of the descriptor block `blk` is computed
+// from the image at LDS byte address img_c (this lane's channel plane) by 32 lanes = 32 channels; then the RoIs the tile
+// owns but the tables cannot describe.  kNG = 32-lane groups of the workgroup. ------------------------------------------
+template <int kSR, int kA, int TH, int TW, int kNG>
+__device__ __forceinline__ void compute_batch(const TileCtx& tc, const typename TileCfg<kSR, kA, TH, TW>::Block* blk,
+                                              unsigned img_c, const float* __restrict__ rois, float* __restrict__ out,
+                                              int channels, int c0, int ah, int aw, int sr, int ablate) {
+  using Cfg = TileCfg<kSR, kA, TH, TW>;
+  constexpr int kPitch = Cfg::kPitch, S = Cfg::S, EB = kEB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), cl = tid & 31;
+  const TabEnt* ytab = &blk->tabs[0][0][0];
+  const TabEnt* xtab = &blk->tabs[1][0][0];
+  const AxEnt* axes = &blk->axes[0][0];
+  const int ne = blk->misc[0];
+  const int bins = ah * aw;
+  const float* __restrict__ feat = tc.feat;
+  const int height = tc.height, width = tc.width;
+  const float spatial_scale = tc.scale;
+  // ---- every wave: per-RoI state in lanes 0..15, prefix of the unit counts ----
+  int e_r = 0, e_pa0 = 0, e_pw = 0, e_flags = 0, e_slow = 0, incl = 0;
+  {
+    int nun = 0;
+    if (lane < ne) {
+      const AxEnt ey = axes[lane], ex = axes[EB + lane];
+      e_flags = ey.flags | ex.flags;
+      e_r = ey.r;
+      e_pa0 = ey.pa;
+      e_pw = (ex.pa & 0xff) | (ex.pb << 8);
+      if (!(e_flags & (kEntNotFast | kEntZero))) {
+        if (ey.pb > ey.pa && ex.pb > ex.pa) nun = ey.pb - ey.pa;
+      } else if (e_flags & kEntZero) {
+        e_slow = 1;
+      } else {
+        // the tile that holds the first anchor computes the whole RoI
+        const int ly = ytab[lane * S].lo_rel, lx = xtab[lane * S].lo_rel;
+        e_slow = (ly >= 0 && ly < TH && lx >= 0 && lx < TW) ? 1 : 0;
+      }
+    }
+    incl = nun;
+#pragma unroll
+    for (int d = 1; d < EB; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+  }
+  const int nunits = __builtin_amdgcn_readlane(incl, EB - 1);
+  const unsigned long long slow_mask = __ballot(e_slow != 0);
+
+  // ---- units: 32 lanes = 32 channels per (RoI, bin row) ----
+  for (int ub = 0; ub < nunits; ub += kNG) {
+    const int u_lo = ub + 2 * wave, u_hi = u_lo + 1;  // the units of this wave's two halves
+    // the RoI of a unit = number of RoIs whose units all come before it
+    const int e_lo = __popcll(__ballot(lane < EB && incl <= u_lo)), e_hi = __popcll(__ballot(lane < EB && incl <= u_hi));
+    const int u = lane < 32 ? u_lo : u_hi;
+    const int e = min(lane < 32 ? e_lo : e_hi, EB - 1);
+    const int r = __shfl(e_r, e), pa0 = __shfl(e_pa0, e), pw = __shfl(e_pw, e);
+    const int before = __shfl(incl, max(e - 1, 0));
+    if (u < nunits) {
+      const int ph = pa0 + (u - (e > 0 ? before : 0));
+      const int pwa = pw & 0xff, pwb = pw >> 8;
+      float* __restrict__ dst = out + (((long long)r * channels + c0 + cl) * ah + ph) * aw;
+      if constexpr (kA > 0) {
+        static_assert(kSR == 2, "the unrolled path is written for 2 x 2 samples");
+        const TabEnt ya = ytab[e * S + ph * 2], yb = ytab[e * S + ph * 2 + 1];
+        const unsigned row_a = img_c + (unsigned)ya.off, row_b = img_c + (unsigned)yb.off;
+        const v2f wya = {ya.hw, ya.lw}, wyb = {yb.hw, yb.lw};
+        const TabEnt* xe = xtab + e * S;
+        float acc[kA];
+        if (ablate & 2) {
+#pragma unroll
+          for (int j = 0; j < kA; j++) acc[j] = 0.f;
+        } else {
+          // one bin at a time; the two x entries of the next bin are fetched before the taps of this one are used (one
+          // LDS latency per bin instead of two).  Bins of the row that belong to another tile cost only that fetch.
+          TabEnt xc0 = xe[0], xc1 = xe[1];
+#pragma unroll
+          for (int j = 0; j < kA; j++) {
+            const TabEnt x0e = xc0, x1e = xc1;
+            const bool mine = j >= pwa && j < pwb;
+            v2f t00, t01, t10, t11, u00, u01, u10, u11;
+            if (mine) {
+              const unsigned a0 = row_a + (unsigned)x0e.off, a1 = row_a + (unsigned)x1e.off;
+              const unsigned b0a = row_b + (unsigned)x0e.off, b1a = row_b + (unsigned)x1e.off;
+              t00 = lds_rows<kPitch, 0>(a0);
+              t01 = lds_rows<kPitch, 1>(a0);
+              t10 = lds_rows<kPitch, 0>(a1);
+              t11 = lds_rows<kPitch, 1>(a1);
+              u00 = lds_rows<kPitch, 0>(b0a);
+              u01 = lds_rows<kPitch, 1>(b0a);
+              u10 = lds_rows<kPitch, 0>(b1a);
+              u11 = lds_rows<kPitch, 1>(b1a);
+            }
+            if (j + 1 < kA) {
+              xc0 = xe[2 * j + 2];
+              xc1 = xe[2 * j + 3];
+            }
+            acc[j] = 0.f;
+            if (mine) {
+              v2f sa = t00 * x0e.hw;
+              sa = __builtin_elementwise_fma(t01, splat(x0e.lw), sa);
+              sa = __builtin_elementwise_fma(t10, splat(x1e.hw), sa);
+              sa = __builtin_elementwise_fma(t11, splat(x1e.lw), sa);
+              v2f sb = u00 * x0e.hw;
+              sb = __builtin_elementwise_fma(u01, splat(x0e.lw), sb);
+              sb = __builtin_elementwise_fma(u10, splat(x1e.hw), sb);
+              sb = __builtin_elementwise_fma(u11, splat(x1e.lw), sb);
+              v2f a2 = sa * wya;
+              a2 = __builtin_elementwise_fma(sb, wyb, a2);
+              acc[j] = a2.x + a2.y;
+            }
+          }
+        }
+        if (ablate & 4) {
+        } else if (pwa == 0 && pwb == kA) {
+          if constexpr (kA == 7) {
+            *reinterpret_cast<f4u*>(dst) = f4u{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f3u*>(dst + 4) = f3u{acc[4], acc[5], acc[6]};
+          } else if constexpr (kA == 14) {
+            *reinterpret_cast<f4u*>(dst) = f4u{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f4u*>(dst + 4) = f4u{acc[4], acc[5], acc[6], acc[7]};
+            *reinterpret_cast<f4u*>(dst + 8) = f4u{acc[8], acc[9], acc[10], acc[11]};
+            *reinterpret_cast<f2u*>(dst + 12) = f2u{acc[12], acc[13]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < kA; j++) dst[j] = acc[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < kA; j++)
+            if (j >= pwa && j < pwb) dst[j] = acc[j];
+        }
+      } else {
+        // any pooled size / sampling grid: bin by bin
+        const int gh = axes[e].g, gw = axes[EB + e].g;
+        for (int pwi = pwa; pwi < pwb; pwi++) {
+          v2f a2 = {0.f, 0.f};
+          for (int iy = 0; iy < gh; iy++) {
+            const TabEnt y = ytab[e * S + ph * gh + iy];
+            v2f sy = {0.f, 0.f};
+            for (int ix = 0; ix < gw; ix++) {
+              const TabEnt x = xtab[e * S + pwi * gw + ix];
+              const unsigned a = img_c + (unsigned)y.off + (unsigned)x.off;
+              sy = __builtin_elementwise_fma(lds_rows<kPitch, 0>(a), splat(x.hw), sy);
+              sy = __builtin_elementwise_fma(lds_rows<kPitch, 1>(a), splat(x.lw), sy);
+            }
+            a2 = __builtin_elementwise_fma(sy, (v2f){y.hw, y.lw}, a2);
+          }
+          dst[pwi] = a2.x + a2.y;
+        }
+      }
+    }
+  }
+
+  // ---- RoIs this tile owns that the tables cannot describe: reference operation order from global memory ----
+  for (unsigned long long todo = slow_mask; todo != 0ull; todo &= todo - 1ull) {
+    const int e = (int)__builtin_ctzll(todo);
+    const int r = __builtin_amdgcn_readlane(e_r, e);
+    const int fl = __builtin_amdgcn_readlane(e_flags, e);
+    float* __restrict__ dst = out + ((long long)r * channels + c0) * bins;
+    if (fl & kEntZero) {
+      for (int i = tid; i < kCt * bins; i += (kNG * 32)) dst[i] = 0.f;
+      continue;
+    }
+    const RoiGeom g = roi_geometry(rois + (long long)r * 5, spatial_scale, ah, aw, sr);
+    const float* src = feat + ((long long)g.batch_ind * channels + c0) * height * width;
+    for (int i = tid; i < kCt * bins; i += (kNG * 32)) {
+      const int c = i / bins, bin = i - c * bins;
+      const int ph = bin / aw, pw = bin - ph * aw;
+      const float* plane = src + (long long)c * height * width;
+      float output_val = 0.f;
+      for (int iy = 0; iy < g.grid_h; iy++) {
+        const float y = sample_y(g, ph, iy);
+        for (int ix = 0; ix < g.grid_w; ix++) {
+          const float x = sample_x(g, pw, ix);
+          const Taps t = sample_taps(height, width, y, x);
+          float val = 0.f;
+          if (t.y_low >= 0) {
+            const float v1 = plane[t.y_low * width + t.x_low], v2 = plane[t.y_low * width + t.x_high];
+            const float v3 = plane[t.y_high * width + t.x_low], v4 = plane[t.y_high * width + t.x_high];
+            val = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t.w1, v1), __fmul_rn(t.w2, v2)), __fmul_rn(t.w3, v3)),
+                            __fmul_rn(t.w4, v4));
+          }
+          output_val = __fadd_rn(output_val, val);
+        }
+      }
+      dst[i] = output_val / g.count;
+    }
+  }
+}
+
 // ---- roi_align_tiles_prepare: one 256-lane workgroup per TILE; leaves the descriptor blocks of the tile's first
 // kPreBlocks * kEB scan survivors (in RoI order) in the workspace ------------------------------------------------------
 constexpr int kPrepThreads = 256;
@@ -485,9 +679,7 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
   const TileCtx tc = decode_tile<TH, TW>(lv, tile_global);
   const float* __restrict__ feat = tc.feat;
   const int height = tc.height, width = tc.width, n = tc.n, x0 = tc.x0, y0 = tc.y0;
-  const float spatial_scale = tc.scale;
   const int c0 = cg * kCt;
-  const int bins = ah * aw;
   const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
   const bool pre = desc != nullptr;
 
@@ -495,9 +687,10 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
   Cand* mycand = cands + axis * kCandCap;
 
   if (!pre) {
-    // ---- fast scan: every lane tests the RoIs tid, tid + 512, ... (fetched together, BEFORE the DMA is issued: waiting
-    // for them must not wait for the image) and appends its survivors to both axis lists through an LDS counter.  The
-    // order of the list is arbitrary; it only matters when the list overflows, and then the axis waves rescan in order.
+    // ---- fast scan: every lane tests the RoIs tid, tid + 512, ... (fetched together, BEFORE the DMA is issued: issued
+    // first, the image delays the RoIs of the DMA waves -- measured 50 us against 40) and appends its survivors to both
+    // axis lists through an LDS counter.  The order of the list is arbitrary; it only matters when the list overflows,
+    // and then the axis waves rescan in order.
     if (tid == 0) {
       ctr[0] = 0;
       ctr[1] = 0;
@@ -542,13 +735,45 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) atomicAdd(&ctr[1], 1);
   }
+  if (wave >= 2) {  // after the scan: in the DMA waves the RoIs must not queue behind the image (in-order vmcnt)
+  // ---- tile image: [channel][row][kPitch] by LDS-DMA, lanes flattened over (row, column), clamped to the map:
+  // rows / columns past it repeat the last row / column, so that "upper tap = lower tap + 1" holds for a sample
+  // clamped to the border too (the reference reads the border pixel twice, weights 1 and 0) ----
+  const float* slab = feat + ((long long)n * channels + c0) * height * width;
+  const srd_t srd = make_srd(slab, (unsigned)kCt * plane_bytes);  // the range check includes the scalar offset
+  const unsigned img_lds = lds_addr_uniform(img);
+  // instruction j = (piece, channel): the six DMA waves take j = wave - 2, wave + 4, ...
+  // Interior tiles of maps with 16-byte aligned rows move 16 bytes per lane (a quarter of the requests); a tile that
+  // reaches past the last column needs the per-pixel clamp of the dword form.
+  const bool vec4 = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && x0 + kPitch <= width &&
+                    (kPitch & 3) == 0 && (TW & 3) == 0;
+  if (vec4) {
+    constexpr int kCPR = kPitch / 4, kChunks = Cfg::kRows * kCPR, kP4 = (kChunks + 63) / 64;
+    for (int k = 0; k < ((ablate & 1) ? 0 : kP4); k++) {
+      const int q = k * 64 + lane;
+      const int row = q / kCPR, j = q - row * kCPR;
+      const unsigned voff = (unsigned)(min(y0 + row, height - 1) * width + x0 + 4 * j) * 4u;
+      if (q < kChunks) {
+        for (int c = (wave - 2 + (kNWaves - 2) * 64 - k * kCt) % (kNWaves - 2); c < kCt; c += kNWaves - 2)
+          dma_dwordx4(srd, img_lds + (unsigned)(c * kPlane + k * 256) * 4u, voff, (unsigned)c * plane_bytes);
+      }
+    }
+  } else {
+    for (int k = 0; k < ((ablate & 1) ? 0 : Cfg::kPieces); k++) {
+      const int p = k * 64 + lane;
+      const int row = p / kPitch, col = p - row * kPitch;
+      const unsigned voff = (unsigned)(min(y0 + row, height - 1) * width + min(x0 + col, width - 1)) * 4u;
+      if (p < Cfg::kPx) {
+        for (int c = (wave - 2 + (kNWaves - 2) * 64 - k * kCt) % (kNWaves - 2); c < kCt; c += kNWaves - 2)
+          dma_dword(srd, img_lds + (unsigned)(c * kPlane + k * 64) * 4u, voff, (unsigned)c * plane_bytes);
+      }
+    }
+  }
+  }
   stamp(1);
 
-  const int grp = tid >> 5, cl = tid & 31;
+  const int cl = tid & 31;
   const unsigned img_c = (unsigned)(uintptr_t)(lds_cfloat_t)(img + cl * kPlane);  // LDS byte address of this lane's plane
-  const TabEnt* ytab = tabs;
-  const TabEnt* xtab = tabs + EB * S;
-  (void)grp;
 
   // Batches of <= 16 survivors.  With descriptors: blocks 0 .. kPreBlocks-1 come from the workspace; survivors past them
   // (a tile under a pile of RoIs) are scanned and built here, in RoI order, like everything without descriptors.
@@ -598,245 +823,178 @@ roi_align_fwd_tiles(const LevelTable lv, const float* __restrict__ rois, const i
       }
       if (first) stamp(3);
     } else if (first) {
-      // ---- tile image: [channel][row][kPitch] by LDS-DMA, lanes flattened over (row, column), clamped to the map:
-      // rows / columns past it repeat the last row / column, so that "upper tap = lower tap + 1" holds for a sample
-      // clamped to the border too (the reference reads the border pixel twice, weights 1 and 0) ----
-      const float* slab = feat + ((long long)n * channels + c0) * height * width;
-      const srd_t srd = make_srd(slab, (unsigned)kCt * plane_bytes);  // the range check includes the scalar offset
-      const unsigned img_lds = lds_addr_uniform(img);
-      // instruction j = (piece, channel): the six DMA waves take j = wave - 2, wave + 4, ...
-      // Interior tiles of maps with 16-byte aligned rows move 16 bytes per lane (a quarter of the requests); a tile that
-      // reaches past the last column needs the per-pixel clamp of the dword form.
-      const bool vec4 = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && x0 + kPitch <= width &&
-                        (kPitch & 3) == 0 && (TW & 3) == 0;
-      if (vec4) {
-        constexpr int kCPR = kPitch / 4, kChunks = Cfg::kRows * kCPR, kP4 = (kChunks + 63) / 64;
-        for (int k = 0; k < ((ablate & 1) ? 0 : kP4); k++) {
-          const int q = k * 64 + lane;
-          const int row = q / kCPR, j = q - row * kCPR;
-          const unsigned voff = (unsigned)(min(y0 + row, height - 1) * width + x0 + 4 * j) * 4u;
-          if (q < kChunks) {
-            for (int c = (wave - 2 + (kNWaves - 2) * 64 - k * kCt) % (kNWaves - 2); c < kCt; c += kNWaves - 2)
-              dma_dwordx4(srd, img_lds + (unsigned)(c * kPlane + k * 256) * 4u, voff, (unsigned)c * plane_bytes);
-          }
-        }
-      } else {
-        for (int k = 0; k < ((ablate & 1) ? 0 : Cfg::kPieces); k++) {
-          const int p = k * 64 + lane;
-          const int row = p / kPitch, col = p - row * kPitch;
-          const unsigned voff = (unsigned)(min(y0 + row, height - 1) * width + min(x0 + col, width - 1)) * 4u;
-          if (p < Cfg::kPx) {
-            for (int c = (wave - 2 + (kNWaves - 2) * 64 - k * kCt) % (kNWaves - 2); c < kCt; c += kNWaves - 2)
-              dma_dword(srd, img_lds + (unsigned)(c * kPlane + k * 64) * 4u, voff, (unsigned)c * plane_bytes);
-          }
-        }
-      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();  // tables built / fetched, image landed
     if (first) stamp(4);
     if (ablate & 16) break;  // tuning builds: nothing after the barrier
-    const int ne = misc[0];
     const bool more = misc[1] != 0;
     if (first && timeline != nullptr && tid == 0) timeline[(long long)blockIdx.x * 8 + 7] = misc[2];
 
-    // ---- every wave: per-RoI state in lanes 0..15, prefix of the unit counts ----
-    int e_r = 0, e_pa0 = 0, e_pw = 0, e_flags = 0, e_slow = 0, incl = 0;
-    {
-      int nun = 0;
-      if (lane < ne) {
-        const AxEnt ey = axes[lane], ex = axes[EB + lane];
-        e_flags = ey.flags | ex.flags;
-        e_r = ey.r;
-        e_pa0 = ey.pa;
-        e_pw = (ex.pa & 0xff) | (ex.pb << 8);
-        if (!(e_flags & (kEntNotFast | kEntZero))) {
-          if (ey.pb > ey.pa && ex.pb > ex.pa) nun = ey.pb - ey.pa;
-        } else if (e_flags & kEntZero) {
-          e_slow = 1;
-        } else {
-          // the tile that holds the first anchor computes the whole RoI
-          const int ly = ytab[lane * S].lo_rel, lx = xtab[lane * S].lo_rel;
-          e_slow = (ly >= 0 && ly < TH && lx >= 0 && lx < TW) ? 1 : 0;
-        }
-      }
-      incl = nun;
-#pragma unroll
-      for (int d = 1; d < EB; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-      }
-    }
-    const int nunits = __builtin_amdgcn_readlane(incl, EB - 1);
-    const unsigned long long slow_mask = __ballot(e_slow != 0);
-
-    // ---- units: 32 lanes = 32 channels per (RoI, bin row) ----
-    for (int ub = 0; ub < nunits; ub += kGroups) {
-      const int u_lo = ub + 2 * wave, u_hi = u_lo + 1;  // the units of this wave's two halves
-      // the RoI of a unit = number of RoIs whose units all come before it
-      const int e_lo = __popcll(__ballot(lane < EB && incl <= u_lo)), e_hi = __popcll(__ballot(lane < EB && incl <= u_hi));
-      const int u = lane < 32 ? u_lo : u_hi;
-      const int e = min(lane < 32 ? e_lo : e_hi, EB - 1);
-      const int r = __shfl(e_r, e), pa0 = __shfl(e_pa0, e), pw = __shfl(e_pw, e);
-      const int before = __shfl(incl, max(e - 1, 0));
-      if (u < nunits) {
-        const int ph = pa0 + (u - (e > 0 ? before : 0));
-        const int pwa = pw & 0xff, pwb = pw >> 8;
-        float* __restrict__ dst = out + (((long long)r * channels + c0 + cl) * ah + ph) * aw;
-        if constexpr (kA > 0) {
-          static_assert(kSR == 2, "the unrolled path is written for 2 x 2 samples");
-          const TabEnt ya = ytab[e * S + ph * 2], yb = ytab[e * S + ph * 2 + 1];
-          const unsigned row_a = img_c + (unsigned)ya.off, row_b = img_c + (unsigned)yb.off;
-          const v2f wya = {ya.hw, ya.lw}, wyb = {yb.hw, yb.lw};
-          const TabEnt* xe = xtab + e * S;
-          float acc[kA];
-          if (ablate & 2) {
-#pragma unroll
-            for (int j = 0; j < kA; j++) acc[j] = 0.f;
-          } else {
-            // two bins at a time; the x entries of the next pair are fetched before the taps of this pair are used, so a
-            // row costs one LDS latency per pair instead of two.  Bins of the row that belong to another tile are computed
-            // too (their table entries point into the image) and dropped by the stores.
-            constexpr int kNB = 2, kBatches = (kA + kNB - 1) / kNB;
-            int xo[2][2 * kNB];
-            float hx[2][2 * kNB], lx[2][2 * kNB];
-            const auto fetch_x = [&](int bi, int buf) {
-#pragma unroll
-              for (int q = 0; q < 2 * kNB; q++) {
-                if (bi * 2 * kNB + q < 2 * kA) {
-                  const TabEnt x = xe[bi * 2 * kNB + q];
-                  xo[buf][q] = x.off;
-                  hx[buf][q] = x.hw;
-                  lx[buf][q] = x.lw;
-                }
-              }
-            };
-            fetch_x(0, 0);
-#pragma unroll
-            for (int bi = 0; bi < kBatches; bi++) {
-              const int buf = bi & 1;
-              const int nb = kA - bi * kNB < kNB ? kA - bi * kNB : kNB;
-              const bool mine = bi * kNB < pwb && bi * kNB + nb > pwa;  // a pair with no bin of this tile costs nothing
-              v2f t[kNB][2][2][2];  // [bin][iy][ix][x tap] = {row y, row y + 1}
-#pragma unroll
-              for (int j = 0; j < kNB; j++) {
-                if (j < nb && mine) {
-#pragma unroll
-                  for (int ix = 0; ix < 2; ix++) {
-                    const unsigned aa = row_a + (unsigned)xo[buf][j * 2 + ix], ab = row_b + (unsigned)xo[buf][j * 2 + ix];
-                    t[j][0][ix][0] = lds_rows<kPitch, 0>(aa);
-                    t[j][0][ix][1] = lds_rows<kPitch, 1>(aa);
-                    t[j][1][ix][0] = lds_rows<kPitch, 0>(ab);
-                    t[j][1][ix][1] = lds_rows<kPitch, 1>(ab);
-                  }
-                }
-              }
-              if (bi + 1 < kBatches) fetch_x(bi + 1, buf ^ 1);
-#pragma unroll
-              for (int j = 0; j < kNB; j++) {
-                if (j < nb) acc[bi * kNB + j] = 0.f;
-                if (j < nb && mine) {
-                  const int q = j * 2;
-                  v2f sa = t[j][0][0][0] * hx[buf][q];
-                  sa = __builtin_elementwise_fma(t[j][0][0][1], splat(lx[buf][q]), sa);
-                  sa = __builtin_elementwise_fma(t[j][0][1][0], splat(hx[buf][q + 1]), sa);
-                  sa = __builtin_elementwise_fma(t[j][0][1][1], splat(lx[buf][q + 1]), sa);
-                  v2f sb = t[j][1][0][0] * hx[buf][q];
-                  sb = __builtin_elementwise_fma(t[j][1][0][1], splat(lx[buf][q]), sb);
-                  sb = __builtin_elementwise_fma(t[j][1][1][0], splat(hx[buf][q + 1]), sb);
-                  sb = __builtin_elementwise_fma(t[j][1][1][1], splat(lx[buf][q + 1]), sb);
-                  v2f a2 = sa * wya;
-                  a2 = __builtin_elementwise_fma(sb, wyb, a2);
-                  acc[bi * kNB + j] = a2.x + a2.y;
-                }
-              }
-            }
-          }
-          if (ablate & 4) {
-          } else if (pwa == 0 && pwb == kA) {
-            if constexpr (kA == 7) {
-              *reinterpret_cast<f4u*>(dst) = f4u{acc[0], acc[1], acc[2], acc[3]};
-              *reinterpret_cast<f3u*>(dst + 4) = f3u{acc[4], acc[5], acc[6]};
-            } else if constexpr (kA == 14) {
-              *reinterpret_cast<f4u*>(dst) = f4u{acc[0], acc[1], acc[2], acc[3]};
-              *reinterpret_cast<f4u*>(dst + 4) = f4u{acc[4], acc[5], acc[6], acc[7]};
-              *reinterpret_cast<f4u*>(dst + 8) = f4u{acc[8], acc[9], acc[10], acc[11]};
-              *reinterpret_cast<f2u*>(dst + 12) = f2u{acc[12], acc[13]};
-            } else {
-#pragma unroll
-              for (int j = 0; j < kA; j++) dst[j] = acc[j];
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < kA; j++)
-              if (j >= pwa && j < pwb) dst[j] = acc[j];
-          }
-        } else {
-          // any pooled size / sampling grid: bin by bin
-          const int gh = axes[e].g, gw = axes[EB + e].g;
-          for (int pwi = pwa; pwi < pwb; pwi++) {
-            v2f a2 = {0.f, 0.f};
-            for (int iy = 0; iy < gh; iy++) {
-              const TabEnt y = ytab[e * S + ph * gh + iy];
-              v2f sy = {0.f, 0.f};
-              for (int ix = 0; ix < gw; ix++) {
-                const TabEnt x = xtab[e * S + pwi * gw + ix];
-                const unsigned a = img_c + (unsigned)y.off + (unsigned)x.off;
-                sy = __builtin_elementwise_fma(lds_rows<kPitch, 0>(a), splat(x.hw), sy);
-                sy = __builtin_elementwise_fma(lds_rows<kPitch, 1>(a), splat(x.lw), sy);
-              }
-              a2 = __builtin_elementwise_fma(sy, (v2f){y.hw, y.lw}, a2);
-            }
-            dst[pwi] = a2.x + a2.y;
-          }
-        }
-      }
-    }
+    compute_batch<kSR, kA, TH, TW, kGroups>(tc, blk, img_c, rois, out, channels, c0, ah, aw, sr, ablate);
     if (first) stamp(5);
-
-    // ---- RoIs this tile owns that the tables cannot describe: reference operation order from global memory ----
-    for (unsigned long long todo = slow_mask; todo != 0ull; todo &= todo - 1ull) {
-      const int e = (int)__builtin_ctzll(todo);
-      const int r = __builtin_amdgcn_readlane(e_r, e);
-      const int fl = __builtin_amdgcn_readlane(e_flags, e);
-      float* __restrict__ dst = out + ((long long)r * channels + c0) * bins;
-      if (fl & kEntZero) {
-        for (int i = tid; i < kCt * bins; i += kThreads) dst[i] = 0.f;
-        continue;
-      }
-      const RoiGeom g = roi_geometry(rois + (long long)r * 5, spatial_scale, ah, aw, sr);
-      const float* src = feat + ((long long)g.batch_ind * channels + c0) * height * width;
-      for (int i = tid; i < kCt * bins; i += kThreads) {
-        const int c = i / bins, bin = i - c * bins;
-        const int ph = bin / aw, pw = bin - ph * aw;
-        const float* plane = src + (long long)c * height * width;
-        float output_val = 0.f;
-        for (int iy = 0; iy < g.grid_h; iy++) {
-          const float y = sample_y(g, ph, iy);
-          for (int ix = 0; ix < g.grid_w; ix++) {
-            const float x = sample_x(g, pw, ix);
-            const Taps t = sample_taps(height, width, y, x);
-            float val = 0.f;
-            if (t.y_low >= 0) {
-              const float v1 = plane[t.y_low * width + t.x_low], v2 = plane[t.y_low * width + t.x_high];
-              const float v3 = plane[t.y_high * width + t.x_low], v4 = plane[t.y_high * width + t.x_high];
-              val = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t.w1, v1), __fmul_rn(t.w2, v2)), __fmul_rn(t.w3, v3)),
-                              __fmul_rn(t.w4, v4));
-            }
-            output_val = __fadd_rn(output_val, val);
-          }
-        }
-        dst[i] = output_val / g.count;
-      }
-    }
     if (!more) break;
     __syncthreads();  // tables and entries are reused by the next batch
   }
   stamp(6);
 }
 
-constexpr int kTH = 12, kTW = 28;
+// ---- roi_align_fwd_tiles_stream: the pooling kernel of the workspace path as a persistent, double-buffered pipeline.
+// A 78 KB tile image lets only two 512-lane workgroups share a CU, and their phases (fetch, barrier, compute) cannot fill
+// each other's gaps: no unit is more than half busy.  Here ONE 1024-lane workgroup per CU walks its items = (tile, channel
+// group), channel group = blockIdx % ncg (one XCD's L2 keeps seeing the same channel slabs): while item k is computed out
+// of one LDS image + descriptor block, all waves have the DMA of item k + 1 (image and block) in flight into the other;
+// one barrier per item.  Descriptor blocks come from roi_align_tiles_prepare. -------------------------------------------
 long long* g_tiles_timeline = nullptr;
+constexpr int kStreamThreads = 1024;
+constexpr int kStreamCandCap = 16;
+template <int kSR, int kA, int TH, int TW>
+__global__ void __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+roi_align_fwd_tiles_stream(const LevelTable lv, const float* __restrict__ rois, const int* __restrict__ levels,
+                           float* __restrict__ out, int num_rois, int batch, int channels, int ah_arg, int aw_arg,
+                           int sr_arg, int ntiles, const unsigned char* __restrict__ desc, int ablate_arg,
+                           long long* __restrict__ timeline) {
+  const int ablate = MI_ABLATE(ablate_arg);
+  // tuning aid (tools/timeline_tiles.py STREAM=1): clock stamps of lane 0 around the workgroup's THIRD item
+  int item_no = 0;
+  const auto stamp = [&](int k) {
+    if (timeline != nullptr && threadIdx.x == 0 && item_no == 2) timeline[(long long)blockIdx.x * 8 + k] = (long long)clock64();
+  };
+  using Cfg = TileCfg<kSR, kA, TH, TW>;
+  using Block = typename Cfg::Block;
+  constexpr int kPitch = Cfg::kPitch, kPlane = Cfg::kPlane, EB = kEB;
+  constexpr int kNW = kStreamThreads / 64, kNG = kStreamThreads / 32;
+  constexpr int kCap = kStreamCandCap;  // survivors per pass of the fallback scan
+  const int ah = kA > 0 ? kA : ah_arg, aw = kA > 0 ? kA : aw_arg;
+  const int sr = kSR > 0 ? kSR : sr_arg;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [image 0][image 1][block 0][block 1][survivor lists of the in-kernel fallback]
+  float* img0 = reinterpret_cast<float*>(smem);
+  Block* blk0 = reinterpret_cast<Block*>(smem + 2 * Cfg::kImgBytes);
+  Cand* cands = reinterpret_cast<Cand*>(smem + 2 * Cfg::kImgBytes + 2 * sizeof(Block));  // [axis][kCap]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), cl = tid & 31;
+  const int ncg = channels / kCt;
+  const int cg = (int)blockIdx.x % ncg;
+  const int tile_first = (int)blockIdx.x / ncg, tile_step = (int)gridDim.x / ncg;
+  const int c0 = cg * kCt;
+
+  // all waves: the DMA of one item into buffer `buf`: instruction j = (piece, channel) of the image for j = wave, wave + 16,
+  // ..., and the 1 KB pieces of the descriptor block
+  const auto issue = [&](int tile_global, int buf) {
+    const TileCtx tc = decode_tile<TH, TW>(lv, tile_global);
+    const int height = tc.height, width = tc.width;
+    const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
+    const float* slab = tc.feat + ((long long)tc.n * channels + c0) * height * width;
+    const srd_t srd = make_srd(slab, (unsigned)kCt * plane_bytes);  // the range check includes the scalar offset
+    const unsigned img_lds = lds_addr_uniform(img0) + (unsigned)buf * (unsigned)Cfg::kImgBytes;
+    // Interior tiles of maps with 16-byte aligned rows move 16 bytes per lane (a quarter of the requests); a tile that
+    // reaches past the last column needs the per-pixel clamp of the dword form.  Rows / columns past the map repeat the
+    // last row / column: "upper tap = lower tap + 1" then also holds for a sample clamped to the border.
+    const bool vec4 = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && tc.x0 + kPitch <= width &&
+                      (kPitch & 3) == 0 && (TW & 3) == 0;
+    if (ablate & 1) {
+    } else if (vec4) {
+      constexpr int kCPR = kPitch / 4, kChunks = Cfg::kRows * kCPR, kP4 = (kChunks + 63) / 64;
+#pragma unroll
+      for (int k = 0; k < kP4; k++) {
+        const int q = k * 64 + lane;
+        const int row = q / kCPR, j = q - row * kCPR;
+        const unsigned voff = (unsigned)(min(tc.y0 + row, height - 1) * width + tc.x0 + 4 * j) * 4u;
+        if (q < kChunks) {
+          for (int c = (wave + kNW * 64 - k * kCt) % kNW; c < kCt; c += kNW)
+            dma_dwordx4(srd, img_lds + (unsigned)(c * kPlane + k * 256) * 4u, voff, (unsigned)c * plane_bytes);
+        }
+      }
+    } else {
+      for (int k = 0; k < Cfg::kPieces; k++) {
+        const int p = k * 64 + lane;
+        const int row = p / kPitch, col = p - row * kPitch;
+        const unsigned voff = (unsigned)(min(tc.y0 + row, height - 1) * width + min(tc.x0 + col, width - 1)) * 4u;
+        if (p < Cfg::kPx) {
+          for (int c = (wave + kNW * 64 - k * kCt) % kNW; c < kCt; c += kNW)
+            dma_dword(srd, img_lds + (unsigned)(c * kPlane + k * 64) * 4u, voff, (unsigned)c * plane_bytes);
+        }
+      }
+    }
+    const unsigned char* src = desc + (size_t)tile_global * kPreBlocks * sizeof(Block);
+    const srd_t bsrd = make_srd(src, (unsigned)sizeof(Block));
+    const unsigned dst_lds = lds_addr_uniform(blk0) + (unsigned)buf * (unsigned)sizeof(Block);
+    for (int k = wave; k * 1024 < (int)sizeof(Block); k += kNW)
+      if (k * 1024 + lane * 16 < (int)sizeof(Block))
+        dma_dwordx4(bsrd, dst_lds + (unsigned)k * 1024u, (unsigned)(k * 1024 + lane * 16), 0u);
+  };
+
+  if (tile_first >= ntiles) return;
+  issue(tile_first, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tile_first + tile_step < ntiles) issue(tile_first + tile_step, 1);
+  int buf = 0, tile_global = tile_first;
+  TileCtx tc = decode_tile<TH, TW>(lv, tile_global);
+  // state of a tile with more than 16 scan survivors (waves 0 and 1 use the last three)
+  const int axis = wave & 1;
+  Cand* mycand = cands + axis * kCap;
+  int nblk = 1, win_lo = kPreBlocks * EB - kCap, b0 = 0, ncand = 0;
+  for (;;) {  // one iteration per batch of <= 16 RoIs; all but a few tiles have one batch
+    Block* blk = blk0 + buf;
+    const unsigned img_c = (unsigned)(uintptr_t)(lds_cfloat_t)(img0 + (size_t)buf * (Cfg::kImgBytes / 4) + cl * kPlane);
+    stamp(1);
+    compute_batch<kSR, kA, TH, TW, kNG>(tc, blk, img_c, rois, out, channels, c0, ah, aw, sr, ablate);
+    stamp(2);
+    if (timeline != nullptr && tid == 0 && item_no == 2) timeline[(long long)blockIdx.x * 8 + 7] = blk->misc[2];
+    if (blk->misc[1] != 0) {
+      // ---- further batches of this tile (the second one precomputed, the rest built here in RoI order by waves 0 and 1,
+      // as in roi_align_fwd_tiles) go through the same LDS block, synchronously ----
+      const int total = blk->misc[2];
+      __syncthreads();  // everybody is done with the block
+      if (nblk < kPreBlocks) {
+        if (wave == 0) {
+          const unsigned char* src = desc + ((size_t)tile_global * kPreBlocks + nblk) * sizeof(Block);
+          const srd_t bsrd = make_srd(src, (unsigned)sizeof(Block));
+          const unsigned dst_lds = lds_addr_uniform(blk);
+          for (int k = 0; k * 1024 < (int)sizeof(Block); k++)
+            if (k * 1024 + lane * 16 < (int)sizeof(Block))
+              dma_dwordx4(bsrd, dst_lds + (unsigned)k * 1024u, (unsigned)(k * 1024 + lane * 16), 0u);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        nblk++;
+      } else if (wave < 2) {
+        b0 += EB;
+        if (b0 >= ncand) {
+          win_lo += kCap;
+          scan_ordered<TH, TW>(tc, lv.count, batch, ntiles, rois, levels, num_rois, win_lo, kCap, mycand, nullptr);
+          ncand = min(total - win_lo, kCap);
+          b0 = 0;
+        }
+        const int ne = min(EB, ncand - b0);
+        build_axis<kSR, kA, TH, TW>(tc, axis, batch, ah, aw, sr, mycand, blk->axes[axis], &blk->tabs[axis][0][0], b0, ne);
+        if (tid == 0) {
+          blk->misc[0] = ne;
+          blk->misc[1] = (b0 + EB < ncand || win_lo + kCap < total) ? 1 : 0;
+          blk->misc[2] = total;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    // ---- next item ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // it has landed
+    stamp(3);
+    __syncthreads();                                  // and everybody is done with this one
+    stamp(4);
+    item_no++;
+    stamp(0);
+    tile_global += tile_step;
+    if (tile_global >= ntiles) break;
+    buf ^= 1;
+    tc = decode_tile<TH, TW>(lv, tile_global);
+    nblk = 1, win_lo = kPreBlocks * EB - kCap, b0 = 0, ncand = 0;
+    if (tile_global + tile_step < ntiles) issue(tile_global + tile_step, buf ^ 1);
+  }
+}
+
+constexpr int kTH = 12, kTW = 28;
 
 template <int kSR, int kA>
 int launch_one(const LevelTable& lv, const float* rois, const int* levels, float* out, int num_rois, int batch,
@@ -852,6 +1010,23 @@ int launch_one(const LevelTable& lv, const float* rois, const int* levels, float
         lv, rois, levels, num_rois, batch, ah, aw, sr, ntiles, desc);
     const int rc = check_launch("roi_align_tiles_prepare");
     if (rc != MI_OK) return rc;
+  }
+  constexpr size_t kStreamLds =
+      2 * Cfg::kImgBytes + 2 * sizeof(typename Cfg::Block) + 2 * kStreamCandCap * sizeof(Cand);
+  if constexpr (kStreamLds <= 160 * 1024) {  // two images and two blocks must fit one CU
+    if (desc != nullptr && !tuning().tiles_no_stream) {
+      static const bool attr2 = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_tiles_stream<kSR, kA, kTH, kTW>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStreamLds) == hipSuccess;
+      }();
+      (void)attr2;
+      // one workgroup per CU (256), a whole number of tiles per pass so that blockIdx % ncg is the channel group
+      const int ncg = channels / kCt;
+      const int tiles_per_pass = ncg >= 256 ? 1 : (256 / ncg < ntiles ? 256 / ncg : ntiles);
+      roi_align_fwd_tiles_stream<kSR, kA, kTH, kTW><<<tiles_per_pass * ncg, kStreamThreads, kStreamLds, stream>>>(
+          lv, rois, levels, out, num_rois, batch, channels, ah, aw, sr, ntiles, desc, tuning().ablate, g_tiles_timeline);
+      return check_launch("roi_align_fwd_tiles_stream");
+    }
   }
   roi_align_fwd_tiles<kSR, kA, kTH, kTW><<<ntiles * (channels / kCt), kThreads, Cfg::kLdsBytes, stream>>>(
       lv, rois, levels, out, num_rois, batch, channels, ah, aw, sr, ntiles, desc, g_tiles_timeline, tuning().ablate);

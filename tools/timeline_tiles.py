@@ -59,6 +59,8 @@ for k in (1, 2, 3, 5):  # stamps a path does not take: carry the previous one
     z = t[:, k] == 0
     t[z, k] = t[z, k - 1]
 names = ["scan (all waves)", "spin + tables", "tail of build", "barrier (image landed)", "units (batch 0)", "rest (slow, more batches)"]
+if os.environ.get("STREAM"):  # persistent kernel: stamps around the third item of every workgroup
+    names = ["decode + issue of next item", "compute", "wait for next item's DMA", "barrier", "-", "-"]
 tb = t[busy]
 tb = t
 for k in range(6):
