@@ -262,8 +262,8 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
     return mi::check_launch("roi_align_legacy_fwd");
   }
   const int cap = ring_words();
-  // NCHW: the tile-centric kernel -- one launch, no scratch, no records (roi_align_fwd_tiles.hip)
-  if (layout == MI_LAYOUT_NCHW && !force_direct() && !mi::tuning().use_records &&
+  // NCHW, MI_ROI_ALIGN_IMPL=tiles: the tile-centric kernels (roi_align_fwd_tiles.hip), no records
+  if (layout == MI_LAYOUT_NCHW && !force_direct() && mi::tuning().use_tiles &&
       mi::roi_align_fwd_tiles_supported(channels, height, width, aligned_height, aligned_width))  // any workspace size
     return mi::launch_roi_align_fwd_tiles(features, rois, output, batch, channels, height, width, num_rois,
                                           aligned_height, aligned_width, spatial_scale, sampling_ratio, workspace,
@@ -413,7 +413,7 @@ bool to_level_table(const mi_fpn_levels* in, int batch, bool forward, mi::LevelT
 namespace {
 // NCHW maps go through the tile-centric forward, which leaves no records in the workspace
 bool fpn_forward_uses_tiles(const mi::LevelTable& lv, int channels, int aligned_height, int aligned_width, int layout) {
-  if (layout != MI_LAYOUT_NCHW || force_direct() || mi::tuning().use_records) return false;
+  if (layout != MI_LAYOUT_NCHW || force_direct() || !mi::tuning().use_tiles) return false;
   for (int l = 0; l < lv.count; l++)
     if (!mi::roi_align_fwd_tiles_supported(channels, lv.height[l], lv.width[l], aligned_height, aligned_width))
       return false;
@@ -425,7 +425,7 @@ extern "C" size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels
                                                              int aligned_width, int sampling_ratio) {
   mi::LevelTable lv;
   if (batch <= 0 || aligned_height <= 0 || aligned_width <= 0 || levels == nullptr || levels->num_levels < 1 ||
-      levels->num_levels > mi::kMaxLevels)
+      levels->num_levels > mi::kMaxLevels || !mi::tuning().use_tiles)
     return 0;
   lv = {};
   lv.count = levels->num_levels;
@@ -532,7 +532,7 @@ extern "C" int mi_roi_align_forward_writes_records(int channels, int height, int
                                                    int aligned_height, int aligned_width, int variant, int layout) {
   if (variant != MI_ROI_ALIGN_CAFFE2 || force_direct() || no_ws() || num_rois <= 0)
     return 0;
-  if (layout == MI_LAYOUT_NCHW && !mi::tuning().use_records &&
+  if (layout == MI_LAYOUT_NCHW && mi::tuning().use_tiles &&
       mi::roi_align_fwd_tiles_supported(channels, height, width, aligned_height, aligned_width))
     return 0;  // the tile-centric forward needs no records; the backward writes its own
   if (layout == MI_LAYOUT_NCHW)

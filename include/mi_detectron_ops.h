@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 /* 2: round-2/3 entry points (top-k, segmented NMS, RPN collect, affine, result formats, FPN-fused RoIAlign), RoIs of a
- * non-existent image pool zeros, tile-centric NCHW forward (no records). */
+ * non-existent image pool zeros, opt-in tile-centric NCHW forward (roi_align_fwd_tiles, no records). */
 #define MI_ABI_VERSION 2
 
 typedef void* mi_stream_t; /* hipStream_t */
@@ -80,10 +80,9 @@ int mi_roi_align_forward(const float* features, const float* rois, float* output
                          int aligned_height, int aligned_width, float spatial_scale,
                          int sampling_ratio, int variant, int layout, mi_stream_t stream);
 
-/* Same operation with caller-provided device scratch.  NCHW features are pooled by the tile-centric kernel
- * (roi_align_fwd_tiles: one launch, the scratch is not touched -- mi_roi_align_forward_writes_records() == 0); on
- * channels-last features (roi_align_fwd_nhwc) a first launch condenses each RoI into a record in `workspace` (tap
- * tables) at its rank along a sweep of the image, a second launch consumes the records.
+/* Same operation with caller-provided device scratch (the fast paths: roi_align_fwd_records on NCHW features,
+ * roi_align_fwd_nhwc on channels-last ones): a first launch condenses each RoI into a record in `workspace` (window,
+ * tap tables, LDS stages) at its rank along a sweep of the image, a second launch consumes the records.
  * `workspace` must hold mi_roi_align_forward_workspace_bytes(num_rois) bytes, 16-byte aligned; its contents are
  * scratch (no initialisation needed, overwritten by every call; two calls that may run concurrently on different
  * streams need distinct workspaces).  workspace == NULL behaves exactly like mi_roi_align_forward. */
@@ -145,11 +144,11 @@ typedef struct mi_fpn_levels {
 } mi_fpn_levels;
 int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
                                int aligned_width, int layout);
-/* Scratch with which the NCHW forward (tile-centric) runs as two launches: a per-TILE pre-kernel builds the tap tables of
- * every tile once, the pooling kernel's workgroups (one per tile and 32 channels) fetch them instead of rebuilding them
- * per channel group.  Pass max(this, mi_roi_align_forward_workspace_bytes(num_rois)) bytes to the _ws / _fpn entry points
- * to cover both layouts; with a smaller workspace (or none) NCHW features are pooled by ONE launch, ~1.6x slower at the
- * config-2 shape.  Only height[] / width[] / num_levels of `levels` are read (one level for the single-map entries). */
+/* Scratch of the tile-centric NCHW forward (opt-in: MI_ROI_ALIGN_IMPL=tiles; 0 when it is not in use): with it a per-TILE
+ * pre-kernel builds the tap tables of every tile once and the pooling workgroups (one per tile and 32 channels) fetch them;
+ * without it every workgroup builds the tables of its tile itself (one launch).  Pass max(this,
+ * mi_roi_align_forward_workspace_bytes(num_rois)) bytes to the _ws / _fpn entry points.  Only height[] / width[] /
+ * num_levels of `levels` are read (one level for the single-map entries). */
 size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels* levels, int batch, int aligned_height,
                                                   int aligned_width, int sampling_ratio);
 /* 1 when mi_roi_align_forward_fpn with these arguments leaves the records of its rois in the workspace (channels-last

@@ -69,19 +69,19 @@ def tuning_env(monkeypatch):
     _lib.lib().mi_dbg_reload_tuning()
 
 
-@pytest.fixture(params=["stream", "records", "direct"])
+@pytest.fixture(params=["stream", "tiles", "direct"])
 def roi_align_impl(request, tuning_env):
     """Run a test against the RoIAlign implementations behind mi_roi_align_*: the default fast paths ("stream": the
-    tile-centric NCHW forward, the record-driven channels-last forward and backward), the per-RoI record forward
-    (MI_ROI_ALIGN_IMPL=records) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
+    record-driven forward and backward), the tile-centric NCHW forward (MI_ROI_ALIGN_IMPL=tiles: one launch without
+    scratch, pre-kernel + persistent kernel with it) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
     tuning_env(MI_ROI_ALIGN_IMPL=None if request.param == "stream" else request.param)
     return request.param
 
 
 def _fwd_is_exact(impl, channels):
     """The direct kernels keep the reference's operation order; the fast paths (FMA, separable) decline channel counts
-    that are no multiple of their channel tile and fall back to them."""
-    return impl == "direct" or channels % (16 if impl == "stream" else 32) != 0
+    that are no multiple of their 32-channel tile and fall back to them."""
+    return impl == "direct" or channels % 32 != 0
 
 
 def test_extension_is_loaded_not_a_fallback(hip_lib_path):
@@ -204,6 +204,64 @@ def test_roi_align_config2_full_shape(oracle_mod, roi_align_impl):
     assert abs(float(grad.sum()) - float(gtop.astype(np.float64).sum())) < 1e-2 * np.abs(gtop).sum() ** 0.5
     out2, _ = _roi_align_gpu(2.0 * feat, rois, 7, 0.25, 2)
     assert torch.equal(out2, 2.0 * out.detach())
+
+
+@pytest.mark.parametrize("variant", ["one_launch", "descriptors", "descriptors_no_stream"])
+@pytest.mark.parametrize("case", ["adversarial", "piled", "nonfinite", "fpn", "sr0"])
+def test_roi_align_tile_kernels(oracle_mod, tuning_env, variant, case):
+    """The tile-centric NCHW forward (MI_ROI_ALIGN_IMPL=tiles) in its three forms -- every workgroup builds its own tables
+    (no scratch); per-tile pre-kernel + persistent double-buffered kernel; pre-kernel + one workgroup per (tile, channel
+    group) -- on inputs that reach every branch: RoIs the tables cannot describe (owner tile, reference-order path), a
+    tile under a pile of 300 RoIs (descriptor blocks, then in-kernel batches in RoI order), non-finite features at the
+    borders (a clamped sample reads the border pixel twice, as the reference), an FPN pyramid in one call, an adaptive
+    sampling grid (generic kernel)."""
+    from detectron_pytorch_amd.roi_align import roi_align_forward, roi_align_fpn
+
+    tuning_env(MI_ROI_ALIGN_IMPL="tiles", MI_ROI_ALIGN_NO_WS="1" if variant == "one_launch" else None,
+               MI_ROI_ALIGN_TILES_NO_STREAM="1" if variant == "descriptors_no_stream" else None)
+    if case == "fpn":
+        if variant == "one_launch":
+            pytest.skip("the fused FPN entry points need a workspace (records of the backward)")
+        frois, flv = syn.rois_fpn_distributed(400, batch=2, seed=5)
+        maps = [syn.feature_map(2, 64, syn.FPN_LEVELS[l][0], syn.FPN_LEVELS[l][1], seed=l) for l in (5, 4, 3, 2)]
+        scales = [syn.FPN_LEVELS[l][2] for l in (5, 4, 3, 2)]
+        idx = np.array([(5, 4, 3, 2).index(int(l)) for l in flv], dtype=np.int32)
+        out = roi_align_fpn([to_dev(m) for m in maps], scales, to_dev(frois), to_dev(idx), 7, 7, 2).cpu().numpy()
+        for li in range(4):
+            sel = np.nonzero(idx == li)[0]
+            ref = oracle_mod.roi_align_forward(maps[li], frois[sel], 7, 7, scales[li], 2, threads=8)
+            assert np.abs(out[sel] - ref).max() <= FAST_ATOL
+        return
+    n, c, h, w, scale, res, sr = 2, 64, 50, 84, 1.0 / 16, 7, 2
+    feat = syn.feature_map(n, c, h, w, seed=3)
+    if case == "adversarial":
+        rois = syn.rois_adversarial(96, n, h, w, scale, seed=9)
+    elif case == "piled":
+        rois = syn.rois_canonical(300, n, seed=4, side=(32.0, 200.0))
+        rois[:, 0] = 1.0
+        rois[:, 1:] = rois[:1, 1:] + np.random.RandomState(0).uniform(-20, 20, (300, 4)).astype(np.float32)
+    elif case == "nonfinite":
+        rois = syn.rois_adversarial(64, n, h, w, scale, seed=11)
+        feat[:, :, -1, :] = np.inf
+        feat[:, :, :, -1] = -np.inf
+        feat[:, :, 0, 0] = np.nan
+        feat[:, :, -2, 5] = np.inf   # second-to-last row: must NOT leak into bins clamped to the last row
+        feat[:, :, 7, -2] = np.nan
+    else:
+        rois = syn.rois_adversarial(80, n, h, w, scale, seed=13)
+        res, sr = 6, 0
+    ref = oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=8)
+    if case == "adversarial":  # RoIs of no image (padding rows of the training path) pool zeros
+        rois[5, 0], rois[6, 0] = -1.0, 7.0
+        ref[5:7] = 0.0
+    out = roi_align_forward(to_dev(feat), to_dev(rois), res, res, scale, sr).cpu().numpy()
+    if case == "nonfinite":
+        assert np.array_equal(np.isnan(out), np.isnan(ref)) and np.array_equal(np.isinf(out), np.isinf(ref))
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.sign(out[~fin & ~np.isnan(ref)]), np.sign(ref[~fin & ~np.isnan(ref)]))
+        assert np.abs(out[fin] - ref[fin]).max() <= FAST_ATOL
+    else:
+        assert np.abs(out - ref).max() <= FAST_ATOL
 
 
 def test_roi_align_mask_head_shape_and_multi_image(oracle_mod, roi_align_impl):
