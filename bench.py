@@ -681,7 +681,10 @@ def main():
     else:
         work.eager_step()
     first_loss = float(work.step())
+    work.reducer.measure_exposed = work.reducer.active and work.mode == "eager"
     elapsed = timed_loop(work.step, args.steps, args.warmup, world, device)
+    work.reducer.measure_exposed = False
+    exposed_ms = work.reducer.exposed_ms()
     last_loss = float(work.last)
     ms_per_step = elapsed / args.steps * 1e3
     value = IMAGES_PER_RANK * world * args.steps / elapsed
@@ -702,6 +705,17 @@ def main():
                        "loss_first": round(first_loss, 4), "loss_last": round(last_loss, 4)},
         }
         if comm is not None:
+            # everything needed to read a scaling curve from this record alone: the group the collectives really ran in,
+            # the exchange by itself (all buckets back to back) and how much of it the backward did not hide
+            import torch.distributed as dist
+
+            comm["rccl_world"] = dist.get_world_size()
+            comm["backend"] = dist.get_backend()
+            comm["average_in_collective"] = bool(getattr(work.reducer, "_avg_in_collective", False))
+            comm["bucket_bytes"] = [int(flat.numel() * 4) for flat, _ in work.reducer.buckets]
+            comm["exposed_ms_per_step"] = None if exposed_ms is None else round(exposed_ms, 3)
+            comm["overlapped_fraction"] = (None if exposed_ms is None or comm["ms"] <= 0
+                                           else round(max(0.0, 1.0 - exposed_ms / comm["ms"]), 3))
             line["allreduce"] = comm
         if not args.no_extras and world == 1:
             line["roofline"] = hp.roofline_roi_align_forward(device, args.kernel_iters)

@@ -49,46 +49,6 @@ def shard_rois_by_image(rois, num_images, rank=None, world_size=None):
     return local, keep
 
 
-def allreduce_gradients(params, bucket_bytes=BUCKET_BYTES, average=True, group=None):
-    """Average (or sum) the .grad of `params` over all ranks with as few collectives as possible: gradients are packed
-    into flat fp32 buckets of up to `bucket_bytes`, each bucket is one all-reduce, then unpacked in place.
-    Parameters whose grad is None on this rank contribute zeros (every rank must call with the same list)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return 0
-    params = [p for p in params if p.requires_grad]
-    n_coll = 0
-    bucket, size = [], 0
-
-    def flush():
-        nonlocal bucket, size, n_coll
-        if not bucket:
-            return
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            flat /= dist.get_world_size(group)
-        off = 0
-        for p in bucket:
-            n = p.numel()
-            g = flat[off:off + n].view_as(p).to(p.dtype)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
-        n_coll += 1
-        bucket, size = [], 0
-
-    for p in params:
-        nbytes = p.numel() * 4
-        if bucket and size + nbytes > bucket_bytes:
-            flush()
-        bucket.append(p)
-        size += nbytes
-    flush()
-    return n_coll
-
-
 class GradientAllReducer(object):
     """The gradient exchange of a data-parallel step, overlapped with the backward that produces the gradients
     (replaces `Broadcast.backward -> ReduceAddCoalesced` to GPU 0, nn/parallel/_functions.py:26-39).
@@ -97,9 +57,11 @@ class GradientAllReducer(object):
     backbone last), into a few large flat fp32 buckets; every `p.grad` is a VIEW into its bucket, so autograd accumulates
     straight into the communication buffer -- no pack / unpack passes over the 176.5 MB payload of e2e_mask_rcnn_R-50-FPN.
     A post-accumulate hook counts a bucket's gradients down; the last one issues the bucket's asynchronous all-reduce
-    (RCCL runs it on its own stream while the rest of the backward continues on the compute stream).  `finish_step()`
-    waits for the handles and turns sums into means (the reference's loss is a mean over GPUs,
-    utils/training_stats.py:84).
+    (RCCL runs it on its own stream while the rest of the backward continues on the compute stream).  The reference's loss
+    is a mean over GPUs (utils/training_stats.py:84): on RCCL the collective itself averages (`ReduceOp.AVG`, no extra pass
+    over the payload); backends without AVG (gloo, the CPU tests) sum and `finish_step()` divides.  A parameter that got
+    no gradient on ANY rank this step leaves finish_step() with `.grad = None`, as in the reference (SGD then skips its
+    weight decay and momentum).
 
     Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring step moves bucket/W bytes per link, so few
     large buckets amortise the per-collective latency; 4 buckets of <= 64 MB still leave 3/4 of the payload overlappable.
@@ -109,11 +71,16 @@ class GradientAllReducer(object):
     (use `optimizer.zero_grad(set_to_none=False)` or none at all: begin_step() zero-fills the buckets and re-attaches the
     views)."""
 
-    def __init__(self, params, bucket_bytes=BUCKET_BYTES, group=None, force=False, overlap=True):
+    def __init__(self, params, bucket_bytes=BUCKET_BYTES, group=None, force=False, overlap=True, detect_unused=False):
         """`overlap=False`: the hooks only count; every bucket is reduced in finish_step() (the mode a hipGraph-captured
-        backward needs: collectives stay outside the captured region -- see reduce_now())."""
+        backward needs: collectives stay outside the captured region -- see reduce_now()).
+        `detect_unused=True`: one more (tiny) all-reduce per step tells every rank which parameters received no gradient
+        on ANY rank; their `.grad` is None after finish_step(), as in the reference.  Off by default: in the shipped graphs
+        every trainable parameter gets a gradient, and without the flag exchange such a parameter simply keeps an all-zero
+        averaged gradient (SGD then still applies weight decay / momentum to it -- the one deviation)."""
         self.group = group
         self.overlap = overlap
+        self.detect_unused = detect_unused
         self.params = [p for p in params if p.requires_grad]
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
@@ -121,8 +88,13 @@ class GradientAllReducer(object):
         self.payload_bytes = sum(p.numel() for p in self.params) * 4
         self._handles = []
         self._hooks = []
+        self.measure_exposed = False  # bench.py: time the compute stream's stall in finish_step() with events
+        self._exposed_events = []
         if not self.active:
             return
+        backend = dist.get_backend(group)
+        self._avg_in_collective = backend == "nccl" and hasattr(dist.ReduceOp, "AVG")
+        self._op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
         order = list(reversed(self.params))
         cur, size = [], 0
         groups = []
@@ -146,25 +118,42 @@ class GradientAllReducer(object):
                 off += p.numel()
             self.buckets.append((flat, slots))
         self._pending = [0] * len(self.buckets)
+        self._next = 0          # first bucket not yet handed to the backend this step
+        # one flag per parameter: "a gradient arrived on this rank this step"; reduced (max) with the buckets so that every
+        # rank knows which parameters got no gradient anywhere
+        self._index = {}
         for b, (_, slots) in enumerate(self.buckets):
             for p, _ in slots:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+                self._index[id(p)] = len(self._index)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b, self._index[id(p)])))
+        self._fired_host = [False] * len(self._index)
 
-    def _make_hook(self, b):
+    def _make_hook(self, b, k):
         def hook(_param):
+            self._fired_host[k] = True
             self._pending[b] -= 1
             if self._pending[b] == 0 and self.overlap:
-                self._launch(b)
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Buckets are reduced strictly in bucket order on every rank: a bucket that is complete waits for its
+        predecessors.  (A rank on which a parameter got no gradient never completes that bucket from its hooks; launching
+        whatever is ready would then pair different buckets across ranks -- found by the two-rank test.)"""
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, b):
         flat = self.buckets[b][0]
-        self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._handles.append(dist.all_reduce(flat, op=self._op, group=self.group, async_op=True))
 
     def begin_step(self):
         if not self.active:
             return
         self._handles = []
+        self._next = 0
+        self._fired_host = [False] * len(self._index)
         for b, (flat, slots) in enumerate(self.buckets):
             flat.zero_()
             self._pending[b] = len(slots)
@@ -176,15 +165,15 @@ class GradientAllReducer(object):
         hipGraph launch, no hook ran).  Returns the number of collectives."""
         if not self.active:
             return 0
-        handles = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                   for flat, _ in self.buckets]
+        handles = [dist.all_reduce(flat, op=self._op, group=self.group, async_op=True) for flat, _ in self.buckets]
         for h in handles:
             h.wait()
         return len(handles)
 
     def average_(self):
-        """Sums -> means, in place (captured into the optimizer graph in replay mode)."""
-        if self.active and self.world > 1:
+        """Sums -> means, in place (captured into the optimizer graph in replay mode); nothing to do when the collective
+        averaged."""
+        if self.active and self.world > 1 and not self._avg_in_collective:
             for flat, _ in self.buckets:
                 flat.div_(self.world)
 
@@ -193,16 +182,42 @@ class GradientAllReducer(object):
         reduced now, so that all ranks issue the same collectives) and average.  Returns the number of collectives."""
         if not self.active:
             return 0
-        for b in range(len(self.buckets)):
-            if self._pending[b] > 0 or not self.overlap:
-                self._pending[b] = 0
-                self._launch(b)
+        for b in range(self._next, len(self.buckets)):  # what the hooks did not launch, in bucket order
+            self._pending[b] = 0
+            self._launch(b)
+        self._next = len(self.buckets)
+        timed = self.measure_exposed and self.buckets[0][0].is_cuda
+        if timed:  # between the two events the compute stream does nothing but wait for the collectives
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for h in self._handles:
             h.wait()
-        if self.world > 1:
+        if timed:
+            ev1.record()
+            self._exposed_events.append((ev0, ev1))
+        if self.world > 1 and not self._avg_in_collective:
             for flat, _ in self.buckets:
                 flat.div_(self.world)
+        if self.detect_unused:
+            # every rank issues this collective: agree on the parameters that got no gradient on any rank
+            flags = torch.tensor([1.0 if f else 0.0 for f in self._fired_host], device=self.buckets[0][0].device)
+            if self.world > 1:
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+            dead = set(k for k, v in enumerate(flags.tolist()) if v == 0.0)
+            for p in self.params:
+                if self._index[id(p)] in dead:
+                    p.grad = None
         return len(self._handles)
+
+    def exposed_ms(self):
+        """Mean time per step the compute stream waited for the gradient exchange (communication the backward did not
+        hide), over the steps recorded while `measure_exposed` was set; None without records.  Synchronises."""
+        if not self._exposed_events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._exposed_events]
+        self._exposed_events = []
+        return sum(ms) / len(ms)
 
     def close(self):
         for h in self._hooks:

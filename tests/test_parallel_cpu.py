@@ -1,8 +1,13 @@
 """Multi-process CPU tests (gloo, world_size 2) of the data-parallel plumbing (detectron_pytorch_amd/parallel.py):
-image sharding without a data-path collective, and the bucketed gradient all-reduce that replaces the reference's
-Broadcast.backward -> ReduceAddCoalesced (lib/nn/parallel/_functions.py:26-39)."""
+image sharding without a data-path collective, and `GradientAllReducer` -- the class every training step uses -- which
+replaces the reference's Broadcast.backward -> ReduceAddCoalesced (lib/nn/parallel/_functions.py:26-39): gradient views
+into flat buckets, all-reduce launched from autograd hooks, a bucket whose hooks did not all fire, the hook-less mode of
+a captured backward, replicas that stay bit-identical."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import torch
@@ -10,6 +15,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from detectron_pytorch_amd import parallel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -38,7 +45,7 @@ def _run(fn, world_size=2):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
     return [ret[r] for r in range(world_size)]
 
@@ -61,29 +68,113 @@ def test_images_and_rois_shard_without_overlap():
     assert out[0][3] == out[1][3] == 1.5  # max over ranks
 
 
-def _grad_job(rank, world_size):
-    torch.manual_seed(0)
-    params = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 1000, 3, 70000)]
-    frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
-    for i, p in enumerate(params):
-        p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
-    params[2].grad = None if rank == 1 else params[2].grad  # a parameter unused on one rank
-    n_coll = parallel.allreduce_gradients(params + [frozen], bucket_bytes=8192)
-    return n_coll, [float(p.grad[0]) for p in params], [bool(torch.all(p.grad == p.grad[0])) for p in params]
+class _Net(torch.nn.Module):
+    """Two heads on a trunk; `head_b` is only used when asked (a head without work on one rank), `spare` never."""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = torch.nn.Linear(32, 300)
+        self.head_a = torch.nn.Linear(300, 7)
+        self.head_b = torch.nn.Linear(300, 70)   # 21 070 floats: a bucket of its own at 32 KB
+        self.spare = torch.nn.Linear(5, 5)
+        self.frozen = torch.nn.Parameter(torch.ones(4), requires_grad=False)
+
+    def forward(self, x, use_b):
+        h = torch.relu(self.trunk(x))
+        out = self.head_a(h).square().mean()
+        if use_b:
+            out = out + self.head_b(h).abs().mean()
+        return out
 
 
-def test_bucketed_gradient_allreduce_averages_like_the_reference():
-    out = _run(_grad_job)
-    for n_coll, firsts, uniform in out:
-        # buckets: [5 + 1000 floats] | [3] is packed with what fits ... the 70000-float tensor alone exceeds a bucket
-        assert 2 <= n_coll <= 4
-        assert all(uniform)
-        np.testing.assert_allclose(firsts, [1.5 * 1, 1.5 * 2, 0.5 * 3, 1.5 * 4])  # mean over ranks; None counts as 0
+def _reducer_job(rank, world_size, overlap, detect_unused):
+    torch.manual_seed(5)
+    net = _Net()
+    ref = _Net()
+    ref.load_state_dict(net.state_dict())
+    red = parallel.GradientAllReducer(net.parameters(), bucket_bytes=32 << 10, overlap=overlap, detect_unused=detect_unused)
+    assert red.active and red.world == 2 and len(red.buckets) >= 2
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
+    opt_ref = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
+    xs = [torch.randn(8, 32, generator=torch.Generator().manual_seed(10 * r + 1)) for r in range(world_size)]
+    log = []
+    for step in range(3):
+        use_b = [step != 1 or r == 0 for r in range(world_size)]  # step 1: head_b has no work on rank 1
+        opt.zero_grad(set_to_none=True)
+        red.begin_step()
+        net(xs[rank], use_b[rank]).backward()
+        # every gradient lives in a bucket: the view, not a copy
+        for flat, slots in red.buckets:
+            for p, off in slots:
+                assert p.grad.data_ptr() == flat[off:off + p.numel()].data_ptr()
+        n_coll = red.finish_step()
+        assert n_coll == len(red.buckets)
+        # the reference semantics on one process: mean over ranks of the per-rank losses (training_stats.py:84)
+        opt_ref.zero_grad(set_to_none=True)
+        (sum(ref(xs[r], use_b[r]) for r in range(world_size)) / world_size).backward()
+        for (name, p), q in zip(net.named_parameters(), ref.parameters()):
+            if not p.requires_grad:
+                continue
+            if q.grad is None:  # `spare`: no gradient on any rank
+                assert (p.grad is None) if detect_unused else bool((p.grad == 0).all()), name
+            else:
+                torch.testing.assert_close(p.grad, q.grad, rtol=1e-6, atol=1e-7, msg=name)
+        opt.step()
+        opt_ref.step()
+        log.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()]).double().sum().item())
+    red.close()
+    return log
+
+
+def _hooks_job(rank, world_size):
+    return _reducer_job(rank, world_size, overlap=True, detect_unused=False)
+
+
+def _no_overlap_job(rank, world_size):
+    return _reducer_job(rank, world_size, overlap=False, detect_unused=True)
+
+
+def test_reducer_hook_mode_matches_the_reference_mean_and_replicas_stay_identical():
+    out = _run(_hooks_job)
+    assert out[0] == out[1]  # bit-identical parameter checksums after every one of the three SGD steps
+
+
+def test_reducer_without_overlap_and_with_unused_parameter_detection():
+    out = _run(_no_overlap_job)
     assert out[0] == out[1]
 
 
+def _graph_mode_job(rank, world_size):
+    """reduce_now() / average_(): the exchange of a step whose backward ran without hooks (a replayed hipGraph)."""
+    torch.manual_seed(1)
+    net = torch.nn.Linear(16, 4)
+    red = parallel.GradientAllReducer(net.parameters(), bucket_bytes=1 << 20, overlap=False)
+    red.begin_step()
+    for p in net.parameters():
+        p.grad.fill_(float(rank + 1))   # what a captured backward would have left in the bucket views
+    n = red.reduce_now()
+    red.average_()
+    return n, [float(p.grad.reshape(-1)[0]) for p in net.parameters()]
+
+
+def test_reduce_now_averages_bucket_views():
+    out = _run(_graph_mode_job)
+    assert out[0] == out[1] == (1, [1.5, 1.5])
+
+
 def test_single_process_is_a_no_op():
-    p = torch.nn.Parameter(torch.ones(3))
-    p.grad = torch.ones(3)
-    assert parallel.allreduce_gradients([p]) == 0 and parallel.world() == (0, 1)
+    net = torch.nn.Linear(3, 3)
+    red = parallel.GradientAllReducer(net.parameters())
+    assert not red.active and red.finish_step() == 0 and red.reduce_now() == 0 and parallel.world() == (0, 1)
     assert parallel.shard_range(3, 0, 1) == [0, 1, 2]
+
+
+def test_bench_selftest_two_ranks_on_gloo():
+    """bench.py --gpus 2 spawns its own ranks under torch.distributed.run; on gloo the whole rank / reducer / timing /
+    JSON plumbing runs without a GPU and checks that the replicas did not diverge."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-cpu", "--gpus", "2", "--steps", "3",
+                          "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["metric"] == "selftest" and line["n_gpus"] == 2 and line["collectives_per_step"] >= 1
