@@ -1,7 +1,9 @@
 """CPU restatement of the test-time RESULT FORMATS: instance masks pasted into the image and
 run-length encoded, keypoints decoded from heat maps.  Test infrastructure: only tests/ may import this.
 
-PARITY UNPINNED.  The reference delegates the numerical work to two third-party packages that are not installed here and
+PARITY PARTLY PINNED: the two resize kernels are cross-checked against an independent implementation of the same published
+algorithm (torch.nn.functional.interpolate(align_corners=False), tests/test_results_cpu.py, <= 1e-4 of the data range);
+the RLE encoder has hand vectors and a round trip only.  The reference delegates the numerical work to two third-party packages that are not installed here and
 cannot be fetched (no network), so this file restates their PUBLISHED algorithms instead of executing them:
   * OpenCV (opencv-python; the reference pins no version, `import cv2` in lib/core/test.py:36, lib/utils/keypoints.py:27):
     `cv2.resize` for float32 input, INTER_LINEAR (default) and INTER_CUBIC -- modules/imgproc/src/resize.cpp:

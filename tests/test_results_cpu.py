@@ -67,6 +67,39 @@ def test_resize_restatement_properties():
         assert np.array_equal(c3[:, :, ch], R.cv2_resize_cubic(b[:, :, ch], 20, 31))
 
 
+def test_resize_restatement_against_an_independent_implementation():
+    """cv2 is not installed, so the restated cv2.resize (coordinate map fx = (dx + .5) * scale - .5, floor, border handling,
+    bilinear weights / bicubic kernel A = -0.75 with a replicated border) is cross-checked against an implementation that
+    shares none of its code: torch.nn.functional.interpolate(align_corners=False), which documents the same coordinate map
+    and the same A = -0.75 kernel.  Sizes: the mask paste (28 x 28 -> box, core/test.py:826-838, both up- and down-scaling
+    boxes) and the key-point heat maps (56 x 56 -> box, utils/keypoints.py:129-152), borders included.  Tolerance 1e-4 of
+    the data range: OpenCV forms the source coordinate in double and rounds it to fp32, torch forms it in fp32 from an
+    fp32 scale, so the interpolation weights differ by ~1e-6 x coordinate (measured: <= 3.5e-5 on these sizes); a wrong
+    coordinate map, a missing half-pixel shift, a different A or border rule is off by 1e-2 or more on these inputs."""
+    import torch
+    import torch.nn.functional as F
+
+    rng = np.random.RandomState(7)
+    cases = [(28, 28, w, h) for (w, h) in ((28, 28), (29, 31), (57, 40), (113, 200), (400, 333), (15, 9), (3, 2), (1, 1))]
+    cases += [(56, 56, w, h) for (w, h) in ((56, 56), (61, 130), (200, 77), (333, 480), (40, 25))]
+    cases += [(30, 30, 77, 13)]  # the padded mask (M + 2) of the paste
+    for (sh, sw, dw, dh) in cases:
+        a = rng.randn(sh, sw).astype(np.float32)
+        t = torch.from_numpy(a)[None, None]
+        lin = F.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False)[0, 0].numpy()
+        got = R.cv2_resize_linear(a, dw, dh)
+        assert got.shape == (dh, dw)
+        # (up- and down-scaling alike: neither cv2.resize with these flags nor interpolate(antialias=False) low-passes)
+        assert np.abs(got - lin).max() <= 1e-4 * max(1.0, np.abs(a).max()), (sh, sw, dw, dh)
+        cub = F.interpolate(t, size=(dh, dw), mode="bicubic", align_corners=False)[0, 0].numpy()
+        got = R.cv2_resize_cubic(a, dw, dh)
+        assert np.abs(got - cub).max() <= 1e-4 * max(1.0, np.abs(a).max()), (sh, sw, dw, dh)
+    # the check has teeth: a restatement without the half-pixel shift differs by far more than the tolerance
+    a = rng.randn(28, 28).astype(np.float32)
+    shifted = F.interpolate(torch.from_numpy(a)[None, None], size=(57, 57), mode="bilinear", align_corners=True)[0, 0].numpy()
+    assert np.abs(R.cv2_resize_linear(a, 57, 57) - shifted).max() > 1e-2
+
+
 def test_paste_and_segm_results_shapes():
     rng = np.random.RandomState(3)
     masks = rng.rand(3, 4, 28, 28).astype(np.float32)
