@@ -141,6 +141,20 @@ def mask_rcnn_r50_fpn():
     return infer(c)
 
 
+def keypoint_rcnn_r50_fpn():
+    """configs/baselines/e2e_keypoint_rcnn_R-50-FPN_1x.yaml on the defaults (the keypoint branch of BASELINE.json config 5 on
+    the R-50 body; tests/test_model_cpu.py checks it against merge_from_file of the reference's yaml)."""
+    c = faster_rcnn_r50_fpn()
+    c.merge(dict(
+        MODEL=dict(KEYPOINTS_ON=True),
+        TRAIN=dict(SCALES=(640, 672, 704, 736, 768, 800)),
+        KRCNN=dict(ROI_KEYPOINTS_HEAD="keypoint_rcnn_heads.roi_pose_head_v1convX", NUM_STACKED_CONVS=8, NUM_KEYPOINTS=17,
+                   USE_DECONV_OUTPUT=True, CONV_INIT="MSRAFill", CONV_HEAD_DIM=512, UP_SCALE=2, HEATMAP_SIZE=56,
+                   ROI_XFORM_METHOD="RoIAlign", ROI_XFORM_RESOLUTION=14, ROI_XFORM_SAMPLING_RATIO=2,
+                   KEYPOINT_CONFIDENCE="bbox")))
+    return infer(c)
+
+
 def mask_keypoint_rcnn_x101_64x4d_fpn():
     """configs/baselines/e2e_mask_rcnn_X-101-64x4d-FPN_1x.yaml plus the keypoint head of
     e2e_keypoint_rcnn_X-101-64x4d-FPN_1x.yaml (BASELINE.json config 5).  The keypoint yaml names a non-existent

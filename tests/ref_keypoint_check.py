@@ -15,7 +15,7 @@ warnings.filterwarnings("ignore")
 
 from oracle import ref_model  # noqa: E402
 import cpu_backend  # noqa: E402
-from scenarios import H, W, NUM_GT, scenario  # noqa: E402
+from scenarios import H, W, NUM_GT, keypoint_scenario  # noqa: E402
 
 YAML = "configs/baselines/e2e_keypoint_rcnn_R-50-FPN_1x.yaml"
 
@@ -38,17 +38,7 @@ def main():
     got_map, got_orph = weights.detectron_weight_mapping(mine)
     assert got_map == want_map and sorted(got_orph) == sorted(want_orph), "Detectron name mapping differs"
 
-    boxes, _, data_np = scenario()
-    rng = np.random.RandomState(17)
-    kps = []
-    for bx in boxes:
-        kx = bx[:, 0:1] + rng.uniform(-0.1, 1.1, (NUM_GT, 17)) * (bx[:, 2:3] - bx[:, 0:1])     # some outside their box
-        ky = bx[:, 1:2] + rng.uniform(-0.1, 1.1, (NUM_GT, 17)) * (bx[:, 3:4] - bx[:, 1:2])
-        vis = rng.randint(0, 3, (NUM_GT, 17))
-        k = np.stack([kx, ky, vis], axis=1).astype(np.int32)
-        k[0, 0, 0], k[0, 1, 0], k[0, 2, 0] = int(bx[0, 2]), int(bx[0, 3]), 2
-        kps.append(k)
-    classes = [np.ones(NUM_GT, np.int32) for _ in boxes]
+    boxes, classes, kps, data_np = keypoint_scenario()
     entries = [ref_model.roidb_entry(H, W, bx, c, 2, keypoints=k) for bx, c, k in zip(boxes, classes, kps)]
     blobs = ref_model.rpn_blobs(entries, [1.0, 1.0], seed=11)
     data = torch.from_numpy(data_np)

@@ -27,3 +27,21 @@ def synthetic_conv_outputs(seed, n, h=H, w=W):
     logits = [(rng.randn(n, 3, a, b) * 2.0).astype(np.float32) for a, b in reversed(sizes)]        # level 2 .. 6
     deltas = [(rng.randn(n, 12, a, b) * 0.3).astype(np.float32) for a, b in reversed(sizes)]
     return blobs, logits, deltas
+
+
+def keypoint_scenario(seed=17):
+    """Person boxes of `scenario()` with 17 key points each ([NUM_GT, 3, 17] int32 per image: x, y, visibility 0..2), some
+    outside their box, the first three of the first box on its lower-right corner (the inclusive-edge rule of
+    utils/keypoints.py:160-211)."""
+    boxes, _, data = scenario()
+    rng = np.random.RandomState(seed)
+    kps = []
+    for bx in boxes:
+        kx = bx[:, 0:1] + rng.uniform(-0.1, 1.1, (NUM_GT, 17)) * (bx[:, 2:3] - bx[:, 0:1])
+        ky = bx[:, 1:2] + rng.uniform(-0.1, 1.1, (NUM_GT, 17)) * (bx[:, 3:4] - bx[:, 1:2])
+        vis = rng.randint(0, 3, (NUM_GT, 17))
+        k = np.stack([kx, ky, vis], axis=1).astype(np.int32)
+        k[0, 0, 0], k[0, 1, 0], k[0, 2, 0] = int(bx[0, 2]), int(bx[0, 3]), 2
+        kps.append(k)
+    classes = [np.ones(NUM_GT, np.int32) for _ in boxes]
+    return boxes, classes, kps, data

@@ -157,6 +157,92 @@ def test_training_post_conv_half_matches_the_reference(nets, golden, layout):
             assert np.linalg.norm(g[nz] - want) <= 5e-3 * np.linalg.norm(want), i
 
 
+def test_keypoint_training_post_conv_half_matches_the_reference(hip_lib_path):
+    """BASELINE config 5's extra branch on the device: key-point RoIs, heat-map targets and weights (roi_data/
+    keypoint_rcnn.py:33-106, utils/keypoints.py:160-211), the v1convX head + deconvolution + bilinear up-sampling and
+    `loss_kps` (keypoint_rcnn_heads.py:17-179), and the gradients the fused HIP RoIAlign backward (14 x 14) hands to the
+    pyramid -- against what the reference's own e2e_keypoint_rcnn_R-50-FPN model computed from the same arrays
+    (tests/golden/model_keypoint.npz, generator tests/golden/generate_model_keypoint.py)."""
+    from scenarios import keypoint_scenario
+    from detectron_pytorch_amd.rcnn import config, data as rdata, model
+
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "model_keypoint.npz"), allow_pickle=False)
+    cfg = config.keypoint_rcnn_r50_fpn()
+    cfg.MODEL.NUM_CLASSES = 2
+    assert cfg.MODEL.KEYPOINTS_ON and cfg.KRCNN.HEATMAP_SIZE == 56
+    torch.manual_seed(3)
+    gpu = model.GeneralizedRCNN(cfg).to(dev())
+    gpu.train()
+    boxes, classes, kps, _ = keypoint_scenario()
+    entries = [dict(height=H, width=W, boxes=b, gt_classes=c, is_crowd=np.zeros(len(c), bool)) for b, c in zip(boxes, classes)]
+    blobs = rdata.add_rpn_blobs(cfg, entries, [1.0, 1.0], np.random.RandomState(11))
+    d = dev()
+    blobs_np, logits_np, deltas_np = synthetic_conv_outputs(seed=23, n=2)
+    blob_g = [torch.from_numpy(b).to(d).requires_grad_() for b in blobs_np]
+    rpn_g = {}
+    for i, lvl in enumerate(range(2, 7)):
+        rpn_g["rpn_cls_logits_fpn%d" % lvl] = torch.from_numpy(logits_np[i]).to(d).requires_grad_()
+        rpn_g["rpn_bbox_pred_fpn%d" % lvl] = torch.from_numpy(deltas_np[i]).to(d).requires_grad_()
+    ngt = 2 * NUM_GT
+    roidb = {"gt_boxes": torch.from_numpy(np.concatenate(boxes)).to(d), "gt_classes": torch.ones(ngt, dtype=torch.long, device=d),
+             "gt_image": torch.tensor([0] * NUM_GT + [1] * NUM_GT, device=d),
+             "gt_keypoints": torch.from_numpy(np.concatenate(kps)).to(d)}
+    rpn_t = {k: torch.from_numpy(v).to(d) for k, v in blobs.items() if k.startswith("rpn_")}
+    priority = torch.from_numpy(np.random.RandomState(7).permutation(ngt + 2000).astype(np.float32)).to(d)
+    want_rois = g["train_collected_rois"]
+    inner = gpu.proposals
+
+    def proposals_in_reference_order(rpn, im_info, static):
+        rois, valid = inner(rpn, im_info, static)
+        got = rois.cpu().numpy()[valid.cpu().numpy()]
+        assert np.array_equal(by_rows(got), by_rows(want_rois)), "collected proposals differ as a set"
+        out = torch.full_like(rois, 0.0)
+        out[:, 0] = -1.0
+        out[:want_rois.shape[0]] = torch.from_numpy(want_rois).to(d)
+        ok = torch.zeros_like(valid)
+        ok[:want_rois.shape[0]] = True
+        return out, ok
+
+    gpu.proposals = proposals_in_reference_order
+    try:
+        gpu.zero_grad()
+        ret = gpu.forward_from_features(blob_g, rpn_g, torch.from_numpy(blobs["im_info"]), roidb, rpn_t, priority)
+        sum(ret["losses"].values()).backward()
+    finally:
+        del gpu.proposals
+    b = {k: v.cpu() for k, v in ret["blobs"].items()}
+    fper = int(round(cfg.TRAIN.FG_FRACTION * cfg.TRAIN.BATCH_SIZE_PER_IM))
+    rows = torch.cat([i * fper + torch.arange(int(n)) for i, n in enumerate(b["num_keypoint_rois"])])
+    assert rows.numel() == g["keypoint_rois"].shape[0] >= ngt
+    assert np.array_equal(b["keypoint_rois"][rows].numpy(), g["keypoint_rois"])
+    k17 = (rows.view(-1, 1) * 17 + torch.arange(17).view(1, -1)).reshape(-1)
+    assert np.array_equal(b["keypoint_locations_int32"][k17].numpy(), g["keypoint_locations_int32"])     # exact
+    assert np.array_equal(b["keypoint_weights"][k17].numpy(), g["keypoint_weights"])                     # exact
+    np.testing.assert_allclose(float(b["keypoint_loss_normalizer"]), float(g["keypoint_loss_normalizer"]), rtol=1e-6)
+    got = {k: float(v) for k, v in ret["losses"].items()}
+    for name, want in zip(g["loss_names"], g["loss_values"]):
+        np.testing.assert_allclose(got[str(name)], want, rtol=2e-4, atol=1e-6, err_msg=str(name))
+    params = dict(gpu.named_parameters())
+    for key in g.files:
+        if not key.startswith("grad_samples/"):
+            continue
+        name = key.split("/", 1)[1]
+        gr = params[name].grad.detach().cpu().numpy().reshape(-1)
+        idx = np.random.RandomState(0).randint(0, gr.size, size=min(256, gr.size))
+        norm = float(g["grad_norm/" + name])
+        assert abs(np.linalg.norm(gr.astype(np.float64)) - norm) <= 2e-3 * norm, name
+        diff = np.linalg.norm((gr[idx] - g[key]).astype(np.float64))
+        assert diff <= 1e-2 * max(np.linalg.norm(g[key].astype(np.float64)), 1e-30), (name, diff)
+    for i, f in enumerate(blob_g[-4:]):   # P5, P4, P3, P2: box head 7 x 7 + key-point head 14 x 14, one fused backward
+        gr = np.zeros(f.numel(), np.float32) if f.grad is None else f.grad.detach().cpu().numpy().reshape(-1)
+        norm = float(g["feat_grad_norm/%d" % i])
+        assert abs(np.linalg.norm(gr.astype(np.float64)) - norm) <= 2e-3 * norm + 1e-12, i
+        idx = np.random.RandomState(i).randint(0, gr.size, size=min(512, gr.size))
+        want = g["feat_grad_samples/%d" % i].astype(np.float64)
+        assert np.linalg.norm(gr[idx] - want) <= 5e-3 * np.linalg.norm(want) + 1e-12, i
+        assert np.array_equal(gr[idx] == 0, want == 0), i
+
+
 def test_inference_post_conv_half_matches_the_reference(nets, golden):
     from detectron_pytorch_amd.rcnn import inference
 

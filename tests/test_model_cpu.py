@@ -71,6 +71,19 @@ def test_yaml_merge_equals_the_builtin_config(ref_cfg):
                 assert (tuple(rv) if isinstance(rv, (list, tuple)) else rv) == v, (sec, k, rv, v)
 
 
+def test_keypoint_yaml_merge_equals_the_builtin_config():
+    """config.keypoint_rcnn_r50_fpn() (what the GPU keypoint parity test builds, the reference's yaml is not on the GPU
+    box) against the reference's own yaml merged on the defaults."""
+    from detectron_pytorch_amd.rcnn import config
+
+    c = config.infer(config.default_config().merge_from_file(
+        os.path.join(ref_model.REFERENCE, "configs/baselines/e2e_keypoint_rcnn_R-50-FPN_1x.yaml")))
+    b = config.keypoint_rcnn_r50_fpn()
+    for sec in ("MODEL", "FPN", "FAST_RCNN", "KRCNN", "MRCNN", "TRAIN", "TEST", "RPN"):
+        for k, v in b[sec].items():
+            assert c[sec][k] == v, (sec, k, c[sec][k], v)
+
+
 def test_seeded_initial_weights_equal_the_reference(models):
     ref, mine, _ = models
     a, b = ref.state_dict(), mine.state_dict()
