@@ -339,9 +339,13 @@ def _small_training_job(net, cfg):
     return rdata.to_device(batch, dev())
 
 
-def test_training_step_eager_and_hipgraph(nets):
+def test_training_step_eager_and_hipgraph_liveness(nets):
     """Three eager steps of the whole model on the GPU (finite losses, parameters move), then the same step captured in a
-    hipGraph and replayed -- the training forward is static-shaped and has no host synchronisation."""
+    hipGraph and replayed -- the training forward is static-shaped and has no host synchronisation.
+    A LIVENESS check of the captured form, not a parity check: replays of captured backward passes are not trustworthy on
+    this PyTorch / ROCm stack (tools/reduce_probe.py reproduces a wrong, stable value with plain torch expressions), so the
+    replayed loss only has to be finite and in the neighbourhood of the eager one; `bench.py --launch graph` stays
+    experimental and the headline launches eagerly."""
     from detectron_pytorch_amd.rcnn import train as rtrain
 
     _, gpu, cfg = nets
@@ -374,6 +378,32 @@ def test_training_step_eager_and_hipgraph(nets):
     torch.cuda.synchronize()
     assert np.isfinite(float(loss)) and abs(float(loss) - float(losses[-1])) < 0.5 * abs(float(losses[-1])) + 0.5
     assert not torch.equal(w0, net.Box_Head.fc1.weight.detach())
+
+
+def test_fixed_batch_loss_decreases_at_a_safe_learning_rate(nets):
+    """The step is pinned piecewise against the reference (forward + backward: tests/test_model_cpu.py and the golden
+    fixtures; the SGD update: test_optimizer_update_equals_the_reference).  This is the smoke check of the whole: on a
+    fixed resident batch, at 1/100 of the schedule's first learning rate, twenty iterations must lower the loss at every
+    step.  (At the schedule's own rate the fixed-batch loss is NOT monotone -- 5.38 -> 1.58 -> 3.6 -> 2.05 over 30 steps,
+    tools/loss_probe.py: momentum 0.9 at a rate tuned for pretrained weights overshoots on a random-init body whose
+    AffineChannel layers are the identity, and the labelled RoIs are re-sampled from the moving proposals every step.)"""
+    from detectron_pytorch_amd.rcnn import train as rtrain
+
+    _, gpu, cfg = nets
+    net = copy.deepcopy(gpu).train()
+    data, im_info, roidb, rpn_t = _small_training_job(net, cfg)
+    opt = rtrain.make_optimizer(net, cfg, lr=cfg.SOLVER.BASE_LR * 2 / 16.0 / 3.0 / 100.0)
+    losses = []
+    for _ in range(20):
+        opt.zero_grad(set_to_none=True)
+        ret = net(data, im_info, roidb=roidb, rpn_targets=rpn_t)
+        loss = sum(ret["losses"].values())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(x) for x in losses)
+    assert all(b < a + 2e-3 * abs(a) for a, b in zip(losses, losses[1:])), losses
+    assert losses[-1] < 0.9 * losses[0], losses
 
 
 def test_gradient_reducer_on_rccl_world_size_one(nets):

@@ -198,6 +198,51 @@ def test_training_forward_and_backward_equal_the_reference(ref_cfg, models):
         assert err <= 2e-4, (name, err)
 
 
+def test_optimizer_update_equals_the_reference(ref_cfg, models):
+    """The UPDATE of a training iteration: the reference's own source text of the parameter-group construction
+    (tools/train_net_step.py:262-307: weights with decay, biases at twice the learning rate without decay, frozen
+    parameters left out) is executed on the reference model and its learning rate set with the reference's
+    utils/net.py:update_learning_rate; rcnn.train.make_optimizer builds the groups here.  Both sides then take three SGD
+    steps on identical (seeded) gradients; every trainable parameter must agree to fp32 rounding."""
+    import copy
+    import utils.net as net_utils
+    from detectron_pytorch_amd.rcnn import train as rtrain
+
+    ref, mine, cfg = models
+    ref, mine = copy.deepcopy(ref), copy.deepcopy(mine)
+    src = open(os.path.join(ref_model.REFERENCE, "tools", "train_net_step.py")).read().split("\n")
+    text = "\n".join(l[4:] if l.startswith("    ") else l for l in src[261:307])      # ":262-307", de-indented
+    assert text.lstrip().startswith("gn_param_nameset") and "torch.optim.SGD" in text
+    ns = {"maskRCNN": ref, "cfg": ref_cfg, "nn": torch.nn, "torch": torch}
+    exec(compile(text, "train_net_step.py:262-307", "exec"), ns)
+    opt_ref = ns["optimizer"]
+    # the learning rate of the bench's step: linear scaling rule to 2 images, first warm-up iteration
+    lr = ref_cfg.SOLVER.BASE_LR * 2 / 16.0 * ref_cfg.SOLVER.WARM_UP_FACTOR
+    net_utils.update_learning_rate(opt_ref, 0, lr)
+    opt = rtrain.make_optimizer(mine, cfg, lr=lr)
+    assert [len(g["params"]) for g in opt.param_groups] == [len(g["params"]) for g in opt_ref.param_groups[:2]]
+    assert len(opt_ref.param_groups[2]["params"]) == 0                                   # no GroupNorm in this model
+    for a, b in zip(opt.param_groups, opt_ref.param_groups):
+        assert a["lr"] == b["lr"] and a["weight_decay"] == b["weight_decay"] and a["momentum"] == b["momentum"]
+    assert opt.param_groups[1]["lr"] == 2 * opt.param_groups[0]["lr"] and opt.param_groups[1]["weight_decay"] == 0
+    pr, pm = dict(ref.named_parameters()), dict(mine.named_parameters())
+    assert list(pr) == list(pm)
+    for step in range(3):
+        gen = torch.Generator().manual_seed(100 + step)
+        for name in pr:
+            if pr[name].requires_grad:
+                g = torch.randn(pr[name].shape, generator=gen) * 0.1
+                pr[name].grad, pm[name].grad = g.clone(), g.clone()
+        opt_ref.step()
+        opt.step()
+    worst = 0.0
+    for name in pr:
+        a, b = pr[name].detach(), pm[name].detach()
+        assert a.requires_grad == b.requires_grad
+        worst = max(worst, ((a - b).abs().max() / a.abs().max().clamp_min(1e-12)).item())
+    assert worst <= 1e-6, worst
+
+
 def test_inference_forward_and_box_decoding_equal_the_reference(ref_cfg, models):
     import cpu_backend
     from detectron_pytorch_amd.rcnn import inference
