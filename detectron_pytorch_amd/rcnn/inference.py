@@ -76,8 +76,10 @@ def im_detect_bbox(model, data, im_info, im_shape=None, autocast_dtype=None, sta
         deltas = deltas[:, -4:]
     pred = bbox_transform(boxes, deltas, cfg.MODEL.BBOX_REG_WEIGHTS, cfg.BBOX_XFORM_CLIP)
     if im_shape is None:
-        im_shape = (im_info[0, 0] / scale, im_info[0, 1] / scale) if static else \
-            (float(im_info[0][0]) / scale, float(im_info[0][1]) / scale)
+        # the reference clips to the INTEGER shape of the original image (core/test.py:178); blob extent / scale is that
+        # shape up to rounding (800 / 1.873536 = 427.0003), so it is rounded -- on the device in the static form
+        im_shape = (torch.round(im_info[0, 0] / scale), torch.round(im_info[0, 1] / scale)) if static else \
+            (float(round(float(im_info[0][0]) / scale)), float(round(float(im_info[0][1]) / scale)))
     pred = clip_tiled_boxes(pred, im_shape[0], im_shape[1])
     if cfg.MODEL.CLS_AGNOSTIC_BBOX_REG:
         pred = pred.repeat(1, scores.shape[1])

@@ -98,6 +98,27 @@ def roi_feature_transform(blobs_in, rpn_ret, blob_rois="rois", method="RoIPoolF"
         if roi_align_fpn_supported(list(blobs_in), rois.size(0), resolution, resolution):
             return roi_align_fpn(list(blobs_in), list(spatial_scale), rois, (k_max - levels).to(torch.int32), resolution,
                                  resolution, sampling_ratio)
+    if levels is not None and ("%s_fpn%d" % (blob_rois, k_min)) not in rpn_ret:
+        # the device-side producers emit only `<blob>` + `<blob>_levels`; when the fused call is not available (RoIPool /
+        # RoICrop, MI_ROI_ALIGN_IMPL=direct, MI_ROI_ALIGN_NO_WS, > 8192 RoIs, FPN.DIM not a multiple of 32, fused=False)
+        # the levels are split here: one operator call per level, results scattered back to the order of the rois.  Rows
+        # whose level is outside [k_min, k_max] (padding) stay zero.  (The row counts come to the host: a fallback.)
+        rois = _as_device_rois(rpn_ret[blob_rois], blobs_in[0].device)
+        out = None
+        for lvl in range(k_min, k_max + 1):
+            idx = torch.nonzero(levels == lvl, as_tuple=False).flatten()
+            if idx.numel() == 0:
+                continue
+            y = _one_level(blobs_in[k_max - lvl], rois.index_select(0, idx).contiguous(), method, resolution,
+                           spatial_scale[k_max - lvl], sampling_ratio, grid_size, crop_resize_with_max_pool)
+            if out is None:
+                out = y.new_zeros((rois.size(0),) + tuple(y.shape[1:]))
+            out = out.index_copy(0, idx, y)
+        if out is None:  # no RoI on any level: the shape still has to be right
+            c = blobs_in[0].size(1)
+            res = resolution if method != "RoICrop" or not crop_resize_with_max_pool else grid_size // 2
+            out = blobs_in[0].new_zeros((rois.size(0), c, res, res))
+        return out
     level_rois = [rpn_ret["%s_fpn%d" % (blob_rois, lvl)] for lvl in range(k_min, k_max + 1)]
     restore = rpn_ret[blob_rois + "_idx_restore_int32"]
     if isinstance(restore, np.ndarray):

@@ -282,7 +282,10 @@ int mi_detection_select(const float* scores, const float* boxes, const float* ma
  * equal values: lower index first (the reference's order of ties is undefined); NaN ranks below -inf.
  * 0 <= k <= n <= 2^24, k <= 4096.  The pointer / size arrays are HOST arrays.  A problem of more than 32768 values is
  * cut into chunks that run side by side and a merge of their winners (second launch); their candidates live in
- * `workspace` (device, 16-byte aligned, mi_topk_batched_workspace_bytes; may be NULL when no problem is that large). */
+ * `workspace` (device, 16-byte aligned, mi_topk_batched_workspace_bytes; may be NULL when no problem is that large).
+ * The arrays are read with 16-byte loads from the 16-byte granules that contain them: up to 12 bytes in front of
+ * values[p] and behind its last element are READ (never used) -- they must be readable memory, which any device
+ * allocation and any row of a larger tensor provide. */
 size_t mi_topk_batched_workspace_bytes(int num_problems, const int* n, const int* k);
 int mi_topk_batched(int num_problems, const float* const* values, const int* n, const int* k, float* const* out_values,
                     int64_t* const* out_indices, void* workspace, size_t workspace_bytes, mi_stream_t stream);

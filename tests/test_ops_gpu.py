@@ -540,6 +540,41 @@ def test_roi_feature_transform_fpn_roi_align_vs_oracle(oracle_mod):
     assert_fwd(out, expected, "fpn roi_feature_transform", exact=False)
 
 
+@pytest.mark.parametrize("why", ["direct", "no_ws", "fused_off", "roi_pool"])
+def test_roi_feature_transform_level_vector_without_the_fused_call(oracle_mod, tuning_env, why):
+    """The device-side producers (rcnn.targets, fpn_proposals, inference) hand over `rois` + `rois_levels` only.  When the
+    fused FPN call declines (MI_ROI_ALIGN_IMPL=direct, MI_ROI_ALIGN_NO_WS, fused=False) or the method is not RoIAlign, the
+    levels are split on the spot: same result as the fused call, gradients on every level, padding rows (image -1, level
+    out of range) give zeros -- instead of the KeyError('rois_fpn2') of round 2."""
+    from detectron_pytorch_amd import roi_xform
+
+    rois, lvls, _, scales, feats = _fpn_inputs(num_rois=200)
+    rois = np.concatenate([rois, np.array([[-1, 0, 0, 0, 0], [-1, 5, 5, 50, 50]], np.float32)])   # padding rows
+    lvls = np.concatenate([lvls, np.array([2, 9], lvls.dtype)])
+    blobs = {"rois": to_dev(rois), "rois_levels": to_dev(lvls.astype(np.int64))}
+    method = "RoIPoolF" if why == "roi_pool" else "RoIAlign"
+    if why == "direct":
+        tuning_env(MI_ROI_ALIGN_IMPL="direct")
+    elif why == "no_ws":
+        tuning_env(MI_ROI_ALIGN_NO_WS="1")
+    dev_feats = [to_dev(f).requires_grad_(True) for f in feats]
+    out = roi_xform.roi_feature_transform(dev_feats, blobs, "rois", method, 7, scales, 2, fused=(why != "fused_off"))
+    assert out.shape == (rois.shape[0], feats[0].shape[1], 7, 7)
+    out.sum().backward()
+    got = out.detach().cpu().numpy()
+    assert (got[-2:] == 0).all()
+    for lvl in range(2, 6):
+        idx = np.nonzero(lvls[:-2] == lvl)[0]
+        feat, sc = feats[5 - lvl], scales[5 - lvl]
+        if method == "RoIAlign":
+            want = oracle_mod.roi_align_forward(feat, rois[idx], 7, 7, sc, 2)
+            assert np.abs(got[idx] - want).max() <= FAST_ATOL
+        else:
+            want, _ = oracle_mod.roi_pool_forward(feat, rois[idx], 7, 7, sc)
+            assert np.array_equal(got[idx], want)
+        assert dev_feats[5 - lvl].grad is not None and float(dev_feats[5 - lvl].grad.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("method", ["RoIPoolF", "RoICrop", "RoIAlign"])
 def test_roi_feature_transform_single_level_methods(oracle_mod, method):
     from detectron_pytorch_amd import roi_xform
