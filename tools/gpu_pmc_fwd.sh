@@ -1,5 +1,5 @@
 #!/bin/bash
-# utilisation counters of the RoIAlign forward kernels; usage: bash tools/gpu_pmc2.sh TAG [ENV=VAL ...]
+# utilisation counters of the RoIAlign forward kernels; usage: bash tools/gpu_pmc_fwd.sh TAG [ENV=VAL ...]
 TAG=$1; shift; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 j=0
