@@ -742,6 +742,12 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 line["mask_inference"] = {"error": repr(exc)[:300]}
             line["config5_x101_mask_keypoint"] = config5(device, rank, args)
+            try:
+                from tools import bwd_clustered
+
+                line["roi_align_step_rois"] = bwd_clustered.measure(device, 20)
+            except Exception as exc:  # noqa: BLE001
+                line["roi_align_step_rois"] = {"error": repr(exc)[:300]}
             line["nms"] = hp.nms_latency(device, args.kernel_iters)
             line["inference_path"] = hp.inference_path(device)
         if not args.no_cpu_baseline and world == 1:

@@ -110,6 +110,18 @@ def _rois_blob(boxes, im_scale, cfg, name):
     return {name: rois, name + "_levels": lvls}
 
 
+def _pad_to_detection_cap(boxes, cfg):
+    """The number of detections differs from image to image, and every new batch size of the head's convolutions makes
+    MIOpen set up kernels for that shape (tens of milliseconds on the host).  The heads therefore always see
+    TEST.DETECTIONS_PER_IM rows: the detections, then copies of the first one (per-RoI results do not depend on the other
+    rows; callers slice the padding off).  (This is NOT the periodic 60-80 ms stall of the eager mask-inference numbers:
+    that one also occurs with exactly 100 detections per image, inside the RPN head's convolutions.)"""
+    cap, r = int(cfg.TEST.DETECTIONS_PER_IM), boxes.size(0)
+    if r == 0 or r >= cap:
+        return boxes
+    return torch.cat([boxes, boxes[:1].expand(cap - r, boxes.size(1))], dim=0)
+
+
 @torch.no_grad()
 def im_detect_mask(model, im_scale, boxes, blob_conv):
     """test.py:365-401: class-specific soft masks [R, K, M, M] (probabilities) of the detected `boxes` [R, 4] (image
@@ -119,8 +131,9 @@ def im_detect_mask(model, im_scale, boxes, blob_conv):
     k = cfg.MODEL.NUM_CLASSES if cfg.MRCNN.CLS_SPECIFIC_MASK else 1
     if boxes.size(0) == 0:
         return torch.zeros((0, k, m, m), dtype=torch.float32, device=boxes.device)
-    pred = model.mask_net(blob_conv, _rois_blob(boxes, im_scale, cfg, "mask_rois"))
-    return pred.float().reshape(-1, k, m, m)
+    r = boxes.size(0)
+    pred = model.mask_net(blob_conv, _rois_blob(_pad_to_detection_cap(boxes, cfg), im_scale, cfg, "mask_rois"))
+    return pred.float().reshape(-1, k, m, m)[:r]
 
 
 @torch.no_grad()
@@ -130,8 +143,9 @@ def im_detect_keypoints(model, im_scale, boxes, blob_conv):
     h = cfg.KRCNN.HEATMAP_SIZE
     if boxes.size(0) == 0:
         return torch.zeros((0, cfg.KRCNN.NUM_KEYPOINTS, h, h), dtype=torch.float32, device=boxes.device)
-    pred = model.keypoint_net(blob_conv, _rois_blob(boxes, im_scale, cfg, "keypoint_rois"))
-    return pred.float().reshape(-1, cfg.KRCNN.NUM_KEYPOINTS, h, h)
+    r = boxes.size(0)
+    pred = model.keypoint_net(blob_conv, _rois_blob(_pad_to_detection_cap(boxes, cfg), im_scale, cfg, "keypoint_rois"))
+    return pred.float().reshape(-1, cfg.KRCNN.NUM_KEYPOINTS, h, h)[:r]
 
 
 @torch.no_grad()
