@@ -33,6 +33,9 @@ Tuning read_tuning() {
   t.cap_px = env_int("MI_ROI_ALIGN_CAP", 336);
   const int th = env_int("MI_ROI_ALIGN_BWD_TH", 16);
   t.bwd_tile_rows = (th == 8 || th == 32) ? th : 16;
+  const int sl = env_int("MI_ROI_ALIGN_BWD_SLICE", 32);
+  t.bwd_slice = 0;  // a power of two in [2, 256], or 0 (no plan)
+  for (int p2 = 2; p2 <= 256 && p2 <= sl; p2 *= 2) t.bwd_slice = p2;
   t.nhwc_vec = env_int("MI_ROI_ALIGN_NHWC_V", 0);
   t.nhwc_pb = env_int("MI_ROI_ALIGN_NHWC_PB", 0);
   const int om = env_int("MI_ROI_ALIGN_NHWC_ORDER_MUL", 1);

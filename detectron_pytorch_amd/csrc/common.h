@@ -56,11 +56,12 @@ inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
 //   MI_ROI_ALIGN_TILES_NO_STREAM=1   workspace path of the NCHW forward without the persistent kernel (A/B)
 //   MI_ROI_ALIGN_CAP=192|256|336|448|640   window pixels per channel of the NCHW forward LDS image
 //   MI_ROI_ALIGN_BWD_TH=8|16|32            rows per backward tile
+//   MI_ROI_ALIGN_BWD_SLICE=n   RoIs per list slice of the planned backward (32; 0: no plan, no atomics)
 //   MI_ROI_ALIGN_NHWC_V / _PB / _ORDER_MUL / _ZIGZAG   channels-last forward variants
 //   MI_ROI_ALIGN_ABLATE=mask   only honoured by builds with -DMI_TUNING (tools/); release kernels compile it out
 struct Tuning {
   bool force_direct, no_ws, use_tiles, tiles_no_stream;
-  int cap_px, bwd_tile_rows;
+  int cap_px, bwd_tile_rows, bwd_slice;
   int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag;
   int ablate;
 };

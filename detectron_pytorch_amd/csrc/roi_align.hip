@@ -356,7 +356,8 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
     if (!force_direct() && !no_ws() &&
         mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
-      return mi::launch_roi_align_bwd_records(top_grad, rois, bottom_grad, workspace, (records_ready & 1) != 0,
+      return mi::launch_roi_align_bwd_records(top_grad, rois, bottom_grad, workspace, workspace_bytes,
+                                              (records_ready & 1) != 0,
                                               (records_ready & 2) != 0, layout == MI_LAYOUT_NHWC, batch, channels,
                                               height, width, num_rois, aligned_height, aligned_width, spatial_scale,
                                               sampling_ratio, ring_words(), s);
@@ -435,6 +436,19 @@ extern "C" size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels
     lv.width[l] = levels->width[l];
   }
   return mi::roi_align_fwd_tiles_workspace_bytes(lv, batch, aligned_height, aligned_width, sampling_ratio);
+}
+
+extern "C" size_t mi_roi_align_backward_workspace_bytes(const mi_fpn_levels* levels, int batch, int num_rois) {
+  if (levels == nullptr || levels->num_levels < 1 || levels->num_levels > mi::kMaxLevels || num_rois <= 0 || batch <= 0)
+    return mi::roi_align_records_workspace_bytes(num_rois);
+  mi::LevelTable lv = {};
+  lv.count = levels->num_levels;
+  for (int l = 0; l < lv.count; l++) {
+    if (levels->height[l] <= 0 || levels->width[l] <= 0) return mi::roi_align_records_workspace_bytes(num_rois);
+    lv.height[l] = levels->height[l];
+    lv.width[l] = levels->width[l];
+  }
+  return mi::roi_align_bwd_workspace_bytes(lv, batch, num_rois);
 }
 
 extern "C" int mi_roi_align_forward_fpn_writes_records(const mi_fpn_levels* levels, int channels, int num_rois,
@@ -522,7 +536,8 @@ extern "C" int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const floa
              "roi_align_fpn: workspace of %zu bytes, %zu needed", workspace_bytes,
              mi::roi_align_records_workspace_bytes(num_rois));
   MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align_fpn: workspace must be 16-byte aligned");
-  return mi::launch_roi_align_bwd_records_levels(top_grad, rois, roi_levels, lv, workspace, (flags & 1) != 0,
+  return mi::launch_roi_align_bwd_records_levels(top_grad, rois, roi_levels, lv, workspace, workspace_bytes,
+                                                 (flags & 1) != 0,
                                                  (flags & 2) != 0, layout == MI_LAYOUT_NHWC, batch, channels, num_rois,
                                                  aligned_height,
                                                  aligned_width, sampling_ratio, ring_words(), mi::as_stream(stream));

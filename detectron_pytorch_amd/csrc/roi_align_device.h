@@ -137,8 +137,8 @@ int launch_roi_align_fwd_records(const float* features, const float* rois, float
 // overwrite: every element of bottom_grad is written (no zero fill needed) instead of accumulated into
 // nhwc: bottom_grad is stored channels-last ([N][H][W][C]); top_grad is always dense [R][C][PH][PW]
 int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float* bottom_grad, void* workspace,
-                                 bool records_ready, bool overwrite, bool nhwc, int batch, int channels, int height,
-                                 int width, int num_rois, int aligned_height, int aligned_width, float spatial_scale,
+                                 size_t workspace_bytes, bool records_ready, bool overwrite, bool nhwc, int batch,
+                                 int channels, int height, int width, int num_rois, int aligned_height, int aligned_width, float spatial_scale,
                                  int sampling_ratio, int cap_px, hipStream_t stream);
 bool roi_align_bwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width);
@@ -146,9 +146,12 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
 int launch_roi_align_fwd_records_levels(const LevelTable& lv, const float* rois, const int* levels, float* output,
                                         void* workspace, int batch, int channels, int num_rois, int aligned_height,
                                         int aligned_width, int sampling_ratio, int cap_px, hipStream_t stream);
+// workspace_bytes >= roi_align_bwd_workspace_bytes(): the planned backward (roi_align_bwd_plan + list slices);
+// a workspace of roi_align_records_workspace_bytes() only: every tile's workgroups scan the RoIs themselves
+size_t roi_align_bwd_workspace_bytes(LevelTable lv, int batch, int num_rois);
 int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois, const int* levels, LevelTable lv,
-                                        void* workspace, bool records_ready, bool overwrite, bool nhwc, int batch,
-                                        int channels, int num_rois, int aligned_height, int aligned_width,
+                                        void* workspace, size_t workspace_bytes, bool records_ready, bool overwrite,
+                                        bool nhwc, int batch, int channels, int num_rois, int aligned_height, int aligned_width,
                                         int sampling_ratio, int cap_px, hipStream_t stream);
 // records only (the first launch of the two-launch paths); `workspace` as roi_align_records_workspace_bytes
 int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,

@@ -28,6 +28,7 @@
 #include "lds_dma.h"
 #include "roi_align_record_layout.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace mi {
@@ -516,6 +517,218 @@ struct BwdLds {
   static constexpr int kGWords = KC * kTileBins * 4;               // g block: up to 224 bins per channel
 };
 
+// roi_align_bwd_plan: one 1024-lane workgroup per tile, in front of roi_align_bwd_tiles when the caller's workspace has
+// room for the plan (roi_align_bwd_workspace_bytes).  It finds the RoIs whose window touches the tile ONCE (the tile kernel
+// used to repeat the scan in each of its channel groups) and leaves their ranks and their number in the workspace; the
+// tile kernel then cuts long lists into slices.  Why slices: the RoIs of a training step cluster on the ground-truth boxes (a few 16 x 32
+// tiles of P4 see 100-200 of the 1024 RoIs, most tiles none), and one workgroup per tile then works for 300 us while
+// the rest of the chip is idle.
+constexpr int kPlanThreads = 1024, kPlanWaves = kPlanThreads / 64;
+__global__ void __launch_bounds__(kPlanThreads)
+roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int batch, int th, int plan_tiles, int plan_cap,
+                   int items_max) {
+  __shared__ int wave_hits[kPlanWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int tile_global = blockIdx.x;
+  int tile_lin = tile_global, lvl = 0;
+  while (lvl + 1 < lv.count && tile_lin >= lv.tile_base[lvl + 1]) lvl++;
+  tile_lin -= lv.tile_base[lvl];
+  const int height = lv.height[lvl], width = lv.width[lvl];
+  const int tiles_x = (width + kTW - 1) / kTW, tiles_y = (height + th - 1) / th;
+  const int n = tile_lin / (tiles_x * tiles_y);
+  const int trem = tile_lin - n * tiles_x * tiles_y;
+  const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+  const int x0 = txi * kTW, y0 = tyi * th;
+  const int img_row0 = lv.row_base[lvl] + n * height;
+  const int gy0 = img_row0 + y0;
+  const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
+  int* __restrict__ counts = ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4);
+  int4* __restrict__ items = reinterpret_cast<int4*>(counts + ((plan_tiles + 3) & ~3));
+  unsigned short* __restrict__ list = reinterpret_cast<unsigned short*>(items + items_max) + (long long)tile_global * plan_cap;
+  // each wave owns a contiguous share of the ranks: count, one barrier, then write at the wave's offset (rank order)
+  const int share = (((num_rois + kPlanWaves - 1) / kPlanWaves) + 63) & ~63;
+  const int r0 = wave * share, r1 = min(num_rois, r0 + share);
+  auto hit_of = [&](int i) {
+    if (i >= r1) return false;
+    const int4 b = bounds[i];
+    return b.y >= x0 && b.x < x0 + kTW && b.w >= gy0 && b.z < gy0 + th && b.z >= img_row0 && b.z < img_row0 + height;
+  };
+  int mine = 0;
+  for (int base = r0; base < r1; base += 64) mine += __popcll(__ballot(hit_of(base + lane)));
+  if (lane == 0) wave_hits[wave] = mine;
+  __syncthreads();
+  int off = 0, total = 0;
+  for (int w = 0; w < kPlanWaves; w++) {
+    off += w < wave ? wave_hits[w] : 0;
+    total += wave_hits[w];
+  }
+  if (mine > 0)
+    for (int base = r0; base < r1; base += 64) {
+      const bool hit = hit_of(base + lane);
+      const unsigned long long m = __ballot(hit);
+      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(base + lane);
+      off += __popcll(m);
+    }
+  if (tid == 0) counts[tile_global] = total;
+}
+
+// roi_align_bwd_items: workgroup 0, between roi_align_bwd_plan and roi_align_bwd_tiles, turns the per-tile counts into the
+// item table the tile kernel's workgroups index with blockIdx / ncg (a release fence + ticket in the plan kernel, so that
+// its last workgroup could do this, cost 350 us: an agent-scope fence writes the whole L2 back, once per tile).
+// Items, in dispatch order: (0) the slices of the long lists, (1) the short lists, (2) under the OVERWRITE contract the
+// tiles without RoIs (their workgroups only store zeros, and do so on the compute units the long items leave idle).
+// Slice length: the first of {1, 2, 4, 8, 32} * slice_min (a power of two), "whole list" whose item total fits the table.
+constexpr int kMaxPlanTiles = 8192;
+__global__ void __launch_bounds__(1024)
+roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int batch, int channels, int th,
+                    int slice_shift, int plan_tiles, int items_max, int overwrite) {
+  if (blockIdx.x > 0) {
+    // ---- workgroups 1..: (tile, group of 32 channels) -- zero-fill the tiles whose list may be cut into slices (their
+    // sums arrive by atomics); launched under the OVERWRITE contract only, next to the table builder ----
+    const int nzg = channels / kCT;
+    const int zg = (blockIdx.x - 1) % nzg, tile_global = (blockIdx.x - 1) / nzg;
+    const const_int_ptr cnt_p =
+        (const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4) + tile_global);
+    if (cnt_p[0] <= (1 << slice_shift)) return;
+    const int tid = threadIdx.x;
+    int tile_lin = tile_global, lvl = 0;
+    while (lvl + 1 < lv.count && tile_lin >= lv.tile_base[lvl + 1]) lvl++;
+    tile_lin -= lv.tile_base[lvl];
+    const int height = lv.height[lvl], width = lv.width[lvl];
+    const int tiles_x = (width + kTW - 1) / kTW, tiles_y = (height + th - 1) / th;
+    const int n = tile_lin / (tiles_x * tiles_y);
+    const int trem = tile_lin - n * tiles_x * tiles_y;
+    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+    const int x0 = txi * kTW, y0 = tyi * th;
+    float* __restrict__ grad = lv.grad[lvl];
+    const int rows = min(th, height - y0), cols = min(kTW, width - x0), c0 = zg * kCT;
+    if (overwrite & 2) {
+      // channels-last: kCT contiguous floats per pixel
+      for (int i = tid; i < rows * cols * (kCT / 4); i += 1024) {
+        const int px = i / (kCT / 4), q = i - px * (kCT / 4);
+        const int rr = px / cols, cc = px - rr * cols;
+        reinterpret_cast<float4*>(grad + (((long long)n * height + y0 + rr) * width + x0 + cc) * channels + c0)[q] =
+            make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else if (cols == kTW && (width & 3) == 0) {
+      // 128-byte row pieces, 16-byte aligned: eight lanes per piece
+      for (int i = tid; i < kCT * rows * 8; i += 1024) {
+        const int seg = i >> 3, q = i & 7;
+        const int c = seg / rows, rr = seg - c * rows;
+        reinterpret_cast<float4*>(grad + (((long long)n * channels + c0 + c) * height + y0 + rr) * width + x0)[q] =
+            make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      const int col = tid & 31;
+      if (col < cols)
+        for (int i = tid >> 5; i < kCT * rows; i += 32) {
+          const int c = i / rows, rr = i - c * rows;
+          grad[(((long long)n * channels + c0 + c) * height + y0 + rr) * width + x0 + col] = 0.f;
+        }
+    }
+    return;
+  }
+  __shared__ int cnts[kMaxPlanTiles];
+  __shared__ int ladder[6];
+  __shared__ int wsum[3][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int* __restrict__ counts = ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4);
+  int4* __restrict__ items = reinterpret_cast<int4*>(const_cast<int*>(counts) + ((plan_tiles + 3) & ~3));
+  auto wave_sum = [&](int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+  };
+  for (int t = tid; t < plan_tiles; t += 1024) cnts[t] = counts[t];
+  if (tid < 6) ladder[tid] = 0;
+  __syncthreads();
+  const int empty_items = (overwrite & 1) ? 1 : 0;
+  {
+    int sums[6] = {0, 0, 0, 0, 0, 0};
+    for (int t = tid; t < plan_tiles; t += 1024) {
+      const int cnt = cnts[t];
+      const int empty = cnt == 0 ? empty_items : 0;
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int sh = slice_shift + (k < 4 ? k : 5);
+        sums[k] += ((cnt + (1 << sh) - 1) >> sh) + empty;
+      }
+      sums[5] += (cnt > 0 ? 1 : 0) + empty;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int v = wave_sum(sums[k]);
+      if (lane == 0 && v != 0) atomicAdd(&ladder[k], v);
+    }
+  }
+  __syncthreads();
+  int shift = 30, nitems = ladder[5];
+#pragma unroll
+  for (int k = 4; k >= 0; k--)
+    if (ladder[k] <= items_max) {
+      shift = slice_shift + (k < 4 ? k : 5);
+      nitems = ladder[k];
+    }
+  auto classify = [&](int t, int& cnt, int& v) {
+    cnt = t < plan_tiles ? cnts[t] : -1;
+    v = cnt > 0 ? ((cnt - 1) >> shift) + 1 : (cnt == 0 ? empty_items : 0);
+    return v == 0 ? 3 : cnt == 0 ? 2 : (v > 1 || (cnt >> (shift - 1)) > 0) ? 0 : 1;
+  };
+  // class totals -> class bases
+  int base[3];
+  {
+    int tot[3] = {0, 0, 0};
+    for (int t = tid; t < plan_tiles; t += 1024) {
+      int cnt, v;
+      const int cls = classify(t, cnt, v);
+#pragma unroll
+      for (int c = 0; c < 3; c++) tot[c] += cls == c ? v : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int v = wave_sum(tot[c]);
+      if (lane == 0) wsum[c][wave] = v;
+    }
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      base[c] = run;
+      for (int w = 0; w < 16; w++) run += wsum[c][w];
+    }
+    __syncthreads();
+  }
+  // positions: exclusive scan of the slice counts inside each class, tile order
+  for (int chunk = 0; chunk < plan_tiles; chunk += 1024) {
+    int cnt, v;
+    const int cls = classify(chunk + tid, cnt, v);
+    int incl[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      int x = cls == c ? v : 0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(x, d);
+        if (lane >= d) x += o;
+      }
+      incl[c] = x;
+      if (lane == 63) wsum[c][wave] = x;
+    }
+    __syncthreads();
+    if (cls < 3) {
+      int pos = base[cls] + (cls == 0 ? incl[0] : cls == 1 ? incl[1] : incl[2]) - v;
+      for (int w = 0; w < wave; w++) pos += wsum[cls][w];
+      const int per = (cnt + v - 1) / v;  // even slices: (v - 1) * per < cnt; an empty tile is one item of length 0
+      for (int sl = 0; sl < v; sl++) items[pos + sl] = make_int4(chunk + tid, sl * per, min(per, cnt - sl * per), v);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      for (int w = 0; w < 16; w++) base[c] += wsum[c][w];
+    __syncthreads();
+  }
+  for (int i = nitems + tid; i < items_max; i += 1024) items[i] = make_int4(-1, 0, 0, 0);
+}
+
 // 16-row tiles with 32 channels: 84 VGPRs would cap a SIMD at 5 waves = two 8-wave workgroups per CU; pinning the
 // kernel to 6 waves per SIMD (<= 80 VGPRs) lets the third workgroup the LDS budget allows become resident.
 // kA > 0: aligned_height == aligned_width == kA at compile time (7 and 14, the sizes of the box / mask heads): the
@@ -526,7 +739,7 @@ __global__ void __launch_bounds__(kTH * 32)
     __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
 roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, const int* __restrict__ ws,
                     int num_rois, int batch, int channels, int aligned_height_arg, int aligned_width_arg, int overwrite,
-                    int ablate_arg, int g_words_arg, int ah_pad_arg, int g_cs_arg) {
+                    int ablate_arg, int g_words_arg, int ah_pad_arg, int g_cs_arg, int plan_tiles, int plan_cap) {
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   const int ah_pad = kA > 0 ? ((kA + 3) & ~3) : ah_pad_arg;
   const int g_cs = kA > 0 ? 4 * ((kA * ((kA + 3) & ~3) / 4) | 1) : g_cs_arg;
@@ -552,6 +765,19 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
   const int ncg = channels / KC;
   const int cg = blockIdx.x % ncg;
   int tile_lin = blockIdx.x / ncg;
+  int nslices = 1, planned_len = 0, planned_first = 0;
+  if (plan_tiles > 0) {
+    // ---- planned launch (roi_align_bwd_plan ran before): blockIdx / ncg is an ITEM = one slice of one tile's list; the
+    // grid is an upper bound of the item count, the entries behind the last item hold -1 ----
+    const const_int_ptr it = (const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4) +
+                                                         ((plan_tiles + 3) & ~3) + 4 * (blockIdx.x / ncg));
+    tile_lin = it[0];
+    if (tile_lin < 0) return;
+    planned_first = it[1];
+    planned_len = it[2];
+    nslices = it[3];
+  }
+  const int tile_global = tile_lin;
   int lvl = 0;  // the level this tile belongs to (tiles of all levels share the grid in an FPN-fused call)
   while (lvl + 1 < lv.count && tile_lin >= lv.tile_base[lvl + 1]) lvl++;
   tile_lin -= lv.tile_base[lvl];
@@ -569,9 +795,14 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
   const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
 
   // ---- RoIs whose window touches this tile, in rank order ----
-  if (tid == 0) list_len = 0;
+  if (tid == 0) list_len = planned_len;
+  if (plan_tiles > 0) {
+    const unsigned short* __restrict__ lists = reinterpret_cast<const unsigned short*>(
+        ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4) + ((plan_tiles + 3) & ~3) + 4 * (gridDim.x / ncg));
+    for (int i = tid; i < planned_len; i += kThreads) list[i] = lists[(long long)tile_global * plan_cap + planned_first + i];
+  }
   __syncthreads();
-  for (int base = 0; base < num_rois; base += kThreads) {
+  for (int base = 0; plan_tiles == 0 && base < num_rois; base += kThreads) {
     const int i = base + tid;
     bool hit = false;
     if (i < num_rois) {
@@ -728,7 +959,16 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
 
   // ---- the tile leaves as 128-byte rows (NCHW) or as one 4*KC-byte run per pixel (channels-last) ----
   const int row = y0 + prow, col = x0 + pcol;
-  if (row < height && col < width) {
+  if (row < height && col < width && nslices > 1) {
+    // the slices of a long list add into the tile the plan kernel zero-filled (or the caller's values): hardware fp32
+    // atomics, the order of the slices' sums is not fixed (the reference's backward is atomic throughout)
+    const long long cs = (overwrite & 2) ? 1 : (long long)height * width;
+    float* dst = (overwrite & 2) ? bottom_grad + (((long long)n * height + row) * width + col) * channels + c0
+                                 : bottom_grad + (((long long)n * channels + c0) * height + row) * width + col;
+#pragma unroll
+    for (int c = 0; c < KC; c++)
+      if (acc[c] != 0.f) atomicAdd(dst + c * cs, acc[c]);
+  } else if (row < height && col < width) {
     if (overwrite & 2) {
       float4* dst = reinterpret_cast<float4*>(bottom_grad + (((long long)n * height + row) * width + col) * channels + c0);
 #pragma unroll
@@ -859,8 +1099,32 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
 
 // Backward over the records.  `lv` carries the gradient map of every level (grad[], height[], width[], scale[],
 // row_base[]); tile_base[] is filled here.  nhwc: the gradient maps are stored channels-last.
+namespace {
+int bwd_tile_count(LevelTable& lv, int batch, int th) {
+  lv.tile_base[0] = 0;
+  for (int l = 0; l < lv.count; l++)
+    lv.tile_base[l + 1] = lv.tile_base[l] + ((lv.width[l] + kTW - 1) / kTW) * ((lv.height[l] + th - 1) / th) * batch;
+  return lv.tile_base[lv.count];
+}
+// the plan region behind the records and bounds: one count per tile, the item table (int4 {tile, first, length,
+// slices of the tile}; the grid of the tile kernel is its capacity), one list of 16-bit ranks per tile
+int bwd_plan_items(int tiles, int num_rois) { return tiles + std::min(std::max(num_rois / 4, 64), 2048); }
+size_t bwd_plan_bytes(int tiles, int num_rois) {
+  return (size_t)((tiles + 3) & ~3) * 4 + (size_t)bwd_plan_items(tiles, num_rois) * 16 +
+         (size_t)tiles * ((num_rois + 7) & ~7) * 2;
+}
+}  // namespace
+
+size_t roi_align_bwd_workspace_bytes(LevelTable lv, int batch, int num_rois) {
+  const size_t rec = roi_align_records_workspace_bytes(num_rois);
+  if (num_rois <= 0 || batch <= 0 || tuning().bwd_slice <= 0) return rec;
+  const int tiles = bwd_tile_count(lv, batch, tuning().bwd_tile_rows);
+  return tiles <= kMaxPlanTiles ? rec + bwd_plan_bytes(tiles, num_rois) : rec;
+}
+
 int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois, const int* levels, LevelTable lv,
-                                        void* workspace, bool records_ready, bool overwrite, bool nhwc, int batch,
+                                        void* workspace, size_t workspace_bytes, bool records_ready, bool overwrite,
+                                        bool nhwc, int batch,
                                         int channels, int num_rois, int aligned_height, int aligned_width,
                                         int sampling_ratio, int cap_px, hipStream_t stream) {
   int* ws = static_cast<int*>(workspace);
@@ -880,10 +1144,25 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   const int g_words = kc * g_cs;
   const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
   const size_t lds = (32 + (size_t)(((num_rois + 1) / 2 + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
-  lv.tile_base[0] = 0;
-  for (int l = 0; l < lv.count; l++)
-    lv.tile_base[l + 1] = lv.tile_base[l] + ((lv.width[l] + kTW - 1) / kTW) * ((lv.height[l] + th - 1) / th) * batch;
-  const int grid = lv.tile_base[lv.count] * (channels / kc);
+  const int tiles = bwd_tile_count(lv, batch, th);
+  // planned launch (see roi_align_bwd_plan) when the workspace has room for the plan: the grid is an upper bound of the
+  // number of list slices (every tile once + room for extra slices of the long lists)
+  const int slice_min = tuning().bwd_slice;
+  const bool planned = slice_min > 0 && tiles <= kMaxPlanTiles &&
+                       workspace_bytes >= roi_align_records_workspace_bytes(num_rois) + bwd_plan_bytes(tiles, num_rois);
+  const int plan_cap = (num_rois + 7) & ~7;
+  const int items = planned ? bwd_plan_items(tiles, num_rois) : tiles;
+  const int grid = items * (channels / kc);
+  if (planned) {
+    roi_align_bwd_plan<<<tiles, kPlanThreads, 0, stream>>>(lv, ws, num_rois, batch, th, tiles, plan_cap, items);
+    int rc = check_launch("roi_align_bwd_plan");
+    if (rc != MI_OK) return rc;
+    roi_align_bwd_items<<<overwrite ? 1 + tiles * (channels / kCT) : 1, 1024, 0, stream>>>(
+        lv, ws, num_rois, batch, channels, th, 31 - __builtin_clz((unsigned)slice_min), tiles, items,
+        (overwrite ? 1 : 0) | (nhwc ? 2 : 0));
+    rc = check_launch("roi_align_bwd_items");
+    if (rc != MI_OK) return rc;
+  }
 #define MI_LAUNCH_TILES_A(SR, KC, TH, A)                                                                              \
   do {                                                                                                                \
     if (lds > 64 * 1024)                                                                                              \
@@ -891,7 +1170,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
     roi_align_bwd_tiles<SR, KC, TH, A><<<grid, TH * 32, lds, stream>>>(                                              \
         top_grad, lv, ws, num_rois, batch, channels, aligned_height, aligned_width,                                   \
-        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs);                                 \
+        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs, planned ? tiles : 0, plan_cap); \
   } while (0)
 #define MI_LAUNCH_TILES_TH(SR, KC, TH)                                                                                \
   do {                                                                                                                \
@@ -934,12 +1213,14 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
 }
 
 int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float* bottom_grad, void* workspace,
-                                 bool records_ready, bool overwrite, bool nhwc, int batch, int channels, int height,
+                                 size_t workspace_bytes, bool records_ready, bool overwrite, bool nhwc, int batch,
+                                 int channels, int height,
                                  int width, int num_rois, int aligned_height, int aligned_width, float spatial_scale,
                                  int sampling_ratio, int cap_px, hipStream_t stream) {
   return launch_roi_align_bwd_records_levels(top_grad, rois, nullptr,
                                              single_level(nullptr, bottom_grad, batch, height, width, spatial_scale),
-                                             workspace, records_ready, overwrite, nhwc, batch, channels, num_rois,
+                                             workspace, workspace_bytes, records_ready, overwrite, nhwc, batch, channels,
+                                             num_rois,
                                              aligned_height, aligned_width, sampling_ratio, cap_px, stream);
 }
 

@@ -72,6 +72,8 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
     ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
     if layout == _lib.LAYOUT_NCHW and variant == _lib.ROI_ALIGN_CAFFE2:
         ws_bytes = max(ws_bytes, _tiles_workspace_bytes([(h, w)], n, aligned_height, aligned_width, sampling_ratio))
+    if records:
+        ws_bytes = max(ws_bytes, _backward_workspace_bytes([(h, w)], n, r))  # a backward reuses this scratch
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=features.device)
     with torch.cuda.device(features.device):
         rc = lib.mi_roi_align_forward_ws(
@@ -90,6 +92,15 @@ def _tiles_workspace_bytes(sizes, batch, aligned_height, aligned_width, sampling
         t.height[i], t.width[i] = int(h), int(w)
     return int(_lib.lib().mi_roi_align_forward_tiles_workspace_bytes(
         ctypes.byref(t), int(batch), int(aligned_height), int(aligned_width), int(sampling_ratio)))
+
+
+def _backward_workspace_bytes(sizes, batch, num_rois):
+    """mi_roi_align_backward_workspace_bytes for gradient maps of the given (height, width)s: records + backward plan."""
+    t = _lib.FpnLevels()
+    t.num_levels = len(sizes)
+    for i, (h, w) in enumerate(sizes):
+        t.height[i], t.width[i] = int(h), int(w)
+    return int(_lib.lib().mi_roi_align_backward_workspace_bytes(ctypes.byref(t), int(batch), int(num_rois)))
 
 
 def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_width, spatial_scale,
@@ -115,7 +126,8 @@ def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_
     # `workspace`: the scratch of the forward over the same rois (records are reused); else a fresh one
     ready = workspace is not None and workspace.numel() >= ws_bytes and workspace.device == grad_output.device
     if not ready:
-        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_output.device)
+        workspace = torch.empty(_backward_workspace_bytes([(h, w)], n, r) if variant == _lib.ROI_ALIGN_CAFFE2 else ws_bytes,
+                                dtype=torch.uint8, device=grad_output.device)
     flags = (_lib.ROI_ALIGN_RECORDS_READY if ready else 0) | (_lib.ROI_ALIGN_OVERWRITE if overwrite else 0)
     with torch.cuda.device(grad_output.device):
         rc = lib.mi_roi_align_backward_ws(
@@ -202,6 +214,7 @@ class _RoIAlignFPN(Function):
         ws_bytes = max(lib.mi_roi_align_forward_workspace_bytes(r),
                        _tiles_workspace_bytes([(f.size(2), f.size(3)) for f in features], n, aligned_height,
                                               aligned_width, sampling_ratio))
+        ws_bytes = max(ws_bytes, _backward_workspace_bytes([(f.size(2), f.size(3)) for f in features], n, r))
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=rois.device)
         table = _fpn_table(features, scales)
         layout = _common_layout(features)

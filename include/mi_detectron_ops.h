@@ -151,6 +151,15 @@ int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int nu
  * num_levels of `levels` are read (one level for the single-map entries). */
 size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels* levels, int batch, int aligned_height,
                                                   int aligned_width, int sampling_ratio);
+/* Workspace with room for the PLANNED backward (>= mi_roi_align_forward_workspace_bytes(num_rois)): behind the records a
+ * pre-kernel (roi_align_bwd_plan) leaves, per 16 x 32 tile of the gradient maps, the list of RoIs that touch it, and the
+ * tile kernel's workgroups each take a slice of at most MI_ROI_ALIGN_BWD_SLICE (32) RoIs of one list -- the RoIs of a
+ * training step cluster on the ground-truth boxes and a few tiles see hundreds of them.  The slices of one list add their
+ * sums with fp32 atomics (order not fixed; lists of <= 32 RoIs are summed in a fixed order as before).  Passing only the
+ * forward size to mi_roi_align_backward_ws / _fpn keeps the unplanned backward (one workgroup per tile walks the whole
+ * list, no atomics).  Only height[] / width[] / num_levels of `levels` are read (one level for the single-map entries).
+ * Replaces: the reference's backward is atomicAdd per tap throughout (roi_align_kernel.cu:195-270). */
+size_t mi_roi_align_backward_workspace_bytes(const mi_fpn_levels* levels, int batch, int num_rois);
 /* 1 when mi_roi_align_forward_fpn with these arguments leaves the records of its rois in the workspace (channels-last
  * maps); 0 when it does not (NCHW maps: the tile-centric forward needs none) -- the backward must then be called
  * without MI_ROI_ALIGN_RECORDS_READY and writes its own. */

@@ -69,12 +69,16 @@ def tuning_env(monkeypatch):
     _lib.lib().mi_dbg_reload_tuning()
 
 
-@pytest.fixture(params=["stream", "tiles", "direct"])
+@pytest.fixture(params=["stream", "stream_unplanned", "stream_sliced", "tiles", "direct"])
 def roi_align_impl(request, tuning_env):
     """Run a test against the RoIAlign implementations behind mi_roi_align_*: the default fast paths ("stream": the
-    record-driven forward and backward), the tile-centric NCHW forward (MI_ROI_ALIGN_IMPL=tiles: one launch without
+    record-driven forward, the planned backward with list slices of 32 RoIs; "stream_unplanned": MI_ROI_ALIGN_BWD_SLICE=0,
+    one workgroup walks a tile's whole list; "stream_sliced": slices of 2 RoIs, so that nearly every tile is summed by
+    several workgroups with atomics), the tile-centric NCHW forward (MI_ROI_ALIGN_IMPL=tiles: one launch without
     scratch, pre-kernel + persistent kernel with it) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
-    tuning_env(MI_ROI_ALIGN_IMPL=None if request.param == "stream" else request.param)
+    stream = request.param.startswith("stream")
+    tuning_env(MI_ROI_ALIGN_IMPL=None if stream else request.param,
+               MI_ROI_ALIGN_BWD_SLICE={"stream_unplanned": 0, "stream_sliced": 2}.get(request.param))
     return request.param
 
 
@@ -849,6 +853,60 @@ def test_roi_align_fpn_fused_matches_per_level_loop_and_oracle(oracle_mod):
                    oracle_mod.roi_align_forward(feats[k], adv[idx], 7, 7, scales[k], 2), "adv fwd %d" % k, exact=False)
         assert_close(dev_feats[k].grad, oracle_mod.roi_align_backward(g2[idx], adv[idx], feats[k].shape, scales[k], 2),
                      "adv bwd %d" % k)
+
+
+def _clustered_rois(num, batch, height, width, scale, boxes_per_image, seed):
+    """RoIs jittered around a few boxes per image (what a training step samples around its ground truth)."""
+    rng = np.random.RandomState(seed)
+    img_w, img_h = width / scale, height / scale
+    gts = []
+    for n in range(batch):
+        for _ in range(boxes_per_image):
+            w, h = rng.uniform(0.08, 0.45) * img_w, rng.uniform(0.08, 0.45) * img_h
+            x, y = rng.uniform(0, img_w - w), rng.uniform(0, img_h - h)
+            gts.append((n, x, y, x + w, y + h))
+    pick = rng.randint(0, len(gts), size=num)
+    rois = np.zeros((num, 5), np.float32)
+    for i, k in enumerate(pick):
+        n, x1, y1, x2, y2 = gts[k]
+        j = rng.uniform(-0.12, 0.12, size=4) * np.array([x2 - x1, y2 - y1, x2 - x1, y2 - y1])
+        rois[i] = (n, max(x1 + j[0], 0), max(y1 + j[1], 0), min(x2 + j[2], img_w - 1), min(y2 + j[3], img_h - 1))
+    return rois
+
+
+@pytest.mark.parametrize("slice_len", [None, 8])
+@pytest.mark.parametrize("res,channels_last", [(7, False), (14, False), (7, True)])
+def test_roi_align_backward_of_clustered_rois_is_cut_into_list_slices(oracle_mod, tuning_env, res, channels_last, slice_len):
+    """The planned backward (roi_align_bwd_plan + roi_align_bwd_tiles over list slices): 600 RoIs on 3 boxes per image make
+    tile lists of 100+ RoIs, which several workgroups sum with atomics into tiles the plan kernel zero-filled; tiles without
+    RoIs get no workgroup.  Against the oracle, overwrite contract (autograd path) and accumulate contract (raw call on a
+    pre-filled buffer), and next to the unplanned backward."""
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import _backward_workspace_bytes
+
+    n, c, h, w, scale = 2, 64, 50, 84, 1.0 / 16
+    feat = syn.feature_map(n, c, h, w, seed=5)
+    rois = _clustered_rois(600, n, h, w, scale, 3, seed=res)
+    gtop = np.random.RandomState(3).randn(600, c, res, res).astype(np.float32)
+    ref = oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2, threads=8)
+    tuning_env(MI_ROI_ALIGN_BWD_SLICE=slice_len)
+    assert _backward_workspace_bytes([(h, w)], n, 600) > _lib.lib().mi_roi_align_forward_workspace_bytes(600)
+    _, grad = _roi_align_gpu(feat, rois, res, scale, 2, gtop, channels_last=channels_last)
+    assert_close(grad, ref, "planned bwd")
+    # accumulate contract through the C-ABI: flags = 0, the buffer keeps what it held
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    buf = torch.full((n, c, h, w), 0.5, device=dev()).contiguous(memory_format=fmt)
+    ws = torch.empty(_backward_workspace_bytes([(h, w)], n, 600), dtype=torch.uint8, device=dev())
+    g, r = to_dev(gtop), to_dev(rois)
+    rc = _lib.lib().mi_roi_align_backward_ws(g.data_ptr(), r.data_ptr(), buf.data_ptr(), n, c, h, w, 600, res, res, scale, 2,
+                                            _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NHWC if channels_last else _lib.LAYOUT_NCHW,
+                                            ws.data_ptr(), ws.numel(), 0, _lib.current_stream_handle(dev()))
+    _lib.check(rc, "mi_roi_align_backward_ws")
+    assert_close(buf, ref + 0.5, "planned bwd, accumulate")
+    tuning_env(MI_ROI_ALIGN_BWD_SLICE=0)
+    assert _backward_workspace_bytes([(h, w)], n, 600) == _lib.lib().mi_roi_align_forward_workspace_bytes(600)
+    _, grad0 = _roi_align_gpu(feat, rois, res, scale, 2, gtop, channels_last=channels_last)
+    assert_close(grad0, ref, "unplanned bwd")
 
 
 @pytest.mark.parametrize("channels_last", [False, True])

@@ -16,10 +16,11 @@ rm -rf $O/trace
 fi
 if [ $STAGE = all ] || [ $STAGE = config2 ]; then
 echo "pass,kernel,calls,avg_ns,min_ns,max_ns" > $O/config2_kernel_durations.csv
-for pass in roi_align_fwd roi_align_bwd nhwc_fwd tiles_one_launch tiles_descriptors; do
-  unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS; k=roi_align_fwd
+for pass in roi_align_fwd roi_align_bwd roi_align_bwd_unplanned nhwc_fwd tiles_one_launch tiles_descriptors; do
+  unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS MI_BENCH_BWD_UNPLANNED; k=roi_align_fwd
   case $pass in
     roi_align_bwd) k=roi_align_bwd;;
+    roi_align_bwd_unplanned) k=roi_align_bwd; export MI_BENCH_BWD_UNPLANNED=1;;
     nhwc_fwd) export MI_BENCH_NHWC=1;;
     tiles_one_launch) export MI_ROI_ALIGN_IMPL=tiles;;
     tiles_descriptors) export MI_ROI_ALIGN_IMPL=tiles MI_BENCH_TILES_WS=1;;
@@ -35,7 +36,13 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
 PY
   rm -rf $O/c2_$pass
 done
-unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS
+unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS MI_BENCH_BWD_UNPLANNED
+fi
+if [ $STAGE = all ] || [ $STAGE = steprois ]; then
+(cd $R && for c in box mask cfg2; do for sl in 0 32; do
+  echo "=== case $c MI_ROI_ALIGN_BWD_SLICE=$sl"
+  CASES=$c SLICES=$sl bash tools/gpu_prof_script.sh bwd_${c}_$sl python tools/bwd_time.py 30 | grep -v "simple_timer"
+done; done) > $O/step_rois_backward_kernels.txt 2>&1
 fi
 if [ $STAGE = all ] || [ $STAGE = pmc ]; then
 for variant in records tiles; do
@@ -53,4 +60,4 @@ for variant in records tiles; do
 done
 unset MI_ROI_ALIGN_IMPL
 fi
-cut -c1-600 $O/bench_line.json 2>/dev/null; echo; head -24 $O/train_step_steady_state.txt 2>/dev/null | cut -c1-150; cat $O/config2_kernel_durations.csv 2>/dev/null; cat $O/pmc_fwd_records.txt $O/pmc_fwd_tiles.txt 2>/dev/null
+cut -c1-600 $O/bench_line.json 2>/dev/null; echo; head -24 $O/train_step_steady_state.txt 2>/dev/null | cut -c1-150; cat $O/config2_kernel_durations.csv $O/step_rois_backward_kernels.txt 2>/dev/null; cat $O/pmc_fwd_records.txt $O/pmc_fwd_tiles.txt 2>/dev/null

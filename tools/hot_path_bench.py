@@ -162,19 +162,33 @@ def roofline_roi_align_forward(device, iters):
     ready = bool(lib.mi_roi_align_forward_writes_records(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, layout))
     bwd_flags = (_lib.ROI_ALIGN_RECORDS_READY if ready else 0) | (_lib.ROI_ALIGN_OVERWRITE if overwrite else 0)
 
-    def launch_bwd():  # zero fill only where the path accumulates
-        if not overwrite:
+    # the workspace the autograd Function allocates: records + room for the backward plan (lists per gradient tile, cut
+    # into slices for the clustered RoIs of a training step); with the forward's size the backward runs unplanned
+    from detectron_pytorch_amd.roi_align import _backward_workspace_bytes
+
+    bws_bytes = max(ws_bytes, _backward_workspace_bytes([(h, w)], 1, r))
+    bws = torch.empty(bws_bytes, dtype=torch.uint8, device=device)
+
+    def launch_bwd(space=bws, size=bws_bytes, flags=bwd_flags & ~_lib.ROI_ALIGN_RECORDS_READY):
+        if not overwrite:  # zero fill only where the path accumulates
             gin.zero_()
         rc = lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
-                                          scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, ws.data_ptr(), ws_bytes,
-                                          bwd_flags, stream)
+                                          scale, sr, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, space.data_ptr(), size,
+                                          flags, stream)
         assert rc == 0
 
-    sec_bwd = time_kernel(launch_bwd, max(iters // 4, 10))
+    launch_bwd()  # leaves the records in `bws`
+    sec_bwd = time_kernel(lambda: launch_bwd(flags=bwd_flags), max(iters // 4, 10))
+    sec_unplanned = time_kernel(lambda: launch_bwd(ws, ws_bytes, bwd_flags), max(iters // 4, 10))
     bwd_bytes = 4 * r * c * res * res + 4 * c * h * w + 20 * r
     info["backward"] = {"zero_fill_needed": not overwrite, "avg_us_incl_zero_fill": round(sec_bwd * 1e6, 2),
                         "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
-                        "algorithmic_bytes": int(bwd_bytes)}
+                        "algorithmic_bytes": int(bwd_bytes), "planned": bws_bytes > ws_bytes,
+                        "unplanned_us": round(sec_unplanned * 1e6, 2),
+                        "what": "planned = roi_align_bwd_plan + _items + _tiles + _slow with the workspace the autograd "
+                                "Function allocates (pays ~10 us on these uniformly spread RoIs, halves the backward on "
+                                "the clustered RoIs of a training step: roi_align_step_rois); unplanned = the same call "
+                                "with a workspace of the forward's size"}
     info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
     if layout == _lib.LAYOUT_NCHW:
         info["channels_last"] = channels_last_variant(device, lib, stream, feat, rois, out, ws, alg_bytes, gtop, iters)
@@ -309,7 +323,9 @@ def other_shapes(device, lib, stream, iters):
         o = torch.empty((r, c, res, res), device=device)
         gtop = torch.randn(r, c, res, res, device=device)
         gin = torch.empty(n, c, h, w, device=device)
-        ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
+        from detectron_pytorch_amd.roi_align import _backward_workspace_bytes
+
+        ws_bytes = max(lib.mi_roi_align_forward_workspace_bytes(r), _backward_workspace_bytes([(h, w)], n, r))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         over = bool(lib.mi_roi_align_backward_overwrites(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
         ready = bool(lib.mi_roi_align_forward_writes_records(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW))
