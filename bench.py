@@ -498,10 +498,12 @@ def mask_inference(device, iters=12, warmup=3):
             "ms_per_image": round(med * 1e3, 3), "images_per_s": round(1.0 / med, 2),
             "ms_per_image_mean": round(mean * 1e3, 3), "ms_per_image_max": round(max(ts) * 1e3, 3),
             "detections": int(sum(len(c) for c in out[0][1:])), "masks_encoded": int(sum(len(c) for c in out[1][1:])),
-            "what": "median over %d images; every third or fourth image stalls 60-80 ms on the host inside torch.conv2d "
-                    "(cProfile: the RPN head's convolutions) once the mask head's shapes are in the mix -- independent "
-                    "of the caching allocator's settings and of Python's garbage collector (gc.freeze), absent from the "
-                    "hipGraph form; the mean and the maximum show it" % iters}
+            "intra_op_threads": torch.get_num_threads(),
+            "what": "median / mean / max over %d images launched eagerly, one host sync per image.  Until round 3 every "
+                    "third or fourth image took 70-80 ms: torch sized its intra-op pool from the 256 host threads, the "
+                    "container's CPU quota is 16, and the kernel throttled the whole process once a CFS period's quota was "
+                    "spun away by idle OpenMP workers (cpu.stat nr_throttled; profiles/r03_eager_stall.txt).  bench.py now "
+                    "caps the pool with detectron_pytorch_amd.hostcpu.respect_cpu_quota()" % iters}
 
 
 def cpu_baseline(images_per_rank):
@@ -512,7 +514,12 @@ def cpu_baseline(images_per_rank):
     touches oracle/."""
     import oracle
 
-    threads = oracle.num_threads_available()
+    from detectron_pytorch_amd import hostcpu
+
+    # as many OpenMP threads as the container may run: its CPU quota when there is one (more threads than that only get
+    # the process throttled; torch's own cap, set in main(), does not apply -- the oracle takes its thread count per call)
+    quota = hostcpu.cpu_quota()
+    threads = max(1, min(os.cpu_count() or 1, int(quota))) if quota is not None else oracle.num_threads_available()
     h, w, scale = syn.FPN_LEVELS[2]
     feat = syn.feature_map(1, syn.FPN_DIM, h, w, seed=0)
     box_rois, mask_rois = syn.rois_canonical(512, 1, seed=0), syn.rois_canonical(128, 1, seed=1)
@@ -663,7 +670,10 @@ def main():
             torch.distributed.destroy_process_group()
         return
     device = torch.device("cuda", local_rank)
+    from detectron_pytorch_amd import hostcpu
     from tools import hot_path_bench as hp
+
+    hostcpu.respect_cpu_quota()  # a 16-CPU container on a 256-thread host: see hostcpu.py
 
     if args.child_inference_graph == "box":
         print(json.dumps(inference_graph_child(device, args.dtype)), flush=True)

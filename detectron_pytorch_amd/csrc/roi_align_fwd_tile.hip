@@ -24,9 +24,10 @@
 //     ds_read2_b32, and all sampling geometry is identical across the half-wave;
 //   * the 8 half-waves take different output columns pw; tap rows/columns (as LDS byte offsets) and the two weights
 //     per axis sample are computed once per workgroup into two small LDS tables;
-//   * clamped border samples are expressed as the pixel pair (size-2, size-1) with weights (0, 1) instead of the
-//     reference's (size-1, size-1) with (1, 0): the same value for finite features, and "high = low + 1" holds for
-//     every sample, which is what makes the fixed +4 / +pitch tap addressing possible;
+//   * clamped border samples are expressed as the pixel pair (size-1, size) with weights (1, 0), the reference's
+//     (size-1, size-1) with (1, 0): the window ends one row / column past the map and the DMA reads that one from the
+//     clamped address, so "high = low + 1" holds for every sample -- which is what makes the fixed +4 / +pitch tap
+//     addressing possible -- and a non-finite border pixel propagates exactly as in the reference (1 * f + 0 * f);
 //   * results are staged in LDS as [channel][bin] and leave as contiguous 16-byte stores.
 // Windows larger than the LDS image are processed in groups of bin rows (each group: DMA, barrier, compute); output
 // tiles larger than the LDS staging area likewise.  RoIs the scheme cannot serve (a sample outside the [-1, size]
@@ -58,9 +59,9 @@ __device__ __forceinline__ void axis_taps(float v, int size, int& lo, float& hw,
   if (v <= 0) v = 0;
   int low = (int)v;
   if (low >= size - 1) {
-    lo = size - 2;
-    hw = 0.f;  // reference: low = high = size - 1, l = 0, h = 1
-    lw = 1.f;
+    lo = size - 1;  // reference: low = high = size - 1, l = 0, h = 1; the pair is (size - 1, size), `size` read clamped
+    hw = 1.f;
+    lw = 0.f;
   } else {
     lo = low;
     lw = v - (float)low;
@@ -69,7 +70,7 @@ __device__ __forceinline__ void axis_taps(float v, int size, int& lo, float& hw,
 }
 __device__ __forceinline__ int axis_lo(float v, int size) {
   if (v <= 0) v = 0;
-  return min((int)v, size - 2);
+  return min((int)v, size - 1);
 }
 
 // Sample coordinates of roi_align_kernel.cu:106-110 with the grid size known at compile time when kS > 0
@@ -199,7 +200,8 @@ roi_align_fwd_tile(const float* __restrict__ feat, const float* __restrict__ roi
       const unsigned p = (unsigned)(k * 64 + lane);
       const unsigned q = (p * magic) >> 20;
       const unsigned col = p - q * (unsigned)ww;
-      const unsigned voff = (((unsigned)row0 + q) * (unsigned)width + (unsigned)wx0 + col) * 4u;
+      const unsigned voff = (min((unsigned)row0 + q, (unsigned)height - 1u) * (unsigned)width +
+                             min((unsigned)wx0 + col, (unsigned)width - 1u)) * 4u;
       if (p < (unsigned)npx) {  // lanes past the window neither read memory nor write LDS
 #pragma unroll
         for (int c = 0; c < kChPerWave; c++)

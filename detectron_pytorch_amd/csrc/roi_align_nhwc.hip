@@ -14,7 +14,8 @@
 //   column pw:   S = sum_ix ( hx * F[row][xlo] + lx * F[row][xlo + 1] ),   acc[pw] += wy(row) * S      (FMAs)
 //   -- the separable evaluation of roi_align_fwd_records (fp32 rounding differences only w.r.t. the reference's
 //   summation order; contract 1e-4, asserted 1e-5).  Border samples come from the record as the pair
-//   (size-2, size-1) with weights (0, 1), so "upper tap = lower tap + 1" always holds.
+//   (size-1, size) with weights (1, 0); the upper tap's address is clamped to size-1 (the reference reads the border
+//   pixel twice, 1 * f + 0 * f).
 //   The 64*V x PH x PW results of the workgroup are transposed through LDS ([k][lane][bin] with an odd bin stride:
 //   conflict-free) and leave as one contiguous run of 16-byte stores (the chunk's output is contiguous in [R][C][PH][PW]).
 //
@@ -168,7 +169,8 @@ roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* _
           }
         }
         if (!touched) continue;
-        const int row_bytes = row * width * pixel_bytes;
+        // row == height / xlo + 1 == width: the upper tap of a border sample (weight 0), read from the last row / column
+        const int row_bytes = min(row, height - 1) * width * pixel_bytes;
         if constexpr (kSR > 0) {
 #pragma unroll
           for (int pw0 = 0; pw0 < PW; pw0 += PB) {
@@ -181,7 +183,7 @@ roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* _
                   const int xlo = xtab(4 * ((pw0 + j) * kSR + ix) + 3);
                   const int tap = row_bytes + xlo * pixel_bytes;
                   load_tap<V>(img, lane_off, tap, f[j][ix][0]);
-                  load_tap<V>(img, lane_off, tap + pixel_bytes, f[j][ix][1]);
+                  load_tap<V>(img, lane_off, tap + (xlo + 1 < width ? pixel_bytes : 0), f[j][ix][1]);
                 }
             __builtin_amdgcn_sched_barrier(0);  // every tap of the batch is in flight before the first FMA
 #pragma unroll
@@ -214,7 +216,7 @@ roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* _
               float f0[V], f1[V];
               const int tap = row_bytes + xlo * pixel_bytes;
               load_tap<V>(img, lane_off, tap, f0);
-              load_tap<V>(img, lane_off, tap + pixel_bytes, f1);
+              load_tap<V>(img, lane_off, tap + (xlo + 1 < width ? pixel_bytes : 0), f1);
 #pragma unroll
               for (int k = 0; k < V; k++) s[k] = fmaf(lx, f1[k], fmaf(hx, f0[k], s[k]));
             }

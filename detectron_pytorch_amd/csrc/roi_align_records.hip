@@ -20,7 +20,7 @@
 // Data movement and arithmetic are those of roi_align_fwd_tile.hip (see its header): LDS-DMA of the compact
 // [row][ww] window into one odd-stride plane per channel, lane & 31 = channel, conflict-free ds_read2_b32 tap pairs,
 // separable FMA evaluation (fp32 rounding differences only w.r.t. the reference's summation order, ~5e-7;
-// contract 1e-4), border samples as (size-2, size-1) with weights (0, 1).
+// contract 1e-4), border samples as (size-1, size) with weights (1, 0) and the address of `size` clamped to size-1.
 // RoIs the LDS image cannot serve are flagged by roi_align_prepare and take the in-kernel direct path (reference
 // operation order, bit-exact).
 #include "common.h"
@@ -45,9 +45,12 @@ __device__ __forceinline__ void axis_taps(float v, int size, int& lo, float& hw,
   if (v <= 0) v = 0;
   int low = (int)v;
   if (low >= size - 1) {
-    lo = size - 2;
-    hw = 0.f;  // reference: low = high = size - 1, l = 0, h = 1
-    lw = 1.f;
+    // reference: low = high = size - 1, l = 0, h = 1.  Encoded as the pair (size - 1, size): the consumers read "row /
+    // column `size`" from the clamped address size - 1, so that the border pixel enters the sum as 1 * f + 0 * f exactly
+    // as in the reference (a non-finite border pixel gives NaN there, and nothing else does)
+    lo = size - 1;
+    hw = 1.f;
+    lw = 0.f;
   } else {
     lo = low;
     lw = v - (float)low;
@@ -361,7 +364,9 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
         const unsigned p = (unsigned)(kk * 64 + lane);
         const unsigned q = (p * (unsigned)magic) >> 20;  // p / ww
         const unsigned col = p - q * (unsigned)ww;
-        const unsigned voff = (((unsigned)row0 + q) * (unsigned)width + (unsigned)wx0 + col) * 4u;
+        // the window may end one row / column past the map (border samples, axis_taps): those read the last one again
+        const unsigned voff = (min((unsigned)row0 + q, (unsigned)height - 1u) * (unsigned)width +
+                               min((unsigned)wx0 + col, (unsigned)width - 1u)) * 4u;
         if (p < (unsigned)npx) {
 #pragma unroll
           for (int c = 0; c < kChPerWave; c++)

@@ -7,8 +7,18 @@ ends in `detection.box_results_with_nms_and_limit` (one batched HIP NMS over all
 """
 import torch
 
-from .. import detection, fpn_proposals
+from .. import detection, fpn_proposals, hostcpu
 from . import results
+
+_checked_cpu_budget = []
+
+
+def _check_cpu_budget():
+    """Once per process: warn when torch's intra-op pool exceeds the container's CPU quota (eager launches then stall
+    periodically, hostcpu.py)."""
+    if not _checked_cpu_budget:
+        _checked_cpu_budget.append(True)
+        hostcpu.warn_if_oversubscribed()
 
 
 def bbox_transform(boxes, deltas, weights, clip):
@@ -92,6 +102,7 @@ def im_detect_bbox(model, data, im_info, im_shape=None, autocast_dtype=None, sta
 def im_detect_all(model, data, im_info, im_shape=None, autocast_dtype=None):
     """test.py:50-125 without test-time augmentation and without the mask / keypoint branches (BASELINE config 3 is
     Faster R-CNN): detections of one image as (scores [D], boxes [D,4], cls_boxes) -- device tensors."""
+    _check_cpu_budget()
     cfg = model.cfg
     scores, boxes, blob_conv = im_detect_bbox(model, data, im_info, im_shape, autocast_dtype)
     t = cfg.TEST
@@ -154,6 +165,7 @@ def im_detect_all_results(model, data, im_info, im_shape=None, autocast_dtype=No
     boxes, in the reference's result formats: (cls_boxes, cls_segms, cls_keyps).  cls_boxes[j] [k_j, 5] device tensors;
     cls_segms[j] a list of COCO RLE dicts (None when MODEL.MASK_ON is off); cls_keyps[j] a list of [4, K] tensors (None
     when MODEL.KEYPOINTS_ON is off)."""
+    _check_cpu_budget()
     cfg = model.cfg
     scale = float(im_info[0][2])
     if im_shape is None:

@@ -17,6 +17,12 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    try:  # a CPU-quota'd container on a many-core host: keep torch's intra-op pool inside the quota (hostcpu.py)
+        from detectron_pytorch_amd import hostcpu
+
+        hostcpu.respect_cpu_quota()
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def _gpu_available():

@@ -210,6 +210,37 @@ def test_roi_align_config2_full_shape(oracle_mod, roi_align_impl):
     assert torch.equal(out2, 2.0 * out.detach())
 
 
+@pytest.mark.parametrize("path", ["records", "channels_last", "no_workspace", "direct"])
+@pytest.mark.parametrize("res,sr", [(7, 2), (6, 0)])
+def test_roi_align_non_finite_border_pixels_propagate_as_in_the_reference(oracle_mod, tuning_env, path, res, sr):
+    """A sample clamped to the last row / column reads the border pixel twice in the reference (weights 1 and 0): an Inf
+    there gives NaN, an Inf in the second-to-last row gives nothing.  Every forward path keeps that: the record kernels
+    encode the pair as (size - 1, size) and read `size` from the clamped address (they used to encode (size - 2, size - 1)
+    with weights (0, 1), which moved the NaN to the wrong bins)."""
+    from detectron_pytorch_amd.roi_align import roi_align_forward
+
+    n, c, h, w, scale = 2, 64, 50, 84, 1.0 / 16
+    feat = syn.feature_map(n, c, h, w, seed=3)
+    rois = syn.rois_adversarial(64, n, h, w, scale, seed=11)
+    feat[:, :, -1, :] = np.inf
+    feat[:, :, :, -1] = -np.inf
+    feat[:, :, 0, 0] = np.nan
+    feat[:, :, -2, 5] = np.inf   # second-to-last row: must NOT leak into bins clamped to the last row
+    feat[:, :, 7, -2] = np.nan
+    ref = oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=8)
+    tuning_env(MI_ROI_ALIGN_IMPL="direct" if path == "direct" else None,
+               MI_ROI_ALIGN_NO_WS="1" if path == "no_workspace" else None)
+    f = to_dev(feat)
+    if path == "channels_last":
+        f = f.contiguous(memory_format=torch.channels_last)
+    out = roi_align_forward(f, to_dev(rois), res, res, scale, sr).cpu().numpy()
+    assert np.isnan(ref).any() and np.isinf(ref).any()
+    assert np.array_equal(np.isnan(out), np.isnan(ref)) and np.array_equal(np.isinf(out), np.isinf(ref))
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.sign(out[~fin & ~np.isnan(ref)]), np.sign(ref[~fin & ~np.isnan(ref)]))
+    assert np.abs(out[fin] - ref[fin]).max() <= FAST_ATOL
+
+
 @pytest.mark.parametrize("variant", ["one_launch", "descriptors", "descriptors_no_stream"])
 @pytest.mark.parametrize("case", ["adversarial", "piled", "nonfinite", "fpn", "sr0"])
 def test_roi_align_tile_kernels(oracle_mod, tuning_env, variant, case):

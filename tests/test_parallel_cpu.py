@@ -178,3 +178,36 @@ def test_bench_selftest_two_ranks_on_gloo():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["metric"] == "selftest" and line["n_gpus"] == 2 and line["collectives_per_step"] >= 1
+
+
+def test_cpu_quota_helper_keeps_the_intra_op_pool_inside_the_container_budget(monkeypatch):
+    """hostcpu: the cgroup quota is parsed (v2 'quota period' / 'max'), and respect_cpu_quota only ever lowers the pool."""
+    import builtins
+    import io
+
+    import torch
+
+    from detectron_pytorch_amd import hostcpu
+
+    real_open = builtins.open
+
+    def fake_open(content):
+        def opener(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                return io.StringIO(content)
+            return real_open(path, *a, **k)
+        return opener
+
+    monkeypatch.setattr(builtins, "open", fake_open("1600000 100000\n"))
+    assert hostcpu.cpu_quota() == 16.0
+    monkeypatch.setattr(builtins, "open", fake_open("max 100000\n"))
+    assert hostcpu.cpu_quota() is None
+    monkeypatch.setattr(builtins, "open", fake_open("800000 100000\n"))
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    before = torch.get_num_threads()
+    try:
+        n = hostcpu.respect_cpu_quota()
+        assert 1 <= n <= max(2, before) and n <= max(before, 2)
+        assert n == min(before, 2)
+    finally:
+        torch.set_num_threads(before)

@@ -13,7 +13,6 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from detectron_pytorch_amd import synthetic as syn  # noqa: E402
-from detectron_pytorch_amd.roi_align import roi_align_fpn  # noqa: E402
 from tools.hot_path_bench import time_kernel  # noqa: E402
 
 
@@ -34,24 +33,42 @@ def step_rois(device):
 
 
 def time_fpn(device, rois, idx, res, iters):
+    """(forward us, backward us) of mi_roi_align_forward_fpn / _backward_fpn on seeded P2..P5 maps of 2 images: the C-ABI
+    calls on preallocated buffers with the workspace the autograd Function allocates (records + backward plan), HIP events
+    on the launch stream -- no allocator, no autograd bookkeeping in the timed region."""
+    import ctypes
+
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import _backward_workspace_bytes, _fpn_table
+
+    lib = _lib.lib()
     maps = [torch.from_numpy(syn.feature_map(2, 256, syn.FPN_LEVELS[l][0], syn.FPN_LEVELS[l][1], seed=l)).to(device)
-            .requires_grad_(True) for l in (5, 4, 3, 2)]
+            for l in (5, 4, 3, 2)]
+    grads = [torch.empty_like(m) for m in maps]
     scales = [syn.FPN_LEVELS[l][2] for l in (5, 4, 3, 2)]
-    out = roi_align_fpn(maps, scales, rois, idx, res, res, 2)
+    rois, idx = rois.contiguous(), idx.to(torch.int32).contiguous()
+    r = int(rois.size(0))
+    out = torch.empty((r, 256, res, res), device=device)
     g = torch.randn_like(out)
+    ws_bytes = max(lib.mi_roi_align_forward_workspace_bytes(r),
+                   _backward_workspace_bytes([(m.size(2), m.size(3)) for m in maps], 2, r))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    ftab, gtab = _fpn_table(maps, scales), _fpn_table(grads, scales, grads=True)
+    stream = _lib.current_stream_handle(device)
+    ready = bool(lib.mi_roi_align_forward_fpn_writes_records(ctypes.byref(ftab), 256, r, res, res, _lib.LAYOUT_NCHW))
+    flags = (_lib.ROI_ALIGN_RECORDS_READY if ready else 0) | _lib.ROI_ALIGN_OVERWRITE
 
     def fwd():
-        with torch.no_grad():
-            roi_align_fpn(maps, scales, rois, idx, res, res, 2)
+        _lib.check(lib.mi_roi_align_forward_fpn(ctypes.byref(ftab), rois.data_ptr(), idx.data_ptr(), out.data_ptr(), 2, 256, r,
+                                                res, res, 2, _lib.LAYOUT_NCHW, ws.data_ptr(), ws_bytes, stream), "fwd")
 
-    def fwd_bwd():
-        for m in maps:
-            m.grad = None
-        roi_align_fpn(maps, scales, rois, idx, res, res, 2).backward(g)
+    def bwd():
+        _lib.check(lib.mi_roi_align_backward_fpn(ctypes.byref(gtab), g.data_ptr(), rois.data_ptr(), idx.data_ptr(), 2, 256, r,
+                                                 res, res, 2, _lib.LAYOUT_NCHW, ws.data_ptr(), ws_bytes, flags, stream), "bwd")
 
     f = time_kernel(fwd, iters) * 1e6
-    fb = time_kernel(fwd_bwd, iters) * 1e6
-    return round(f, 1), round(fb - f, 1)
+    b = time_kernel(bwd, iters) * 1e6
+    return round(f, 1), round(b, 1)
 
 
 def tile_list_lengths(rois, lvls, res, th=16, tw=32):
@@ -92,8 +109,8 @@ def measure(dev, iters):
         res[name] = {"step_rois": {"fwd_us": f, "bwd_us": b, "real_rows": int(real.sum()), "per_level": per_level},
                      "uniform_rois": {"fwd_us": uf, "bwd_us": ub}}
     res["what"] = ("fused FPN RoIAlign (P2-P5, 2 images) on the RoIs a training step samples after 12 iterations on the fixed "
-                   "batch (they cluster on the 8 gt boxes per image) next to as many uniformly spread RoIs; times through the "
-                   "autograd Function, host launch overhead included (kernel durations: profiles/)")
+                   "batch (they cluster on the 8 gt boxes per image) next to as many uniformly spread RoIs; the C-ABI calls "
+                   "on preallocated buffers, HIP events (kernel durations: profiles/)")
     return res
 
 

@@ -11,7 +11,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from detectron_pytorch_amd import _lib, synthetic as syn  # noqa: E402
-from detectron_pytorch_amd.roi_align import roi_align_backward, roi_align_forward, roi_align_fpn  # noqa: E402
+from detectron_pytorch_amd.roi_align import roi_align_backward, roi_align_forward  # noqa: E402
 from tools.hot_path_bench import time_kernel  # noqa: E402
 
 FIXTURE = os.path.join(ROOT, "tests", "golden", "step_rois.npz")
@@ -31,24 +31,9 @@ def load_step_rois(dev):
 
 
 def fpn_case(dev, rois, lvls, res, iters):
-    maps = [torch.from_numpy(syn.feature_map(2, 256, syn.FPN_LEVELS[l][0], syn.FPN_LEVELS[l][1], seed=l)).to(dev)
-            .requires_grad_(True) for l in (5, 4, 3, 2)]
-    scales = [syn.FPN_LEVELS[l][2] for l in (5, 4, 3, 2)]
-    idx = (5 - lvls).clamp(0, 3).to(torch.int32)
-    out = roi_align_fpn(maps, scales, rois.contiguous(), idx, res, res, 2)
-    g = torch.randn_like(out)
+    from tools.bwd_clustered import time_fpn
 
-    def fwd():
-        with torch.no_grad():
-            roi_align_fpn(maps, scales, rois, idx, res, res, 2)
-
-    def fwd_bwd():
-        for m in maps:
-            m.grad = None
-        roi_align_fpn(maps, scales, rois, idx, res, res, 2).backward(g)
-
-    f = time_kernel(fwd, iters)
-    return (time_kernel(fwd_bwd, iters) - f) * 1e6
+    return time_fpn(dev, rois, (5 - lvls).clamp(0, 3), res, iters)[1]
 
 
 def config2_case(dev, iters):
