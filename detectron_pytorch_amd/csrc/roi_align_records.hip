@@ -584,7 +584,8 @@ roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int 
 // tiles without RoIs (their workgroups only store zeros, and do so on the compute units the long items leave idle).
 // Slice length: the first of {1, 2, 4, 8, 32} * slice_min (a power of two), "whole list" whose item total fits the table.
 constexpr int kMaxPlanTiles = 8192;
-__global__ void __launch_bounds__(1024)
+constexpr int kItemThreads = 256, kItemWaves = kItemThreads / 64;  // the zero-fill workgroups are launched at this size too
+__global__ void __launch_bounds__(kItemThreads)
 roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int batch, int channels, int th,
                     int slice_shift, int plan_tiles, int items_max, int overwrite) {
   if (blockIdx.x > 0) {
@@ -609,7 +610,7 @@ roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int
     const int rows = min(th, height - y0), cols = min(kTW, width - x0), c0 = zg * kCT;
     if (overwrite & 2) {
       // channels-last: kCT contiguous floats per pixel
-      for (int i = tid; i < rows * cols * (kCT / 4); i += 1024) {
+      for (int i = tid; i < rows * cols * (kCT / 4); i += kItemThreads) {
         const int px = i / (kCT / 4), q = i - px * (kCT / 4);
         const int rr = px / cols, cc = px - rr * cols;
         reinterpret_cast<float4*>(grad + (((long long)n * height + y0 + rr) * width + x0 + cc) * channels + c0)[q] =
@@ -617,7 +618,7 @@ roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int
       }
     } else if (cols == kTW && (width & 3) == 0) {
       // 128-byte row pieces, 16-byte aligned: eight lanes per piece
-      for (int i = tid; i < kCT * rows * 8; i += 1024) {
+      for (int i = tid; i < kCT * rows * 8; i += kItemThreads) {
         const int seg = i >> 3, q = i & 7;
         const int c = seg / rows, rr = seg - c * rows;
         reinterpret_cast<float4*>(grad + (((long long)n * channels + c0 + c) * height + y0 + rr) * width + x0)[q] =
@@ -626,7 +627,7 @@ roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int
     } else {
       const int col = tid & 31;
       if (col < cols)
-        for (int i = tid >> 5; i < kCT * rows; i += 32) {
+        for (int i = tid >> 5; i < kCT * rows; i += kItemThreads / 32) {
           const int c = i / rows, rr = i - c * rows;
           grad[(((long long)n * channels + c0 + c) * height + y0 + rr) * width + x0 + col] = 0.f;
         }
@@ -635,7 +636,7 @@ roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int
   }
   __shared__ int cnts[kMaxPlanTiles];
   __shared__ int ladder[6];
-  __shared__ int wsum[3][16];
+  __shared__ int wsum[3][kItemWaves];
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int* __restrict__ counts = ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4);
   int4* __restrict__ items = reinterpret_cast<int4*>(const_cast<int*>(counts) + ((plan_tiles + 3) & ~3));
@@ -644,13 +645,13 @@ roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     return v;
   };
-  for (int t = tid; t < plan_tiles; t += 1024) cnts[t] = counts[t];
+  for (int t = tid; t < plan_tiles; t += kItemThreads) cnts[t] = counts[t];
   if (tid < 6) ladder[tid] = 0;
   __syncthreads();
   const int empty_items = (overwrite & 1) ? 1 : 0;
   {
     int sums[6] = {0, 0, 0, 0, 0, 0};
-    for (int t = tid; t < plan_tiles; t += 1024) {
+    for (int t = tid; t < plan_tiles; t += kItemThreads) {
       const int cnt = cnts[t];
       const int empty = cnt == 0 ? empty_items : 0;
 #pragma unroll
@@ -683,7 +684,7 @@ roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int
   int base[3];
   {
     int tot[3] = {0, 0, 0};
-    for (int t = tid; t < plan_tiles; t += 1024) {
+    for (int t = tid; t < plan_tiles; t += kItemThreads) {
       int cnt, v;
       const int cls = classify(t, cnt, v);
 #pragma unroll
@@ -699,12 +700,12 @@ roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       base[c] = run;
-      for (int w = 0; w < 16; w++) run += wsum[c][w];
+      for (int w = 0; w < kItemWaves; w++) run += wsum[c][w];
     }
     __syncthreads();
   }
   // positions: exclusive scan of the slice counts inside each class, tile order
-  for (int chunk = 0; chunk < plan_tiles; chunk += 1024) {
+  for (int chunk = 0; chunk < plan_tiles; chunk += kItemThreads) {
     int cnt, v;
     const int cls = classify(chunk + tid, cnt, v);
     int incl[3];
@@ -728,10 +729,10 @@ roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int
     }
 #pragma unroll
     for (int c = 0; c < 3; c++)
-      for (int w = 0; w < 16; w++) base[c] += wsum[c][w];
+      for (int w = 0; w < kItemWaves; w++) base[c] += wsum[c][w];
     __syncthreads();
   }
-  for (int i = nitems + tid; i < items_max; i += 1024) items[i] = make_int4(-1, 0, 0, 0);
+  for (int i = nitems + tid; i < items_max; i += kItemThreads) items[i] = make_int4(-1, 0, 0, 0);
 }
 
 // 16-row tiles with 32 channels: 84 VGPRs would cap a SIMD at 5 waves = two 8-wave workgroups per CU; pinning the
@@ -1162,7 +1163,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
     roi_align_bwd_plan<<<tiles, kPlanThreads, 0, stream>>>(lv, ws, num_rois, batch, th, tiles, plan_cap, items);
     int rc = check_launch("roi_align_bwd_plan");
     if (rc != MI_OK) return rc;
-    roi_align_bwd_items<<<overwrite ? 1 + tiles * (channels / kCT) : 1, 1024, 0, stream>>>(
+    roi_align_bwd_items<<<overwrite ? 1 + tiles * (channels / kCT) : 1, kItemThreads, 0, stream>>>(
         lv, ws, num_rois, batch, channels, th, 31 - __builtin_clz((unsigned)slice_min), tiles, items,
         (overwrite ? 1 : 0) | (nhwc ? 2 : 0));
     rc = check_launch("roi_align_bwd_items");

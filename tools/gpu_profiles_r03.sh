@@ -45,19 +45,20 @@ if [ $STAGE = all ] || [ $STAGE = steprois ]; then
 done; done) > $O/step_rois_backward_kernels.txt 2>&1
 fi
 if [ $STAGE = all ] || [ $STAGE = pmc ]; then
-for variant in records tiles; do
+for variant in records tiles bwd; do
   unset MI_ROI_ALIGN_IMPL; [ $variant = tiles ] && export MI_ROI_ALIGN_IMPL=tiles
+  k=roi_align_fwd; [ $variant = bwd ] && k=roi_align_bwd
   j=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
              "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
              "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
              "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE"; do
     j=$((j+1))
-    timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc_${variant}_$j -o p -- python $R/tools/run_one_kernel.py roi_align_fwd 5 > $O/pmc_${variant}_$j.log 2>&1
+    timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc_${variant}_$j -o p -- python $R/tools/run_one_kernel.py $k 5 > $O/pmc_${variant}_$j.log 2>&1
   done
-  python $R/tools/rocpd_pmc.py --json $O/pmc_fwd_$variant.json $O/pmc_${variant}_*/*.db | grep -v "Fill\|distribution\|elementwise" | cut -c1-120 > $O/pmc_fwd_$variant.txt
+  python $R/tools/rocpd_pmc.py --json $O/pmc_$variant.json $O/pmc_${variant}_*/*.db | grep -v "Fill\|distribution\|elementwise" | cut -c1-120 > $O/pmc_$variant.txt
   rm -rf $O/pmc_${variant}_*/
 done
 unset MI_ROI_ALIGN_IMPL
 fi
-cut -c1-600 $O/bench_line.json 2>/dev/null; echo; head -24 $O/train_step_steady_state.txt 2>/dev/null | cut -c1-150; cat $O/config2_kernel_durations.csv $O/step_rois_backward_kernels.txt 2>/dev/null; cat $O/pmc_fwd_records.txt $O/pmc_fwd_tiles.txt 2>/dev/null
+cut -c1-600 $O/bench_line.json 2>/dev/null; echo; head -24 $O/train_step_steady_state.txt 2>/dev/null | cut -c1-150; cat $O/config2_kernel_durations.csv $O/step_rois_backward_kernels.txt 2>/dev/null; cat $O/pmc_records.txt $O/pmc_tiles.txt $O/pmc_bwd.txt 2>/dev/null
