@@ -15,9 +15,19 @@ constexpr int kRecStages = kRecHeader;                 // kMaxStages x {ph0 | ph
 constexpr int kRecY = kRecStages + 4 * kMaxStages;     // kMaxS x {row_lo * ww * 4, hw / count, lw / count, row_lo}
 constexpr int kRecX = kRecY + 4 * kMaxS;               // kMaxS x {(col_lo - wx0) * 4, hw, lw, col_lo}
 constexpr int kMaxWin = 63;                            // window rows / columns the backward tables cover
-constexpr int kRecXF = kRecX + 4 * kMaxS;              // kMaxWin+1 ints: xfirst[c] = #x samples with col_lo < wx0 + c
-constexpr int kRecYF = kRecXF + kMaxWin + 1;           // kMaxWin+1 ints: yfirst[r] = #y samples with row_lo < wy0 + r
-constexpr int kRecDwords = kRecYF + kMaxWin + 1;       // 528 dwords = 2112 B
+// backward block: the weights of the tile kernel's two passes, merged per window column / row by roi_align_prepare.
+//   column c of the window receives, from output column pw, the weight  Wx = sum of the x samples of bin pw that tap c
+//   (hw of the samples whose lower tap is c, lw of those whose lower tap is c - 1); rows likewise with hw / count,
+//   lw / count.  Entries of one column are contiguous: cf[c] .. cf[c + 1].  At most window + 2 * bins <= 125 entries.
+constexpr int kBwdEnt = 128;
+constexpr int kRecB = kRecX + 4 * kMaxS;               // dwords: wx[128] f32 | wy[128] f32 | then bytes, see below
+constexpr int kBwdWx = 0, kBwdWy = kBwdEnt * 4;        // byte offsets inside the block
+constexpr int kBwdPx = 2 * kBwdEnt * 4;                // u8 pw of entry k
+constexpr int kBwdPy = kBwdPx + kBwdEnt;               // u8 ph of entry k
+constexpr int kBwdCf = kBwdPy + kBwdEnt;               // u8 cf[64]: first entry of window column c (cf[ww] = number of entries)
+constexpr int kBwdRf = kBwdCf + 64;                    // u8 rf[64]: first entry of window row r
+constexpr int kBwdTabDw = (kBwdRf + 64) / 4;           // 352 dwords = 1408 B
+constexpr int kRecDwords = kRecB + kBwdTabDw;          // 752 dwords = 3008 B
 // after the records: one int4 per rank {x0, x1, batch*H + y0, batch*H + y1} = window of a backward-capable RoI
 // ({0x3fffffff, -1, ..} otherwise), read by the backward tiles to find the RoIs that touch them
 constexpr int kCounterDwords = 64;                     // ticket counters, zeroed by prepare

@@ -143,16 +143,19 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
   const bool tabs = fast;  // the axis tables below are valid whatever the LDS stages decide
   // this lane's y sample (lane < nsy) and x sample (lane < nsx)
   int ylo = wy0, xlo = wx0;
+  float yhw = 0.f, ylw = 0.f, xhw = 0.f, xlw = 0.f;  // this lane's sample: weights of (lo, lo + 1); y: divided by count
   if (fast) {
     float hw = 0.f, lw = 0.f;
     if (lane < nsy) {
       const int ph = lane / gh;
       axis_taps(coord(start_h, bin_h, ph, lane - ph * gh, gh), height, ylo, hw, lw);
       ylo = min(max(ylo, wy0), wy1 - 1);
+      yhw = hw / count;
+      ylw = lw / count;
       int4 e;
       e.x = ylo * ww * 4;
-      e.y = __float_as_int(hw / count);
-      e.z = __float_as_int(lw / count);
+      e.y = __float_as_int(yhw);
+      e.z = __float_as_int(ylw);
       e.w = ylo;
       reinterpret_cast<int4*>(rec + kRecY)[lane] = e;
     }
@@ -160,6 +163,8 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
       const int pw = lane / gw;
       axis_taps(coord(start_w, bin_w, pw, lane - pw * gw, gw), width, xlo, hw, lw);
       xlo = min(max(xlo, wx0), wx1 - 1);
+      xhw = hw;
+      xlw = lw;
       int4 e;
       e.x = (xlo - wx0) * 4;
       e.y = __float_as_int(hw);
@@ -168,15 +173,55 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
       reinterpret_cast<int4*>(rec + kRecX)[lane] = e;
     }
   }
-  // backward tables: number of samples whose lower tap lies left of / above each window column / row
+  // backward block (roi_align_record_layout.h): per window column / row (lane = column / row) the output columns /
+  // rows that reach it and the summed weight of their samples -- what the tile kernel's two passes multiply with.
+  // A sample whose lower tap is c taps c with hw and c + 1 with lw; samples are sorted by their lower tap, so the
+  // samples that tap column c are the contiguous range [first(c - 1), first(c + 1)) with first(c) = #samples with
+  // lower tap < c.  The weights of one bin are summed in sample order (fp32, the order the kernel used to sum them in).
   const int nrows_win = wy1 - wy0 + 1;
   const bool bwd_ok = fast && ww <= kMaxWin && nrows_win <= kMaxWin;
   if (bwd_ok) {
-    int cx = 0, cy = 0;
-    for (int i = 0; i < nsx; i++) cx += (__builtin_amdgcn_readlane(xlo, i) < wx0 + lane) ? 1 : 0;
-    for (int i = 0; i < nsy; i++) cy += (__builtin_amdgcn_readlane(ylo, i) < wy0 + lane) ? 1 : 0;
-    rec[kRecXF + lane] = cx;
-    rec[kRecYF + lane] = cy;
+    char* blk = reinterpret_cast<char*>(rec + kRecB);
+    auto merge_axis = [&](int lo, float hwv, float lwv, int ns, int g, int w0, int nwin, int off_w, int off_p, int off_f) {
+      int first = 0;
+      for (int i = 0; i < ns; i++) first += (__builtin_amdgcn_readlane(lo, i) < w0 + lane) ? 1 : 0;
+      const int sa = first;
+      int sb = __shfl_down(first, 1);
+      if (lane == 63) sb = ns;
+      int sp = __shfl_up(first, 1);
+      if (lane == 0) sp = 0;
+      const bool inside = lane < nwin;
+      const int nb = (inside && sb > sp) ? (sb - 1) / g - sp / g + 1 : 0;
+      int incl = nb;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+      }
+      const int at = incl - nb;  // lanes past the window hold the total
+      reinterpret_cast<unsigned char*>(blk + off_f)[lane] = (unsigned char)at;
+      int most = nb;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) most = max(most, __shfl_xor(most, d));
+      float* wdst = reinterpret_cast<float*>(blk + off_w);
+      unsigned char* pdst = reinterpret_cast<unsigned char*>(blk + off_p);
+      for (int b = 0; b < most; b++) {  // wave-uniform trip count: every lane takes part in the shuffles
+        const int p = sp / g + b;
+        float wgt = 0.f;
+        for (int i = 0; i < g; i++) {
+          const int sidx = p * g + i;
+          const int src = min(max(sidx, 0), 63);
+          const float l = __shfl(lwv, src), h = __shfl(hwv, src);
+          if (b < nb && sidx >= sp && sidx < sb) wgt += sidx < sa ? l : h;
+        }
+        if (b < nb) {
+          wdst[at + b] = wgt;
+          pdst[at + b] = (unsigned char)p;
+        }
+      }
+    };
+    merge_axis(xlo, xhw, xlw, nsx, gw, wx0, ww, kBwdWx, kBwdPx, kBwdCf);
+    merge_axis(ylo, yhw, ylw, nsy, gh, wy0, nrows_win, kBwdWy, kBwdPy, kBwdRf);
   }
   if (lane == 0) {
     int4 bnd;
@@ -502,22 +547,26 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
 // The bilinear scatter is separable:  dF[row][col] = sum_ph wy(ph,row) * ( sum_pw wx(pw,col) * g[ph][pw] ).
 // One 256-lane workgroup owns an 8-row x 32-column tile of dF for KC channels and walks the RoIs whose window touches
 // the tile (found by scanning the int4 window of every rank; kept in sweep order, so the summation order is fixed):
-//   pass 1  lanes = (channel, column): T[c][ph][col] = sum over the x samples whose taps hit `col` of w * g[c][ph][pw]
-//           (the samples are contiguous ranges given by the record's xfirst table; 7 register accumulators)
-//   pass 2  lanes = (row, column), a half-wave per row: acc[c] += sum over the y samples whose taps hit `row` of
-//           w * T[c][ph][col], for the KC channels held in registers (yfirst table)
-// g, the axis tables and xfirst/yfirst of the NEXT RoI arrive by LDS-DMA while the current one is processed.
+//   pass 1  lanes = (channel, column): T[c][ph][col] = sum over the output columns pw that reach `col` of
+//           Wx(col, pw) * g[c][ph][pw]   (7 register accumulators)
+//   pass 2  lanes = (row, column), a half-wave per row: acc[c] += sum over the bin rows ph that reach `row` of
+//           Wy(row, ph) * T[c][ph][col], for the KC channels held in registers
+// Wx / Wy -- per window column / row the list of bins and the summed weight of their samples -- come merged from
+// roi_align_prepare (the record's backward block; the passes used to rebuild them per lane from the sample tables:
+// PMC showed them bound by that integer work).  g and the block of the NEXT RoI arrive by LDS-DMA while the current
+// one is processed.
 // At the end each lane stores its KC sums as 128-byte rows (or adds them to what the caller supplied).
 // RoIs the tables cannot describe (a sample outside the [-1, size] band, window > 63 rows or columns, > 32 samples
 // per axis) are added afterwards by roi_align_bwd_slow with the reference's arithmetic and atomics.
 // Weights: g * (hy / count) * hx instead of the reference's g * (hy * hx) / count -- fp32 rounding only (the
 // accumulation order of the reference's atomics is unspecified; contract 1e-4).
 // -------------------------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kTW = 32;  // columns of the dF tile owned by a workgroup (rows: template parameter, 32 lanes each)
 
 template <int KC>
 struct BwdLds {
-  static constexpr int kTabDw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);  // y table, x table, xfirst, yfirst (record order)
+  static constexpr int kTabDw = kBwdTabDw;  // the record's backward block: merged weights of both passes
   static constexpr int kTStride = kMaxStages * kTW + 1;            // words per channel of T (odd): up to 32 bin rows
   static constexpr int kGWords = KC * kTileBins * 4;               // g block: up to 224 bins per channel
 };
@@ -833,9 +882,9 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
 
   // pass-2 identity of this lane: one pixel of the tile
   const int prow = tid >> 5, pcol = tid & 31;
-  float acc[KC];
+  v2f acc2[KC / 2];  // channel pairs: pass 2 runs on v_pk_fma_f32
 #pragma unroll
-  for (int c = 0; c < KC; c++) acc[c] = 0.f;
+  for (int c = 0; c < KC / 2; c++) acc2[c] = v2f{0.f, 0.f};
 
   // source byte offsets of this lane's pieces of the transposed g block (the same for every RoI)
   constexpr int kGP = 64 / kNWaves;  // pieces per wave at most: KC * g_cs <= 64 * 64 words
@@ -856,7 +905,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
   auto issue_loads = [&](int pos, int buf) {
     const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)uniform(pos) * kRecDwords);
     const int r = rec[8];
-    const srd_t tsrd = make_srd(records + (long long)uniform(pos) * kRecDwords + kRecY, kTabDw * 4);
+    const srd_t tsrd = make_srd(records + (long long)uniform(pos) * kRecDwords + kRecB, kTabDw * 4);
     const unsigned tdst = lds_addr_uniform(tab0 + buf * kTabDw);
     for (int k = wave; k * 64 < kTabDw; k += kNWaves)
       if (k * 64 + lane < kTabDw) dma_dword(tsrd, tdst + (unsigned)k * 256u, (unsigned)(k * 64 + lane) * 4u, 0u);
@@ -877,15 +926,17 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
     const int buf = li & 1;
     const int pos = uniform(list[li]);
     const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)pos * kRecDwords);
-    const int wx0 = rec[2], ww = rec[3], rgh = rec[6], rgw = rec[7], wy0 = rec[9], wy1 = rec[10];
-    const int gh = kSR > 0 ? kSR : rgh, gw = kSR > 0 ? kSR : rgw;
+    const int wx0 = rec[2], ww = rec[3], wy0 = rec[9], wy1 = rec[10];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // B1: buffers of this RoI have landed; everybody is done with the previous RoI (T, other buffer)
     if (li + 1 < nlist) issue_loads(list[li + 1], buf ^ 1);
-    const TabEntry* ty = reinterpret_cast<const TabEntry*>(tab0 + buf * kTabDw);
-    const TabEntry* tx = ty + kMaxS;
-    const int* xfirst = tab0 + buf * kTabDw + 8 * kMaxS;
-    const int* yfirst = xfirst + kMaxWin + 1;
+    const char* blk = reinterpret_cast<const char*>(tab0 + buf * kTabDw);
+    const float* wxt = reinterpret_cast<const float*>(blk + kBwdWx);
+    const float* wyt = reinterpret_cast<const float*>(blk + kBwdWy);
+    const unsigned char* pxt = reinterpret_cast<const unsigned char*>(blk + kBwdPx);
+    const unsigned char* pyt = reinterpret_cast<const unsigned char*>(blk + kBwdPy);
+    const unsigned char* cft = reinterpret_cast<const unsigned char*>(blk + kBwdCf);
+    const unsigned char* rft = reinterpret_cast<const unsigned char*>(blk + kBwdRf);
     const float* g = g0 + buf * g_words;
 
     // ---- pass 1: T[ph][col][c] for the tile columns inside the window ----
@@ -895,39 +946,26 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
       for (int col = slot; col < kTW; col += kColStep) {
         const int lc = x0 + col - wx0;
         if (lc < 0 || lc >= ww) continue;
-        const int sa = xfirst[lc], sb = xfirst[lc + 1];   // samples with col_lo == this column   (weight hw)
-        const int sp = lc > 0 ? xfirst[lc - 1] : 0;        // samples with col_lo == column - 1  : [sp, sa)  (weight lw)
+        const int k0 = cft[lc], k1 = cft[lc + 1];  // the output columns that reach this column, with their weights
         const float* gc = g + c * g_cs;
         for (int ph0 = 0; ph0 < aligned_height; ph0 += 8) {
-          float t[8];
+          v2f t[4];  // bin rows ph0 .. ph0 + 7, two per register pair: v_pk_fma_f32
 #pragma unroll
-          for (int j = 0; j < 8; j++) t[j] = 0.f;
-          const int kg = kSR > 0 ? kSR : gw;
-          for (int pw = sp / kg; pw * kg < sb; pw++) {
-            // combined weight of this output column's samples that hit `col`
-            float wgt = 0.f;
-            for (int ix = 0; ix < kg; ix++) {
-              const int sidx = pw * kg + ix;
-              if (sidx >= sp && sidx < sb) {
-                const TabEntry ex = tx[sidx];
-                wgt += sidx < sa ? ex.lw : ex.hw;
-              }
-            }
+          for (int j = 0; j < 4; j++) t[j] = v2f{0.f, 0.f};
+          for (int k = k0; k < k1; k++) {
+            const v2f wgt = {wxt[k], wxt[k]};
+            const int pw = pxt[k];
             const float4* gp = reinterpret_cast<const float4*>(gc + pw * ah_pad + ph0);
             const float4 ga = gp[0];
             const float4 gb = (ph0 + 4 < ah_pad) ? gp[1] : float4{0.f, 0.f, 0.f, 0.f};
-            t[0] = __builtin_fmaf(wgt, ga.x, t[0]);
-            t[1] = __builtin_fmaf(wgt, ga.y, t[1]);
-            t[2] = __builtin_fmaf(wgt, ga.z, t[2]);
-            t[3] = __builtin_fmaf(wgt, ga.w, t[3]);
-            t[4] = __builtin_fmaf(wgt, gb.x, t[4]);
-            t[5] = __builtin_fmaf(wgt, gb.y, t[5]);
-            t[6] = __builtin_fmaf(wgt, gb.z, t[6]);
-            t[7] = __builtin_fmaf(wgt, gb.w, t[7]);
+            t[0] = __builtin_elementwise_fma(wgt, v2f{ga.x, ga.y}, t[0]);
+            t[1] = __builtin_elementwise_fma(wgt, v2f{ga.z, ga.w}, t[1]);
+            t[2] = __builtin_elementwise_fma(wgt, v2f{gb.x, gb.y}, t[2]);
+            t[3] = __builtin_elementwise_fma(wgt, v2f{gb.z, gb.w}, t[3]);
           }
 #pragma unroll
           for (int j = 0; j < 8; j++)
-            if (ph0 + j < aligned_height) T[((ph0 + j) * kTW + col) * kCS + c] = t[j];
+            if (ph0 + j < aligned_height) T[((ph0 + j) * kTW + col) * kCS + c] = t[j >> 1][j & 1];
         }
       }
     }
@@ -937,26 +975,18 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
     if (!(ablate & 2)) {
       const int lr = y0 + prow - wy0, lc = x0 + pcol - wx0;
       if (lr >= 0 && lr <= wy1 - wy0 && lc >= 0 && lc < ww) {
-        const int sa = yfirst[lr], sb = yfirst[lr + 1];
-        const int sp = lr > 0 ? yfirst[lr - 1] : 0;
-        const int gdiv = kSR > 0 ? kSR : gh;
-        for (int sidx = sp; sidx < sb;) {
-          // the samples of one bin row that tap this feature row share T[ph]: their weights are summed first, so that the
-          // KC-channel row of T is read once per (pixel, bin row) instead of once per sample
-          const int ph = sidx / gdiv;
-          const int send = min(sb, (ph + 1) * gdiv);
-          float wgt = 0.f;
-          for (; sidx < send; sidx++) wgt += sidx < sa ? ty[sidx].lw : ty[sidx].hw;
+        const int k0 = rft[lr], k1 = rft[lr + 1];  // the bin rows that reach this feature row, with their weights
+        for (int k = k0; k < k1; k++) {
+          const v2f wgt = {wyt[k], wyt[k]};
+          const int ph = pyt[k];
           // T is [ph][col][channel] with a column stride of KC + 4 words: the lane's KC channels are KC / 4
           // conflict-free ds_read_b128 (16-lane groups land on 16 distinct 4-bank slots)
           const float4* tp = reinterpret_cast<const float4*>(T + (ph * kTW + pcol) * kCS);
 #pragma unroll
           for (int c4 = 0; c4 < KC / 4; c4++) {
             const float4 tv = tp[c4];
-            acc[4 * c4 + 0] = __builtin_fmaf(wgt, tv.x, acc[4 * c4 + 0]);
-            acc[4 * c4 + 1] = __builtin_fmaf(wgt, tv.y, acc[4 * c4 + 1]);
-            acc[4 * c4 + 2] = __builtin_fmaf(wgt, tv.z, acc[4 * c4 + 2]);
-            acc[4 * c4 + 3] = __builtin_fmaf(wgt, tv.w, acc[4 * c4 + 3]);
+            acc2[2 * c4 + 0] = __builtin_elementwise_fma(wgt, v2f{tv.x, tv.y}, acc2[2 * c4 + 0]);
+            acc2[2 * c4 + 1] = __builtin_elementwise_fma(wgt, v2f{tv.z, tv.w}, acc2[2 * c4 + 1]);
           }
         }
       }
@@ -964,6 +994,9 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
   }
 
   // ---- the tile leaves as 128-byte rows (NCHW) or as one 4*KC-byte run per pixel (channels-last) ----
+  float acc[KC];
+#pragma unroll
+  for (int c = 0; c < KC; c++) acc[c] = acc2[c >> 1][c & 1];
   const int row = y0 + prow, col = x0 + pcol;
   if (row < height && col < width && nslices > 1) {
     // the slices of a long list add into the tile the plan kernel zero-filled (or the caller's values): hardware fp32
@@ -1148,7 +1181,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   const int ah_pad = (aligned_height + 3) & ~3;
   const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);  // channel stride of the transposed g block: 4 * odd
   const int g_words = kc * g_cs;
-  const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
+  const int tab_dw = kBwdTabDw;
   const size_t lds = (32 + (size_t)(((num_rois + 1) / 2 + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
   const int tiles = bwd_tile_count(lv, batch, th);
   // planned launch (see roi_align_bwd_plan) when the workspace has room for the plan: the grid is an upper bound of the
@@ -1234,7 +1267,7 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
                                      int aligned_width) {
   const int bins = aligned_height * aligned_width;
   const int kc = (bins <= 64) ? 32 : 16;
-  const int tab_dw = 2 * 4 * kMaxS + 2 * (kMaxWin + 1);
+  const int tab_dw = kBwdTabDw;
   const int ah_pad = (aligned_height + 3) & ~3;
   const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);
   const size_t lds = (32 + (size_t)(((num_rois + 1) / 2 + 3) & ~3) + 2 * tab_dw + 2 * (size_t)kc * g_cs +
