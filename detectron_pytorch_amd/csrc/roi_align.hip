@@ -273,16 +273,20 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
                mi::roi_align_records_workspace_bytes(num_rois));
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
+    // a workspace with room for the (planned) backward announces one: the records then carry the backward block
+    const bool bwd_tables =
+        workspace_bytes >= mi::roi_align_bwd_workspace_bytes(mi::single_level(nullptr, nullptr, batch, height, width,
+                                                                              spatial_scale), batch, num_rois);
     if (layout == MI_LAYOUT_NCHW && !force_direct() && !no_ws() &&
         mi::roi_align_fwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
       return mi::launch_roi_align_fwd_records(features, rois, output, workspace, batch, channels, height, width,
                                               num_rois, aligned_height, aligned_width, spatial_scale,
-                                              sampling_ratio, cap, s);
+                                              sampling_ratio, cap, bwd_tables, s);
     if (layout == MI_LAYOUT_NHWC && !force_direct() && !no_ws() &&
         num_rois <= 8192 &&
         mi::roi_align_fwd_nhwc_supported(channels, height, width, num_rois, aligned_height, aligned_width)) {
       rc = mi::launch_roi_align_prepare(rois, workspace, batch, height, width, num_rois, aligned_height,
-                                        aligned_width, spatial_scale, sampling_ratio, s);
+                                        aligned_width, spatial_scale, sampling_ratio, bwd_tables, s);
       if (rc != MI_OK) return rc;
       return mi::launch_roi_align_fwd_nhwc(features, rois, output, workspace, batch, channels, height, width,
                                            num_rois, aligned_height, aligned_width, spatial_scale, sampling_ratio, s);
@@ -498,15 +502,16 @@ extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float
   MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
              "roi_align_fpn: workspace of %zu bytes, %zu needed", workspace_bytes,
              mi::roi_align_records_workspace_bytes(num_rois));
+  const bool bwd_tables = workspace_bytes >= mi::roi_align_bwd_workspace_bytes(lv, batch, num_rois);
   if (layout == MI_LAYOUT_NHWC) {
     int rc = mi::launch_roi_align_prepare_levels(lv, rois, roi_levels, workspace, batch, num_rois, aligned_height,
-                                                 aligned_width, sampling_ratio, mi::as_stream(stream));
+                                                 aligned_width, sampling_ratio, bwd_tables, mi::as_stream(stream));
     if (rc != MI_OK) return rc;
     return mi::launch_roi_align_fwd_nhwc_levels(lv, rois, output, workspace, batch, channels, num_rois, aligned_height,
                                                 aligned_width, sampling_ratio, mi::as_stream(stream));
   }
   return mi::launch_roi_align_fwd_records_levels(lv, rois, roi_levels, output, workspace, batch, channels, num_rois,
-                                                 aligned_height, aligned_width, sampling_ratio, cap,
+                                                 aligned_height, aligned_width, sampling_ratio, cap, bwd_tables,
                                                  mi::as_stream(stream));
 }
 

@@ -131,7 +131,7 @@ bool roi_align_fwd_records_supported(int channels, int height, int width, int nu
                                      int aligned_width);
 int launch_roi_align_fwd_records(const float* features, const float* rois, float* output, void* workspace, int batch,
                                  int channels, int height, int width, int num_rois, int aligned_height,
-                                 int aligned_width, float spatial_scale, int sampling_ratio, int cap_px,
+                                 int aligned_width, float spatial_scale, int sampling_ratio, int cap_px, bool bwd_tables,
                                  hipStream_t stream);
 // records_ready: the workspace already holds the records of THESE rois at THIS geometry (written by a forward call)
 // overwrite: every element of bottom_grad is written (no zero fill needed) instead of accumulated into
@@ -145,7 +145,8 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
 // the same two paths over up to kMaxLevels feature maps in one call (`levels`: device int32 per RoI, or nullptr)
 int launch_roi_align_fwd_records_levels(const LevelTable& lv, const float* rois, const int* levels, float* output,
                                         void* workspace, int batch, int channels, int num_rois, int aligned_height,
-                                        int aligned_width, int sampling_ratio, int cap_px, hipStream_t stream);
+                                        int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables,
+                                        hipStream_t stream);
 // workspace_bytes >= roi_align_bwd_workspace_bytes(): the planned backward (roi_align_bwd_plan + list slices);
 // a workspace of roi_align_records_workspace_bytes() only: every tile's workgroups scan the RoIs themselves
 size_t roi_align_bwd_workspace_bytes(LevelTable lv, int batch, int num_rois);
@@ -154,9 +155,10 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
                                         bool nhwc, int batch, int channels, int num_rois, int aligned_height, int aligned_width,
                                         int sampling_ratio, int cap_px, hipStream_t stream);
 // records only (the first launch of the two-launch paths); `workspace` as roi_align_records_workspace_bytes
+// bwd_tables: also write the record's backward block (merged pass weights; +2 us) -- the caller will run a backward
 int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,
                              int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
-                             hipStream_t stream);
+                             bool bwd_tables, hipStream_t stream);
 // channels-last features, record-driven (roi_align_nhwc.hip)
 void roi_align_fwd_nhwc_set_timeline(long long* device_buffer);
 bool roi_align_fwd_nhwc_supported(int channels, int height, int width, int num_rois, int aligned_height,
@@ -170,6 +172,6 @@ int launch_roi_align_fwd_nhwc_levels(const LevelTable& lv, const float* rois, fl
 // records of `rois` for a table of levels (first launch of the fused paths)
 int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, const int* levels, void* workspace,
                                     int batch, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
-                                    hipStream_t stream);
+                                    bool bwd_tables, hipStream_t stream);
 
 }  // namespace mi

@@ -81,7 +81,7 @@ __device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int
 __global__ void __launch_bounds__(256)
 roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels, int num_rois, int batch,
                   const LevelTable lv, int aligned_height, int aligned_width, int sampling_ratio, int cap_px,
-                  int stage_px, int max_rows_tile, int* __restrict__ ws) {
+                  int stage_px, int max_rows_tile, int bwd_tables, int* __restrict__ ws) {
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x < kCounterDwords) ws[threadIdx.x] = 0;
@@ -180,7 +180,7 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
   // lower tap < c.  The weights of one bin are summed in sample order (fp32, the order the kernel used to sum them in).
   const int nrows_win = wy1 - wy0 + 1;
   const bool bwd_ok = fast && ww <= kMaxWin && nrows_win <= kMaxWin;
-  if (bwd_ok) {
+  if (bwd_ok && bwd_tables) {  // forward-only callers (a workspace without room for a backward) skip these 2 us
     char* blk = reinterpret_cast<char*>(rec + kRecB);
     auto merge_axis = [&](int lo, float hwv, float lwv, int ns, int g, int w0, int nwin, int off_w, int off_p, int off_f) {
       int first = 0;
@@ -1096,19 +1096,21 @@ size_t records_lds_bytes(int cap, int ct) {
 }
 
 int launch_prepare(const float* rois, const int* levels, int* ws, int batch, const LevelTable& lv, int num_rois,
-                   int aligned_height, int aligned_width, int sampling_ratio, int cap_px, hipStream_t stream) {
+                   int aligned_height, int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables,
+                   hipStream_t stream) {
   const int max_rows_tile = kTileBins / aligned_width;
   roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
-      rois, levels, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile, ws);
+      rois, levels, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile,
+      bwd_tables ? 1 : 0, ws);
   return check_launch("roi_align_prepare");
 }
 
 template <int kCap>
 int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float* output, int* ws, int batch,
-               int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
+               int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio, bool bwd_tables,
                hipStream_t stream) {
   int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio, kCap,
-                          stream);
+                          bwd_tables, stream);
   if (rc != MI_OK) return rc;
   // the LDS images of MI_ROI_ALIGN_CAP >= 448 exceed the 64 KB a kernel may ask for without opting in
 #define MI_LAUNCH_REC(SR, A)                                                                                          \
@@ -1167,10 +1169,13 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
                                         int channels, int num_rois, int aligned_height, int aligned_width,
                                         int sampling_ratio, int cap_px, hipStream_t stream) {
   int* ws = static_cast<int*>(workspace);
+  // the forward writes the record's backward block only into a workspace with room for a backward (it costs the
+  // records launch 2 us): RECORDS_READY is honoured for such a workspace, otherwise the records are rewritten here
+  if (records_ready && workspace_bytes < roi_align_bwd_workspace_bytes(lv, batch, num_rois)) records_ready = false;
   if (!records_ready) {
     // backward tables do not depend on the LDS capacity the forward stages were cut for
     int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio,
-                            cap_px >= 336 ? 336 : 192, stream);
+                            cap_px >= 336 ? 336 : 192, true, stream);
     if (rc != MI_OK) return rc;
   }
   const int bins = aligned_height * aligned_width;
@@ -1279,17 +1284,17 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
 
 int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,
                              int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
-                             hipStream_t stream) {
+                             bool bwd_tables, hipStream_t stream) {
   return launch_prepare(rois, nullptr, static_cast<int*>(workspace), batch,
                         single_level(nullptr, nullptr, batch, height, width, spatial_scale), num_rois, aligned_height,
-                        aligned_width, sampling_ratio, 336, stream);
+                        aligned_width, sampling_ratio, 336, bwd_tables, stream);
 }
 
 int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, const int* levels, void* workspace,
                                     int batch, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
-                                    hipStream_t stream) {
+                                    bool bwd_tables, hipStream_t stream) {
   return launch_prepare(rois, levels, static_cast<int*>(workspace), batch, lv, num_rois, aligned_height, aligned_width,
-                        sampling_ratio, 336, stream);
+                        sampling_ratio, 336, bwd_tables, stream);
 }
 
 size_t roi_align_records_workspace_bytes(int num_rois) {
@@ -1305,11 +1310,12 @@ bool roi_align_fwd_records_supported(int channels, int height, int width, int nu
 
 int launch_roi_align_fwd_records_levels(const LevelTable& lv, const float* rois, const int* levels, float* output,
                                         void* workspace, int batch, int channels, int num_rois, int aligned_height,
-                                        int aligned_width, int sampling_ratio, int cap_px, hipStream_t stream) {
+                                        int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables,
+                                        hipStream_t stream) {
   int* ws = static_cast<int*>(workspace);
 #define MI_CAP(C)                                                                                                     \
   return launch_cap<C>(lv, rois, levels, output, ws, batch, channels, num_rois, aligned_height, aligned_width,        \
-                       sampling_ratio, stream)
+                       sampling_ratio, bwd_tables, stream)
   if (cap_px >= 640) MI_CAP(640);
   if (cap_px >= 448) MI_CAP(448);
   if (cap_px >= 336) MI_CAP(336);
@@ -1320,11 +1326,11 @@ int launch_roi_align_fwd_records_levels(const LevelTable& lv, const float* rois,
 
 int launch_roi_align_fwd_records(const float* features, const float* rois, float* output, void* workspace, int batch,
                                  int channels, int height, int width, int num_rois, int aligned_height,
-                                 int aligned_width, float spatial_scale, int sampling_ratio, int cap_px,
+                                 int aligned_width, float spatial_scale, int sampling_ratio, int cap_px, bool bwd_tables,
                                  hipStream_t stream) {
   return launch_roi_align_fwd_records_levels(single_level(features, nullptr, batch, height, width, spatial_scale), rois,
                                              nullptr, output, workspace, batch, channels, num_rois, aligned_height,
-                                             aligned_width, sampling_ratio, cap_px, stream);
+                                             aligned_width, sampling_ratio, cap_px, bwd_tables, stream);
 }
 
 }  // namespace mi

@@ -51,10 +51,13 @@ def _check_inputs(features, rois):
 
 
 def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_scale, sampling_ratio,
-                      variant=_lib.ROI_ALIGN_CAFFE2, return_workspace=False):
+                      variant=_lib.ROI_ALIGN_CAFFE2, return_workspace=False, want_backward=None):
     """Raw forward (no autograd): returns a new [R, C, ah, aw] tensor and, on request, the device scratch holding the
     per-RoI records a backward over the same rois can reuse -- None when the forward wrote none (NCHW features: the
-    tile-centric kernel needs no scratch at all)."""
+    tile-centric kernel needs no scratch at all).  want_backward (default: return_workspace): size the scratch for the
+    planned backward, which also makes the forward write the records' backward block (2 us; an inference call skips it)."""
+    if want_backward is None:
+        want_backward = return_workspace
     _check_inputs(features, rois)
     features, layout = _layout_of(features)
     if variant == _lib.ROI_ALIGN_LEGACY and layout != _lib.LAYOUT_NCHW:
@@ -72,7 +75,7 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
     ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
     if layout == _lib.LAYOUT_NCHW and variant == _lib.ROI_ALIGN_CAFFE2:
         ws_bytes = max(ws_bytes, _tiles_workspace_bytes([(h, w)], n, aligned_height, aligned_width, sampling_ratio))
-    if records:
+    if records and want_backward:
         ws_bytes = max(ws_bytes, _backward_workspace_bytes([(h, w)], n, r))  # a backward reuses this scratch
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=features.device)
     with torch.cuda.device(features.device):
@@ -149,7 +152,8 @@ class _RoIAlign(Function):
         ctx.channels_last = (features.dim() == 4 and not features.is_contiguous()
                              and features.is_contiguous(memory_format=torch.channels_last))
         # records a forward left in its scratch (channels-last features) serve the backward over the same rois
-        output, workspace = roi_align_forward(features, rois, *ctx.cfg, return_workspace=True)
+        output, workspace = roi_align_forward(features, rois, *ctx.cfg, return_workspace=True,
+                                              want_backward=bool(ctx.needs_input_grad[0]))
         ctx.save_for_backward(rois, workspace if workspace is not None else rois.new_empty(0))
         return output
 
@@ -214,7 +218,8 @@ class _RoIAlignFPN(Function):
         ws_bytes = max(lib.mi_roi_align_forward_workspace_bytes(r),
                        _tiles_workspace_bytes([(f.size(2), f.size(3)) for f in features], n, aligned_height,
                                               aligned_width, sampling_ratio))
-        ws_bytes = max(ws_bytes, _backward_workspace_bytes([(f.size(2), f.size(3)) for f in features], n, r))
+        if any(ctx.needs_input_grad[6:]):  # room for the planned backward; the forward then writes its tables too
+            ws_bytes = max(ws_bytes, _backward_workspace_bytes([(f.size(2), f.size(3)) for f in features], n, r))
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=rois.device)
         table = _fpn_table(features, scales)
         layout = _common_layout(features)

@@ -157,7 +157,10 @@ size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels* levels, i
  * training step cluster on the ground-truth boxes and a few tiles see hundreds of them.  The slices of one list add their
  * sums with fp32 atomics (order not fixed; lists of <= 32 RoIs are summed in a fixed order as before).  Passing only the
  * forward size to mi_roi_align_backward_ws / _fpn keeps the unplanned backward (one workgroup per tile walks the whole
- * list, no atomics).  Only height[] / width[] / num_levels of `levels` are read (one level for the single-map entries).
+ * list, no atomics).  A forward given a workspace of at least this size also writes the records' backward block (merged
+ * pass weights, +2 us in its records launch); MI_ROI_ALIGN_RECORDS_READY is honoured for such a workspace only -- with a
+ * smaller one the backward rewrites the records.  Only height[] / width[] / num_levels of `levels` are read (one level
+ * for the single-map entries).
  * Replaces: the reference's backward is atomicAdd per tap throughout (roi_align_kernel.cu:195-270). */
 size_t mi_roi_align_backward_workspace_bytes(const mi_fpn_levels* levels, int batch, int num_rois);
 /* 1 when mi_roi_align_forward_fpn with these arguments leaves the records of its rois in the workspace (channels-last

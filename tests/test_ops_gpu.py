@@ -940,6 +940,37 @@ def test_roi_align_backward_of_clustered_rois_is_cut_into_list_slices(oracle_mod
     assert_close(grad0, ref, "unplanned bwd")
 
 
+@pytest.mark.parametrize("room_for_backward", [True, False])
+def test_roi_align_records_ready_with_and_without_room_for_the_backward(oracle_mod, room_for_backward):
+    """C-ABI contract of MI_ROI_ALIGN_RECORDS_READY: a forward given a workspace of mi_roi_align_backward_workspace_bytes
+    writes the records' backward block and the backward reuses the records; with a workspace of the forward's size the
+    forward skips the block (inference pays nothing for it) and a backward that passes RECORDS_READY anyway rewrites the
+    records itself -- same gradients either way."""
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import _backward_workspace_bytes
+
+    lib = _lib.lib()
+    n, c, h, w, scale, res, r = 2, 64, 50, 84, 1.0 / 16, 7, 200
+    feat = syn.feature_map(n, c, h, w, seed=8)
+    rois = syn.rois_adversarial(r, n, h, w, scale, seed=21)
+    gtop = np.random.RandomState(5).randn(r, c, res, res).astype(np.float32)
+    fwd_bytes = int(lib.mi_roi_align_forward_workspace_bytes(r))
+    ws_bytes = _backward_workspace_bytes([(h, w)], n, r) if room_for_backward else fwd_bytes
+    assert (ws_bytes > fwd_bytes) == room_for_backward
+    f, ro, g = to_dev(feat), to_dev(rois), to_dev(gtop)
+    out = torch.empty((r, c, res, res), device=dev())
+    grad = torch.empty((n, c, h, w), device=dev())
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev())
+    stream = _lib.current_stream_handle(dev())
+    _lib.check(lib.mi_roi_align_forward_ws(f.data_ptr(), ro.data_ptr(), out.data_ptr(), n, c, h, w, r, res, res, scale, 2,
+                                          _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, ws.data_ptr(), ws_bytes, stream), "fwd")
+    _lib.check(lib.mi_roi_align_backward_ws(g.data_ptr(), ro.data_ptr(), grad.data_ptr(), n, c, h, w, r, res, res, scale, 2,
+                                           _lib.ROI_ALIGN_CAFFE2, _lib.LAYOUT_NCHW, ws.data_ptr(), ws_bytes,
+                                           _lib.ROI_ALIGN_RECORDS_READY | _lib.ROI_ALIGN_OVERWRITE, stream), "bwd")
+    assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, res, res, scale, 2, threads=8), "fwd", exact=False)
+    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2, threads=8), "bwd, records ready")
+
+
 @pytest.mark.parametrize("channels_last", [False, True])
 @pytest.mark.parametrize("res,sr,channels", [(14, 2, 32), (7, 0, 64), (7, 3, 32), (7, 2, 256)])
 def test_roi_align_fpn_fused_other_resolutions(oracle_mod, res, sr, channels, channels_last):

@@ -177,9 +177,19 @@ def roofline_roi_align_forward(device, iters):
                                           flags, stream)
         assert rc == 0
 
-    launch_bwd()  # leaves the records in `bws`
+    launch_bwd()  # leaves the records (with their backward block) in `bws`
     sec_bwd = time_kernel(lambda: launch_bwd(flags=bwd_flags), max(iters // 4, 10))
-    sec_unplanned = time_kernel(lambda: launch_bwd(ws, ws_bytes, bwd_flags), max(iters // 4, 10))
+    # the unplanned kernel (one workgroup per tile walks the whole list): MI_ROI_ALIGN_BWD_SLICE=0, records ready
+    prev = os.environ.get("MI_ROI_ALIGN_BWD_SLICE")
+    os.environ["MI_ROI_ALIGN_BWD_SLICE"] = "0"
+    lib.mi_dbg_reload_tuning()
+    launch_bwd()
+    sec_unplanned = time_kernel(lambda: launch_bwd(flags=bwd_flags), max(iters // 4, 10))
+    if prev is None:
+        del os.environ["MI_ROI_ALIGN_BWD_SLICE"]
+    else:
+        os.environ["MI_ROI_ALIGN_BWD_SLICE"] = prev
+    lib.mi_dbg_reload_tuning()
     bwd_bytes = 4 * r * c * res * res + 4 * c * h * w + 20 * r
     info["backward"] = {"zero_fill_needed": not overwrite, "avg_us_incl_zero_fill": round(sec_bwd * 1e6, 2),
                         "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
@@ -188,7 +198,7 @@ def roofline_roi_align_forward(device, iters):
                         "what": "planned = roi_align_bwd_plan + _items + _tiles + _slow with the workspace the autograd "
                                 "Function allocates (pays ~10 us on these uniformly spread RoIs, halves the backward on "
                                 "the clustered RoIs of a training step: roi_align_step_rois); unplanned = the same call "
-                                "with a workspace of the forward's size"}
+                                "under MI_ROI_ALIGN_BWD_SLICE=0 (one workgroup per tile walks the whole list)"}
     info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
     if layout == _lib.LAYOUT_NCHW:
         info["channels_last"] = channels_last_variant(device, lib, stream, feat, rois, out, ws, alg_bytes, gtop, iters)
