@@ -31,12 +31,18 @@ def cpu_quota():
         return None
 
 
-def respect_cpu_quota(share=0.25):
-    """Cap torch's intra-op pool at `share` of the cgroup quota (at least 1 thread; the launching thread, the HSA runtime
-    threads and MIOpen's need the rest).  No-op without a quota or when OMP_NUM_THREADS is set.  Returns the thread count."""
+def respect_cpu_quota(share=0.25, processes=None):
+    """Cap torch's intra-op pool at `share` of the cgroup quota divided by the processes that share it (default: the
+    LOCAL_WORLD_SIZE torchrun exports, else 1); at least 1 thread -- the launching thread, the HSA runtime threads and
+    MIOpen's need the rest.  No-op without a quota or when OMP_NUM_THREADS is set.  Returns the thread count."""
     quota = cpu_quota()
+    if processes is None:
+        try:
+            processes = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        except ValueError:
+            processes = 1
     if quota is not None and "OMP_NUM_THREADS" not in os.environ:
-        want = max(1, int(quota * share))
+        want = max(1, int(quota * share / processes))
         if torch.get_num_threads() > want:
             torch.set_num_threads(want)
     return torch.get_num_threads()
