@@ -536,8 +536,9 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// Backward (roi_align_kernel.cu:150-270) as a GATHER over tiles of the feature-map gradient -- no atomics, no
-// zero fill, deterministic.
+// Backward (roi_align_kernel.cu:150-270) as a GATHER over tiles of the feature-map gradient -- no zero fill, and no
+// atomics except where a planned launch cuts a tile's RoI list into slices (their sums are added atomically; lists of
+// up to 32 RoIs, and every list of the unplanned launch, are summed in a fixed order).
 //
 // Measured first on MI355X (512 RoIs x 256 ch x 7x7 on 200x336): scatter formulations are bound by the atomic units,
 // not by bandwidth -- 37 M global_atomic_add_f32 (one per window pixel and channel, already coalesced) cost ~190 us,

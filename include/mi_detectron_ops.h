@@ -101,12 +101,16 @@ int mi_roi_align_backward(const float* top_grad, const float* rois, float* botto
 /* Backward with caller scratch (same workspace contract as mi_roi_align_forward_ws).  `flags`:
  *   MI_ROI_ALIGN_RECORDS_READY  `workspace` still holds the records written by mi_roi_align_forward_ws for the SAME
  *                               rois, feature-map size, aligned size, spatial_scale and sampling_ratio (nothing else
- *                               touched it since): the record launch is skipped;
+ *                               touched it since) AND the workspace is at least
+ *                               mi_roi_align_backward_workspace_bytes() large (only then did the forward write the records'
+ *                               backward block): the record launch is skipped; otherwise the flag is ignored;
  *   MI_ROI_ALIGN_OVERWRITE      bottom_grad is fully WRITTEN (no zero fill by the caller needed) instead of
  *                               accumulated into (the reference contract, functions/roi_align.py:39-44).  Honoured on
  *                               the tile path only (NCHW or channels-last bottom_grad); test
  *                               mi_roi_align_backward_overwrites() before relying on it.
- * The tile path is a gather over tiles of bottom_grad: no atomics, deterministic summation order. */
+ * The tile path is a gather over tiles of bottom_grad: a fixed summation order per tile; with a workspace of
+ * mi_roi_align_backward_workspace_bytes() lists of more than 32 RoIs are cut into slices whose sums are added with fp32
+ * atomics (see there). */
 #define MI_ROI_ALIGN_RECORDS_READY 1
 #define MI_ROI_ALIGN_OVERWRITE 2
 int mi_roi_align_backward_ws(const float* top_grad, const float* rois, float* bottom_grad,
