@@ -905,7 +905,7 @@ def _clustered_rois(num, batch, height, width, scale, boxes_per_image, seed):
     return rois
 
 
-@pytest.mark.parametrize("slice_len", [None, 8])
+@pytest.mark.parametrize("slice_len", [None, 8, 2])   # 2: more slices than the item table holds -> the slice length doubles
 @pytest.mark.parametrize("res,channels_last", [(7, False), (14, False), (7, True)])
 def test_roi_align_backward_of_clustered_rois_is_cut_into_list_slices(oracle_mod, tuning_env, res, channels_last, slice_len):
     """The planned backward (roi_align_bwd_plan + roi_align_bwd_tiles over list slices): 600 RoIs on 3 boxes per image make
