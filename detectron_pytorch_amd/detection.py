@@ -9,7 +9,8 @@ result sizes cross to the host (the reference's return type, one array per class
 
 The reference reads its thresholds from the global cfg; here they are arguments with the reference's defaults
 (TEST.SCORE_THRESH 0.05, TEST.NMS 0.5, TEST.DETECTIONS_PER_IM 100, TEST.SOFT_NMS.* : core/config.py:222-227,358-368).
-Bounding-box voting (TEST.BBOX_VOTE, off by default) is not implemented.
+Bounding-box voting (TEST.BBOX_VOTE, core/test.py:766-773, off by default) runs as one more call over all classes
+(`mi_box_voting`) between the NMS and the detections_per_im cut.
 """
 import ctypes
 
@@ -19,6 +20,36 @@ import torch
 from . import _lib
 from . import topk as topk_mod
 from .nms import SOFT_NMS_METHODS
+
+
+VOTE_SCORING_METHODS = {"ID": 0, "TEMP_AVG": 1, "AVG": 2, "IOU_AVG": 3, "GENERALIZED_AVG": 4, "QUASI_SUM": 5}  # boxes.py:285-311
+
+
+def box_voting(top_dets, all_dets, thresh, scoring_method="ID", beta=1.0, top_segments=None, all_offsets=None):
+    """utils.boxes.box_voting (lib/utils/boxes.py:268-317) on the device: every row of top_dets [K,5] is refined by the
+    rows of all_dets [M,5] with IoU >= thresh (score-weighted box average; the score per `scoring_method`).  numpy in ->
+    numpy out, device tensors in -> device tensor out.  top_segments [K] / all_offsets [S+1] (int32 tensors) run the
+    classes of an image side by side: a top row is voted on by the rows of its own segment only."""
+    if scoring_method not in VOTE_SCORING_METHODS:
+        raise NotImplementedError("Unknown scoring method {}".format(scoring_method))       # boxes.py:312-315
+    as_numpy = isinstance(top_dets, np.ndarray)
+    device = torch.device("cuda", torch.cuda.current_device()) if as_numpy else top_dets.device
+    top, alld = _to_device(top_dets, device).contiguous(), _to_device(all_dets, device).contiguous()
+    _lib.require_cuda(top, "top_dets")
+    k, m = int(top.size(0)), int(alld.size(0))
+    out = torch.empty_like(top)
+    if k:
+        if top_segments is None:
+            top_segments = torch.zeros((k,), dtype=torch.int32, device=device)
+            all_offsets = torch.tensor([0, m], dtype=torch.int32, device=device)
+        top_segments = top_segments.to(dtype=torch.int32).contiguous()
+        all_offsets = all_offsets.to(dtype=torch.int32).contiguous()
+        with torch.cuda.device(device):
+            rc = _lib.lib().mi_box_voting(top.data_ptr(), top_segments.data_ptr(), k, alld.data_ptr(), all_offsets.data_ptr(),
+                                          int(all_offsets.numel()) - 1, float(thresh), VOTE_SCORING_METHODS[scoring_method],
+                                          float(beta), out.data_ptr(), _lib.current_stream_handle(device))
+        _lib.check(rc, "mi_box_voting")
+    return out.cpu().numpy() if as_numpy else out
 
 
 def _to_device(a, device):
@@ -127,7 +158,8 @@ def _results_from_static(res, as_numpy):
 
 
 def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=0.5, detections_per_im=100,
-                                   soft_nms=False, soft_nms_sigma=0.5, soft_nms_method="linear", device=None):
+                                   soft_nms=False, soft_nms_sigma=0.5, soft_nms_method="linear", device=None,
+                                   bbox_vote=False, bbox_vote_thresh=0.8, bbox_vote_method="ID"):
     """core/test.py:732-790.  scores [R, C], boxes [R, 4C] (numpy or tensors; class 0 = background).  Returns
     (scores [D], boxes [D,4], cls_boxes) with cls_boxes[j] a float32 [k_j, 5] array (cls_boxes[0] == []), numpy out for
     numpy in and device tensors out for tensors in -- the same rows in the same order as the reference.
@@ -136,7 +168,9 @@ def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=
     side, class sizes never on the host), the detections_per_im cut and the final gather are one asynchronous sequence of
     fixed shapes; the only device-to-host copy is the vector of result sizes the reference's return type needs.
     Soft-NMS re-scores rows, so its candidates are compacted first (one more synchronisation for their number) and
-    `mi_soft_nms_segmented` runs the classes side by side."""
+    `mi_soft_nms_segmented` runs the classes side by side.  bbox_vote (TEST.BBOX_VOTE.ENABLED / VOTE_TH / SCORING_METHOD,
+    core/test.py:766-773): the survivors of every class are refined by `mi_box_voting` against the class's candidates
+    before the detections_per_im cut (compacting path; the call site passes no beta, so box_voting's default 1.0 applies)."""
     as_numpy = isinstance(scores, np.ndarray)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if as_numpy else scores.device
@@ -152,7 +186,7 @@ def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=
             e = empty.cpu().numpy()
             return e[:, 4], e[:, :4], [[]] + [e] * nseg
         return empty[:, 4], empty[:, :4], [[]] + [empty] * nseg
-    if not soft_nms and r <= 4096:
+    if not soft_nms and not bbox_vote and r <= 4096:
         out = _results_from_static(box_results_static(scores_d, boxes_d, score_thresh, nms_thresh, detections_per_im),
                                    as_numpy)
         if out is not None:
@@ -208,6 +242,11 @@ def box_results_with_nms_and_limit(scores, boxes, score_thresh=0.05, nms_thresh=
         kept_mask = torch.zeros((m + 1,), dtype=torch.bool, device=device)
         kept_mask[src] = True
         kept_mask = kept_mask[:m]
+    if bbox_vote and m:                                                    # :766-773
+        voted = box_voting(rows[kept_mask], dets, bbox_vote_thresh, bbox_vote_method, top_segments=seg[kept_mask],
+                           all_offsets=offsets)
+        rows = rows.clone()
+        rows[kept_mask] = voted
     # limit to detections_per_im over all classes (:776-785): image_thresh = the D-th largest kept score
     if detections_per_im > 0 and m > detections_per_im:
         masked = torch.where(kept_mask, rows[:, 4], torch.full_like(rows[:, 4], float("-inf")))

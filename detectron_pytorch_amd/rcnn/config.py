@@ -39,7 +39,8 @@ def _defaults():
     c.TEST = Node(                                            # config.py:166-370
         SCALE=600, MAX_SIZE=1000, NMS=0.3, RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000,
         RPN_MIN_SIZE=0, DETECTIONS_PER_IM=100, SCORE_THRESH=0.05,
-        SOFT_NMS=Node(ENABLED=False, METHOD="linear", SIGMA=0.5))
+        SOFT_NMS=Node(ENABLED=False, METHOD="linear", SIGMA=0.5),
+        BBOX_VOTE=Node(ENABLED=False, VOTE_TH=0.8, SCORING_METHOD="ID", SCORING_METHOD_BETA=1.0))   # config.py:371-386
     c.MODEL = Node(                                           # config.py:390-450
         TYPE="", CONV_BODY="", NUM_CLASSES=81, CLS_AGNOSTIC_BBOX_REG=False, BBOX_REG_WEIGHTS=(10.0, 10.0, 5.0, 5.0),
         FASTER_RCNN=False, MASK_ON=False, KEYPOINTS_ON=False, RPN_ONLY=False, SHARE_RES5=False,

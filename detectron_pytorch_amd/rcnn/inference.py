@@ -108,7 +108,8 @@ def im_detect_all(model, data, im_info, im_shape=None, autocast_dtype=None):
     t = cfg.TEST
     return detection.box_results_with_nms_and_limit(
         scores, boxes, score_thresh=t.SCORE_THRESH, nms_thresh=t.NMS, detections_per_im=t.DETECTIONS_PER_IM,
-        soft_nms=t.SOFT_NMS.ENABLED, soft_nms_sigma=t.SOFT_NMS.SIGMA, soft_nms_method=t.SOFT_NMS.METHOD)
+        soft_nms=t.SOFT_NMS.ENABLED, soft_nms_sigma=t.SOFT_NMS.SIGMA, soft_nms_method=t.SOFT_NMS.METHOD,
+        bbox_vote=t.BBOX_VOTE.ENABLED, bbox_vote_thresh=t.BBOX_VOTE.VOTE_TH, bbox_vote_method=t.BBOX_VOTE.SCORING_METHOD)
 
 
 def _rois_blob(boxes, im_scale, cfg, name):
@@ -174,7 +175,8 @@ def im_detect_all_results(model, data, im_info, im_shape=None, autocast_dtype=No
     t = cfg.TEST
     _, boxes_out, cls_boxes = detection.box_results_with_nms_and_limit(
         scores, boxes, score_thresh=t.SCORE_THRESH, nms_thresh=t.NMS, detections_per_im=t.DETECTIONS_PER_IM,
-        soft_nms=t.SOFT_NMS.ENABLED, soft_nms_sigma=t.SOFT_NMS.SIGMA, soft_nms_method=t.SOFT_NMS.METHOD)
+        soft_nms=t.SOFT_NMS.ENABLED, soft_nms_sigma=t.SOFT_NMS.SIGMA, soft_nms_method=t.SOFT_NMS.METHOD,
+        bbox_vote=t.BBOX_VOTE.ENABLED, bbox_vote_thresh=t.BBOX_VOTE.VOTE_TH, bbox_vote_method=t.BBOX_VOTE.SCORING_METHOD)
     cls_segms = cls_keyps = None
     if cfg.MODEL.MASK_ON:
         masks = im_detect_mask(model, scale, boxes_out, blob_conv)
@@ -198,6 +200,8 @@ def im_detect_all_static(model, data, im_info, autocast_dtype=None, mask_im_shap
     cfg = model.cfg
     if cfg.TEST.SOFT_NMS.ENABLED:
         raise NotImplementedError("the static detection path runs hard NMS (Soft-NMS compacts its candidates first)")
+    if cfg.TEST.BBOX_VOTE.ENABLED:
+        raise NotImplementedError("the static detection path has no bounding-box voting (im_detect_all does it)")
     scores, boxes, blob_conv, valid = im_detect_bbox(model, data, im_info, None, autocast_dtype, static=True)
     t = cfg.TEST
     res = detection.box_results_static(scores, boxes, t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, roi_valid=valid)

@@ -326,6 +326,18 @@ int mi_rpn_collect_finish(const float* top_scores, const int64_t* top_indices, c
                           int mark_invalid, int k_min, int k_max, float canonical_scale, float canonical_level,
                           float* rois, uint8_t* valid, int32_t* levels, mi_stream_t stream);
 
+/* Bounding-box voting (lib/utils/boxes.py:268-317 box_voting; call site lib/core/test.py:766-773, TEST.BBOX_VOTE): every
+ * row of top_dets [num_top, 5] (x1, y1, x2, y2, score: the detections that survived NMS) is refined by the rows of its
+ * class in all_dets (every candidate above the score threshold, before NMS) whose IoU with it is >= thresh (IoU =
+ * utils.cython_bbox.bbox_overlaps bit for bit): box = score-weighted average of the voters' boxes; score per
+ * scoring_method: 0 ID (unchanged), 1 TEMP_AVG, 2 AVG, 3 IOU_AVG, 4 GENERALIZED_AVG, 5 QUASI_SUM (`beta` as in the
+ * reference).  All classes in one call: all_dets is class-major with all_offsets int32 [num_segments + 1];
+ * top_segments int32 [num_top] names the segment of every top row.  out [num_top, 5] (may not alias top_dets).
+ * Asynchronous, no workspace.  Averages are accumulated in fp64 and rounded once (numpy: fp32 pairwise): 1e-5 relative. */
+int mi_box_voting(const float* top_dets, const int32_t* top_segments, int num_top, const float* all_dets,
+                  const int32_t* all_offsets, int num_segments, float thresh, int scoring_method, float beta, float* out,
+                  mi_stream_t stream);
+
 /* Independent NMS problems in one call (no reference counterpart: the reference runs one cython_nms per FPN level and
  * image on the host, modeling/generate_proposals.py:91-99,161).  `dets`, `n`, `keep`, `num_keep` are HOST arrays of
  * `num_problems` entries (device pointers / box counts); each problem follows the mi_nms contract, with at most 4096

@@ -167,6 +167,44 @@ def gen_detection():
     save("detection.npz", **out)
 
 
+def gen_box_voting():
+    """utils.boxes.box_voting of the reference, its own source text executed with bbox_overlaps bound to the reference's
+    cython_bbox build (oracle/_ref); and box_results_with_nms_and_limit with TEST.BBOX_VOTE.ENABLED (core/test.py:766-773)."""
+    import re
+    import types
+
+    bsrc = open("/root/reference/lib/utils/boxes.py").read()
+    body = re.search(r"^def box_voting\(.*?(?=^def )", bsrc, re.S | re.M).group(0)
+    ns = {"np": np, "bbox_overlaps": ref._mod("cython_bbox").bbox_overlaps}
+    exec(compile(body, "/root/reference/lib/utils/boxes.py", "exec"), ns)
+    box_voting = ns["box_voting"]
+    rng = np.random.RandomState(5)
+    all_dets = syn.boxes_clustered(400, seed=21).astype(np.float32)
+    all_dets[:, 4] = rng.uniform(0.05, 0.99, 400).astype(np.float32)
+    top = all_dets[rng.choice(400, 60, replace=False)].copy()
+    out = {"all_dets": all_dets, "top_dets": top, "thresh": np.float32(0.8), "beta": np.float32(1.5)}
+    for method in ("ID", "TEMP_AVG", "AVG", "IOU_AVG", "GENERALIZED_AVG", "QUASI_SUM"):
+        out["voted_" + method] = box_voting(top, all_dets, 0.8, scoring_method=method, beta=1.5).astype(np.float32)
+    out["voted_loose_ID"] = box_voting(top, all_dets, 0.5).astype(np.float32)
+    # the detection post-processing with voting switched on (the call site passes no beta: box_voting's default 1.0)
+    make, types_ = _reference_box_results()
+    make_voting = make
+    scores, boxes = syn.detection_head_outputs(300, 21, seed=3)
+    for tag, soft, vote_method in (("hard_ID", False, "ID"), ("linear_IOU_AVG", True, "IOU_AVG")):
+        cfg = types.SimpleNamespace(
+            MODEL=types.SimpleNamespace(NUM_CLASSES=21),
+            TEST=types.SimpleNamespace(SCORE_THRESH=0.05, NMS=0.5, DETECTIONS_PER_IM=100,
+                                       SOFT_NMS=types.SimpleNamespace(ENABLED=soft, METHOD="linear", SIGMA=0.5),
+                                       BBOX_VOTE=types.SimpleNamespace(ENABLED=True, VOTE_TH=0.8, SCORING_METHOD=vote_method)))
+        fn = make_voting(cfg)
+        fn.__globals__["box_utils"].box_voting = box_voting
+        s, b, cls_boxes = fn(scores, boxes)
+        out["det_scores_" + tag], out["det_boxes_" + tag] = s.astype(np.float32), b.astype(np.float32)
+        out["det_counts_" + tag] = np.array([len(c) for c in cls_boxes], dtype=np.int64)
+    out["det_in_scores"], out["det_in_boxes"] = scores, boxes
+    save("box_voting.npz", **out)
+
+
 def _reference_generate_proposals():
     """The reference's GenerateProposalsOp and generate_anchors, executed from their own source text.
     generate_anchors.py uses np.float (removed from numpy); the same one-token patch as for cython_nms.pyx
@@ -290,6 +328,7 @@ def main():
     gen_detection()
     gen_proposals()
     gen_fpn()
+    gen_box_voting()
 
 
 if __name__ == "__main__":

@@ -723,6 +723,46 @@ def test_detection_postprocess_golden_bit_exact(name, tag, soft, method):
     assert np.array_equal(s, g["out_scores_" + key]) and np.array_equal(b, g["out_boxes_" + key])
 
 
+@pytest.mark.parametrize("method", ["ID", "TEMP_AVG", "AVG", "IOU_AVG", "GENERALIZED_AVG", "QUASI_SUM"])
+def test_box_voting_golden(method):
+    """mi_box_voting against the reference's own utils.boxes.box_voting (fixture from its source text): the voter set is
+    exact (IoU bit for bit), boxes and scores within 2e-6 relative (fp64 accumulation here, fp32 pairwise sums there)."""
+    from detectron_pytorch_amd import detection
+
+    g = load_golden("box_voting.npz")
+    out = detection.box_voting(g["top_dets"], g["all_dets"], float(g["thresh"]), scoring_method=method, beta=float(g["beta"]))
+    ref = g["voted_" + method]
+    assert out.dtype == np.float32 and out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 2e-6 * np.abs(ref).max(), np.abs(out - ref).max()
+    moved = np.abs(ref[:, :4] - g["top_dets"][:, :4]).max(axis=1) > 1e-3
+    assert np.array_equal(np.abs(out[:, :4] - g["top_dets"][:, :4]).max(axis=1) > 1e-3, moved)   # same rows moved
+    loose = detection.box_voting(to_dev(g["top_dets"]), to_dev(g["all_dets"]), 0.5)
+    assert np.abs(loose.cpu().numpy() - g["voted_loose_ID"]).max() <= 2e-6 * np.abs(ref).max()
+    with pytest.raises(NotImplementedError):
+        detection.box_voting(g["top_dets"], g["all_dets"], 0.8, scoring_method="MEDIAN")
+
+
+@pytest.mark.parametrize("tag,soft,method", [("hard_ID", False, "ID"), ("linear_IOU_AVG", True, "IOU_AVG")])
+def test_detection_postprocess_with_box_voting(oracle_mod, tag, soft, method):
+    """core/test.py:732-790 with TEST.BBOX_VOTE.ENABLED: all classes voted in one call between the NMS and the
+    detections_per_im cut; against the reference's function (fixture) and against the oracle on a second input."""
+    from detectron_pytorch_amd import detection
+    from oracle import postprocess
+
+    g = load_golden("box_voting.npz")
+    s, b, cls_boxes = detection.box_results_with_nms_and_limit(g["det_in_scores"], g["det_in_boxes"], soft_nms=soft,
+                                                               bbox_vote=True, bbox_vote_method=method)
+    assert np.array_equal(np.array([len(c) for c in cls_boxes]), g["det_counts_" + tag])
+    assert np.abs(s - g["det_scores_" + tag]).max() <= 2e-6 and np.abs(b - g["det_boxes_" + tag]).max() <= 2e-3
+    scores, boxes = syn.detection_head_outputs(500, 81, seed=9)
+    rs, rb, rcls = postprocess.box_results_with_nms_and_limit(scores, boxes, soft_nms=soft, bbox_vote=True,
+                                                              bbox_vote_thresh=0.6, bbox_vote_method=method)
+    s, b, cls_boxes = detection.box_results_with_nms_and_limit(to_dev(scores), to_dev(boxes), soft_nms=soft, bbox_vote=True,
+                                                               bbox_vote_thresh=0.6, bbox_vote_method=method)
+    assert [len(c) for c in cls_boxes] == [len(c) for c in rcls]
+    assert np.abs(s.cpu().numpy() - rs).max() <= 2e-6 and np.abs(b.cpu().numpy() - rb).max() <= 2e-3
+
+
 @pytest.mark.parametrize("soft", [False, True])
 def test_detection_postprocess_vs_oracle(oracle_mod, soft):
     from detectron_pytorch_amd import detection

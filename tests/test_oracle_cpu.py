@@ -275,6 +275,27 @@ def test_detection_postprocess_matches_golden(oracle_mod):
         assert np.array_equal(np.vstack(cls_boxes[1:]), g["cls_rows_" + key]), key
 
 
+def test_box_voting_matches_golden(oracle_mod):
+    """box_voting.npz holds the outputs of the reference's own utils.boxes.box_voting source (all six scoring methods) and
+    of its box_results_with_nms_and_limit with TEST.BBOX_VOTE.ENABLED (generate.py:gen_box_voting): the restatement is
+    bit-identical."""
+    from oracle import postprocess
+
+    g = load_golden("box_voting.npz")
+    top, alld = g["top_dets"], g["all_dets"]
+    for method in ("ID", "TEMP_AVG", "AVG", "IOU_AVG", "GENERALIZED_AVG", "QUASI_SUM"):
+        out = postprocess.box_voting(top, alld, float(g["thresh"]), scoring_method=method, beta=float(g["beta"]))
+        assert np.array_equal(out.astype(np.float32), g["voted_" + method]), method
+    assert np.array_equal(postprocess.box_voting(top, alld, 0.5).astype(np.float32), g["voted_loose_ID"])
+    assert (np.abs(g["voted_loose_ID"][:, :4] - top[:, :4]).max(axis=1) > 1e-3).sum() > 30   # voting really moves boxes
+    for tag, soft, method in (("hard_ID", False, "ID"), ("linear_IOU_AVG", True, "IOU_AVG")):
+        s, b, cls_boxes = postprocess.box_results_with_nms_and_limit(g["det_in_scores"], g["det_in_boxes"], soft_nms=soft,
+                                                                     bbox_vote=True, bbox_vote_method=method)
+        assert np.array_equal(s.astype(np.float32), g["det_scores_" + tag])
+        assert np.array_equal(b.astype(np.float32), g["det_boxes_" + tag])
+        assert np.array_equal(np.array([len(c) for c in cls_boxes]), g["det_counts_" + tag])
+
+
 def test_detection_postprocess_without_limit_and_empty_classes(oracle_mod):
     from oracle import postprocess
 
