@@ -52,6 +52,7 @@ SIGNATURES = {
     "mi_rpn_collect_finish": (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_float, _c_float] + [_c_void_p] * 4),
     "mi_roi_align_fpn_supported": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "mi_roi_align_forward_tiles_workspace_bytes": (_c_size_t, [_c_void_p, _c_int, _c_int, _c_int, _c_int]),
+    "mi_keypoint_nms_oks": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, _c_void_p, _c_void_p, _c_void_p]),
     "mi_box_voting": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_float, _c_int, _c_float,
                               _c_void_p, _c_void_p]),
     "mi_roi_align_backward_workspace_bytes": (_c_size_t, [_c_void_p, _c_int, _c_int]),

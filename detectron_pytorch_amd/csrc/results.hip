@@ -338,6 +338,79 @@ keypoint_decode(const float* __restrict__ maps, const float* __restrict__ rois, 
   }
 }
 
+
+// ---- OKS-NMS of keypoint predictions (lib/utils/keypoints.py:225-266; call site lib/core/test.py:857-862) ---------
+// One workgroup: scores = numpy's fp32 mean of the 17 keypoint logits (its pairwise order), rank by counting, the
+// N x N relation "OKS(src = i, dst = j) > thresh" as bit rows in LDS (fp32 squared distances, then fp64 exactly as
+// numpy promotes them: / vars / (area + spacing(1)) / 2, exp, pairwise sum, / 17), then the greedy walk.
+constexpr int kOksMax = 512;  // persons per image
+constexpr int kOksK = 17;     // the reference's sigma table is COCO's 17 keypoints
+__device__ __forceinline__ double oks_var(int k) {
+  const double s[kOksK] = {.26, .25, .25, .35, .35, .79, .79, .72, .72, .62, .62, 1.07, 1.07, .87, .87, .89, .89};
+  const double v = (s[k] / 10.0) * 2;
+  return v * v;
+}
+template <typename T>
+__device__ __forceinline__ T numpy_sum17(const T* a) {  // numpy's pairwise_sum for 8 <= n <= 128, n = 17
+  T r[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) r[j] = a[j];
+#pragma unroll
+  for (int j = 0; j < 8; j++) r[j] += a[8 + j];
+  T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  res += a[16];
+  return res;
+}
+__global__ void __launch_bounds__(kThreads)
+keypoint_nms_oks(const float* __restrict__ kp, const float* __restrict__ rois, int n, double thresh,
+                 int64_t* __restrict__ keep, int32_t* __restrict__ num_keep) {
+  __shared__ float score[kOksMax];
+  __shared__ int order[kOksMax];
+  __shared__ unsigned long long sup[kOksMax * (kOksMax / 64)];
+  const int tid = threadIdx.x, words = (n + 63) / 64;
+  for (int i = tid; i < n; i += kThreads) score[i] = numpy_sum17(kp + ((long long)i * 4 + 2) * kOksK) / (float)kOksK;
+  for (int i = tid; i < n * words; i += kThreads) sup[i] = 0ull;
+  __syncthreads();
+  // scores.argsort()[::-1]: descending; equal scores: the higher index first (a stable ascending sort, reversed)
+  for (int i = tid; i < n; i += kThreads) {
+    const float s = score[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) rank += (score[j] > s || (score[j] == s && j > i)) ? 1 : 0;
+    order[rank] = i;
+  }
+  for (int p = tid; p < n * n; p += kThreads) {
+    const int i = p / n, j = p - i * n;  // src i, dst j
+    if (i == j) continue;
+    const float* ri = rois + (long long)i * 4;
+    const float area = (ri[2] - ri[0] + 1.f) * (ri[3] - ri[1] + 1.f);
+    const double denom = (double)area + 2.220446049250313e-16;  // np.spacing(1)
+    const float* si = kp + (long long)i * 4 * kOksK;
+    const float* dj = kp + (long long)j * 4 * kOksK;
+    double ex[kOksK];
+#pragma unroll
+    for (int k = 0; k < kOksK; k++) {
+      const float dx = dj[k] - si[k], dy = dj[kOksK + k] - si[kOksK + k];
+      const float d2 = dx * dx + dy * dy;
+      ex[k] = exp(-((double)d2 / oks_var(k) / denom / 2));
+    }
+    const double oks = numpy_sum17(ex) / (double)kOksK;
+    if (!(oks <= thresh)) atomicOr(&sup[i * words + (j >> 6)], 1ull << (j & 63));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long dead[kOksMax / 64];
+    for (int w = 0; w < words; w++) dead[w] = 0ull;
+    int kept = 0;
+    for (int r = 0; r < n; r++) {
+      const int i = order[r];
+      if ((dead[i >> 6] >> (i & 63)) & 1ull) continue;
+      keep[kept++] = i;
+      for (int w = 0; w < words; w++) dead[w] |= sup[i * words + w];
+    }
+    *num_keep = kept;
+  }
+}
+
 }  // namespace
 
 extern "C" int mi_mask_paste_rle(const float* masks, const int32_t* boxes, int num_masks, int mask_size, int im_height,
@@ -367,4 +440,22 @@ extern "C" int mi_keypoint_decode(const float* heatmaps, const float* rois, int 
   keypoint_decode<<<num_rois * num_keypoints, kThreads, 0, mi::as_stream(stream)>>>(heatmaps, rois, num_keypoints,
                                                                                    heatmap_size, min_size, xy_preds);
   return mi::check_launch("keypoint_decode");
+}
+
+extern "C" int mi_keypoint_nms_oks(const float* xy_preds, const float* rois, int num_rois, int num_keypoints, double thresh,
+                                   int64_t* keep, int32_t* num_keep, mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(num_rois >= 0, "keypoint_nms_oks: negative size");
+  MI_REQUIRE(num_keypoints == kOksK, "keypoint_nms_oks: the reference's sigma table has %d keypoints (got %d)", kOksK,
+             num_keypoints);
+  MI_REQUIRE(num_rois <= kOksMax, "keypoint_nms_oks: at most %d persons per call (got %d)", kOksMax, num_rois);
+  MI_REQUIRE(num_keep != nullptr, "keypoint_nms_oks: null pointer");
+  if (num_rois == 0) {
+    if (hipMemsetAsync(num_keep, 0, sizeof(int32_t), mi::as_stream(stream)) != hipSuccess)
+      return mi::check_launch("keypoint_nms_oks: zero count");
+    return MI_OK;
+  }
+  MI_REQUIRE(xy_preds != nullptr && rois != nullptr && keep != nullptr, "keypoint_nms_oks: null pointer");
+  keypoint_nms_oks<<<1, kThreads, 0, mi::as_stream(stream)>>>(xy_preds, rois, num_rois, thresh, keep, num_keep);
+  return mi::check_launch("keypoint_nms_oks");
 }

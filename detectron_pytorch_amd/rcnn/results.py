@@ -155,13 +155,33 @@ def heatmaps_to_keypoints(maps, rois, min_size=0):
     return out
 
 
+def nms_oks(kp_predictions, rois, thresh):
+    """lib/utils/keypoints.py:225-240 on the device: kp_predictions [R, 4, 17] (heatmaps_to_keypoints), rois [R, 4] ->
+    int64 tensor of the kept rows, best mean keypoint logit first (one host copy: their number)."""
+    _lib.require_cuda(kp_predictions, "kp_predictions")
+    kp = kp_predictions.contiguous().float()
+    rois = rois.contiguous().float()
+    r = int(kp.size(0))
+    keep = torch.empty((r,), dtype=torch.int64, device=kp.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=kp.device)
+    with torch.cuda.device(kp.device):
+        rc = _lib.lib().mi_keypoint_nms_oks(kp.data_ptr(), rois.data_ptr(), r, int(kp.size(2)), float(thresh), keep.data_ptr(),
+                                            num.data_ptr(), _lib.current_stream_handle(kp.device))
+    _lib.check(rc, "mi_keypoint_nms_oks")
+    return keep[:int(num.item())]
+
+
 def keypoint_results(cls_boxes, pred_heatmaps, ref_boxes, cfg, person_idx=1):
     """lib/core/test.py:850-866 (`person_idx`: datasets' 'person' class, 1 for COCO).  Returns cls_keyps: per class a list
-    of [4, K] arrays (device tensors)."""
-    if cfg.KRCNN.NMS_OKS:
-        raise NotImplementedError("KRCNN.NMS_OKS (utils/keypoints.py:225-266) is off in every shipped yaml and not built")
+    of [4, K] arrays (device tensors).  With cfg.KRCNN.NMS_OKS the person detections are thinned by OKS-NMS (:857-862; like
+    the reference, cls_boxes[person_idx] is replaced in place)."""
     cls_keyps = [[] for _ in range(cfg.MODEL.NUM_CLASSES)]
     xy_preds = heatmaps_to_keypoints(pred_heatmaps, ref_boxes, cfg.KRCNN.INFERENCE_MIN_SIZE)
+    if cfg.KRCNN.NMS_OKS:
+        keep = nms_oks(xy_preds, ref_boxes, 0.3)                                   # :858, the 0.3 is the reference's literal
+        xy_preds = xy_preds[keep]
+        boxes = cls_boxes[person_idx]
+        cls_boxes[person_idx] = boxes[keep.cpu().numpy()] if isinstance(boxes, np.ndarray) else boxes[keep.to(boxes.device)]
     cls_keyps[person_idx] = [xy_preds[i] for i in range(xy_preds.size(0))]
     return cls_keyps
 

@@ -395,6 +395,14 @@ int mi_mask_paste_rle(const float* masks, const int32_t* boxes, int num_masks, i
                       uint8_t* strings, int32_t* num_bytes, mi_stream_t stream);
 int mi_keypoint_decode(const float* heatmaps, const float* rois, int num_rois, int num_keypoints, int heatmap_size,
                        int min_size, float* xy_preds, mi_stream_t stream);
+/* OKS-NMS of the keypoint predictions of one image (lib/utils/keypoints.py:225-266 nms_oks / compute_oks; call site
+ * lib/core/test.py:857-862, cfg.KRCNN.NMS_OKS): xy_preds [num_rois, 4, 17] as mi_keypoint_decode writes them, rois
+ * [num_rois, 4]; persons are visited by descending mean keypoint logit (numpy's fp32 mean; equal means: higher index
+ * first) and one is dropped when its OKS with respect to a kept one exceeds `thresh` (a double, as the reference's Python
+ * float: the OKS is evaluated in fp64 exactly as numpy promotes it).  keep int64 [num_rois] receives the kept indices in
+ * visiting order, *num_keep their number.  num_keypoints must be 17 (the reference's sigma table), num_rois <= 512. */
+int mi_keypoint_nms_oks(const float* xy_preds, const float* rois, int num_rois, int num_keypoints, double thresh,
+                        int64_t* keep, int32_t* num_keep, mi_stream_t stream);
 
 /* ---- diagnostics (no reference counterpart) ---------------------------------------------------
  * Tuning aid used by tools/timeline.py: while a non-NULL device buffer of 8 int64 per forward workgroup is set,

@@ -257,3 +257,31 @@ def heatmaps_to_keypoints(maps, rois, min_size=0):
             xy_preds[i, 2, k] = temp[y_int, x_int]
             xy_preds[i, 3, k] = prob
     return xy_preds
+
+
+# ---- lib/utils/keypoints.py:225-266 ---------------------------------------------------------------------------------
+def compute_oks(src_keypoints, src_roi, dst_keypoints, dst_roi):
+    """keypoints.py:243-266: OKS of the predicted keypoints [N,4,K] with respect to src_keypoints [4,K]; numpy only in the
+    reference, so this restatement is pinned by executing the reference's own text (tests/test_results_cpu.py)."""
+    sigmas = np.array([.26, .25, .25, .35, .35, .79, .79, .72, .72, .62, .62, 1.07, 1.07, .87, .87, .89, .89]) / 10.0
+    vars = (sigmas * 2) ** 2
+    src_area = (src_roi[2] - src_roi[0] + 1) * (src_roi[3] - src_roi[1] + 1)      # :257
+    dx = dst_keypoints[:, 0, :] - src_keypoints[0, :]                              # :260-261
+    dy = dst_keypoints[:, 1, :] - src_keypoints[1, :]
+    e = (dx ** 2 + dy ** 2) / vars / (src_area + np.spacing(1)) / 2                # :263
+    e = np.sum(np.exp(-e), axis=1) / e.shape[1]                                    # :264
+    return e
+
+
+def nms_oks(kp_predictions, rois, thresh):
+    """keypoints.py:225-240: greedy NMS on OKS, best mean keypoint logit first."""
+    scores = np.mean(kp_predictions[:, 2, :], axis=1)
+    order = scores.argsort()[::-1]
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(i)
+        ovr = compute_oks(kp_predictions[i], rois[i], kp_predictions[order[1:]], rois[order[1:]])
+        inds = np.where(ovr <= thresh)[0]
+        order = order[inds + 1]
+    return keep

@@ -213,3 +213,43 @@ def test_reference_call_sites_run_on_the_restated_packages():
         want = ns["heatmaps_to_keypoints"](maps.copy(), rois)
         got = R.heatmaps_to_keypoints(maps, rois, min_size)
         assert want.dtype == got.dtype == np.float32 and np.array_equal(want, got)
+
+
+def _people(n, seed):
+    """xy_preds [n, 4, 17] of persons that come in overlapping groups (so that OKS-NMS has something to do) and their boxes."""
+    rng = np.random.RandomState(seed)
+    base = rng.uniform(50, 600, size=(max(n // 4, 1), 2, 17)).astype(np.float32)
+    kp = np.zeros((n, 4, 17), np.float32)
+    rois = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        b = base[i % len(base)]
+        jitter = rng.normal(0, rng.choice([1.0, 6.0, 40.0]), size=(2, 17)).astype(np.float32)
+        kp[i, :2] = b + jitter
+        kp[i, 2] = rng.normal(2.0, 1.5, 17).astype(np.float32)
+        kp[i, 3] = rng.uniform(0, 1, 17).astype(np.float32)
+        x1, y1 = kp[i, 0].min() - 5, kp[i, 1].min() - 5
+        rois[i] = (x1, y1, kp[i, 0].max() + 5, kp[i, 1].max() + 5)
+    return kp, rois
+
+
+def test_nms_oks_restatement_equals_the_reference_text():
+    """utils/keypoints.py:225-266 is numpy only: the reference's own nms_oks / compute_oks source is executed and must give
+    the kept list of oracle/results.py's restatement, value for value (OKS in float64)."""
+    import re
+
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference tree is not present on this machine")
+    src = open(os.path.join(REFERENCE, "utils", "keypoints.py")).read()
+    text = "".join(re.search(r"^def %s\(.*?(?=^def |\Z)" % name, src, re.S | re.M).group(0) for name in ("nms_oks", "compute_oks"))
+    ns = {"np": np}
+    exec(compile(text, "utils/keypoints.py", "exec"), ns)
+    for n, seed in ((1, 0), (12, 1), (60, 2), (200, 3)):
+        kp, rois = _people(n, seed)
+        for thresh in (0.3, 0.05, 0.9):
+            want = [int(i) for i in ns["nms_oks"](kp, rois, thresh)]
+            got = [int(i) for i in R.nms_oks(kp, rois, thresh)]
+            assert got == want
+            assert 1 <= len(got) <= n
+        assert np.array_equal(ns["compute_oks"](kp[0], rois[0], kp, rois), R.compute_oks(kp[0], rois[0], kp, rois))
+    kp, rois = _people(60, 2)
+    assert len(R.nms_oks(kp, rois, 0.3)) < 60          # the groups really collapse

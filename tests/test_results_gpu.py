@@ -116,6 +116,23 @@ def test_keypoint_decode_matches_the_restatement(min_size):
     np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=1e-4, atol=1e-9)
 
 
+@pytest.mark.parametrize("n,seed", [(1, 0), (12, 1), (60, 2), (200, 3), (512, 4)])
+def test_nms_oks_matches_the_restatement(n, seed):
+    """mi_keypoint_nms_oks against oracle/results.py's nms_oks (itself pinned to the reference's text on the CPU): the
+    kept indices in visiting order, for the reference's threshold and two others; the model-level switch KRCNN.NMS_OKS."""
+    from detectron_pytorch_amd.rcnn import results
+    from oracle import results as R
+    from tests.test_results_cpu import _people
+
+    kp, rois = _people(n, seed)
+    for thresh in (0.3, 0.05, 0.9):
+        want = [int(i) for i in R.nms_oks(kp, rois, thresh)]
+        got = results.nms_oks(torch.from_numpy(kp).to(dev()), torch.from_numpy(rois).to(dev()), thresh)
+        assert got.dtype == torch.int64 and got.cpu().tolist() == want
+    with pytest.raises(RuntimeError):
+        results.nms_oks(torch.zeros((3, 4, 16), device=dev()), torch.zeros((3, 4), device=dev()), 0.3)
+
+
 def test_im_detect_all_results_mask_and_keypoints(hip_lib_path):
     """test.py:50-112 on the device for a mask + keypoint model: boxes, masks and keypoints in the reference's result
     formats; every RLE decodes to an image-sized mask confined to its (expanded) box."""
@@ -148,6 +165,16 @@ def test_im_detect_all_results_mask_and_keypoints(hip_lib_path):
     assert kp.shape == (n, 4, cfg.KRCNN.NUM_KEYPOINTS)
     assert (kp[:, 0] >= boxes[:, None, 0]).all() and (kp[:, 0] <= boxes[:, None, 2] + 1).all()
     assert (kp[:, 3] > 0).all() and (kp[:, 3] <= 1).all()
+    # KRCNN.NMS_OKS (test.py:857-862): the person boxes and keypoints are thinned together, the survivors are the rows
+    # the restatement keeps of the unthinned result
+    cfg.KRCNN.NMS_OKS = True
+    cls_boxes2, _, cls_keyps2 = inference.im_detect_all_results(
+        net, torch.from_numpy(data_np[:1]).to(dev()), torch.tensor([[float(H), float(W), 1.0]]))
+    keep = [int(i) for i in R.nms_oks(kp, boxes, 0.3)]
+    assert len(cls_boxes2[1]) == len(cls_keyps2[1]) == len(keep) <= n
+    # (two forward passes of the convolutions are not bit-identical on this stack: compare with a tolerance)
+    np.testing.assert_allclose(cls_boxes2[1].cpu().numpy(), cls_boxes[1].cpu().numpy()[keep], rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(torch.stack(cls_keyps2[1]).cpu().numpy()[:, 2:], kp[keep][:, 2:], rtol=1e-3, atol=1e-3)
 
 
 def test_mask_detection_graph_equals_the_eager_result_formats(hip_lib_path):
