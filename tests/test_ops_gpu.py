@@ -980,6 +980,21 @@ def test_roi_align_backward_of_clustered_rois_is_cut_into_list_slices(oracle_mod
     assert_close(grad0, ref, "unplanned bwd")
 
 
+def test_roi_align_backward_with_more_tiles_than_the_plan_holds(oracle_mod):
+    """2200 small images give 8800 gradient tiles, more than the item-table kernel stages (8192): the workspace query then
+    asks for the records only and the backward runs unplanned -- same gradients."""
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import _backward_workspace_bytes
+
+    n, c, h, w, scale, res, r = 2200, 32, 17, 33, 1.0 / 16, 7, 96
+    feat = syn.feature_map(n, c, h, w, seed=2)
+    rois = syn.rois_adversarial(r, n, h, w, scale, seed=4)
+    gtop = np.random.RandomState(6).randn(r, c, res, res).astype(np.float32)
+    assert _backward_workspace_bytes([(h, w)], n, r) == _lib.lib().mi_roi_align_forward_workspace_bytes(r)
+    _, grad = _roi_align_gpu(feat, rois, res, scale, 2, gtop)
+    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, 2, threads=8), "bwd, 8800 tiles")
+
+
 @pytest.mark.parametrize("room_for_backward", [True, False])
 def test_roi_align_records_ready_with_and_without_room_for_the_backward(oracle_mod, room_for_backward):
     """C-ABI contract of MI_ROI_ALIGN_RECORDS_READY: a forward given a workspace of mi_roi_align_backward_workspace_bytes
