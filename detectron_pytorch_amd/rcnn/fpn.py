@@ -113,14 +113,15 @@ class FpnRpnOutputs(nn.Module):
 
     def __init__(self, dim_in, spatial_scales, cfg):
         super().__init__()
-        if cfg.RPN.CLS_ACTIVATION != "sigmoid":
-            raise NotImplementedError("softmax RPN activation (FPN.py:393-398) is not built; every shipped FPN yaml uses sigmoid")
+        if cfg.RPN.CLS_ACTIVATION not in ("sigmoid", "softmax"):
+            raise ValueError("RPN.CLS_ACTIVATION must be 'sigmoid' or 'softmax' (config.py:661-663)")
         self.cfg = cfg
         self.dim_in = self.dim_out = dim_in
         self.spatial_scales = spatial_scales
         num_anchors = len(cfg.FPN.RPN_ASPECT_RATIOS)
         self.FPN_RPN_conv = nn.Conv2d(dim_in, self.dim_out, 3, 1, 1)
-        self.FPN_RPN_cls_score = nn.Conv2d(self.dim_out, num_anchors, 1, 1, 0)
+        dim_score = num_anchors * 2 if cfg.RPN.CLS_ACTIVATION == "softmax" else num_anchors   # FPN.py:335-336
+        self.FPN_RPN_cls_score = nn.Conv2d(self.dim_out, dim_score, 1, 1, 0)
         self.FPN_RPN_bbox_pred = nn.Conv2d(self.dim_out, 4 * num_anchors, 1, 1, 0)
         self.k_min, self.k_max = cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL
         self.level_anchors = []
@@ -152,8 +153,17 @@ class FpnRpnOutputs(nn.Module):
         return ret
 
 
+def rpn_cls_probs(cfg, logits):
+    """FPN.py:399-404: objectness of every anchor [N, A, H, W] from the classification logits -- sigmoid of the A logits, or
+    (jwyang's convention, RPN.CLS_ACTIVATION = 'softmax') the foreground half of a softmax over the 2 x A logits."""
+    if cfg.RPN.CLS_ACTIVATION == "softmax":
+        b, c, h, w = logits.shape
+        return F.softmax(logits.view(b, 2, c // 2, h, w), dim=1)[:, 1]
+    return torch.sigmoid(logits)
+
+
 def fpn_rpn_losses(cfg, rpn_ret, rpn_targets):
-    """FPN.py:422-463 (sigmoid branch).  `rpn_targets` holds the data layer's "wide" blobs
+    """FPN.py:422-463 (both activations).  `rpn_targets` holds the data layer's "wide" blobs
     ('rpn_labels_int32_wide_fpn<l>' [N,A,F,F] int32 in {-1,0,1}, 'rpn_bbox_targets_wide_fpn<l>' and the two weight blobs
     [N,4A,F,F]); they are narrowed to each level's map.  Returns ([loss_cls per level], [loss_bbox per level])."""
     losses_cls, losses_bbox = [], []
@@ -163,8 +173,13 @@ def fpn_rpn_losses(cfg, rpn_ret, rpn_targets):
         logits, pred = rpn_ret["rpn_cls_logits_fpn" + s], rpn_ret["rpn_bbox_pred_fpn" + s]
         h, w = logits.shape[2:]
         labels = rpn_targets["rpn_labels_int32_wide_fpn" + s][:, :, :h, :w]
-        weight = (labels >= 0).float()
-        loss_cls = F.binary_cross_entropy_with_logits(logits, labels.float(), weight, reduction="sum") / norm
+        if cfg.RPN.CLS_ACTIVATION == "softmax":                                   # FPN.py:438-445
+            b, c = logits.shape[:2]
+            pairs = logits.view(b, 2, c // 2, h, w).permute(0, 2, 3, 4, 1).contiguous().view(-1, 2)
+            loss_cls = F.cross_entropy(pairs, labels.contiguous().view(-1).long(), ignore_index=-1)   # mean over non-ignored
+        else:
+            weight = (labels >= 0).float()
+            loss_cls = F.binary_cross_entropy_with_logits(logits, labels.float(), weight, reduction="sum") / norm
         h, w = pred.shape[2:]
         loss_bbox = smooth_l1_loss(pred, rpn_targets["rpn_bbox_targets_wide_fpn" + s][:, :, :h, :w],
                                    rpn_targets["rpn_bbox_inside_weights_wide_fpn" + s][:, :, :h, :w],

@@ -82,9 +82,9 @@ class GeneralizedRCNN(nn.Module):
 
     # ---- proposals -----------------------------------------------------------------------------------------------------
     def proposals(self, rpn_ret, im_info, static, with_levels=False):
-        """FPN.py:390-417 without leaving the device: sigmoid, GenerateProposals on every level, collect."""
+        """FPN.py:390-417 without leaving the device: objectness (sigmoid / softmax), GenerateProposals on every level, collect."""
         cfg = self.cfg
-        heads_ = [(torch.sigmoid(rpn_ret["rpn_cls_logits_fpn%d" % lvl].detach().float()).contiguous(),
+        heads_ = [(fpn_mod.rpn_cls_probs(cfg, rpn_ret["rpn_cls_logits_fpn%d" % lvl].detach().float()).contiguous(),
                    rpn_ret["rpn_bbox_pred_fpn%d" % lvl].detach().float().contiguous())
                   for lvl in range(cfg.FPN.RPN_MIN_LEVEL, cfg.FPN.RPN_MAX_LEVEL + 1)]
         key = "TRAIN" if self.training else "TEST"

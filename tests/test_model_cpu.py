@@ -283,3 +283,14 @@ def test_keypoint_branch_equals_the_reference():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_keypoint_check.py")], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "KEYPOINT_PARITY_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_softmax_rpn_activation_equals_the_reference():
+    """tests/ref_softmax_rpn_check.py in a process of its own: RPN.CLS_ACTIVATION = 'softmax' (2 x A objectness channels,
+    softmax over the pair, cross-entropy with ignore_index): seeded weights, Detectron names, collected proposals, losses,
+    RPN gradients."""
+    import subprocess
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_softmax_rpn_check.py")], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "SOFTMAX_RPN_PARITY_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
