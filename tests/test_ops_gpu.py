@@ -69,12 +69,13 @@ def tuning_env(monkeypatch):
     _lib.lib().mi_dbg_reload_tuning()
 
 
-@pytest.fixture(params=["stream", "stream_unplanned", "stream_sliced", "tiles", "direct"])
+@pytest.fixture(params=["stream", "stream_unplanned", "stream_sliced", "pipe", "tiles", "direct"])
 def roi_align_impl(request, tuning_env):
     """Run a test against the RoIAlign implementations behind mi_roi_align_*: the default fast paths ("stream": the
     record-driven forward, the planned backward with list slices of 32 RoIs; "stream_unplanned": MI_ROI_ALIGN_BWD_SLICE=0,
     one workgroup walks a tile's whole list; "stream_sliced": slices of 2 RoIs, so that nearly every tile is summed by
-    several workgroups with atomics), the tile-centric NCHW forward (MI_ROI_ALIGN_IMPL=tiles: one launch without
+    several workgroups with atomics), the persistent pipelined forward over the same records (MI_ROI_ALIGN_IMPL=pipe, NCHW
+    and channels-last), the tile-centric NCHW forward (MI_ROI_ALIGN_IMPL=tiles: one launch without
     scratch, pre-kernel + persistent kernel with it) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
     stream = request.param.startswith("stream")
     tuning_env(MI_ROI_ALIGN_IMPL=None if stream else request.param,
