@@ -294,3 +294,29 @@ def test_softmax_rpn_activation_equals_the_reference():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_softmax_rpn_check.py")], capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0 and "SOFTMAX_RPN_PARITY_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("which", ["x101", "faster"])
+def test_builtin_configs_3_and_5_equal_the_reference(which):
+    """tests/ref_config_check.py in a process of its own per configuration: BASELINE.json config 5
+    (e2e_mask_rcnn_X-101-64x4d-FPN_1x.yaml + the keypoint head: 33 grouped 3x3 convolutions with groups = 64, the stride on the
+    3x3) and config 3 (e2e_faster_rcnn_R-50-FPN_1x.yaml) -- yaml merge == built-in configuration, parameter names / shapes /
+    seeded weights / trainable set / Detectron names == the reference's Generalized_RCNN, body + FPN outputs and the inference
+    forward equal on a small image."""
+    import subprocess
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_config_check.py"), which], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "CONFIG_PARITY_OK " + which in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_reference_roi_feature_transform_runs_through_the_dropin_overlay():
+    """tests/ref_overlay_check.py in a process of its own: the reference's REAL modeling/model_builder.py imported with
+    detectron_pytorch_amd/dropin/lib in front of the reference's lib/ on sys.path; its roi_feature_transform (FPN branch with an
+    empty level, and the single-level branch) is executed through the overlay's RoIAlignFunction (the HIP launch bound to the
+    oracle, there is no GPU here), forward and backward, against the oracle and against roi_xform.roi_feature_transform."""
+    import subprocess
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_overlay_check.py")], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "OVERLAY_ROI_FEATURE_TRANSFORM_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
