@@ -253,3 +253,135 @@ def test_nms_oks_restatement_equals_the_reference_text():
         assert np.array_equal(ns["compute_oks"](kp[0], rois[0], kp, rois), R.compute_oks(kp[0], rois[0], kp, rois))
     kp, rois = _people(60, 2)
     assert len(R.nms_oks(kp, rois, 0.3)) < 60          # the groups really collapse
+
+
+# ---- cross-checks that share no code with oracle/results.py (the restatement stays "parity unpinned": pycocotools and cv2 are
+# absent; these rule out that restatement and kernel agree with each other only because one hand wrote both) -------------------
+def _indep_counts(mask):
+    """COCO RLE counts straight from the format description: walk the pixels column by column, count runs, start with zeros."""
+    h, w = mask.shape
+    counts, run, val = [], 0, 0
+    for x in range(w):
+        for y in range(h):
+            if int(mask[y, x]) != val:
+                counts.append(run)
+                run, val = 0, 1 - val
+            run += 1
+    counts.append(run)
+    return counts
+
+
+def _indep_string(counts):
+    """The compressed form from its description: every count from the fourth on is replaced by its difference to the count two
+    places back; each value is written little-endian in 5-bit groups of a two's-complement number, shortest form that still
+    sign-extends correctly (the last group's bit 4 is the sign), bit 5 of a character = another group follows, + 48."""
+    chars = []
+    for i, c in enumerate(counts):
+        v = c - counts[i - 2] if i > 2 else c
+        ngroups = 1
+        while not (-(1 << (5 * ngroups - 1)) <= v < (1 << (5 * ngroups - 1))):
+            ngroups += 1
+        u = v & ((1 << (5 * ngroups)) - 1)                  # two's complement on 5 * ngroups bits
+        for g in range(ngroups):
+            d = (u >> (5 * g)) & 31
+            chars.append(chr(48 + d + (32 if g < ngroups - 1 else 0)))
+    return "".join(chars)
+
+
+def _indep_decode_string(s, h, w):
+    vals, i = [], 0
+    while i < len(s):
+        groups = []
+        while True:
+            d = ord(s[i]) - 48
+            i += 1
+            groups.append(d & 31)
+            if not d & 32:
+                break
+        u = sum(g << (5 * k) for k, g in enumerate(groups))
+        bits = 5 * len(groups)
+        v = u - (1 << bits) if u >> (bits - 1) else u
+        vals.append(v + vals[-2] if len(vals) > 2 else v)
+    out, pos, val = np.zeros(h * w, np.uint8), 0, 0
+    for c in vals:
+        out[pos:pos + c] = val
+        pos += c
+        val ^= 1
+    assert pos == h * w
+    return np.ascontiguousarray(out.reshape(w, h).T)
+
+
+def _adversarial_masks():
+    rng = np.random.RandomState(11)
+    yield np.zeros((7, 5), np.uint8)
+    yield np.ones((7, 5), np.uint8)
+    yield (np.indices((9, 6)).sum(0) & 1).astype(np.uint8)                       # checkerboard: every run is 1
+    m = np.zeros((300, 400), np.uint8)
+    m[:, 150:] = 1                                                               # runs of 45 000 and 75 000: four groups
+    yield m
+    m = np.zeros((64, 64), np.uint8)
+    m[10:50, 3] = 1
+    m[11:14, 40] = 1
+    m[63, 63] = 1                                                                # long, short, long ... : negative differences
+    yield m
+    m = np.zeros((1, 40), np.uint8)
+    m[0, ::3] = 1
+    yield m
+    yield (rng.rand(120, 90) < 0.5).astype(np.uint8)
+    yield (rng.rand(200, 333) < 0.02).astype(np.uint8)
+    blob = np.zeros((100, 100), np.uint8)
+    yy, xx = np.mgrid[:100, :100]
+    blob[(yy - 40) ** 2 + (xx - 55) ** 2 < 900] = 1                              # a disc, as a real mask would be
+    yield blob
+
+
+def test_rle_against_an_independent_codec():
+    for mask in _adversarial_masks():
+        h, w = mask.shape
+        counts = _indep_counts(mask)
+        assert R.rle_counts(mask) == counts
+        s = _indep_string(counts)
+        assert R.rle_to_string(counts) == s
+        assert all(48 <= ord(ch) < 48 + 64 for ch in s)
+        assert np.array_equal(_indep_decode_string(R.mask_encode(mask)["counts"], h, w), mask)   # decode(encode(m)) == m
+        assert R.rle_from_string(s) == counts
+
+
+def _dense_paste(mask_mm, box, im_h, im_w, thresh=0.5):
+    """The paste of core/test.py:826-845 as dense tensor operations: zero-pad, bilinear interpolation to the box
+    (half-pixel centres, no anti-aliasing), threshold, scatter the pixels that fall inside the image."""
+    import torch
+    import torch.nn.functional as F
+
+    m = mask_mm.shape[0]
+    padded = F.pad(torch.from_numpy(mask_mm)[None, None], (1, 1, 1, 1))
+    w, h = max(int(box[2] - box[0] + 1), 1), max(int(box[3] - box[1] + 1), 1)
+    soft = F.interpolate(padded, size=(h, w), mode="bilinear", align_corners=False)[0, 0]
+    ys, xs = torch.meshgrid(torch.arange(h) + int(box[1]), torch.arange(w) + int(box[0]), indexing="ij")
+    inside = (ys >= 0) & (ys < im_h) & (xs >= 0) & (xs < im_w)
+    im = torch.zeros((im_h, im_w), dtype=torch.uint8)
+    im.index_put_((ys[inside], xs[inside]), (soft > thresh)[inside].to(torch.uint8))
+    return im.numpy(), soft.numpy()
+
+
+def test_paste_against_a_dense_interpolate_threshold_scatter():
+    rng = np.random.RandomState(13)
+    im_h, im_w = 427, 640
+    boxes = np.array([[100, 120, 300, 420], [-40, -30, 90, 60], [560, 380, 700, 500], [0, 0, 639, 426], [320, -10, 330, 500],
+                      [200, 100, 200, 100], [900, 100, 950, 200], [10, 420, 300, 426], [33, 44, 61, 57]], np.int32)
+    for i, box in enumerate(boxes):
+        yy, xx = np.mgrid[:28, :28]
+        mask = np.exp(-(((yy - 13.0 - i) ** 2) + (xx - 14.0 + i) ** 2) / (30.0 + 10 * i)).astype(np.float32)
+        mask = np.clip(mask + 0.1 * rng.randn(28, 28).astype(np.float32), 0, 1)
+        got = R.paste_mask(mask, box, im_h, im_w)
+        want, soft = _dense_paste(mask, box, im_h, im_w)
+        # pixels whose interpolated value is within fp32 noise of the threshold may fall on either side (OpenCV forms the
+        # source coordinate in double, interpolate in fp32): everywhere else the two must agree exactly
+        x0, y0 = int(box[0]), int(box[1])
+        near = np.zeros((im_h, im_w), bool)
+        ys, xs = np.nonzero(np.abs(soft - 0.5) < 1e-4)
+        ok = (ys + y0 >= 0) & (ys + y0 < im_h) & (xs + x0 >= 0) & (xs + x0 < im_w)
+        near[ys[ok] + y0, xs[ok] + x0] = True
+        assert np.array_equal(got[~near], want[~near]), "box %d" % i
+        assert near.sum() <= 0.002 * max(got.size, 1)
+        assert got.sum() > 0 or i in (5, 6) or want.sum() == 0

@@ -208,3 +208,36 @@ def test_mask_detection_graph_equals_the_eager_result_formats(hip_lib_path):
                 a = R.rle_decode(R.rle_from_string(g["counts"]), H, W)
                 b = R.rle_decode(R.rle_from_string(w["counts"]), H, W)
                 assert (a != b).sum() <= 0.005 * max(int(b.sum()), 200)
+
+
+def test_mask_paste_rle_against_an_independent_dense_path():
+    """mi_mask_paste_rle against code that shares nothing with oracle/results.py: its strings are decoded by the test's own
+    COCO-RLE decoder (written from the format description) and compared with a dense paste -- F.interpolate (half-pixel
+    centres), threshold, scatter -- on the device.  Pixels whose interpolated value is within 1e-4 of the threshold may fall on
+    either side (fp32 coordinate arithmetic differs); everywhere else the masks must be equal."""
+    import torch.nn.functional as F
+
+    from detectron_pytorch_amd.rcnn import results
+    from test_results_cpu import _indep_decode_string
+
+    im_h, im_w = 427, 640
+    boxes = np.array([[100, 120, 300, 420], [-40, -30, 90, 60], [560, 380, 700, 500], [0, 0, 639, 426], [320, -10, 330, 500],
+                      [200, 100, 200, 100], [900, 100, 950, 200], [10, 420, 300, 426], [33, 44, 61, 57]], np.int32)
+    masks = soft_masks(len(boxes), 28, seed=3)
+    _, num, strings = results.mask_rle(torch.from_numpy(masks).to(dev()), torch.from_numpy(boxes).to(dev()), im_h, im_w)
+    for i, box in enumerate(boxes):
+        got = _indep_decode_string(strings[i], im_h, im_w)
+        padded = F.pad(torch.from_numpy(masks[i]).to(dev())[None, None], (1, 1, 1, 1))
+        w, h = max(int(box[2] - box[0] + 1), 1), max(int(box[3] - box[1] + 1), 1)
+        soft = F.interpolate(padded, size=(h, w), mode="bilinear", align_corners=False)[0, 0]
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev()) + int(box[1]), torch.arange(w, device=dev()) + int(box[0]),
+                                indexing="ij")
+        inside = (ys >= 0) & (ys < im_h) & (xs >= 0) & (xs < im_w)
+        want = torch.zeros((im_h, im_w), dtype=torch.uint8, device=dev())
+        want.index_put_((ys[inside], xs[inside]), (soft > 0.5)[inside].to(torch.uint8))
+        near = torch.zeros((im_h, im_w), dtype=torch.bool, device=dev())
+        close = ((soft - 0.5).abs() < 1e-4) & inside
+        near.index_put_((ys[close], xs[close]), torch.ones(int(close.sum()), dtype=torch.bool, device=dev()))
+        near = near.cpu().numpy()
+        assert np.array_equal(got[~near], want.cpu().numpy()[~near]), "detection %d" % i
+        assert near.sum() <= 0.002 * got.size
