@@ -211,3 +211,119 @@ def test_cpu_quota_helper_keeps_the_intra_op_pool_inside_the_container_budget(mo
         assert n == min(before, 2)
     finally:
         torch.set_num_threads(before)
+
+
+# ---- the REAL training step at world size 2 (rcnn.train.train_step + GradientAllReducer; CPU backends of tests/cpu_backend.py) ----
+def _rcnn_setup():
+    """A small Mask R-CNN R-50-FPN job: seeded model, two images of 128 x 160 with two gt boxes each, the data layer's RPN
+    target blobs per image, fixed sampling priorities (so that no random stream has to line up between processes)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_backend  # noqa: F401  (import check: the spawned workers need the same path)
+    from detectron_pytorch_amd.rcnn import config, data as rdata, model as rmodel
+
+    torch.set_num_threads(1)      # identical summation orders in every process
+    from detectron_pytorch_amd.rcnn import targets
+
+    if not getattr(targets.label_proposals, "_sliced", False):
+        # the CPU backend collects however many proposals survive NMS: cut the (long) fixed priority vector to fit
+        inner = targets.label_proposals
+
+        def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, scales, priority, *a, **k):
+            return inner(cfg, rois, gt_boxes, gt_classes, gt_image, scales, priority[:gt_boxes.size(0) + rois.size(0)], *a, **k)
+
+        label_proposals._sliced = True
+        targets.label_proposals = label_proposals
+    cfg = config.mask_rcnn_r50_fpn()
+    cfg.merge(dict(TRAIN=dict(BATCH_SIZE_PER_IM=32, RPN_PRE_NMS_TOP_N=100, RPN_POST_NMS_TOP_N=60)))
+    torch.manual_seed(cfg.RNG_SEED)
+    net = rmodel.GeneralizedRCNN(cfg).train()
+    h, w, g = 128, 160, 2
+    rng = np.random.RandomState(23)
+    shards = []
+    for i in range(2):
+        bw, bh = rng.uniform(20, 110, g), rng.uniform(20, 90, g)
+        x1, y1 = rng.uniform(0, w - 1 - bw), rng.uniform(0, h - 1 - bh)
+        boxes = np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+        classes = rng.randint(1, 81, g).astype(np.int32)
+        entry = dict(height=h, width=w, boxes=boxes, gt_classes=classes, is_crowd=np.zeros(g, bool))
+        blobs = rdata.add_rpn_blobs(cfg, [entry], [1.0], np.random.RandomState(31 + i))
+        shards.append(dict(
+            data=torch.from_numpy((rng.randn(1, 3, h, w) * 50).astype(np.float32)),
+            im_info=torch.from_numpy(blobs["im_info"]),
+            roidb={"gt_boxes": torch.from_numpy(boxes), "gt_classes": torch.from_numpy(classes).long(),
+                   "gt_image": torch.zeros(g, dtype=torch.long)},
+            rpn_t={k: torch.from_numpy(v) for k, v in blobs.items() if k.startswith("rpn_")},
+            priority=torch.from_numpy(rng.permutation(g + 600).astype(np.float32))))
+    return cfg, net, shards
+
+
+def _rcnn_rank_job(rank, world_size):
+    import cpu_backend
+    from detectron_pytorch_amd.rcnn import train as rtrain
+
+    cfg, net, shards = _rcnn_setup()
+    s = shards[rank]                                   # a different image on every rank
+    opt = rtrain.make_optimizer(net, cfg, lr=2e-3)
+    reducer = parallel.GradientAllReducer(net.parameters(), bucket_bytes=16 << 20)
+    assert reducer.active and len(reducer.buckets) >= 3
+    losses = []
+    with cpu_backend.cpu_ops(net):
+        for _ in range(3):
+            ret = rtrain.train_step(net, opt, s["data"], s["im_info"], s["roidb"], s["rpn_t"], reducer=reducer,
+                                    priority=s["priority"])
+            losses.append(float(ret["total_loss"]))
+    digest = torch.cat([p.detach().reshape(-1)[:64] for p in net.parameters() if p.requires_grad])
+    full = {"Box_Outs.cls_score.weight": None, "Conv_Body.conv_body.res5.2.conv3.weight": None, "RPN.FPN_RPN_conv.bias": None}
+    named = dict(net.named_parameters())
+    return losses, digest.numpy(), {k: named[k].detach().numpy().copy() for k in full}
+
+
+def test_real_training_step_replicas_stay_identical_and_equal_the_sharded_single_process_step():
+    """Three iterations of rcnn.train.train_step (Mask R-CNN R-50-FPN, 44 M trainable parameters in four buckets) on two gloo
+    ranks with DIFFERENT images: the replicas' parameters stay bit-identical, and equal what one process computes when it
+    runs the two shards one after the other and averages their gradients -- the reference's semantics (the loss of a step is
+    the mean over GPUs of per-GPU means, utils/training_stats.py:84; gradients are summed on GPU 0 by ReduceAddCoalesced,
+    nn/parallel/_functions.py:26-39, and the per-GPU losses were already divided by their own normalisers)."""
+    out = _run(_rcnn_rank_job)
+    (l0, d0, p0), (l1, d1, p1) = out
+    assert np.array_equal(d0, d1), "replicas diverged"
+    for k in p0:
+        assert np.array_equal(p0[k], p1[k]), k
+    assert l0 != l1, "the ranks were meant to see different images"
+    # one process, both shards, gradients averaged by hand
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_backend
+    from detectron_pytorch_amd.rcnn import train as rtrain
+    from detectron_pytorch_amd.rcnn.model import total_loss
+
+    threads = torch.get_num_threads()
+    try:
+        cfg, net, shards = _rcnn_setup()
+        opt = rtrain.make_optimizer(net, cfg, lr=2e-3)
+        params = [p for p in net.parameters() if p.requires_grad]
+        seen = []
+        with cpu_backend.cpu_ops(net):
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                grads, step_losses = None, []
+                for s in shards:
+                    for p in params:
+                        p.grad = None
+                    ret = net(s["data"], s["im_info"], roidb=s["roidb"], rpn_targets=s["rpn_t"], priority=s["priority"])
+                    loss = total_loss(ret)
+                    loss.backward()
+                    step_losses.append(float(loss.detach()))
+                    g = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+                    grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+                for p, g in zip(params, grads):
+                    p.grad = g / 2
+                opt.step()
+                seen.append(step_losses)
+        digest = torch.cat([p.detach().reshape(-1)[:64] for p in params]).numpy()
+        named = dict(net.named_parameters())
+    finally:
+        torch.set_num_threads(threads)
+    assert [s[0] for s in seen] == l0 and [s[1] for s in seen] == l1, "per-rank losses differ from the shard losses"
+    assert np.array_equal(digest, d0), "the replicas do not equal the sharded single-process step"
+    for k in p0:
+        assert np.array_equal(named[k].detach().numpy(), p0[k]), k
