@@ -111,6 +111,89 @@ def box_results_static(scores, boxes, score_thresh=0.05, nms_thresh=0.5, detecti
     return {"dets": dets, "cls": cls, "sizes": sizes, "count": sizes[0], "total": sizes[1], "class_counts": sizes[2:]}
 
 
+def box_results_static_general(scores, boxes, score_thresh=0.05, nms_thresh=0.5, detections_per_im=100, roi_valid=None,
+                               soft_nms=False, soft_nms_sigma=0.5, soft_nms_method="linear", bbox_vote=False,
+                               bbox_vote_thresh=0.8, bbox_vote_method="ID"):
+    """core/test.py:732-790 with Soft-NMS (:753-760) and / or bounding-box voting (:766-773), shapes fixed by the inputs'
+    shapes and NO host synchronisation -- `box_results_static` for the two options that re-score or move rows.  Same result
+    dict; the rows of a class come in the reference's order (hard NMS: RoI-ascending; Soft-NMS: its pick order).
+
+    How the variable sizes stay on the device: the (class, RoI) pairs above the score threshold are compacted class-major
+    into a buffer of nseg * R rows by a prefix sum and one index_copy (rows that are no candidates land in a dump row);
+    the class offsets are a device vector, which is all `mi_soft_nms_segmented` and `mi_box_voting` need.  Voting runs over
+    EVERY buffer row with the rows that did not survive NMS pointed at an empty segment (they leave at once); the
+    detections_per_im cut is a top-k of fixed size and a second prefix-sum compaction into the result rows."""
+    r, c = scores.shape
+    nseg = c - 1
+    device = scores.device
+    if r > 4096:
+        raise NotImplementedError("the static Soft-NMS / voting path holds one class in one workgroup: at most 4096 RoIs")
+    if roi_valid is not None:
+        scores = torch.where(roi_valid.view(r, 1), scores, torch.full_like(scores, float("-inf")))
+    scores, boxes = scores.contiguous(), boxes.contiguous()
+    m = nseg * r
+    valid = (scores[:, 1:] > score_thresh).t().contiguous()                   # [nseg, R], class-major
+    vflat = valid.view(m)
+    pos = torch.cumsum(vflat, 0) - 1
+    idx = torch.where(vflat, pos, torch.full_like(pos, m))                    # candidates -> their rank; the rest -> dump row
+    counts = valid.sum(dim=1, dtype=torch.int32)
+    offsets = torch.zeros(nseg + 2, dtype=torch.int32, device=device)         # + one empty segment behind the classes
+    offsets[1:nseg + 1] = torch.cumsum(counts, 0)
+    offsets[nseg + 1] = offsets[nseg]
+    cls_of = torch.arange(nseg, device=device).view(-1, 1).expand(nseg, r).reshape(m)
+    pairs = torch.cat([boxes.view(r, c, 4)[:, 1:, :].permute(1, 0, 2).reshape(m, 4), scores[:, 1:].t().reshape(m, 1)], dim=1)
+    cand = torch.zeros((m + 1, 5), dtype=torch.float32, device=device).index_copy_(0, idx, pairs)
+    seg = torch.full((m + 1,), nseg, dtype=torch.int64, device=device).index_copy_(0, idx, cls_of)
+    seg[m] = nseg                                                             # (the dump row took arbitrary writes)
+    seg_m = seg[:m]
+    lib, stream = _lib.lib(), _lib.current_stream_handle(device)
+    if soft_nms:
+        if soft_nms_method not in SOFT_NMS_METHODS:
+            raise AssertionError("Unknown soft_nms method: {}".format(soft_nms_method))
+        rows = torch.zeros((m + 1, 5), dtype=torch.float32, device=device)
+        out_inds = torch.empty((m + 1,), dtype=torch.int64, device=device)
+        num_out = torch.zeros((nseg + 1,), dtype=torch.int32, device=device)  # + the empty segment: 0
+        with torch.cuda.device(device):
+            rc = lib.mi_soft_nms_segmented(cand.data_ptr(), offsets.data_ptr(), nseg, r, float(soft_nms_sigma),
+                                           float(nms_thresh), 0.0001, SOFT_NMS_METHODS[soft_nms_method], rows.data_ptr(),
+                                           out_inds.data_ptr(), num_out.data_ptr(), stream)
+        _lib.check(rc, "mi_soft_nms_segmented")
+        slot = torch.arange(m, device=device) - offsets[:-1].long()[seg_m]
+        kept = slot < num_out.long()[seg_m]                                   # each class's result is a prefix of its segment
+        rows = rows[:m]
+    else:
+        from .nms import nms_segmented
+        _, _, masked = nms_segmented(scores, boxes, score_thresh, nms_thresh, with_masked_scores=True)
+        kept_pairs = masked.view(m) > float("-inf")                           # (class, RoI) layout -> compacted layout
+        kept = torch.zeros((m + 1,), dtype=torch.bool, device=device).index_copy_(0, idx, kept_pairs & vflat)[:m]
+        rows = cand[:m]
+    if bbox_vote:
+        voted = box_voting(rows, cand[:m], bbox_vote_thresh, bbox_vote_method,
+                           top_segments=torch.where(kept, seg_m, torch.full_like(seg_m, nseg)), all_offsets=offsets)
+        rows = torch.where(kept.view(m, 1), voted, rows)
+    # limit to detections_per_im over all classes (:776-785): image_thresh = the D-th largest kept score, ties stay
+    d = detections_per_im if detections_per_im > 0 else m
+    cap = min(m, d + TIE_SLACK)
+    sel = kept
+    if d < m:
+        masked_final = torch.where(kept, rows[:, 4], torch.full_like(rows[:, 4], float("-inf")))
+        sel = kept & (rows[:, 4] >= torch.topk(masked_final, d).values[-1])
+    total = sel.sum()
+    outpos = torch.cumsum(sel, 0) - 1
+    deliver = sel & (outpos < cap)
+    oidx = torch.where(deliver, outpos, torch.full_like(outpos, cap))
+    dets = torch.zeros((cap + 1, 5), dtype=torch.float32, device=device).index_copy_(0, oidx, rows)[:cap]
+    cls = torch.zeros((cap + 1,), dtype=torch.int32, device=device).index_copy_(0, oidx, (seg_m + 1).to(torch.int32))[:cap]
+    count = torch.clamp_max(total, cap)
+    live = torch.arange(cap, device=device) < count                           # (the dump row's writes never reach [:cap], but
+    dets = torch.where(live.view(cap, 1), dets, torch.zeros_like(dets))       # rows past `count` must read as unused)
+    cls = torch.where(live, cls, torch.zeros_like(cls))
+    class_counts = torch.zeros((nseg + 1,), dtype=torch.int64, device=device)
+    class_counts.index_add_(0, torch.where(deliver, seg_m, torch.full_like(seg_m, nseg)), torch.ones_like(seg_m))
+    sizes = torch.cat([count.view(1), total.view(1), class_counts[:nseg]])
+    return {"dets": dets, "cls": cls, "sizes": sizes, "count": sizes[0], "total": sizes[1], "class_counts": sizes[2:]}
+
+
 def _box_results_static_torch(scores, boxes, score_thresh, nms_thresh, detections_per_im):
     """`box_results_static` for results beyond one workgroup's reach (no detections_per_im limit: up to R * (C - 1)
     rows): the cut and the gather as tensor expressions, same outputs."""

@@ -193,18 +193,21 @@ RLE_CAPACITY, RLE_STRING_CAPACITY = 1024, 4096      # per mask, static path (a n
 @torch.no_grad()
 def im_detect_all_static(model, data, im_info, autocast_dtype=None, mask_im_shape=None):
     """`im_detect_all` as one asynchronous sequence of fixed shapes: image blob and `im_info` ([1,3] float32) are device
-    tensors, nothing is read back.  Returns detection.box_results_static's dict (hard NMS only).
+    tensors, nothing is read back.  Returns detection.box_results_static's dict (TEST.SOFT_NMS / TEST.BBOX_VOTE:
+    detection.box_results_static_general's, same layout).
     `mask_im_shape` = (height, width) of the original image: the mask branch runs too (model with MODEL.MASK_ON) -- the
     fixed-size detection rows go through the mask head (unused rows carry image index -1 and pool zeros) and
     `mi_mask_paste_rle`; the dict gains 'rle_counts', 'rle_sizes', 'rle_strings' (results.mask_rle_static)."""
     cfg = model.cfg
-    if cfg.TEST.SOFT_NMS.ENABLED:
-        raise NotImplementedError("the static detection path runs hard NMS (Soft-NMS compacts its candidates first)")
-    if cfg.TEST.BBOX_VOTE.ENABLED:
-        raise NotImplementedError("the static detection path has no bounding-box voting (im_detect_all does it)")
     scores, boxes, blob_conv, valid = im_detect_bbox(model, data, im_info, None, autocast_dtype, static=True)
     t = cfg.TEST
-    res = detection.box_results_static(scores, boxes, t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, roi_valid=valid)
+    if t.SOFT_NMS.ENABLED or t.BBOX_VOTE.ENABLED:     # core/test.py:753-773, still without a host round trip
+        res = detection.box_results_static_general(
+            scores, boxes, t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, roi_valid=valid, soft_nms=t.SOFT_NMS.ENABLED,
+            soft_nms_sigma=t.SOFT_NMS.SIGMA, soft_nms_method=t.SOFT_NMS.METHOD, bbox_vote=t.BBOX_VOTE.ENABLED,
+            bbox_vote_thresh=t.BBOX_VOTE.VOTE_TH, bbox_vote_method=t.BBOX_VOTE.SCORING_METHOD)
+    else:
+        res = detection.box_results_static(scores, boxes, t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, roi_valid=valid)
     if mask_im_shape is not None:
         m = cfg.MRCNN.RESOLUTION
         det_boxes, cls = res["dets"][:, :4], res["cls"].long()

@@ -499,6 +499,21 @@ def test_detection_static_path_and_hipgraph_equal_the_dynamic_path(nets):
         cfg.TEST.SCORE_THRESH = saved
 
 
+@pytest.mark.parametrize("soft,vote", [(True, False), (False, True), (True, True)])
+def test_detection_hipgraph_with_soft_nms_and_voting(nets, soft, vote):
+    """TEST.SOFT_NMS / TEST.BBOX_VOTE inside the static path and its hipGraph (core/test.py:753-773 without a host round trip)."""
+    from detectron_pytorch_amd.rcnn import inference
+
+    _, gpu, cfg = nets
+    gpu.eval()
+    saved = (cfg.TEST.SCORE_THRESH, cfg.TEST.SOFT_NMS.ENABLED, cfg.TEST.BBOX_VOTE.ENABLED)
+    cfg.TEST.SCORE_THRESH, cfg.TEST.SOFT_NMS.ENABLED, cfg.TEST.BBOX_VOTE.ENABLED = 0.012, soft, vote
+    try:
+        _check_static_detection(gpu, cfg, inference)
+    finally:
+        cfg.TEST.SCORE_THRESH, cfg.TEST.SOFT_NMS.ENABLED, cfg.TEST.BBOX_VOTE.ENABLED = saved
+
+
 def _check_static_detection(gpu, cfg, inference):
     graph, seen = None, 0
     for seed, scale in ((2, 1.0), (5, 1.0), (7, 0.5)):

@@ -855,6 +855,41 @@ def test_detection_static_result_and_tie_overflow(oracle_mod):
     assert len(want[0]) == 207 and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
+@pytest.mark.parametrize("soft,method,vote,vote_method", [(True, "linear", False, "ID"), (True, "gaussian", False, "ID"),
+                                                          (False, "linear", True, "ID"), (False, "linear", True, "IOU_AVG"),
+                                                          (True, "linear", True, "TEMP_AVG"), (True, "hard", True, "QUASI_SUM")])
+def test_detection_static_path_with_soft_nms_and_voting_equals_the_dynamic_path(soft, method, vote, vote_method):
+    """box_results_static_general (TEST.SOFT_NMS / TEST.BBOX_VOTE without a host round trip: what DetectionGraph captures)
+    delivers the rows of box_results_with_nms_and_limit -- itself pinned against the reference's function by the goldens
+    above -- bit for bit, padding rows of a static RoI blob included; with and without the detections_per_im cut."""
+    from detectron_pytorch_amd import detection
+
+    scores, boxes = syn.detection_head_outputs(600, 81, seed=12)
+    valid = np.ones(600, bool)
+    valid[520:] = False
+    for dets_per_im in (100, 0, 7):
+        kw = dict(score_thresh=0.05, nms_thresh=0.5, detections_per_im=dets_per_im, soft_nms=soft, soft_nms_method=method,
+                  bbox_vote=vote, bbox_vote_thresh=0.7, bbox_vote_method=vote_method)
+        ws, wb, wcls = detection.box_results_with_nms_and_limit(to_dev(scores[:520]), to_dev(boxes[:520]), **kw)
+        res = detection.box_results_static_general(to_dev(scores), to_dev(boxes), roi_valid=to_dev(valid), **kw)
+        count, total = int(res["count"]), int(res["total"])
+        assert total == ws.numel(), (dets_per_im, total, ws.numel())
+        cap = res["dets"].size(0)
+        assert count == min(total, cap)
+        want = torch.cat([ws.view(-1, 1)[:0].expand(0, 5)] + [c for c in wcls[1:] if len(c)]) if total else torch.zeros((0, 5))
+        assert torch.equal(res["dets"][:count].cpu(), want[:count].cpu()), dets_per_im
+        if total <= cap:
+            assert torch.equal(res["class_counts"].cpu(), torch.tensor([len(c) for c in wcls[1:]]))
+            assert torch.equal(res["cls"][:count].cpu().long(),
+                               torch.cat([torch.full((len(c),), j + 1, dtype=torch.long) for j, c in enumerate(wcls[1:])]))
+        assert not bool(res["cls"][count:].any()) and float(res["dets"][count:].abs().sum()) == 0
+        out = detection._results_from_static(res, False)
+        if total <= cap:
+            assert torch.equal(out[0], ws) and torch.equal(out[1], wb)
+        else:
+            assert out is None                                   # the caller then takes the dynamic path
+
+
 def test_soft_nms_segmented_matches_single_calls(oracle_mod):
     from detectron_pytorch_amd import _lib
 
