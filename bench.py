@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="headline only (no roofline / breakdown / inference objects)")
     ap.add_argument("--kernel-iters", type=int, default=200, help="back-to-back launches per roofline timing")
     ap.add_argument("--only-roofline", action="store_true", help="tuning aid: print only the roofline object")
+    ap.add_argument("--only-config5", action="store_true",
+                    help="profiling aid: run only the config-5 (X-101-64x4d-FPN + keypoint head) step and print its object")
     ap.add_argument("--child-inference-graph", nargs="?", const="box", default=None, choices=["box", "mask"],
                     help="internal: measure the hipGraph form of the config-3 detection in this (child) process and print "
                          "one JSON object -- a failed capture must not take the parent's bench line with it")
@@ -684,6 +686,9 @@ def main():
     if args.only_roofline:
         print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("MI_")},
                           "roofline": hp.roofline_roi_align_forward(device, args.kernel_iters)}), flush=True)
+        return
+    if args.only_config5:
+        print(json.dumps({"config5_x101_mask_keypoint": config5(device, rank, args, steps=args.steps)}), flush=True)
         return
     work = TrainHarness(device, rank, world, args.dtype, args.launch, layout=args.layout)
     if args.launch == "graph":

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mi_keypoint_decode": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "mi_dbg_roi_align_timeline": (None, [_c_void_p]),
     "mi_dbg_reload_tuning": (None, []),
+    "mi_dbg_copy_float4": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_void_p]),
 }
 
 

@@ -62,6 +62,36 @@ void reload_tuning() {
 }
 }  // namespace mi
 
+// Measurement aid, not part of include/mi_detectron_ops.h: the streaming ceiling of the box the roofline fractions are also
+// quoted against (bench.py: roofline.copy_ceiling) -- a grid-stride copy with 16 bytes per lane and four independent
+// loads in flight per lane, the form /opt/skills/guides/MI355X_MICROARCH.md measures at ~6.3 TB/s (read + write bytes).
+namespace {
+__global__ void __launch_bounds__(256) copy_float4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+}  // namespace
+extern "C" int mi_dbg_copy_float4(const void* src, void* dst, size_t bytes, mi_stream_t stream) {
+  mi::begin_call();
+  if (bytes == 0) return MI_OK;
+  MI_REQUIRE(src != nullptr && dst != nullptr && bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+             "mi_dbg_copy_float4: 16-byte aligned buffers of a multiple of 16 bytes");
+  const size_t n4 = bytes / 16;
+  const size_t want = (n4 + 256 * 4 - 1) / (256 * 4);
+  copy_float4<<<(unsigned)(want < 256 * 32 ? (want ? want : 1) : 256 * 32), 256, 0, mi::as_stream(stream)>>>(
+      static_cast<const float4*>(src), static_cast<float4*>(dst), n4);
+  return mi::check_launch("copy_float4");
+}
+
 // Test / tuning aid, not part of include/mi_detectron_ops.h: re-read the MI_ROI_ALIGN_* environment into the tuning
 // struct.  The only writer of that struct after its one-time initialisation; call it with no launch in flight on any
 // thread (the tests do, between cases).

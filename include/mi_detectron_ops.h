@@ -406,12 +406,16 @@ int mi_keypoint_nms_oks(const float* xy_preds, const float* rois, int num_rois, 
 
 /* ---- diagnostics (no reference counterpart) ---------------------------------------------------
  * Tuning aid used by tools/timeline.py: while a non-NULL device buffer of 8 int64 per forward workgroup is set,
- * the self-contained RoIAlign forward kernel stamps s_memtime at its phase boundaries into it. */
+ * the RoIAlign forward kernels stamp the shader clock at their phase boundaries into it (layout per kernel: see the tools). */
 void mi_dbg_roi_align_timeline(long long* device_buffer);
 /* The MI_ROI_ALIGN_* tuning variables (csrc/common.h) are read from the environment ONCE, at the first RoIAlign call, and
  * never on the launch path.  Tests and tuning scripts that change them inside a process make the change visible with this
  * call -- the only writer of that state; call it with no RoIAlign launch in flight on any thread. */
 void mi_dbg_reload_tuning(void);
+/* Measurement aid of bench.py (roofline.copy_ceiling): a plain streaming copy of `bytes` (a multiple of 16; both buffers
+ * 16-byte aligned) with 16 bytes per lane and four loads in flight per lane -- the box's own ceiling the RoIAlign
+ * roofline fractions are also quoted against. */
+int mi_dbg_copy_float4(const void* src, void* dst, size_t bytes, mi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -207,10 +207,12 @@ def roofline_roi_align_forward(device, iters):
                                                 scale, sr, max(iters // 2, 20))
     if layout == _lib.LAYOUT_NCHW and not os.environ.get("MI_ROI_ALIGN_IMPL"):
         info["tile_centric"] = tile_centric_variant(device, lib, stream, feat, rois, out, alg_bytes, iters)
-    copy_gbs = copy_ceiling(device)
+    copy_gbs, torch_gbs = copy_ceiling(device)
     info["copy_ceiling"] = {"measured": round(copy_gbs, 1), "unit": "GB/s", "frac_of_copy": round(achieved / copy_gbs, 4),
                             "ceiling_frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 3),
-                            "what": "torch device-to-device copy of 256 MiB, read + write bytes / time"}
+                            "torch_d2d_copy": round(torch_gbs, 1),
+                            "what": "mi_dbg_copy_float4 (16 B / lane, 4 loads in flight) over 256 MiB, read + write bytes / "
+                                    "time; torch_d2d_copy: the same buffers through torch's copy_ (rounds 1-3 quoted this one)"}
     return info
 
 
@@ -312,11 +314,22 @@ def cold_cache_variant(device, lib, stream, feat, rois, ws, ws_bytes, alg_bytes,
 
 
 def copy_ceiling(device):
-    """The box's own streaming ceiling (SURVEY.md section 8d asks for both denominators): a plain device copy."""
+    """The box's own streaming ceiling (SURVEY.md section 8d asks for both denominators): the library's float4 copy kernel
+    (mi_dbg_copy_float4: 16 bytes per lane, four loads in flight; read + write bytes of a 256 MiB buffer) and, beside it,
+    what torch's device-to-device copy reaches (the denominator of rounds 1-3, ~14 % lower)."""
+    from detectron_pytorch_amd import _lib
+
     a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=device)
     b = torch.empty_like(a)
-    sec = time_kernel(lambda: b.copy_(a), 20)
-    return 2 * a.numel() * 4 / sec / 1e9
+    lib, stream = _lib.lib(), _lib.current_stream_handle(device)
+    nbytes = a.numel() * 4
+
+    def launch():
+        assert lib.mi_dbg_copy_float4(a.data_ptr(), b.data_ptr(), nbytes, stream) == 0
+
+    sec = time_kernel(launch, 20)
+    sec_torch = time_kernel(lambda: b.copy_(a), 20)
+    return 2 * nbytes / sec / 1e9, 2 * nbytes / sec_torch / 1e9
 
 
 def other_shapes(device, lib, stream, iters):
