@@ -27,10 +27,8 @@ Tuning read_tuning() {
   Tuning t = {};
   const char* impl = std::getenv("MI_ROI_ALIGN_IMPL");
   t.force_direct = impl != nullptr && std::strcmp(impl, "direct") == 0;
-  t.use_tiles = impl != nullptr && std::strcmp(impl, "tiles") == 0;
   t.use_pipe = impl != nullptr && std::strcmp(impl, "pipe") == 0;
   t.no_ws = std::getenv("MI_ROI_ALIGN_NO_WS") != nullptr;
-  t.tiles_no_stream = std::getenv("MI_ROI_ALIGN_TILES_NO_STREAM") != nullptr;
   t.cap_px = env_int("MI_ROI_ALIGN_CAP", 336);
   const int th = env_int("MI_ROI_ALIGN_BWD_TH", 16);
   t.bwd_tile_rows = (th == 8 || th == 32) ? th : 16;

@@ -50,19 +50,16 @@ inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
 // getenv or writes process-wide state, so concurrent calls from several host threads (the reference's thread-per-GPU
 // convention, nn/parallel/parallel_apply.py:41-59) see one consistent configuration.
 //   MI_ROI_ALIGN_IMPL=direct   generic one-lane-per-output kernels only (tests of the generic path, A/B baselines)
-//   MI_ROI_ALIGN_IMPL=tiles    NCHW forward through the tile-centric kernels (roi_align_fwd_tiles.hip) instead of the
-//                              per-RoI record kernels: faster when the RoIs cover the map densely, slower otherwise
 //   MI_ROI_ALIGN_IMPL=pipe     forward (NCHW and channels-last) through the persistent pipelined kernel
 //                              (roi_align_fwd_pipe.hip) instead of one workgroup per (RoI, channel tile)
 //   MI_ROI_ALIGN_NO_WS=1       ignore the caller's workspace (no records path)
-//   MI_ROI_ALIGN_TILES_NO_STREAM=1   workspace path of the NCHW forward without the persistent kernel (A/B)
 //   MI_ROI_ALIGN_CAP=192|256|336|448|640   window pixels per channel of the NCHW forward LDS image
 //   MI_ROI_ALIGN_BWD_TH=8|16|32            rows per backward tile
 //   MI_ROI_ALIGN_BWD_SLICE=n   RoIs per list slice of the planned backward (32; 0: no plan, no atomics)
 //   MI_ROI_ALIGN_NHWC_V / _PB / _ORDER_MUL / _ZIGZAG   channels-last forward variants
 //   MI_ROI_ALIGN_ABLATE=mask   only honoured by builds with -DMI_TUNING (tools/); release kernels compile it out
 struct Tuning {
-  bool force_direct, no_ws, use_tiles, use_pipe, tiles_no_stream;
+  bool force_direct, no_ws, use_pipe;
   int cap_px, bwd_tile_rows, bwd_slice;
   int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag;
   int ablate;

@@ -238,7 +238,6 @@ int check_common(const void* a, const void* rois, const void* b, int batch, int 
 // (tools/timeline.py); nullptr switches the stamps off.
 extern "C" void mi_dbg_roi_align_timeline(long long* device_buffer) {
   mi::roi_align_fwd_tile_set_timeline(device_buffer);
-  mi::roi_align_fwd_tiles_set_timeline(device_buffer);
   mi::roi_align_fwd_nhwc_set_timeline(device_buffer);
   mi::roi_align_fwd_pipe_set_timeline(device_buffer);
 }
@@ -263,12 +262,6 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
     return mi::check_launch("roi_align_legacy_fwd");
   }
   const int cap = ring_words();
-  // NCHW, MI_ROI_ALIGN_IMPL=tiles: the tile-centric kernels (roi_align_fwd_tiles.hip), no records
-  if (layout == MI_LAYOUT_NCHW && !force_direct() && mi::tuning().use_tiles &&
-      mi::roi_align_fwd_tiles_supported(channels, height, width, aligned_height, aligned_width))  // any workspace size
-    return mi::launch_roi_align_fwd_tiles(features, rois, output, batch, channels, height, width, num_rois,
-                                          aligned_height, aligned_width, spatial_scale, sampling_ratio, workspace,
-                                          workspace_bytes, s);
   if (workspace != nullptr) {
     MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
@@ -298,7 +291,7 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
         num_rois <= 8192 &&
         mi::roi_align_fwd_nhwc_supported(channels, height, width, num_rois, aligned_height, aligned_width)) {
       rc = mi::launch_roi_align_prepare(rois, workspace, batch, height, width, num_rois, aligned_height,
-                                        aligned_width, spatial_scale, sampling_ratio, bwd_tables, s);
+                                        aligned_width, spatial_scale, sampling_ratio, bwd_tables, s, 0, channels, features);
       if (rc != MI_OK) return rc;
       return mi::launch_roi_align_fwd_nhwc(features, rois, output, workspace, batch, channels, height, width,
                                            num_rois, aligned_height, aligned_width, spatial_scale, sampling_ratio, s);
@@ -427,33 +420,6 @@ bool to_level_table(const mi_fpn_levels* in, int batch, bool forward, mi::LevelT
 }
 }  // namespace
 
-namespace {
-// NCHW maps go through the tile-centric forward, which leaves no records in the workspace
-bool fpn_forward_uses_tiles(const mi::LevelTable& lv, int channels, int aligned_height, int aligned_width, int layout) {
-  if (layout != MI_LAYOUT_NCHW || force_direct() || !mi::tuning().use_tiles) return false;
-  for (int l = 0; l < lv.count; l++)
-    if (!mi::roi_align_fwd_tiles_supported(channels, lv.height[l], lv.width[l], aligned_height, aligned_width))
-      return false;
-  return true;
-}
-}  // namespace
-
-extern "C" size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels* levels, int batch, int aligned_height,
-                                                             int aligned_width, int sampling_ratio) {
-  mi::LevelTable lv;
-  if (batch <= 0 || aligned_height <= 0 || aligned_width <= 0 || levels == nullptr || levels->num_levels < 1 ||
-      levels->num_levels > mi::kMaxLevels || !mi::tuning().use_tiles)
-    return 0;
-  lv = {};
-  lv.count = levels->num_levels;
-  for (int l = 0; l < lv.count; l++) {
-    if (levels->height[l] <= 0 || levels->width[l] <= 0) return 0;
-    lv.height[l] = levels->height[l];
-    lv.width[l] = levels->width[l];
-  }
-  return mi::roi_align_fwd_tiles_workspace_bytes(lv, batch, aligned_height, aligned_width, sampling_ratio);
-}
-
 extern "C" size_t mi_roi_align_backward_workspace_bytes(const mi_fpn_levels* levels, int batch, int num_rois) {
   if (levels == nullptr || levels->num_levels < 1 || levels->num_levels > mi::kMaxLevels || num_rois <= 0 || batch <= 0)
     return mi::roi_align_records_workspace_bytes(num_rois);
@@ -465,14 +431,6 @@ extern "C" size_t mi_roi_align_backward_workspace_bytes(const mi_fpn_levels* lev
     lv.width[l] = levels->width[l];
   }
   return mi::roi_align_bwd_workspace_bytes(lv, batch, num_rois);
-}
-
-extern "C" int mi_roi_align_forward_fpn_writes_records(const mi_fpn_levels* levels, int channels, int num_rois,
-                                                       int aligned_height, int aligned_width, int layout) {
-  mi::LevelTable lv;
-  if (!to_level_table(levels, 1, true, &lv)) return 0;
-  if (mi_roi_align_fpn_supported(levels, channels, num_rois, aligned_height, aligned_width, layout) != 1) return 0;
-  return fpn_forward_uses_tiles(lv, channels, aligned_height, aligned_width, layout) ? 0 : 1;
 }
 
 extern "C" int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
@@ -506,10 +464,6 @@ extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float
              "roi_align_fpn: shapes not served by the fused path (mi_roi_align_fpn_supported() == 0)");
   MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align_fpn: workspace must be 16-byte aligned");
   const int cap = ring_words();
-  if (fpn_forward_uses_tiles(lv, channels, aligned_height, aligned_width, layout))  // any workspace size, also none
-    return mi::launch_roi_align_fwd_tiles_levels(lv, rois, roi_levels, output, batch, channels, num_rois,
-                                                 aligned_height, aligned_width, sampling_ratio, workspace,
-                                                 workspace_bytes, mi::as_stream(stream));
   MI_REQUIRE(workspace != nullptr, "roi_align_fpn: null pointer");
   MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
              "roi_align_fpn: workspace of %zu bytes, %zu needed", workspace_bytes,
@@ -532,7 +486,7 @@ extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float
   }
   if (layout == MI_LAYOUT_NHWC) {
     int rc = mi::launch_roi_align_prepare_levels(lv, rois, roi_levels, workspace, batch, num_rois, aligned_height,
-                                                 aligned_width, sampling_ratio, bwd_tables, mi::as_stream(stream));
+                                                 aligned_width, sampling_ratio, bwd_tables, mi::as_stream(stream), 0, channels);
     if (rc != MI_OK) return rc;
     return mi::launch_roi_align_fwd_nhwc_levels(lv, rois, output, workspace, batch, channels, num_rois, aligned_height,
                                                 aligned_width, sampling_ratio, mi::as_stream(stream));
@@ -579,9 +533,6 @@ extern "C" int mi_roi_align_forward_writes_records(int channels, int height, int
                                                    int aligned_height, int aligned_width, int variant, int layout) {
   if (variant != MI_ROI_ALIGN_CAFFE2 || force_direct() || no_ws() || num_rois <= 0)
     return 0;
-  if (layout == MI_LAYOUT_NCHW && mi::tuning().use_tiles &&
-      mi::roi_align_fwd_tiles_supported(channels, height, width, aligned_height, aligned_width))
-    return 0;  // the tile-centric forward needs no records; the backward writes its own
   if (layout == MI_LAYOUT_NCHW)
     return mi::roi_align_fwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width) ? 1 : 0;
   if (layout == MI_LAYOUT_NHWC)

@@ -111,20 +111,6 @@ int launch_roi_align_fwd_tile(const float* features, const float* rois, float* o
                               int height, int width, int num_rois, int aligned_height, int aligned_width,
                               float spatial_scale, int sampling_ratio, int ring_words, hipStream_t stream);
 void roi_align_fwd_tile_set_timeline(long long* device_buffer);
-// tile-centric forward, one launch, no scratch (roi_align_fwd_tiles.hip)
-void roi_align_fwd_tiles_set_timeline(long long* device_buffer);
-bool roi_align_fwd_tiles_supported(int channels, int height, int width, int aligned_height, int aligned_width);
-// workspace (roi_align_fwd_tiles_workspace_bytes, 16-byte aligned): per-tile descriptors built once by a pre-kernel;
-// nullptr or too small: one launch, every workgroup builds the tables of its tile itself
-size_t roi_align_fwd_tiles_workspace_bytes(LevelTable lv, int batch, int aligned_height, int aligned_width,
-                                           int sampling_ratio);
-int launch_roi_align_fwd_tiles(const float* features, const float* rois, float* output, int batch, int channels,
-                               int height, int width, int num_rois, int aligned_height, int aligned_width,
-                               float spatial_scale, int sampling_ratio, void* workspace, size_t workspace_bytes,
-                               hipStream_t stream);
-int launch_roi_align_fwd_tiles_levels(LevelTable lv, const float* rois, const int* levels, float* output, int batch,
-                                      int channels, int num_rois, int aligned_height, int aligned_width,
-                                      int sampling_ratio, void* workspace, size_t workspace_bytes, hipStream_t stream);
 // two-launch forward fast path with caller scratch (roi_align_records.hip)
 size_t roi_align_records_workspace_bytes(int num_rois);
 bool roi_align_fwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,

@@ -274,8 +274,8 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
   int nstages = 0;
   if (fast) {
     const int half = stage_px;
-    // the pipelined forward lays a window row out on a pitch of whole 16-byte groups (its DMA moves 4 pixels per lane)
-    const int wwp = chunks > 0 ? (ww + 3) & ~3 : ww;
+    // the NCHW forward kernels lay a window row out on a pitch of whole 16-byte groups (their DMA moves 4 pixels per lane)
+    const int wwp = (ww + 3) & ~3;
     int ph0 = 0;
     while (ph0 < aligned_height) {
       const int row0 = __builtin_amdgcn_readlane(ylo, ph0 * gh);
@@ -405,12 +405,15 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
   const float* img_c = s.img + cl * kPlane;
   const int* __restrict__ records = ws + kCounterDwords;
   const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)pos * kRecDwords);
-  const int flags = rec[0], batch_ind = rec[1], wx0 = rec[2], ww = rec[3], magic = rec[4], nstages = rec[5];
+  const int flags = rec[0], wx0 = rec[2], ww = rec[3], nstages = rec[5];
   const int rgh = rec[6], rgw = rec[7], r = rec[8], lvl = rec[11];
+  // address of channel 0 of the RoI's image, size of its map, the two division constants of the window pitch (the record
+  // carries them: no indexed walk of the level table between the record and the first DMA)
+  const uintptr_t img_base = ((uintptr_t)(unsigned)rec[17] << 32) | (unsigned)rec[16];
+  const int rec_h = rec[18], rec_w = rec[19];
+  const unsigned gmagic = (unsigned)rec[20], pmagic = (unsigned)rec[21];
   // the feature map of the RoI's level (one entry unless the call is an FPN-fused one)
-  const float* __restrict__ feat = lv.feat[lvl];
-  const int height = lv.height[lvl], width = lv.width[lvl];
-  const float spatial_scale = lv.scale[lvl];
+  const int height = rec_h, width = rec_w;
   const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
   float* __restrict__ dst = out + ((long long)r * channels + c0) * bins;
 
@@ -419,8 +422,8 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
       for (int i = tid; i < kCT * bins; i += kThreads) dst[i] = 0.f;
       return;
     }
-    const RoiGeom g = roi_geometry(rois + (long long)r * 5, spatial_scale, aligned_height, aligned_width, sampling_ratio);
-    const float* src = feat + ((long long)g.batch_ind * channels + c0) * height * width;
+    const RoiGeom g = roi_geometry(rois + (long long)r * 5, lv.scale[lvl], aligned_height, aligned_width, sampling_ratio);
+    const float* src = lv.feat[lvl] + ((long long)g.batch_ind * channels + c0) * height * width;
     for (int i = tid; i < kCT * bins; i += kThreads) {
       const int c = i / bins, bin = i - c * bins;
       const int ph = bin / aligned_width, pw = bin - ph * aligned_width;
@@ -446,10 +449,13 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     return;
   }
 
-  const float* src = feat + ((long long)batch_ind * channels + c0 + wave * kChPerWave) * height * width;
-  const srd_t srd = make_srd(src, (unsigned)kChPerWave * plane_bytes);
+  const srd_t srd = make_srd(reinterpret_cast<const char*>(img_base) + (size_t)(c0 + wave * kChPerWave) * plane_bytes,
+                             (unsigned)kChPerWave * plane_bytes);
   const unsigned plane0 = lds_addr_uniform(s.img + wave * kChPerWave * kPlane);
-  const int pitch = ww * 4;
+  // a window row lies in LDS on a pitch of whole 16-byte groups: the copy moves 4 pixels per lane (buffer_load_dwordx4 ...
+  // lds; neither side needs more than dword alignment) -- a quarter of the DMA instructions of a pixel-per-lane copy
+  const unsigned pitch_px = ((unsigned)ww + 3u) & ~3u;
+  const int pitch = (int)pitch_px * 4;
   const int gh = kSR > 0 ? kSR : rgh, gw = kSR > 0 ? kSR : rgw;
   const TabEntry* ty = s.tab;
   const TabEntry* tx = s.tab + kMaxS;
@@ -460,18 +466,36 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     const int ph0 = pp & 0xffff, ph1 = pp >> 16;
     if (k > 0) __syncthreads();  // image and tile are reused
     if (!(ablate & 1)) {
-      const int npx = nrows * ww;
-      for (int kk = 0; kk * 64 < npx; kk++) {
-        const unsigned p = (unsigned)(kk * 64 + lane);
-        const unsigned q = (p * (unsigned)magic) >> 20;  // p / ww
-        const unsigned col = p - q * (unsigned)ww;
-        // the window may end one row / column past the map (border samples, axis_taps): those read the last one again
-        const unsigned voff = (min((unsigned)row0 + q, (unsigned)height - 1u) * (unsigned)width +
-                               min((unsigned)wx0 + col, (unsigned)width - 1u)) * 4u;
-        if (p < (unsigned)npx) {
+      if ((unsigned)wx0 + pitch_px <= (unsigned)width && !(ablate & 32)) {
+        // lanes flattened over the window's (row, 16-byte group)
+        const unsigned gpr = pitch_px >> 2, groups = (unsigned)nrows * gpr;
+        for (int kk = 0; kk * 64 < (int)groups; kk++) {
+          const unsigned g = (unsigned)(kk * 64 + lane);
+          const unsigned q = __umul24(g, gmagic) >> 20;  // g / gpr
+          const unsigned gc = g - __umul24(q, gpr);
+          const unsigned voff = (__umul24(min((unsigned)row0 + q, (unsigned)height - 1u), (unsigned)width) + (unsigned)wx0 +
+                                 gc * 4u) * 4u;
+          if (g < groups) {
 #pragma unroll
-          for (int c = 0; c < kChPerWave; c++)
-            dma_dword(srd, plane0 + (unsigned)(c * kPlane + kk * 64) * 4u, voff, (unsigned)c * plane_bytes);
+            for (int c = 0; c < kChPerWave; c++)
+              dma_dwordx4(srd, plane0 + (unsigned)(c * kPlane + kk * 256) * 4u, voff, (unsigned)c * plane_bytes);
+          }
+        }
+      } else {
+        // a window that touches the map's right edge (its last group would run into the next row, and the column one past
+        // the map has to read the border pixel again, axis_taps): pixel by pixel on the same pitch
+        const unsigned npp = (unsigned)nrows * pitch_px;
+        for (int kk = 0; kk * 64 < (int)npp; kk++) {
+          const unsigned p = (unsigned)(kk * 64 + lane);
+          const unsigned q = __umul24(p, pmagic) >> 20;  // p / pitch
+          const unsigned col = p - __umul24(q, pitch_px);
+          const unsigned voff = (__umul24(min((unsigned)row0 + q, (unsigned)height - 1u), (unsigned)width) +
+                                 min((unsigned)wx0 + col, (unsigned)width - 1u)) * 4u;
+          if (p < npp) {
+#pragma unroll
+            for (int c = 0; c < kChPerWave; c++)
+              dma_dword(srd, plane0 + (unsigned)(c * kPlane + kk * 64) * 4u, voff, (unsigned)c * plane_bytes);
+          }
         }
       }
     }
@@ -514,9 +538,10 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
               const TabEntry ey = ty[(ph + b) * kS + iy];
               wy[b][iy][0] = ey.hw;
               wy[b][iy][1] = ey.lw;
+              const int yo = __mul24(ey.lo, pitch);
 #pragma unroll
               for (int ix = 0; ix < kS; ix++) {
-                const unsigned a = xa[ix] + (unsigned)ey.off;
+                const unsigned a = xa[ix] + (unsigned)yo;
                 lds_pair(a, v[b][iy][0][ix][0], v[b][iy][0][ix][1]);
                 lds_pair(a + (unsigned)pitch, v[b][iy][1][ix][0], v[b][iy][1][ix][1]);
               }
@@ -560,7 +585,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
             float r0s = 0.f, r1s = 0.f;
             for (int ix = 0; ix < gw; ix++) {
               const TabEntry ex = tx[pw * gw + ix];
-              const float* a = lds_at(img_c, ey.off + ex.off - base_off);
+              const float* a = lds_at(img_c, ey.lo * pitch + ex.off - base_off);
               const float* b = lds_at(a, pitch);
               r0s = __builtin_fmaf(ex.hw, a[0], r0s);
               r0s = __builtin_fmaf(ex.lw, a[1], r0s);
@@ -1168,7 +1193,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
                int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio, bool bwd_tables,
                hipStream_t stream) {
   int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio, kCap,
-                          bwd_tables, stream);
+                          bwd_tables, stream, 0, channels);
   if (rc != MI_OK) return rc;
   // the LDS images of MI_ROI_ALIGN_CAP >= 448 exceed the 64 KB a kernel may ask for without opting in
 #define MI_LAUNCH_REC(SR, A)                                                                                          \

@@ -165,6 +165,7 @@ class GradientAllReducer(object):
         hipGraph launch, no hook ran).  Returns the number of collectives."""
         if not self.active:
             return 0
+        assert not self.detect_unused, "detect_unused reads the autograd hooks' flags: incompatible with a replayed backward"
         handles = [dist.all_reduce(flat, op=self._op, group=self.group, async_op=True) for flat, _ in self.buckets]
         for h in handles:
             h.wait()
@@ -200,6 +201,11 @@ class GradientAllReducer(object):
                 flat.div_(self.world)
         if self.detect_unused:
             # every rank issues this collective: agree on the parameters that got no gradient on any rank
+            if not any(self._fired_host):
+                # no hook ran at all: the backward was replayed from a hipGraph (hooks do not run on replay) or begin_step()
+                # was skipped -- every flag would read "unused" and the whole model's gradients would be dropped silently
+                raise RuntimeError("GradientAllReducer(detect_unused=True): no gradient hook fired in this step; "
+                                   "detect_unused needs an eagerly executed backward between begin_step() and finish_step()")
             flags = torch.tensor([1.0 if f else 0.0 for f in self._fired_host], device=self.buckets[0][0].device)
             if self.world > 1:
                 dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)

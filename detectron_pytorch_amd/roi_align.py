@@ -70,11 +70,8 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
     lib = _lib.lib()
     records = variant == _lib.ROI_ALIGN_CAFFE2 and bool(lib.mi_roi_align_forward_writes_records(
         c, h, w, r, int(aligned_height), int(aligned_width), int(variant), layout))
-    # device scratch (a free-list pop of the caching allocator): per-RoI records of the channels-last path, or the per-tile
-    # descriptors with which the NCHW tile kernel does not rebuild its tables per channel group
+    # device scratch (a free-list pop of the caching allocator): the per-RoI records of the fast paths
     ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
-    if layout == _lib.LAYOUT_NCHW and variant == _lib.ROI_ALIGN_CAFFE2:
-        ws_bytes = max(ws_bytes, _tiles_workspace_bytes([(h, w)], n, aligned_height, aligned_width, sampling_ratio))
     if records and want_backward:
         ws_bytes = max(ws_bytes, _backward_workspace_bytes([(h, w)], n, r))  # a backward reuses this scratch
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=features.device)
@@ -87,18 +84,14 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
     return (output, workspace if records else None) if return_workspace else output
 
 
-def _tiles_workspace_bytes(sizes, batch, aligned_height, aligned_width, sampling_ratio):
-    """mi_roi_align_forward_tiles_workspace_bytes for maps of the given (height, width)s."""
-    t = _lib.FpnLevels()
-    t.num_levels = len(sizes)
-    for i, (h, w) in enumerate(sizes):
-        t.height[i], t.width[i] = int(h), int(w)
-    return int(_lib.lib().mi_roi_align_forward_tiles_workspace_bytes(
-        ctypes.byref(t), int(batch), int(aligned_height), int(aligned_width), int(sampling_ratio)))
-
-
 def _backward_workspace_bytes(sizes, batch, num_rois):
-    """mi_roi_align_backward_workspace_bytes for gradient maps of the given (height, width)s: records + backward plan."""
+    """mi_roi_align_backward_workspace_bytes for gradient maps of the given (height, width)s: records + backward plan.
+
+    Under `torch.use_deterministic_algorithms(True)` only the records' size is returned: the backward then runs unplanned --
+    one workgroup sums a tile's whole RoI list in sweep order, no atomics, bit-reproducible from run to run -- where the
+    planned backward adds the slices of a long list with fp32 atomics in whatever order they finish."""
+    if torch.are_deterministic_algorithms_enabled():
+        return int(_lib.lib().mi_roi_align_forward_workspace_bytes(int(num_rois)))
     t = _lib.FpnLevels()
     t.num_levels = len(sizes)
     for i, (h, w) in enumerate(sizes):
@@ -215,9 +208,7 @@ class _RoIAlignFPN(Function):
         n, c = features[0].size(0), features[0].size(1)
         r = rois.size(0)
         output = torch.empty((r, c, aligned_height, aligned_width), dtype=torch.float32, device=rois.device)
-        ws_bytes = max(lib.mi_roi_align_forward_workspace_bytes(r),
-                       _tiles_workspace_bytes([(f.size(2), f.size(3)) for f in features], n, aligned_height,
-                                              aligned_width, sampling_ratio))
+        ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
         if any(ctx.needs_input_grad[6:]):  # room for the planned backward; the forward then writes its tables too
             ws_bytes = max(ws_bytes, _backward_workspace_bytes([(f.size(2), f.size(3)) for f in features], n, r))
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=rois.device)
@@ -231,9 +222,7 @@ class _RoIAlignFPN(Function):
                                               int(sampling_ratio), layout, workspace.data_ptr(), ws_bytes,
                                               _lib.current_stream_handle(rois.device))
         _lib.check(rc, "mi_roi_align_forward_fpn")
-        # NCHW maps: the tile-centric forward leaves no records, the backward writes its own
-        ctx.records_ready = bool(lib.mi_roi_align_forward_fpn_writes_records(
-            ctypes.byref(table), c, r, int(aligned_height), int(aligned_width), layout))
+        ctx.records_ready = True   # the fused forward leaves the records of its rois in the workspace
         ctx.cfg = (int(aligned_height), int(aligned_width), int(sampling_ratio), tuple(float(s) for s in scales))
         ctx.shapes = [tuple(f.shape) for f in features]
         ctx.layout = layout

@@ -116,7 +116,8 @@ def roi_feature_transform(blobs_in, rpn_ret, blob_rois="rois", method="RoIPoolF"
             out = out.index_copy(0, idx, y)
         if out is None:  # no RoI on any level: the shape still has to be right
             c = blobs_in[0].size(1)
-            res = resolution if method != "RoICrop" or not crop_resize_with_max_pool else grid_size // 2
+            # (RoICrop samples a grid_size x grid_size grid, halved by the max-pool: _one_level's shapes)
+            res = resolution if method != "RoICrop" else (grid_size // 2 if crop_resize_with_max_pool else grid_size)
             out = blobs_in[0].new_zeros((rois.size(0), c, res, res))
         return out
     level_rois = [rpn_ret["%s_fpn%d" % (blob_rois, lvl)] for lvl in range(k_min, k_max + 1)]

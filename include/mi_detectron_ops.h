@@ -37,8 +37,10 @@ extern "C" {
 #endif
 
 /* 2: round-2/3 entry points (top-k, segmented NMS, RPN collect, affine, result formats, FPN-fused RoIAlign), RoIs of a
- * non-existent image pool zeros, opt-in tile-centric NCHW forward (roi_align_fwd_tiles, no records). */
-#define MI_ABI_VERSION 2
+ * non-existent image pool zeros.  3 (round 4): the opt-in tile-centric NCHW forward and its two entry points
+ * (mi_roi_align_forward_tiles_workspace_bytes, mi_roi_align_forward_fpn_writes_records) are gone -- measured slower on
+ * every shape but one; every fast forward now leaves its records (mi_roi_align_forward_writes_records). */
+#define MI_ABI_VERSION 3
 
 typedef void* mi_stream_t; /* hipStream_t */
 
@@ -148,13 +150,6 @@ typedef struct mi_fpn_levels {
 } mi_fpn_levels;
 int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int channels, int num_rois, int aligned_height,
                                int aligned_width, int layout);
-/* Scratch of the tile-centric NCHW forward (opt-in: MI_ROI_ALIGN_IMPL=tiles; 0 when it is not in use): with it a per-TILE
- * pre-kernel builds the tap tables of every tile once and the pooling workgroups (one per tile and 32 channels) fetch them;
- * without it every workgroup builds the tables of its tile itself (one launch).  Pass max(this,
- * mi_roi_align_forward_workspace_bytes(num_rois)) bytes to the _ws / _fpn entry points.  Only height[] / width[] /
- * num_levels of `levels` are read (one level for the single-map entries). */
-size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels* levels, int batch, int aligned_height,
-                                                  int aligned_width, int sampling_ratio);
 /* Workspace with room for the PLANNED backward (>= mi_roi_align_forward_workspace_bytes(num_rois)): behind the records a
  * pre-kernel (roi_align_bwd_plan) leaves, per 16 x 32 tile of the gradient maps, the list of RoIs that touch it, and the
  * tile kernel's workgroups each take a slice of at most MI_ROI_ALIGN_BWD_SLICE (32) RoIs of one list -- the RoIs of a
@@ -167,11 +162,6 @@ size_t mi_roi_align_forward_tiles_workspace_bytes(const mi_fpn_levels* levels, i
  * for the single-map entries).
  * Replaces: the reference's backward is atomicAdd per tap throughout (roi_align_kernel.cu:195-270). */
 size_t mi_roi_align_backward_workspace_bytes(const mi_fpn_levels* levels, int batch, int num_rois);
-/* 1 when mi_roi_align_forward_fpn with these arguments leaves the records of its rois in the workspace (channels-last
- * maps); 0 when it does not (NCHW maps: the tile-centric forward needs none) -- the backward must then be called
- * without MI_ROI_ALIGN_RECORDS_READY and writes its own. */
-int mi_roi_align_forward_fpn_writes_records(const mi_fpn_levels* levels, int channels, int num_rois,
-                                            int aligned_height, int aligned_width, int layout);
 int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels, float* output,
                              int batch, int channels, int num_rois, int aligned_height, int aligned_width,
                              int sampling_ratio, int layout, void* workspace, size_t workspace_bytes,

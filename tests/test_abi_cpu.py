@@ -128,3 +128,20 @@ def test_dropin_overlay_merges_with_the_reference_tree(tmp_path, monkeypatch):
     assert importlib.import_module("utils.cython_nms").soft_nms.__module__ == "detectron_pytorch_amd.nms"
     for name in [m for m in sys.modules if m.split(".")[0] in ("modeling", "utils", "core", "model")]:
         monkeypatch.delitem(sys.modules, name, raising=False)
+
+
+def test_deterministic_mode_asks_for_the_unplanned_backward(hip_lib_path):
+    """torch.use_deterministic_algorithms(True): the autograd Functions size their scratch for the records only, which makes
+    the backward run without list slices and their fp32 atomics (host-side sizing only: no launch here)."""
+    import torch
+
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import _backward_workspace_bytes
+
+    fwd = _lib.lib().mi_roi_align_forward_workspace_bytes(1024)
+    assert _backward_workspace_bytes([(200, 336)], 2, 1024) > fwd
+    torch.use_deterministic_algorithms(True)
+    try:
+        assert _backward_workspace_bytes([(200, 336)], 2, 1024) == fwd
+    finally:
+        torch.use_deterministic_algorithms(False)

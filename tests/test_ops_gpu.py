@@ -69,14 +69,13 @@ def tuning_env(monkeypatch):
     _lib.lib().mi_dbg_reload_tuning()
 
 
-@pytest.fixture(params=["stream", "stream_unplanned", "stream_sliced", "pipe", "tiles", "direct"])
+@pytest.fixture(params=["stream", "stream_unplanned", "stream_sliced", "pipe", "direct"])
 def roi_align_impl(request, tuning_env):
     """Run a test against the RoIAlign implementations behind mi_roi_align_*: the default fast paths ("stream": the
     record-driven forward, the planned backward with list slices of 32 RoIs; "stream_unplanned": MI_ROI_ALIGN_BWD_SLICE=0,
     one workgroup walks a tile's whole list; "stream_sliced": slices of 2 RoIs, so that nearly every tile is summed by
     several workgroups with atomics), the persistent pipelined forward over the same records (MI_ROI_ALIGN_IMPL=pipe, NCHW
-    and channels-last), the tile-centric NCHW forward (MI_ROI_ALIGN_IMPL=tiles: one launch without
-    scratch, pre-kernel + persistent kernel with it) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
+    and channels-last) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
     stream = request.param.startswith("stream")
     tuning_env(MI_ROI_ALIGN_IMPL=None if stream else request.param,
                MI_ROI_ALIGN_BWD_SLICE={"stream_unplanned": 0, "stream_sliced": 2}.get(request.param))
@@ -242,27 +241,30 @@ def test_roi_align_non_finite_border_pixels_propagate_as_in_the_reference(oracle
     assert np.abs(out[fin] - ref[fin]).max() <= FAST_ATOL
 
 
-@pytest.mark.parametrize("variant", ["one_launch", "descriptors", "descriptors_no_stream"])
+@pytest.mark.parametrize("variant", ["records", "pipe", "pipe_channels_last"])
 @pytest.mark.parametrize("case", ["adversarial", "piled", "nonfinite", "fpn", "sr0"])
-def test_roi_align_tile_kernels(oracle_mod, tuning_env, variant, case):
-    """The tile-centric NCHW forward (MI_ROI_ALIGN_IMPL=tiles) in its three forms -- every workgroup builds its own tables
-    (no scratch); per-tile pre-kernel + persistent double-buffered kernel; pre-kernel + one workgroup per (tile, channel
-    group) -- on inputs that reach every branch: RoIs the tables cannot describe (owner tile, reference-order path), a
-    tile under a pile of 300 RoIs (descriptor blocks, then in-kernel batches in RoI order), non-finite features at the
-    borders (a clamped sample reads the border pixel twice, as the reference), an FPN pyramid in one call, an adaptive
+def test_roi_align_forward_kernels_on_hard_inputs(oracle_mod, tuning_env, variant, case):
+    """The record-driven forward kernels -- one workgroup per (RoI, channel tile), and the persistent pipelined kernel
+    (MI_ROI_ALIGN_IMPL=pipe, NCHW and channels-last) -- on inputs that reach every branch: RoIs the tables cannot describe
+    (reference-order path inside the kernel) and RoIs of no image, a pile of 300 RoIs on one spot (one workgroup's run of
+    the sweep is a single box), non-finite features at the borders (a clamped sample reads the border pixel twice, as the
+    reference; windows that touch the right edge are copied pixel by pixel), an FPN pyramid in one call, an adaptive
     sampling grid (generic kernel)."""
     from detectron_pytorch_amd.roi_align import roi_align_forward, roi_align_fpn
 
-    tuning_env(MI_ROI_ALIGN_IMPL="tiles", MI_ROI_ALIGN_NO_WS="1" if variant == "one_launch" else None,
-               MI_ROI_ALIGN_TILES_NO_STREAM="1" if variant == "descriptors_no_stream" else None)
+    tuning_env(MI_ROI_ALIGN_IMPL=None if variant == "records" else "pipe")
+    nhwc = variant == "pipe_channels_last"
+
+    def to_maps(a):
+        t = to_dev(a)
+        return t.contiguous(memory_format=torch.channels_last) if nhwc else t
+
     if case == "fpn":
-        if variant == "one_launch":
-            pytest.skip("the fused FPN entry points need a workspace (records of the backward)")
         frois, flv = syn.rois_fpn_distributed(400, batch=2, seed=5)
         maps = [syn.feature_map(2, 64, syn.FPN_LEVELS[l][0], syn.FPN_LEVELS[l][1], seed=l) for l in (5, 4, 3, 2)]
         scales = [syn.FPN_LEVELS[l][2] for l in (5, 4, 3, 2)]
         idx = np.array([(5, 4, 3, 2).index(int(l)) for l in flv], dtype=np.int32)
-        out = roi_align_fpn([to_dev(m) for m in maps], scales, to_dev(frois), to_dev(idx), 7, 7, 2).cpu().numpy()
+        out = roi_align_fpn([to_maps(m) for m in maps], scales, to_dev(frois), to_dev(idx), 7, 7, 2).cpu().numpy()
         for li in range(4):
             sel = np.nonzero(idx == li)[0]
             ref = oracle_mod.roi_align_forward(maps[li], frois[sel], 7, 7, scales[li], 2, threads=8)
@@ -290,7 +292,7 @@ def test_roi_align_tile_kernels(oracle_mod, tuning_env, variant, case):
     if case == "adversarial":  # RoIs of no image (padding rows of the training path) pool zeros
         rois[5, 0], rois[6, 0] = -1.0, 7.0
         ref[5:7] = 0.0
-    out = roi_align_forward(to_dev(feat), to_dev(rois), res, res, scale, sr).cpu().numpy()
+    out = roi_align_forward(to_maps(feat), to_dev(rois), res, res, scale, sr).cpu().numpy()
     if case == "nonfinite":
         assert np.array_equal(np.isnan(out), np.isnan(ref)) and np.array_equal(np.isinf(out), np.isinf(ref))
         fin = np.isfinite(ref)
@@ -1010,6 +1012,15 @@ def test_roi_align_backward_of_clustered_rois_is_cut_into_list_slices(oracle_mod
                                             ws.data_ptr(), ws.numel(), 0, _lib.current_stream_handle(dev()))
     _lib.check(rc, "mi_roi_align_backward_ws")
     assert_close(buf, ref + 0.5, "planned bwd, accumulate")
+    # torch.use_deterministic_algorithms(True): no list slices, no atomics -- two runs agree to the last bit
+    torch.use_deterministic_algorithms(True)
+    try:
+        _, det_a = _roi_align_gpu(feat, rois, res, scale, 2, gtop, channels_last=channels_last)
+        _, det_b = _roi_align_gpu(feat, rois, res, scale, 2, gtop, channels_last=channels_last)
+    finally:
+        torch.use_deterministic_algorithms(False)
+    assert torch.equal(det_a, det_b)
+    assert_close(det_a, ref, "deterministic bwd")
     tuning_env(MI_ROI_ALIGN_BWD_SLICE=0)
     assert _backward_workspace_bytes([(h, w)], n, 600) == _lib.lib().mi_roi_align_forward_workspace_bytes(600)
     _, grad0 = _roi_align_gpu(feat, rois, res, scale, 2, gtop, channels_last=channels_last)

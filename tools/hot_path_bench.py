@@ -149,8 +149,7 @@ def roofline_roi_align_forward(device, iters):
     traffic, traffic_src = pmc_traffic("forward")
     info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": ("roi_align_prepare + roi_align_fwd_records" if ready_fwd else "roi_align_fwd_tiles")
-            + " (one mi_roi_align_forward_ws call)",
+            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
             "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
             "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
     # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
@@ -205,8 +204,6 @@ def roofline_roi_align_forward(device, iters):
     if layout == _lib.LAYOUT_NCHW:
         info["cold_cache"] = cold_cache_variant(device, lib, stream, feat, rois, ws, ws_bytes, alg_bytes, r, c, h, w, res,
                                                 scale, sr, max(iters // 2, 20))
-    if layout == _lib.LAYOUT_NCHW and not os.environ.get("MI_ROI_ALIGN_IMPL"):
-        info["tile_centric"] = tile_centric_variant(device, lib, stream, feat, rois, out, alg_bytes, iters)
     copy_gbs, torch_gbs = copy_ceiling(device)
     info["copy_ceiling"] = {"measured": round(copy_gbs, 1), "unit": "GB/s", "frac_of_copy": round(achieved / copy_gbs, 4),
                             "ceiling_frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 3),
@@ -244,47 +241,6 @@ def channels_last_variant(device, lib, stream, feat_nchw, rois, out, ws, alg_byt
     return {"kernel": "roi_align_prepare + roi_align_fwd_nhwc", "avg_launch_us": round(sec * 1e6, 2),
             "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "bwd_us": round(sec_bwd * 1e6, 2)}
-
-
-def tile_centric_variant(device, lib, stream, feat, rois, out, alg_bytes, iters):
-    """The same call through the opt-in tile-centric kernels (MI_ROI_ALIGN_IMPL=tiles, csrc/roi_align_fwd_tiles.hip): a
-    workgroup owns a feature-map tile for 32 channels instead of a RoI.  Reported beside the headline, not as it: on this
-    dense shape it is on par (and less dependent on the Infinity Cache), on sparse RoI sets it loses.  The
-    library reads its switches once; the debug entry mi_dbg_reload_tuning re-reads them for this measurement and back."""
-    import ctypes
-
-    from detectron_pytorch_amd import _lib
-
-    n, c, h, w = feat.shape
-    r, _, res, _ = out.shape
-    scale, sr = syn.FPN_LEVELS[2][2], 2
-    res_out = {}
-    try:
-        os.environ["MI_ROI_ALIGN_IMPL"] = "tiles"
-        lib.mi_dbg_reload_tuning()
-        lv = _lib.FpnLevels()
-        lv.num_levels, lv.height[0], lv.width[0] = 1, h, w
-        wsb = int(lib.mi_roi_align_forward_tiles_workspace_bytes(ctypes.byref(lv), n, res, res, sr))
-        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=device)
-
-        def one_launch():
-            assert lib.mi_roi_align_forward(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), n, c, h, w, r, res, res, scale,
-                                            sr, 0, 0, stream) == 0
-
-        def two_launches():
-            assert lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), n, c, h, w, r, res, res,
-                                               scale, sr, 0, 0, ws.data_ptr(), ws.numel(), stream) == 0
-
-        for name, fn, what in (("one_launch_no_scratch", one_launch, "roi_align_fwd_tiles"),
-                               ("descriptors_persistent", two_launches, "roi_align_tiles_prepare + roi_align_fwd_tiles_stream")):
-            sec = time_kernel(fn, iters)
-            res_out[name] = {"kernel": what, "avg_launch_us": round(sec * 1e6, 2), "achieved": round(alg_bytes / sec / 1e9, 1),
-                             "unit": "GB/s", "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4)}
-        res_out["descriptors_persistent"]["scratch_bytes"] = wsb
-    finally:
-        os.environ.pop("MI_ROI_ALIGN_IMPL", None)
-        lib.mi_dbg_reload_tuning()
-    return res_out
 
 
 def cold_cache_variant(device, lib, stream, feat, rois, ws, ws_bytes, alg_bytes, r, c, h, w, res, scale, sr, iters):

@@ -37,12 +37,6 @@ num = torch.empty(1, dtype=torch.int32, device=dev)
 wsb = lib.mi_nms_workspace_bytes(2000)
 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 fws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
-if os.environ.get("MI_BENCH_TILES_WS"):  # MI_ROI_ALIGN_IMPL=tiles with per-tile descriptors (pre-kernel + persistent kernel)
-    import ctypes
-
-    lvt = _lib.FpnLevels()
-    lvt.num_levels, lvt.height[0], lvt.width[0] = 1, h, w
-    fws_bytes = max(fws_bytes, lib.mi_roi_align_forward_tiles_workspace_bytes(ctypes.byref(lvt), 1, res, res, sr))
 if which == "roi_align_bwd" and not os.environ.get("MI_BENCH_BWD_UNPLANNED"):  # room for the backward plan
     from detectron_pytorch_amd.roi_align import _backward_workspace_bytes
 
