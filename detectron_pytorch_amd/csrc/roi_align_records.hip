@@ -274,8 +274,8 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
   int nstages = 0;
   if (fast) {
     const int half = stage_px;
-    // the NCHW forward kernels lay a window row out on a pitch of whole 16-byte groups (their DMA moves 4 pixels per lane)
-    const int wwp = (ww + 3) & ~3;
+    // the pipelined forward lays a window row out on a pitch of whole 16-byte groups (its DMA moves 4 pixels per lane)
+    const int wwp = chunks > 0 ? (ww + 3) & ~3 : ww;
     int ph0 = 0;
     while (ph0 < aligned_height) {
       const int row0 = __builtin_amdgcn_readlane(ylo, ph0 * gh);
@@ -407,11 +407,11 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
   const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)pos * kRecDwords);
   const int flags = rec[0], wx0 = rec[2], ww = rec[3], nstages = rec[5];
   const int rgh = rec[6], rgw = rec[7], r = rec[8], lvl = rec[11];
-  // address of channel 0 of the RoI's image, size of its map, the two division constants of the window pitch (the record
-  // carries them: no indexed walk of the level table between the record and the first DMA)
+  // address of channel 0 of the RoI's image and the size of its map: the record carries them, no indexed walk of the level
+  // table between the record and the first DMA
   const uintptr_t img_base = ((uintptr_t)(unsigned)rec[17] << 32) | (unsigned)rec[16];
   const int rec_h = rec[18], rec_w = rec[19];
-  const unsigned gmagic = (unsigned)rec[20], pmagic = (unsigned)rec[21];
+  const unsigned pmagic = (unsigned)rec[4];  // 2^20 / ww + 1
   // the feature map of the RoI's level (one entry unless the call is an FPN-fused one)
   const int height = rec_h, width = rec_w;
   const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
@@ -452,9 +452,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
   const srd_t srd = make_srd(reinterpret_cast<const char*>(img_base) + (size_t)(c0 + wave * kChPerWave) * plane_bytes,
                              (unsigned)kChPerWave * plane_bytes);
   const unsigned plane0 = lds_addr_uniform(s.img + wave * kChPerWave * kPlane);
-  // a window row lies in LDS on a pitch of whole 16-byte groups: the copy moves 4 pixels per lane (buffer_load_dwordx4 ...
-  // lds; neither side needs more than dword alignment) -- a quarter of the DMA instructions of a pixel-per-lane copy
-  const unsigned pitch_px = ((unsigned)ww + 3u) & ~3u;
+  const unsigned pitch_px = (unsigned)ww;
   const int pitch = (int)pitch_px * 4;
   const int gh = kSR > 0 ? kSR : rgh, gw = kSR > 0 ? kSR : rgw;
   const TabEntry* ty = s.tab;
@@ -466,36 +464,23 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     const int ph0 = pp & 0xffff, ph1 = pp >> 16;
     if (k > 0) __syncthreads();  // image and tile are reused
     if (!(ablate & 1)) {
-      if ((unsigned)wx0 + pitch_px <= (unsigned)width && !(ablate & 32)) {
-        // lanes flattened over the window's (row, 16-byte group)
-        const unsigned gpr = pitch_px >> 2, groups = (unsigned)nrows * gpr;
-        for (int kk = 0; kk * 64 < (int)groups; kk++) {
-          const unsigned g = (unsigned)(kk * 64 + lane);
-          const unsigned q = __umul24(g, gmagic) >> 20;  // g / gpr
-          const unsigned gc = g - __umul24(q, gpr);
-          const unsigned voff = (__umul24(min((unsigned)row0 + q, (unsigned)height - 1u), (unsigned)width) + (unsigned)wx0 +
-                                 gc * 4u) * 4u;
-          if (g < groups) {
+      // lanes flattened over the window's (row, column): every piece moves 64 useful pixels of one channel; the per-lane
+      // offset uses 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter).  Measured against it inside one run, per
+      // config-2 call / two-image box head: rows on a pitch of whole 16-byte groups 38.9 / 64.8 us against 38.5 / 63.6;
+      // that pitch with 4 pixels per lane (buffer_load_dwordx4 ... lds, a quarter of the DMA instructions) 38.8 / 65.2
+      // against 37.6 / 61.5.
+      const unsigned npp = (unsigned)nrows * pitch_px;
+      for (int kk = 0; kk * 64 < (int)npp; kk++) {
+        const unsigned p = (unsigned)(kk * 64 + lane);
+        const unsigned q = __umul24(p, pmagic) >> 20;  // p / pitch
+        const unsigned col = p - __umul24(q, pitch_px);
+        // the window may end one row / column past the map (border samples, axis_taps): those read the last one again
+        const unsigned voff = (__umul24(min((unsigned)row0 + q, (unsigned)height - 1u), (unsigned)width) +
+                               min((unsigned)wx0 + col, (unsigned)width - 1u)) * 4u;
+        if (p < npp) {
 #pragma unroll
-            for (int c = 0; c < kChPerWave; c++)
-              dma_dwordx4(srd, plane0 + (unsigned)(c * kPlane + kk * 256) * 4u, voff, (unsigned)c * plane_bytes);
-          }
-        }
-      } else {
-        // a window that touches the map's right edge (its last group would run into the next row, and the column one past
-        // the map has to read the border pixel again, axis_taps): pixel by pixel on the same pitch
-        const unsigned npp = (unsigned)nrows * pitch_px;
-        for (int kk = 0; kk * 64 < (int)npp; kk++) {
-          const unsigned p = (unsigned)(kk * 64 + lane);
-          const unsigned q = __umul24(p, pmagic) >> 20;  // p / pitch
-          const unsigned col = p - __umul24(q, pitch_px);
-          const unsigned voff = (__umul24(min((unsigned)row0 + q, (unsigned)height - 1u), (unsigned)width) +
-                                 min((unsigned)wx0 + col, (unsigned)width - 1u)) * 4u;
-          if (p < npp) {
-#pragma unroll
-            for (int c = 0; c < kChPerWave; c++)
-              dma_dword(srd, plane0 + (unsigned)(c * kPlane + kk * 64) * 4u, voff, (unsigned)c * plane_bytes);
-          }
+          for (int c = 0; c < kChPerWave; c++)
+            dma_dword(srd, plane0 + (unsigned)(c * kPlane + kk * 64) * 4u, voff, (unsigned)c * plane_bytes);
         }
       }
     }
@@ -538,10 +523,9 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
               const TabEntry ey = ty[(ph + b) * kS + iy];
               wy[b][iy][0] = ey.hw;
               wy[b][iy][1] = ey.lw;
-              const int yo = __mul24(ey.lo, pitch);
 #pragma unroll
               for (int ix = 0; ix < kS; ix++) {
-                const unsigned a = xa[ix] + (unsigned)yo;
+                const unsigned a = xa[ix] + (unsigned)ey.off;
                 lds_pair(a, v[b][iy][0][ix][0], v[b][iy][0][ix][1]);
                 lds_pair(a + (unsigned)pitch, v[b][iy][1][ix][0], v[b][iy][1][ix][1]);
               }
@@ -585,7 +569,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
             float r0s = 0.f, r1s = 0.f;
             for (int ix = 0; ix < gw; ix++) {
               const TabEntry ex = tx[pw * gw + ix];
-              const float* a = lds_at(img_c, ey.lo * pitch + ex.off - base_off);
+              const float* a = lds_at(img_c, ey.off + ex.off - base_off);
               const float* b = lds_at(a, pitch);
               r0s = __builtin_fmaf(ex.hw, a[0], r0s);
               r0s = __builtin_fmaf(ex.lw, a[1], r0s);
