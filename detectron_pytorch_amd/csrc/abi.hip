@@ -27,7 +27,6 @@ Tuning read_tuning() {
   Tuning t = {};
   const char* impl = std::getenv("MI_ROI_ALIGN_IMPL");
   t.force_direct = impl != nullptr && std::strcmp(impl, "direct") == 0;
-  t.use_pipe = impl != nullptr && std::strcmp(impl, "pipe") == 0;
   t.no_ws = std::getenv("MI_ROI_ALIGN_NO_WS") != nullptr;
   t.cap_px = env_int("MI_ROI_ALIGN_CAP", 336);
   const int th = env_int("MI_ROI_ALIGN_BWD_TH", 16);
@@ -61,18 +60,25 @@ void reload_tuning() {
 }  // namespace mi
 
 // Measurement aid, not part of include/mi_detectron_ops.h: the streaming ceiling of the box the roofline fractions are also
-// quoted against (bench.py: roofline.copy_ceiling) -- a grid-stride copy with 16 bytes per lane and four independent
-// loads in flight per lane, the form /opt/skills/guides/MI355X_MICROARCH.md measures at ~6.3 TB/s (read + write bytes).
+// quoted against (bench.py: roofline.copy_ceiling) -- a grid-stride copy with 16 bytes per lane, the form
+// /opt/skills/guides/MI355X_MICROARCH.md measures at ~6.3 TB/s (read + write bytes).
 namespace {
-__global__ void __launch_bounds__(256) copy_float4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <int kU, bool kNT>
+__global__ void __launch_bounds__(256) copy_float4(const v4f_t* __restrict__ src, v4f_t* __restrict__ dst, size_t n4) {
   const size_t stride = (size_t)gridDim.x * 256;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a;
-    dst[i + stride] = b;
-    dst[i + 2 * stride] = c;
-    dst[i + 3 * stride] = d;
+  for (; i + (kU - 1) * stride < n4; i += kU * stride) {
+    v4f_t v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) v[u] = kNT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      if (kNT)
+        __builtin_nontemporal_store(v[u], dst + i + u * stride);
+      else
+        dst[i + u * stride] = v[u];
+    }
   }
   for (; i < n4; i += stride) dst[i] = src[i];
 }
@@ -84,9 +90,30 @@ extern "C" int mi_dbg_copy_float4(const void* src, void* dst, size_t bytes, mi_s
                  (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
              "mi_dbg_copy_float4: 16-byte aligned buffers of a multiple of 16 bytes");
   const size_t n4 = bytes / 16;
-  const size_t want = (n4 + 256 * 4 - 1) / (256 * 4);
-  copy_float4<<<(unsigned)(want < 256 * 32 ? (want ? want : 1) : 256 * 32), 256, 0, mi::as_stream(stream)>>>(
-      static_cast<const float4*>(src), static_cast<float4*>(dst), n4);
+  // MI_COPY_VARIANT = blocks_per_cu * 100 + unroll * 10 + nontemporal (tools/copy_sweep.py).  Default: 4 workgroups per CU,
+  // one 16-byte load in flight per lane and loop trip, non-temporal loads and stores -- 6.48 TB/s on a 256 MiB buffer, the
+  // best of the sweep (2..64 workgroups per CU x unroll 1 / 4 / 8 x nt: 4.1-6.5 TB/s; torch's copy_: 5.40)
+  const char* var = std::getenv("MI_COPY_VARIANT");
+  const int v = var != nullptr ? std::atoi(var) : 411;
+  const int per_cu = v / 100 > 0 ? v / 100 : 8, unroll = (v / 10) % 10, nt = v % 10;
+  size_t blocks = (size_t)256 * per_cu;
+  const size_t want = (n4 + 255) / 256;
+  if (blocks > want) blocks = want ? want : 1;
+  const v4f_t* s4 = static_cast<const v4f_t*>(src);
+  v4f_t* d4 = static_cast<v4f_t*>(dst);
+  hipStream_t st = mi::as_stream(stream);
+  if (unroll >= 8 && nt)
+    copy_float4<8, true><<<(unsigned)blocks, 256, 0, st>>>(s4, d4, n4);
+  else if (unroll >= 8)
+    copy_float4<8, false><<<(unsigned)blocks, 256, 0, st>>>(s4, d4, n4);
+  else if (unroll >= 4 && nt)
+    copy_float4<4, true><<<(unsigned)blocks, 256, 0, st>>>(s4, d4, n4);
+  else if (unroll >= 4)
+    copy_float4<4, false><<<(unsigned)blocks, 256, 0, st>>>(s4, d4, n4);
+  else if (nt)
+    copy_float4<1, true><<<(unsigned)blocks, 256, 0, st>>>(s4, d4, n4);
+  else
+    copy_float4<1, false><<<(unsigned)blocks, 256, 0, st>>>(s4, d4, n4);
   return mi::check_launch("copy_float4");
 }
 

@@ -50,8 +50,6 @@ inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
 // getenv or writes process-wide state, so concurrent calls from several host threads (the reference's thread-per-GPU
 // convention, nn/parallel/parallel_apply.py:41-59) see one consistent configuration.
 //   MI_ROI_ALIGN_IMPL=direct   generic one-lane-per-output kernels only (tests of the generic path, A/B baselines)
-//   MI_ROI_ALIGN_IMPL=pipe     forward (NCHW and channels-last) through the persistent pipelined kernel
-//                              (roi_align_fwd_pipe.hip) instead of one workgroup per (RoI, channel tile)
 //   MI_ROI_ALIGN_NO_WS=1       ignore the caller's workspace (no records path)
 //   MI_ROI_ALIGN_CAP=192|256|336|448|640   window pixels per channel of the NCHW forward LDS image
 //   MI_ROI_ALIGN_BWD_TH=8|16|32            rows per backward tile
@@ -59,7 +57,7 @@ inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
 //   MI_ROI_ALIGN_NHWC_V / _PB / _ORDER_MUL / _ZIGZAG   channels-last forward variants
 //   MI_ROI_ALIGN_ABLATE=mask   only honoured by builds with -DMI_TUNING (tools/); release kernels compile it out
 struct Tuning {
-  bool force_direct, no_ws, use_pipe;
+  bool force_direct, no_ws;
   int cap_px, bwd_tile_rows, bwd_slice;
   int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag;
   int ablate;

@@ -239,7 +239,6 @@ int check_common(const void* a, const void* rois, const void* b, int batch, int 
 extern "C" void mi_dbg_roi_align_timeline(long long* device_buffer) {
   mi::roi_align_fwd_tile_set_timeline(device_buffer);
   mi::roi_align_fwd_nhwc_set_timeline(device_buffer);
-  mi::roi_align_fwd_pipe_set_timeline(device_buffer);
 }
 
 namespace {
@@ -271,17 +270,6 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
     const bool bwd_tables =
         workspace_bytes >= mi::roi_align_bwd_workspace_bytes(mi::single_level(nullptr, nullptr, batch, height, width,
                                                                               spatial_scale), batch, num_rois);
-    if (mi::tuning().use_pipe && !force_direct() && !no_ws() &&
-        mi::roi_align_fwd_pipe_supported(channels, height, width, num_rois, aligned_height, aligned_width,
-                                         layout == MI_LAYOUT_NHWC)) {
-      rc = mi::launch_roi_align_prepare(rois, workspace, batch, height, width, num_rois, aligned_height,
-                                        aligned_width, spatial_scale, sampling_ratio, bwd_tables, s,
-                                        mi::roi_align_fwd_pipe_chunks(channels, num_rois), channels, features);
-      if (rc != MI_OK) return rc;
-      return mi::launch_roi_align_fwd_pipe_levels(mi::single_level(features, nullptr, batch, height, width, spatial_scale),
-                                                  rois, output, workspace, batch, channels, num_rois, aligned_height,
-                                                  aligned_width, sampling_ratio, layout == MI_LAYOUT_NHWC, s);
-    }
     if (layout == MI_LAYOUT_NCHW && !force_direct() && !no_ws() &&
         mi::roi_align_fwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
       return mi::launch_roi_align_fwd_records(features, rois, output, workspace, batch, channels, height, width,
@@ -291,7 +279,7 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
         num_rois <= 8192 &&
         mi::roi_align_fwd_nhwc_supported(channels, height, width, num_rois, aligned_height, aligned_width)) {
       rc = mi::launch_roi_align_prepare(rois, workspace, batch, height, width, num_rois, aligned_height,
-                                        aligned_width, spatial_scale, sampling_ratio, bwd_tables, s, 0, channels, features);
+                                        aligned_width, spatial_scale, sampling_ratio, bwd_tables, s, channels, features);
       if (rc != MI_OK) return rc;
       return mi::launch_roi_align_fwd_nhwc(features, rois, output, workspace, batch, channels, height, width,
                                            num_rois, aligned_height, aligned_width, spatial_scale, sampling_ratio, s);
@@ -469,24 +457,9 @@ extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float
              "roi_align_fpn: workspace of %zu bytes, %zu needed", workspace_bytes,
              mi::roi_align_records_workspace_bytes(num_rois));
   const bool bwd_tables = workspace_bytes >= mi::roi_align_bwd_workspace_bytes(lv, batch, num_rois);
-  if (mi::tuning().use_pipe) {
-    bool ok = true;
-    for (int l = 0; l < lv.count; l++)
-      ok = ok && mi::roi_align_fwd_pipe_supported(channels, lv.height[l], lv.width[l], num_rois, aligned_height,
-                                                  aligned_width, layout == MI_LAYOUT_NHWC);
-    if (ok) {
-      int rc = mi::launch_roi_align_prepare_levels(lv, rois, roi_levels, workspace, batch, num_rois, aligned_height,
-                                                   aligned_width, sampling_ratio, bwd_tables, mi::as_stream(stream),
-                                                   mi::roi_align_fwd_pipe_chunks(channels, num_rois), channels);
-      if (rc != MI_OK) return rc;
-      return mi::launch_roi_align_fwd_pipe_levels(lv, rois, output, workspace, batch, channels, num_rois, aligned_height,
-                                                  aligned_width, sampling_ratio, layout == MI_LAYOUT_NHWC,
-                                                  mi::as_stream(stream));
-    }
-  }
   if (layout == MI_LAYOUT_NHWC) {
     int rc = mi::launch_roi_align_prepare_levels(lv, rois, roi_levels, workspace, batch, num_rois, aligned_height,
-                                                 aligned_width, sampling_ratio, bwd_tables, mi::as_stream(stream), 0, channels);
+                                                 aligned_width, sampling_ratio, bwd_tables, mi::as_stream(stream), channels);
     if (rc != MI_OK) return rc;
     return mi::launch_roi_align_fwd_nhwc_levels(lv, rois, output, workspace, batch, channels, num_rois, aligned_height,
                                                 aligned_width, sampling_ratio, mi::as_stream(stream));

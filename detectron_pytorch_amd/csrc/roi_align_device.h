@@ -144,8 +144,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
 // bwd_tables: also write the record's backward block (merged pass weights; +2 us) -- the caller will run a backward
 int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,
                              int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
-                             bool bwd_tables, hipStream_t stream, int chunks = 0, int channels = 0,
-                             const float* features = nullptr);
+                             bool bwd_tables, hipStream_t stream, int channels = 0, const float* features = nullptr);
 // channels-last features, record-driven (roi_align_nhwc.hip)
 void roi_align_fwd_nhwc_set_timeline(long long* device_buffer);
 bool roi_align_fwd_nhwc_supported(int channels, int height, int width, int num_rois, int aligned_height,
@@ -156,19 +155,9 @@ int launch_roi_align_fwd_nhwc(const float* features, const float* rois, float* o
 int launch_roi_align_fwd_nhwc_levels(const LevelTable& lv, const float* rois, float* output, const void* workspace,
                                      int batch, int channels, int num_rois, int aligned_height, int aligned_width,
                                      int sampling_ratio, hipStream_t stream);
-// persistent pipelined forward over the records, NCHW or channels-last (roi_align_fwd_pipe.hip); the records must be in
-// `workspace` already, together with the chunk table: launch_roi_align_prepare[_levels] on the same stream with
-// chunks = roi_align_fwd_pipe_chunks()
-void roi_align_fwd_pipe_set_timeline(long long* device_buffer);
-int roi_align_fwd_pipe_chunks(int channels, int num_rois);
-bool roi_align_fwd_pipe_supported(int channels, int height, int width, int num_rois, int aligned_height,
-                                  int aligned_width, bool nhwc);
-int launch_roi_align_fwd_pipe_levels(const LevelTable& lv, const float* rois, float* output, void* workspace, int batch,
-                                     int channels, int num_rois, int aligned_height, int aligned_width,
-                                     int sampling_ratio, bool nhwc, hipStream_t stream);
 // records of `rois` for a table of levels (first launch of the fused paths)
 int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, const int* levels, void* workspace,
                                     int batch, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
-                                    bool bwd_tables, hipStream_t stream, int chunks = 0, int channels = 0);
+                                    bool bwd_tables, hipStream_t stream, int channels = 0);
 
 }  // namespace mi

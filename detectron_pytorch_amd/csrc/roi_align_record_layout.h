@@ -12,8 +12,7 @@ constexpr int kMaxStages = 32;             // == max aligned_height on the fast 
 constexpr int kRecHeader = 24;  // [0] flags [1] batch_ind [2] wx0 [3] ww [4] magic [5] nstages [6] gh [7] gw [8] roi
                                 // [9] wy0 [10] wy1 (last window row) [11] level [12..15] stage 0
                                 // [16..17] address of channel 0 of the RoI's image in its level's map (forward calls)
-                                // [18] height [19] width of that map; with pitch = ww rounded up to a multiple of 4:
-                                // [20] 2^20 / (pitch / 4) + 1 [21] 2^20 / pitch + 1 [22..23] spare
+                                // [18] height [19] width of that map [20..23] spare
 constexpr int kRecStages = kRecHeader;                 // kMaxStages x {ph0 | ph1 << 16, row0, nrows, 0}
 constexpr int kRecY = kRecStages + 4 * kMaxStages;     // kMaxS x {row_lo * ww * 4, hw / count, lw / count, row_lo}
 constexpr int kRecX = kRecY + 4 * kMaxS;               // kMaxS x {(col_lo - wx0) * 4, hw, lw, col_lo}
@@ -33,12 +32,7 @@ constexpr int kBwdTabDw = (kBwdRf + 64) / 4;           // 352 dwords = 1408 B
 constexpr int kRecDwords = kRecB + kBwdTabDw;          // 752 dwords = 3008 B
 // after the records: one int4 per rank {x0, x1, batch*H + y0, batch*H + y1} = window of a backward-capable RoI
 // ({0x3fffffff, -1, ..} otherwise), read by the backward tiles to find the RoIs that touch them
-// head of the workspace, in front of the records: 64 counters (zeroed by prepare), then the chunk table of the
-// pipelined forward -- chunk_start[w] = first rank of workgroup w's contiguous, cost-balanced run of the sweep
-// (roi_align_prepare with chunks > 0), chunk_start[chunks] = num_rois
-constexpr int kTicketDwords = 64;
-constexpr int kChunkBase = kTicketDwords, kMaxChunks = 256;
-constexpr int kCounterDwords = kChunkBase + kMaxChunks + 4;  // 324 dwords: the records stay 16-byte aligned
+constexpr int kCounterDwords = 64;                     // counters in front of the records, zeroed by prepare
 constexpr int kNoItem = 0x7fffffff;
 
 // forward LDS path / no such image / backward tile path / y and x tables valid

@@ -78,27 +78,13 @@ __device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int
   return ((unsigned)b << 24) | ((unsigned)band << 16) | (unsigned)x;
 }
 
-// What a RoI costs the pipelined forward (roi_align_fwd_pipe.hip), in window pixels per channel: its window (the DMA
-// bytes) plus a fixed share per item (stage).  An estimate from the box alone, so that every wave can evaluate it for
-// every RoI: it only has to balance the chunks.
-__device__ __forceinline__ unsigned roi_cost(const float* __restrict__ roi, float spatial_scale, int height, int width,
-                                             int aligned_height, int max_rows_tile) {
-  const float w = fmaxf(roi[3] * spatial_scale - roi[1] * spatial_scale, 1.f);
-  const float h = fmaxf(roi[4] * spatial_scale - roi[2] * spatial_scale, 1.f);
-  const float px = fminf(w + 3.f, (float)width) * fminf(h + 3.f, (float)height);
-  const float stages = fmaxf(ceilf(px * (1.f / 336.f)), ceilf((float)aligned_height / (float)max_rows_tile));
-  const float c = px + 128.f * stages;
-  return c < 65535.f ? (unsigned)c : 65535u;
-}
-
 __global__ void __launch_bounds__(256)
 roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels, int num_rois, int batch,
                   const LevelTable lv, int aligned_height, int aligned_width, int sampling_ratio, int cap_px,
-                  int stage_px, int max_rows_tile, int bwd_tables, int chunks, int channels, int* __restrict__ ws) {
-  extern __shared__ unsigned keys[];  // [num_rois], then (chunks > 0) unsigned short costs[num_rois]
-  unsigned short* costs = reinterpret_cast<unsigned short*>(keys + num_rois);
+                  int stage_px, int max_rows_tile, int bwd_tables, int channels, int* __restrict__ ws) {
+  extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
-  if (blockIdx.x == 0 && threadIdx.x < kTicketDwords) ws[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < kCounterDwords) ws[threadIdx.x] = 0;
   // This wave's RoI: its five floats and its level are fetched FIRST (wave-uniform address -> scalar loads), so that
   // their latency passes under the key phase below instead of after the barrier.
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -110,9 +96,6 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
   for (int i = threadIdx.x; i < num_rois; i += 256) {
     const int l = level_of(levels, i, lv);
     keys[i] = sweep_key(rois + (long long)i * 5, l, lv.scale[l], lv.height[l]);
-    if (chunks > 0)
-      costs[i] = (unsigned short)roi_cost(rois + (long long)i * 5, lv.scale[l], lv.height[l], lv.width[l], aligned_height,
-                                          max_rows_tile);
   }
   __syncthreads();
   if (r >= num_rois) return;
@@ -126,27 +109,6 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) rank += __shfl_xor(rank, d);
-    if (chunks > 0) {
-      // chunk table of the pipelined forward: the sweep is cut where the running cost crosses a multiple of total / chunks;
-      // the RoI whose cost interval [before, before + own) holds such a boundary starts that chunk
-      unsigned before = 0, total = 0;
-      for (int j = lane; j < num_rois; j += 64) {
-        const unsigned k = keys[j], c = costs[j];
-        before += (k < mine || (k == mine && j < r)) ? c : 0u;
-        total += c;
-      }
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        before += __shfl_xor(before, d);
-        total += __shfl_xor(total, d);
-      }
-      if (lane == 0) {
-        const unsigned long long g = (unsigned long long)chunks, lo = (unsigned long long)before * g,
-                                 hi = (unsigned long long)(before + costs[r]) * g;
-        for (unsigned long long w = (lo + total - 1) / total; w * total < hi && w < g; w++) ws[kChunkBase + (int)w] = rank;
-        if (r == 0) ws[kChunkBase + chunks] = num_rois;
-      }
-    }
   }
   int* __restrict__ rec = ws + kCounterDwords + (long long)rank * kRecDwords;
   const int height = lv.height[lvl], width = lv.width[lvl];
@@ -274,8 +236,6 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
   int nstages = 0;
   if (fast) {
     const int half = stage_px;
-    // the pipelined forward lays a window row out on a pitch of whole 16-byte groups (its DMA moves 4 pixels per lane)
-    const int wwp = chunks > 0 ? (ww + 3) & ~3 : ww;
     int ph0 = 0;
     while (ph0 < aligned_height) {
       const int row0 = __builtin_amdgcn_readlane(ylo, ph0 * gh);
@@ -283,7 +243,7 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
       int row1 = row0;
       while (e < aligned_height && e < ph0 + max_rows_tile) {
         const int hi = __builtin_amdgcn_readlane(ylo, e * gh + gh - 1) + 1;
-        const int px = (hi - row0 + 1) * wwp;
+        const int px = (hi - row0 + 1) * ww;
         if (px > (e == ph0 ? cap_px : half)) break;
         row1 = hi;
         e++;
@@ -334,13 +294,6 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
     h4.z = height;
     h4.w = width;
     reinterpret_cast<int4*>(rec)[4] = h4;
-    const unsigned pitch_px = (unsigned)(ww + 3) & ~3u;  // [20], [21]: p / (pitch / 4) and p / pitch as multiply + shift
-    int4 h5;
-    h5.x = (int)((1u << 20) / (pitch_px >> 2) + 1u);
-    h5.y = (int)((1u << 20) / pitch_px + 1u);
-    h5.z = 0;
-    h5.w = 0;
-    reinterpret_cast<int4*>(rec)[5] = h5;
   }
 }
 
@@ -1163,12 +1116,11 @@ size_t records_lds_bytes(int cap, int ct) {
 
 int launch_prepare(const float* rois, const int* levels, int* ws, int batch, const LevelTable& lv, int num_rois,
                    int aligned_height, int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables,
-                   hipStream_t stream, int chunks = 0, int channels = 0) {
+                   hipStream_t stream, int channels = 0) {
   const int max_rows_tile = kTileBins / aligned_width;
-  if (chunks > kMaxChunks) chunks = kMaxChunks;
-  roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * (chunks > 0 ? 6 : 4) + 8, stream>>>(
+  roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
       rois, levels, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile,
-      bwd_tables ? 1 : 0, chunks, channels, ws);
+      bwd_tables ? 1 : 0, channels, ws);
   return check_launch("roi_align_prepare");
 }
 
@@ -1177,7 +1129,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
                int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio, bool bwd_tables,
                hipStream_t stream) {
   int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio, kCap,
-                          bwd_tables, stream, 0, channels);
+                          bwd_tables, stream, channels);
   if (rc != MI_OK) return rc;
   // the LDS images of MI_ROI_ALIGN_CAP >= 448 exceed the 64 KB a kernel may ask for without opting in
 #define MI_LAUNCH_REC(SR, A)                                                                                          \
@@ -1351,17 +1303,17 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
 
 int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,
                              int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
-                             bool bwd_tables, hipStream_t stream, int chunks, int channels, const float* features) {
+                             bool bwd_tables, hipStream_t stream, int channels, const float* features) {
   return launch_prepare(rois, nullptr, static_cast<int*>(workspace), batch,
                         single_level(features, nullptr, batch, height, width, spatial_scale), num_rois, aligned_height,
-                        aligned_width, sampling_ratio, 336, bwd_tables, stream, chunks, channels);
+                        aligned_width, sampling_ratio, 336, bwd_tables, stream, channels);
 }
 
 int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, const int* levels, void* workspace,
                                     int batch, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
-                                    bool bwd_tables, hipStream_t stream, int chunks, int channels) {
+                                    bool bwd_tables, hipStream_t stream, int channels) {
   return launch_prepare(rois, levels, static_cast<int*>(workspace), batch, lv, num_rois, aligned_height, aligned_width,
-                        sampling_ratio, 336, bwd_tables, stream, chunks, channels);
+                        sampling_ratio, 336, bwd_tables, stream, channels);
 }
 
 size_t roi_align_records_workspace_bytes(int num_rois) {
@@ -1370,7 +1322,7 @@ size_t roi_align_records_workspace_bytes(int num_rois) {
 
 bool roi_align_fwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width) {
-  return channels > 0 && channels % kCT == 0 && channels / kCT <= kTicketDwords && aligned_width <= kTileBins &&
+  return channels > 0 && channels % kCT == 0 && channels / kCT <= kCounterDwords && aligned_width <= kTileBins &&
          aligned_height > 0 && aligned_width > 0 && num_rois <= kMaxRois &&
          (long long)kCT * height * width * 4 < (1LL << 31);
 }

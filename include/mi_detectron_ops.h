@@ -403,8 +403,8 @@ void mi_dbg_roi_align_timeline(long long* device_buffer);
  * call -- the only writer of that state; call it with no RoIAlign launch in flight on any thread. */
 void mi_dbg_reload_tuning(void);
 /* Measurement aid of bench.py (roofline.copy_ceiling): a plain streaming copy of `bytes` (a multiple of 16; both buffers
- * 16-byte aligned) with 16 bytes per lane and four loads in flight per lane -- the box's own ceiling the RoIAlign
- * roofline fractions are also quoted against. */
+ * 16-byte aligned) with 16 bytes per lane, non-temporal -- the box's own ceiling the RoIAlign roofline fractions are also
+ * quoted against. */
 int mi_dbg_copy_float4(const void* src, void* dst, size_t bytes, mi_stream_t stream);
 
 #ifdef __cplusplus

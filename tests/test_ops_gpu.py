@@ -69,13 +69,12 @@ def tuning_env(monkeypatch):
     _lib.lib().mi_dbg_reload_tuning()
 
 
-@pytest.fixture(params=["stream", "stream_unplanned", "stream_sliced", "pipe", "direct"])
+@pytest.fixture(params=["stream", "stream_unplanned", "stream_sliced", "direct"])
 def roi_align_impl(request, tuning_env):
     """Run a test against the RoIAlign implementations behind mi_roi_align_*: the default fast paths ("stream": the
     record-driven forward, the planned backward with list slices of 32 RoIs; "stream_unplanned": MI_ROI_ALIGN_BWD_SLICE=0,
     one workgroup walks a tile's whole list; "stream_sliced": slices of 2 RoIs, so that nearly every tile is summed by
-    several workgroups with atomics), the persistent pipelined forward over the same records (MI_ROI_ALIGN_IMPL=pipe, NCHW
-    and channels-last) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
+    several workgroups with atomics) and the generic direct kernels (MI_ROI_ALIGN_IMPL=direct)."""
     stream = request.param.startswith("stream")
     tuning_env(MI_ROI_ALIGN_IMPL=None if stream else request.param,
                MI_ROI_ALIGN_BWD_SLICE={"stream_unplanned": 0, "stream_sliced": 2}.get(request.param))
@@ -241,19 +240,16 @@ def test_roi_align_non_finite_border_pixels_propagate_as_in_the_reference(oracle
     assert np.abs(out[fin] - ref[fin]).max() <= FAST_ATOL
 
 
-@pytest.mark.parametrize("variant", ["records", "pipe", "pipe_channels_last"])
+@pytest.mark.parametrize("variant", ["records", "channels_last"])
 @pytest.mark.parametrize("case", ["adversarial", "piled", "nonfinite", "fpn", "sr0"])
 def test_roi_align_forward_kernels_on_hard_inputs(oracle_mod, tuning_env, variant, case):
-    """The record-driven forward kernels -- one workgroup per (RoI, channel tile), and the persistent pipelined kernel
-    (MI_ROI_ALIGN_IMPL=pipe, NCHW and channels-last) -- on inputs that reach every branch: RoIs the tables cannot describe
-    (reference-order path inside the kernel) and RoIs of no image, a pile of 300 RoIs on one spot (one workgroup's run of
-    the sweep is a single box), non-finite features at the borders (a clamped sample reads the border pixel twice, as the
-    reference; windows that touch the right edge are copied pixel by pixel), an FPN pyramid in one call, an adaptive
-    sampling grid (generic kernel)."""
+    """The record-driven forward kernels (NCHW: roi_align_fwd_records; channels-last: roi_align_fwd_nhwc) on inputs that reach
+    every branch: RoIs the tables cannot describe (reference-order path inside the kernel) and RoIs of no image, a pile of
+    300 RoIs on one spot, non-finite features at the borders (a clamped sample reads the border pixel twice, as the
+    reference), an FPN pyramid in one call, an adaptive sampling grid (generic kernel)."""
     from detectron_pytorch_amd.roi_align import roi_align_forward, roi_align_fpn
 
-    tuning_env(MI_ROI_ALIGN_IMPL=None if variant == "records" else "pipe")
-    nhwc = variant == "pipe_channels_last"
+    nhwc = variant == "channels_last"
 
     def to_maps(a):
         t = to_dev(a)

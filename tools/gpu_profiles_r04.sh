@@ -29,14 +29,12 @@ rm -rf $O/pmc_mfma5
 fi
 if [ $STAGE = all ] || [ $STAGE = config2 ]; then
 echo "pass,kernel,calls,avg_ns,min_ns,max_ns" > $O/config2_kernel_durations.csv
-for pass in roi_align_fwd roi_align_bwd roi_align_bwd_unplanned nhwc_fwd pipe_fwd pipe_nhwc_fwd; do
+for pass in roi_align_fwd roi_align_bwd roi_align_bwd_unplanned nhwc_fwd; do
   unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS MI_BENCH_BWD_UNPLANNED; k=roi_align_fwd
   case $pass in
     roi_align_bwd) k=roi_align_bwd;;
     roi_align_bwd_unplanned) k=roi_align_bwd; export MI_BENCH_BWD_UNPLANNED=1;;
     nhwc_fwd) export MI_BENCH_NHWC=1;;
-    pipe_fwd) export MI_ROI_ALIGN_IMPL=pipe;;
-    pipe_nhwc_fwd) export MI_ROI_ALIGN_IMPL=pipe MI_BENCH_NHWC=1;;
   esac
   timeout 120 rocprofv3 --kernel-trace --stats -d $O/c2_$pass -o c -f csv -- python $R/tools/run_one_kernel.py $k 50 > $O/c2_$pass.log 2>&1
   python - $O/c2_$pass $pass >> $O/config2_kernel_durations.csv <<'PY'
@@ -52,8 +50,7 @@ done
 unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS MI_BENCH_BWD_UNPLANNED
 fi
 if [ $STAGE = all ] || [ $STAGE = pmc ]; then
-for variant in records pipe bwd; do
-  unset MI_ROI_ALIGN_IMPL; [ $variant = pipe ] && export MI_ROI_ALIGN_IMPL=pipe
+for variant in records bwd; do
   k=roi_align_fwd; [ $variant = bwd ] && k=roi_align_bwd
   j=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
@@ -68,4 +65,4 @@ for variant in records pipe bwd; do
 done
 unset MI_ROI_ALIGN_IMPL
 fi
-cut -c1-600 $O/bench_line.json 2>/dev/null; echo; head -24 $O/train_step_steady_state.txt 2>/dev/null | cut -c1-150; head -14 $O/train_step_mfma_util.txt $O/config5_mfma_util.txt 2>/dev/null | cut -c1-130; cat $O/config2_kernel_durations.csv 2>/dev/null; cat $O/pmc_records.txt $O/pmc_pipe.txt $O/pmc_bwd.txt 2>/dev/null
+cut -c1-600 $O/bench_line.json 2>/dev/null; echo; head -24 $O/train_step_steady_state.txt 2>/dev/null | cut -c1-150; head -14 $O/train_step_mfma_util.txt $O/config5_mfma_util.txt 2>/dev/null | cut -c1-130; cat $O/config2_kernel_durations.csv 2>/dev/null; cat $O/pmc_records.txt $O/pmc_bwd.txt 2>/dev/null

@@ -208,7 +208,7 @@ def roofline_roi_align_forward(device, iters):
     info["copy_ceiling"] = {"measured": round(copy_gbs, 1), "unit": "GB/s", "frac_of_copy": round(achieved / copy_gbs, 4),
                             "ceiling_frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 3),
                             "torch_d2d_copy": round(torch_gbs, 1),
-                            "what": "mi_dbg_copy_float4 (16 B / lane, 4 loads in flight) over 256 MiB, read + write bytes / "
+                            "what": "mi_dbg_copy_float4 (16 B / lane, non-temporal, 4 workgroups / CU) over 256 MiB, read + write bytes / "
                                     "time; torch_d2d_copy: the same buffers through torch's copy_ (rounds 1-3 quoted this one)"}
     return info
 
@@ -271,7 +271,7 @@ def cold_cache_variant(device, lib, stream, feat, rois, ws, ws_bytes, alg_bytes,
 
 def copy_ceiling(device):
     """The box's own streaming ceiling (SURVEY.md section 8d asks for both denominators): the library's float4 copy kernel
-    (mi_dbg_copy_float4: 16 bytes per lane, four loads in flight; read + write bytes of a 256 MiB buffer) and, beside it,
+    (mi_dbg_copy_float4: 16 bytes per lane, non-temporal; read + write bytes of a 256 MiB buffer) and, beside it,
     what torch's device-to-device copy reaches (the denominator of rounds 1-3, ~14 % lower)."""
     from detectron_pytorch_amd import _lib
 
@@ -283,8 +283,8 @@ def copy_ceiling(device):
     def launch():
         assert lib.mi_dbg_copy_float4(a.data_ptr(), b.data_ptr(), nbytes, stream) == 0
 
-    sec = time_kernel(launch, 20)
-    sec_torch = time_kernel(lambda: b.copy_(a), 20)
+    sec = time_kernel(launch, 50)
+    sec_torch = time_kernel(lambda: b.copy_(a), 50)
     return 2 * nbytes / sec / 1e9, 2 * nbytes / sec_torch / 1e9
 
 
