@@ -523,13 +523,20 @@ __global__ void __launch_bounds__(256) nms_prepare_segmented(const SegmentArgs a
                            a.n_live + s);
 }
 
+// kMaskGrid workgroups per segment walk the segment's col_blocks x col_blocks tile pairs (the segment's live size is a
+// device value: a grid of the worst case, (rows / 64)^2 pairs x 80 classes = 20 480 workgroups of which a detection's
+// ~100 live ones did anything, cost 39 us; a class above the score threshold rarely has more than a few tile pairs)
+constexpr int kMaskGrid = 16;
 __global__ void __launch_bounds__(kTile) nms_mask_segmented(const SegmentArgs a, float thresh) {
-  const int s = blockIdx.z;
+  const int s = blockIdx.y;
   const int n = a.n_live[s];
   const int col_blocks = (n + kTile - 1) / kTile;
-  if ((int)blockIdx.x >= col_blocks || (int)blockIdx.y >= col_blocks) return;
   const Workspace ws = carve(a.workspace + (size_t)s * a.seg_bytes, a.rows);
-  mask_body<true>(ws.boxes, ws.areas, n, thresh, ws.mask, ws.diag_t, blockIdx.x, blockIdx.y, col_blocks);
+  for (int t = blockIdx.x; t < col_blocks * col_blocks; t += kMaskGrid) {
+    const int row = t / col_blocks, col = t - row * col_blocks;
+    mask_body<true>(ws.boxes, ws.areas, n, thresh, ws.mask, ws.diag_t, col, row, col_blocks);
+    __syncthreads();  // the tile's LDS boxes are reused by the next pair
+  }
 }
 
 __global__ void __launch_bounds__(256) nms_reduce_segmented(const SegmentArgs a) {
@@ -877,7 +884,7 @@ extern "C" int mi_nms_segmented(const float* boxes, long long box_segment_stride
   int rc;
   nms_prepare_segmented<<<dim3(cb, num_segments), 256, 0, s>>>(a);
   if ((rc = mi::check_launch("nms_prepare_segmented")) != MI_OK) return rc;
-  nms_mask_segmented<<<dim3(cb, cb, num_segments), kTile, 0, s>>>(a, nms_thresh);
+  nms_mask_segmented<<<dim3(std::min(cb * cb, kMaskGrid), num_segments), kTile, 0, s>>>(a, nms_thresh);
   if ((rc = mi::check_launch("nms_mask_segmented")) != MI_OK) return rc;
   nms_reduce_segmented<<<num_segments, 256, 0, s>>>(a);
   return mi::check_launch("nms_reduce_segmented");

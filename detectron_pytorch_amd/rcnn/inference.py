@@ -101,7 +101,10 @@ def im_detect_bbox(model, data, im_info, im_shape=None, autocast_dtype=None, sta
 @torch.no_grad()
 def im_detect_all(model, data, im_info, im_shape=None, autocast_dtype=None):
     """test.py:50-125 without test-time augmentation and without the mask / keypoint branches (BASELINE config 3 is
-    Faster R-CNN): detections of one image as (scores [D], boxes [D,4], cls_boxes) -- device tensors."""
+    Faster R-CNN): detections of one image as (scores [D], boxes [D,4], cls_boxes) -- device tensors.
+    `im_shape` = (height, width) of the ORIGINAL image, what the reference clips the boxes to (core/test.py:178): pass it
+    whenever the loader has it.  None reconstructs it as round(blob extent / scale) -- exact for the up-scaled images of the
+    shipped configurations, but off by one pixel for some down-scaled ones (641 px at scale 0.5 -> blob 320 -> 640)."""
     _check_cpu_budget()
     cfg = model.cfg
     scores, boxes, blob_conv = im_detect_bbox(model, data, im_info, im_shape, autocast_dtype)
