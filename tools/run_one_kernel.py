@@ -13,6 +13,8 @@ from detectron_pytorch_amd import _lib, synthetic as syn  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "roi_align_fwd"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda", 0)
+if os.environ.get("MI_LIB_OVERRIDE"):      # tuning builds of the library (tools/)
+    _lib.LIB_PATH = os.path.abspath(os.environ["MI_LIB_OVERRIDE"])
 lib = _lib.lib()
 stream = _lib.current_stream_handle(dev)
 h, w, scale = syn.FPN_LEVELS[2]
@@ -43,7 +45,11 @@ if which == "roi_align_bwd" and not os.environ.get("MI_BENCH_BWD_UNPLANNED"):  #
     fws_bytes = max(fws_bytes, _backward_workspace_bytes([(h, w)], 1, r))
 fws = torch.empty(fws_bytes, dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
-for _ in range(iters):
+t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+warm = 20 if os.environ.get("MI_BENCH_TIME") else 0       # MI_BENCH_TIME: 20 untimed calls, then `iters` timed ones
+for it in range(warm + iters):
+    if it == warm:
+        t0.record()
     if which == "roi_align_fwd":
         rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, scale,
                                          sr, 0, layout, fws.data_ptr(), fws.numel(), stream)
@@ -53,5 +59,6 @@ for _ in range(iters):
     else:
         rc = lib.mi_nms(dets.data_ptr(), 2000, 0.7, 0, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), wsb, stream)
     assert rc == 0
+t1.record()
 torch.cuda.synchronize()
-print("done", which, iters)
+print("done", which, iters, ("%.2f us per call" % (t0.elapsed_time(t1) * 1e3 / iters)) if warm else "")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Tuning aid: per-workgroup phase timeline of the RoIAlign forward tile kernel (config-2 shape).
-The kernel stamps s_memtime at 8 points per workgroup into a device buffer (mi_dbg_roi_align_timeline);
-this prints per-phase durations and the concurrency picture.  usage: python tools/timeline.py [sorted]"""
+The kernel stamps clock64() -- shader-clock ticks (~2.1 GHz), a counter whose base differs from compute unit to compute
+unit, so only differences inside one workgroup mean anything -- at 8 points per workgroup into a device buffer
+(mi_dbg_roi_align_timeline); this prints the per-phase durations in ticks.  usage: python tools/timeline.py [sorted]"""
 import ctypes
 import os
 import sys
@@ -44,19 +45,13 @@ t = tl.cpu().numpy()
 meta = t[:, 7] * 0
 t[:, 7] &= (1 << 44) - 1
 t[:, :7] &= (1 << 44) - 1
-t0 = t[:, 0].min()
-t = t - t0
+t = t - t[:, :1]
 names = ["roi+geom", "dma issue", "tables", "wait dma+barrier", "compute", "barrier", "store"]
-print("workgroups", nwg, "kernel span (cycles)", t[:, 7].max(), "= us @100MHz-const?", )
+print("workgroups", nwg, "(ticks of the shader clock, ~2100 per us)")
 for k in range(7):
     d = t[:, k + 1] - t[:, k]
     print("%-18s mean %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f" % (names[k], d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 tot = t[:, 7] - t[:, 0]
 print("%-18s mean %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f" % ("total", tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max()))
-start = np.sort(t[:, 0])
-print("start times: p10 %d p50 %d p90 %d max %d" % tuple(np.percentile(start, [10, 50, 90, 100])))
-# concurrency: average number of workgroups alive
-span = t[:, 7].max()
-print("avg WGs alive: %.1f (of %d slots at 3/CU)" % (tot.sum() / span, 768))
 xcc = meta & 0xf
 print("xcc histogram", np.bincount(xcc.astype(int), minlength=8))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Tuning aid: per-workgroup phase timeline of roi_align_fwd_nhwc (config-2 shape, channels-last features).
-Wave 0 of every workgroup stamps s_memtime (100 MHz) at 6 points (mi_dbg_roi_align_timeline)."""
+Wave 0 of every workgroup stamps clock64() -- the shader clock, one time base per XCD -- at 6 points, and where it ran
+(XCC_ID / HW_ID) and which RoI it pooled (mi_dbg_roi_align_timeline).  Times are normalised per XCD; MHZ is nominal."""
 import ctypes
 import os
 import sys
@@ -37,16 +38,60 @@ lib.mi_dbg_roi_align_timeline(tl.data_ptr())
 launch()
 torch.cuda.synchronize()
 lib.mi_dbg_roi_align_timeline(None)
-t = tl.cpu().numpy()
-t = t[t[:, 0] != 0]
-print("workgroups stamped", len(t))
-t = t[:, :6] - t[:, 0].min()
+MHZ = float(os.environ.get("MI_SHADER_MHZ", "2100"))
+raw = tl.cpu().numpy()
+raw = raw[raw[:, 0] != 0]
+print("workgroups stamped", len(raw))
+xcc = (raw[:, 6] >> 32) & 0xf
+hw = raw[:, 6] & 0xffffffff
+cu_key = (xcc << 16) | (hw & 0x7f00)         # HW_ID: cu_id [11:8], sh_id [12], se_id [14:13] (bit 16: which of the unit's two slots)
+roi = raw[:, 7]
+t = raw[:, :6].astype(np.float64)
+t = (t - t[:, :1]) / MHZ                     # the counters of different compute units do not share a base: differences only
 names = ["record fetch", "taps (wave 0)", "tile write", "barrier (other waves)", "copy-out"]
 for k in range(5):
-    d = (t[:, k + 1] - t[:, k]) * 0.01
+    d = t[:, k + 1] - t[:, k]
     print("%-22s mean %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % (names[k], d.mean(), np.median(d), np.percentile(d, 90), d.max()))
-tot = (t[:, 5] - t[:, 0]) * 0.01
-print("%-22s mean %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % ("workgroup life", tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max()))
-print("kernel span %.2f us; start times p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (
-    (t[:, 5].max()) * 0.01, *(np.percentile(t[:, 0], [10, 50, 90, 100]) * 0.01)))
-print("avg workgroups alive: %.1f" % (tot.sum() / (t[:, 5].max() * 0.01)))
+life = t[:, 5] - t[:, 0]
+print("%-22s mean %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % ("workgroup life", life.mean(), np.median(life), np.percentile(life, 90), life.max()))
+
+# cost of a RoI = tap loads of its seven waves: per bin row, (distinct feature rows its y samples tap) x 4 * PW * sr / 2
+rois_h = rois.cpu().numpy()
+y1 = rois_h[:, 2] * np.float32(scale)
+rh = np.maximum(rois_h[:, 4] * np.float32(scale) - y1, 1.0)
+bh = rh / res
+cost = np.zeros(r)
+for ph in range(res):
+    rows = [set() for _ in range(r)]
+    for iy in range(sr):
+        y = np.clip(y1 + ph * bh + (iy + 0.5) * bh / sr, 0, h - 1)
+        lo = np.floor(y).astype(int)
+        for i in range(r):
+            rows[i].update((lo[i], min(lo[i] + 1, h)))
+    cost += np.array([len(s) for s in rows]) * 2 * sr * res
+c = cost[roi]
+taps = t[:, 2] - t[:, 1]
+print("tap loads per RoI: mean %.0f min %.0f max %.0f" % (cost.mean(), cost.min(), cost.max()))
+print("corr(taps time of wave 0, own cost) = %.2f" % np.corrcoef(taps, c)[0, 1])
+keys, inv, cnt = np.unique(cu_key, return_inverse=True, return_counts=True)
+print("compute units used %d; workgroups per unit: %s" % (len(keys), dict(zip(*np.unique(cnt, return_counts=True)))))
+cu_cost = np.bincount(inv, weights=c)
+print("corr(life, cost of all workgroups on the same unit) = %.2f" % np.corrcoef(life, cu_cost[inv])[0, 1])
+print("corr(taps time, cost of the unit) = %.2f" % np.corrcoef(taps, cu_cost[inv])[0, 1])
+print("unit cost: mean %.0f p90 %.0f max %.0f" % (cu_cost.mean(), np.percentile(cu_cost, 90), cu_cost.max()))
+d = []
+unit_life = np.zeros(len(keys))
+np.maximum.at(unit_life, inv, life)
+for k in range(len(keys)):
+    members = np.nonzero(inv == k)[0]          # row index == blockIdx (every workgroup is stamped)
+    if len(members) == 2:
+        d.append(abs(int(members[1] // 8) - int(members[0] // 8)))
+print("blockIdx / 8 distance of the two workgroups of a unit: %s" % dict(zip(*np.unique(d, return_counts=True))))
+wwin = np.floor(rois_h[:, 3] * scale) - np.floor(rois_h[:, 1] * scale) + 2
+px = np.bincount(inv, weights=((cost / (2 * sr * res)) * wwin)[roi])
+print("life of a unit (its longer workgroup): mean %.2f p90 %.2f max %.2f us; corr with its tap loads %.2f, with rows x window "
+      "width (distinct pixels) %.2f" % (unit_life.mean(), np.percentile(unit_life, 90), unit_life.max(),
+                                       np.corrcoef(unit_life, cu_cost)[0, 1], np.corrcoef(unit_life, px)[0, 1]))
+for x in np.unique(xcc):
+    m = xcc == x
+    print("XCD %d: workgroups %3d  cost %7.0f  life mean %5.2f max %5.2f us" % (x, m.sum(), c[m].sum(), life[m].mean(), life[m].max()))
