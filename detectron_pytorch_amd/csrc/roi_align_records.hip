@@ -542,7 +542,11 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     } else if (nb == bins && ts == nb && ((kCT * nb) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
       const float4* t4 = reinterpret_cast<const float4*>(s.tile);
       float4* d4 = reinterpret_cast<float4*>(dst);
-      for (int i = tid; i < kCT * nb / 4; i += kThreads) d4[i] = t4[i];
+      // non-temporal: the pooled features are read next by another kernel, and a streaming store lets the workgroup's LDS go
+      // ~1 % earlier (38.55 -> 38.25 us per config-2 call, three alternating runs)
+      typedef float v4f_t __attribute__((ext_vector_type(4)));
+      for (int i = tid; i < kCT * nb / 4; i += kThreads)
+        __builtin_nontemporal_store(reinterpret_cast<const v4f_t*>(t4)[i], reinterpret_cast<v4f_t*>(d4) + i);
     } else {
       const unsigned nb_magic = (1u << 20) / (unsigned)nb + 1u;
       for (int i = tid; i < kCT * nb; i += kThreads) {

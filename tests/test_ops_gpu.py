@@ -888,6 +888,31 @@ def test_detection_static_path_with_soft_nms_and_voting_equals_the_dynamic_path(
             assert out is None                                   # the caller then takes the dynamic path
 
 
+@pytest.mark.parametrize("soft,vote", [(True, False), (False, True), (True, True)])
+def test_detection_static_general_path_degenerate_inputs(soft, vote):
+    """No score above the threshold (every class segment empty), a single candidate, and a blob whose rows are all padding:
+    the static path returns zero rows / the one row without touching memory behind its buffers, as the dynamic path does."""
+    from detectron_pytorch_amd import detection
+
+    scores, boxes = syn.detection_head_outputs(64, 81, seed=3)
+    kw = dict(nms_thresh=0.5, detections_per_im=100, soft_nms=soft, soft_nms_method="linear", bbox_vote=vote,
+              bbox_vote_thresh=0.8, bbox_vote_method="ID")
+    res = detection.box_results_static_general(to_dev(scores), to_dev(boxes), score_thresh=2.0, **kw)   # nothing passes
+    assert int(res["count"]) == 0 and int(res["total"]) == 0 and float(res["dets"].abs().sum()) == 0
+    assert not bool(res["class_counts"].any())
+    one = np.zeros_like(scores)
+    one[:, 0] = 1.0
+    one[17, 5] = 0.9                                                 # exactly one candidate, class 5
+    one[17, 0] = 0.1
+    ws, wb, wcls = detection.box_results_with_nms_and_limit(to_dev(one), to_dev(boxes), score_thresh=0.5, **kw)
+    res = detection.box_results_static_general(to_dev(one), to_dev(boxes), score_thresh=0.5, **kw)
+    assert int(res["count"]) == 1 == ws.numel() and int(res["cls"][0]) == 5
+    assert torch.equal(res["dets"][:1].cpu(), wcls[5].cpu())
+    res = detection.box_results_static_general(to_dev(scores), to_dev(boxes), score_thresh=0.05,
+                                               roi_valid=to_dev(np.zeros(64, bool)), **kw)     # all rows are padding
+    assert int(res["count"]) == 0 and int(res["total"]) == 0
+
+
 def test_soft_nms_segmented_matches_single_calls(oracle_mod):
     from detectron_pytorch_amd import _lib
 
