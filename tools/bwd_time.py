@@ -46,6 +46,8 @@ def config2_case(dev, iters):
 
 
 def main():
+    if os.environ.get("MI_LIB_OVERRIDE"):      # tuning builds of the library
+        _lib.LIB_PATH = os.path.abspath(os.environ["MI_LIB_OVERRIDE"])
     dev = torch.device("cuda", 0)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     rois, lvls, mrois, mlvls = load_step_rois(dev)
