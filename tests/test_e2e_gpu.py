@@ -525,15 +525,17 @@ def _check_static_detection(gpu, cfg, inference):
         count = int(res["count"])
         assert count == int(res["total"]) == want[0].numel()
         # the static RoI blob has more rows than the dynamic one: the box-head GEMMs run at another M and may round the
-        # last bit differently -- same detections, scores to 1e-6
+        # last bit differently -- same detections, scores to 1e-6.  Soft-NMS re-scores a row with a function of its IoU with
+        # the rows picked before it: boxes that differ by 1e-3 px move an IoU, and with it a score of ~0.1, by up to ~1e-5
+        score_atol = 5e-5 if cfg.TEST.SOFT_NMS.ENABLED else 1e-6
         stat = res["dets"][:count].clone()
-        assert torch.allclose(stat[:, 4], want[0], rtol=0, atol=1e-6) and torch.allclose(stat[:, :4], want[1], rtol=0, atol=1e-3)
+        assert torch.allclose(stat[:, 4], want[0], rtol=0, atol=score_atol) and torch.allclose(stat[:, :4], want[1], rtol=0, atol=1e-3)
         assert torch.equal(res["class_counts"].cpu(), torch.tensor([len(c) for c in want[2][1:]]))
         if graph is None:
             graph = inference.DetectionGraph(gpu, tuple(blob.shape), dev()).capture(blob, im_info)
         replays = [graph(blob, im_info) for _ in range(2)]
         for got in replays:          # the replay is the static sequence (MIOpen / hipBLASLt may pick other kernels under
-            assert torch.allclose(got[0], stat[:, 4], rtol=0, atol=1e-6)      # capture: last-bit differences allowed)
+            assert torch.allclose(got[0], stat[:, 4], rtol=0, atol=score_atol)  # capture: last-bit differences allowed)
             assert torch.allclose(got[1], stat[:, :4], rtol=0, atol=1e-3)
             assert [len(c) for c in got[2]] == [len(c) for c in want[2]]
         # (the box head's split-K GEMM accumulates with atomics: not even two replays agree to the last bit)
