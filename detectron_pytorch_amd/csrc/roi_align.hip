@@ -239,6 +239,7 @@ int check_common(const void* a, const void* rois, const void* b, int batch, int 
 extern "C" void mi_dbg_roi_align_timeline(long long* device_buffer) {
   mi::roi_align_fwd_tile_set_timeline(device_buffer);
   mi::roi_align_fwd_nhwc_set_timeline(device_buffer);
+  mi::roi_align_fwd_records_set_timeline(device_buffer);
 }
 
 namespace {

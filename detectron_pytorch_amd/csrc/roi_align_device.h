@@ -113,6 +113,7 @@ int launch_roi_align_fwd_tile(const float* features, const float* rois, float* o
 void roi_align_fwd_tile_set_timeline(long long* device_buffer);
 // two-launch forward fast path with caller scratch (roi_align_records.hip)
 size_t roi_align_records_workspace_bytes(int num_rois);
+void roi_align_fwd_records_set_timeline(long long* device_buffer);  // tuning builds only (no-op otherwise)
 bool roi_align_fwd_records_supported(int channels, int height, int width, int num_rois, int aligned_height,
                                      int aligned_width);
 int launch_roi_align_fwd_records(const float* features, const float* rois, float* output, void* workspace, int batch,

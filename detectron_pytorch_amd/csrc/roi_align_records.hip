@@ -27,6 +27,22 @@
 #include "roi_align_device.h"
 #include "lds_dma.h"
 #include "roi_align_record_layout.h"
+// Tuning builds (MI_TUNING_BUILD=1) only: wave 0 of every forward workgroup stamps clock64() at the phase boundaries of its
+// life (tools/timeline_records.py); the release kernel has neither the parameter nor the stamps.
+#if MI_TUNING
+#define MI_TL_PARAM , long long* __restrict__ timeline
+#define MI_TL_ARG , g_records_timeline
+#define MI_STAMP(k)                                                                                                    \
+  do {                                                                                                                \
+    if (timeline != nullptr && threadIdx.x == 0) timeline[(long long)blockIdx.x * 8 + (k)] = (long long)clock64();     \
+  } while (0)
+#else
+#define MI_TL_PARAM
+#define MI_TL_ARG
+#define MI_STAMP(k)                                                                                                    \
+  do {                                                                                                                \
+  } while (0)
+#endif
 
 #include <algorithm>
 #include <type_traits>
@@ -329,7 +345,8 @@ template <int kSR, int kCap, int kCTt, int kHalves, int kA = 0>
 __global__ void __launch_bounds__(kCTt * 8 * kHalves)
 roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
                       const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height_arg,
-                      int aligned_width_arg, int sampling_ratio, int ablate_arg) {
+                      int aligned_width_arg, int sampling_ratio, int ablate_arg MI_TL_PARAM) {
+  MI_STAMP(0);
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   const int ablate = MI_ABLATE(ablate_arg);
   // kCTt channels per workgroup (32: half-waves own output columns; 16: quarter-waves do, twice as many workgroups
@@ -369,6 +386,12 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
   const int height = rec_h, width = rec_w;
   const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
   float* __restrict__ dst = out + ((long long)r * channels + c0) * bins;
+  if (flags != 0x7fffffff) MI_STAMP(1);  // the record header has arrived
+#if MI_TUNING
+  if (timeline != nullptr && threadIdx.x == 0)  // where it ran (XCC_ID, HW_ID) and how many stages
+    timeline[(long long)blockIdx.x * 8 + 7] = ((long long)nstages << 48) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
 
   if (!(flags & kFlagFast)) {
     if (flags & kFlagZero) {
@@ -454,8 +477,10 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
       const unsigned dstl = lds_addr_uniform(s.tab + wave * kMaxS);
       for (int kk = 0; kk * 64 < n; kk++) dma_dword(tsrd, dstl + (unsigned)kk * 256u, (unsigned)(kk * 64 + lane) * 4u, 0u);
     }
+    if (k == 0) MI_STAMP(2);  // window and table pieces issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (k == 0) MI_STAMP(3);  // landed, published
 
     const int base_off = row0 * pitch;
     const int nb = (ph1 - ph0) * aligned_width;
@@ -547,7 +572,9 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
         }
       }
     }
+    MI_STAMP(4);  // this wave's bins are in the tile
     __syncthreads();
+    MI_STAMP(5);
     float* gdst = dst + ph0 * aligned_width;
     if (ablate & 4) {
     } else if (nb == bins && ts == nb && ((kCT * nb) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
@@ -565,6 +592,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
         gdst[(long long)c * bins + b] = s.tile[c * ts + b];
       }
     }
+    MI_STAMP(6);  // stores issued
   }
 }
 
@@ -1139,6 +1167,10 @@ int launch_prepare(const float* rois, const int* levels, int* ws, int batch, con
   return check_launch("roi_align_prepare");
 }
 
+#if MI_TUNING
+long long* g_records_timeline = nullptr;
+#endif
+
 template <int kCap>
 int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float* output, int* ws, int batch,
                int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio, bool bwd_tables,
@@ -1155,7 +1187,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
     roi_align_fwd_records<SR, kCap, kCT, 1, A>                                                                        \
         <<<num_rois * (channels / kCT), kCT * 8, records_lds_bytes(kCap, kCT), stream>>>(                             \
             lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio,           \
-            tuning().ablate);                                                                                         \
+            tuning().ablate MI_TL_ARG);                                                                                         \
   } while (0)
   const int a = aligned_height == aligned_width ? aligned_height : 0;
   if (sampling_ratio == 2 && kCap == 336 && a == 7)
@@ -1329,6 +1361,14 @@ int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, con
                                     bool bwd_tables, hipStream_t stream, int channels) {
   return launch_prepare(rois, levels, static_cast<int*>(workspace), batch, lv, num_rois, aligned_height, aligned_width,
                         sampling_ratio, 336, bwd_tables, stream, channels);
+}
+
+void roi_align_fwd_records_set_timeline(long long* device_buffer) {
+#if MI_TUNING
+  g_records_timeline = device_buffer;
+#else
+  (void)device_buffer;
+#endif
 }
 
 size_t roi_align_records_workspace_bytes(int num_rois) {
