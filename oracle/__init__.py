@@ -44,6 +44,15 @@ def _f32(a):
     return a, a.ctypes.data_as(_f32p)
 
 
+def _check_batch(rois, n):
+    """The reference indexes `bottom_data + roi_batch_ind * channels * height * width` unchecked (roi_align_kernel.cu:90-91,
+    :230-231): a RoI of no image reads -- and in the backward WRITES -- outside the arrays.  The HIP operators define such
+    rows (the padding rows of the static training path carry image -1) as "pool zeros, no gradient"; a caller of the oracle
+    has to take them out first (tests/cpu_backend.py does)."""
+    if rois.shape[0] and ((rois[:, 0] < 0) | (rois[:, 0] >= n)).any():
+        raise ValueError("oracle: RoI with an image index outside [0, %d): the reference's arithmetic is undefined there" % n)
+
+
 def num_threads_available():
     return int(lib().oracle_num_threads_available())
 
@@ -53,6 +62,7 @@ def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_sca
     rois, rp = _f32(rois)
     n, c, h, w = features.shape
     r = rois.shape[0]
+    _check_batch(rois, n)
     out = np.zeros((r, c, aligned_height, aligned_width), np.float32)
     lib().oracle_roi_align_forward(fp, rp, out.ctypes.data_as(_f32p), n, c, h, w, r, int(aligned_height),
                                    int(aligned_width), ctypes.c_float(spatial_scale), int(sampling_ratio),
@@ -65,6 +75,7 @@ def roi_align_backward(top_grad, rois, feature_shape, spatial_scale, sampling_ra
     rois, rp = _f32(rois)
     n, c, h, w = feature_shape
     r, _, ah, aw = top_grad.shape
+    _check_batch(rois, n)
     grad = np.zeros((n, c, h, w), np.float32)
     lib().oracle_roi_align_backward(tp, rp, grad.ctypes.data_as(_f32p), n, c, h, w, r, ah, aw,
                                     ctypes.c_float(spatial_scale), int(sampling_ratio), int(threads))

@@ -31,8 +31,11 @@ def roi_align_fpn(features, scales, rois, roi_levels, ah, aw, sr):
     """Same contract as roi_align.roi_align_fpn: output rows in the order of `rois`."""
     out = torch.zeros((rois.size(0), features[0].size(1), ah, aw))
     pieces, index = [], []
+    # rows of no image (the padding rows of the static training path: image -1) pool zeros and get no gradient -- the
+    # contract of the HIP operators; the reference's arithmetic, which the oracle restates, indexes out of bounds for them
+    of_an_image = (rois[:, 0] >= 0) & (rois[:, 0] < features[0].size(0))
     for k, (f, sc) in enumerate(zip(features, scales)):
-        idx = torch.nonzero(roi_levels == k, as_tuple=False).flatten()
+        idx = torch.nonzero((roi_levels == k) & of_an_image, as_tuple=False).flatten()
         if idx.numel():
             pieces.append(_RoIAlignOracle.apply(f, rois[idx].contiguous(), ah, aw, float(sc), sr))
             index.append(idx)
