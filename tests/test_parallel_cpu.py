@@ -180,6 +180,26 @@ def test_bench_selftest_two_ranks_on_gloo():
     assert line["metric"] == "selftest" and line["n_gpus"] == 2 and line["collectives_per_step"] >= 1
 
 
+def test_bench_selftest_under_an_external_launcher():
+    """The form the measurement driver uses for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` -- bench.py must take the ranks it is given (no second
+    spawn) and rank 0 must print exactly one JSON line."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--selftest-cpu", "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["metric"] == "selftest" and line["n_gpus"] == 2 and line["steps"] == 2
+
+
 def test_cpu_quota_helper_keeps_the_intra_op_pool_inside_the_container_budget(monkeypatch):
     """hostcpu: the cgroup quota is parsed (v2 'quota period' / 'max'), and respect_cpu_quota only ever lowers the pool."""
     import builtins
