@@ -352,6 +352,8 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
                mi::roi_align_records_workspace_bytes(num_rois));
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
+    // the tile kernel takes a RoI's block of top gradients in 16-byte pieces
+    MI_REQUIRE((reinterpret_cast<uintptr_t>(top_grad) & 15) == 0, "roi_align: top_grad must be 16-byte aligned");
     if (!force_direct() && !no_ws() &&
         mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
       return mi::launch_roi_align_bwd_records(top_grad, rois, bottom_grad, workspace, workspace_bytes,
@@ -496,6 +498,7 @@ extern "C" int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const floa
              "roi_align_fpn: workspace of %zu bytes, %zu needed", workspace_bytes,
              mi::roi_align_records_workspace_bytes(num_rois));
   MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align_fpn: workspace must be 16-byte aligned");
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(top_grad) & 15) == 0, "roi_align_fpn: top_grad must be 16-byte aligned");
   return mi::launch_roi_align_bwd_records_levels(top_grad, rois, roi_levels, lv, workspace, workspace_bytes,
                                                  (flags & 1) != 0,
                                                  (flags & 2) != 0, layout == MI_LAYOUT_NHWC, batch, channels, num_rois,

@@ -856,11 +856,10 @@ __global__ void __launch_bounds__(kTH * 32)
     __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
 roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, const int* __restrict__ ws,
                     int num_rois, int batch, int channels, int aligned_height_arg, int aligned_width_arg, int overwrite,
-                    int ablate_arg, int g_words_arg, int ah_pad_arg, int g_cs_arg, int plan_tiles, int plan_cap) {
+                    int ablate_arg, int plan_tiles, int plan_cap) {
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
-  const int ah_pad = kA > 0 ? ((kA + 3) & ~3) : ah_pad_arg;
-  const int g_cs = kA > 0 ? 4 * ((kA * ((kA + 3) & ~3) / 4) | 1) : g_cs_arg;
-  const int g_words = kA > 0 ? KC * (4 * ((kA * ((kA + 3) & ~3) / 4) | 1)) : g_words_arg;
+  // the block of top gradients of one RoI and KC channels, as it lies in memory: [c][ph][pw], KC * bins floats
+  const int g_words = (KC * aligned_height * aligned_width + 3) & ~3;
   const int ablate = MI_ABLATE(ablate_arg);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kTabDw = BwdLds<KC>::kTabDw;
@@ -948,39 +947,27 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
 #pragma unroll
   for (int c = 0; c < KC / 2; c++) acc2[c] = v2f{0.f, 0.f};
 
-  // source byte offsets of this lane's pieces of the transposed g block (the same for every RoI)
-  constexpr int kGP = 64 / kNWaves;  // pieces per wave at most: KC * g_cs <= 64 * 64 words
-  unsigned gsrc_off[kGP];
-  {
-    const int per_c = aligned_width * ah_pad;
-#pragma unroll
-    for (int kk = 0; kk < kGP; kk++) {
-      const int i = (wave + kNWaves * kk) * 64 + lane;  // LDS word index
-      const int c = i / g_cs, rem = i - c * g_cs;
-      const int pw = rem / ah_pad, ph = rem - pw * ah_pad;
-      gsrc_off[kk] = (c < KC && rem < per_c && ph < aligned_height) ? (unsigned)(c * bins + ph * aligned_width + pw) * 4u
-                                                                      : 0xffffffffu;
-    }
-  }
-
   // LDS-DMA of RoI `pos`: tables + xfirst/yfirst (contiguous in the record) and the [KC][bins] block of top gradients
   auto issue_loads = [&](int pos, int buf) {
     const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)uniform(pos) * kRecDwords);
     const int r = rec[8];
     const srd_t tsrd = make_srd(records + (long long)uniform(pos) * kRecDwords + kRecB, kTabDw * 4);
     const unsigned tdst = lds_addr_uniform(tab0 + buf * kTabDw);
-    for (int k = wave; k * 64 < kTabDw; k += kNWaves)
-      if (k * 64 + lane < kTabDw) dma_dword(tsrd, tdst + (unsigned)k * 256u, (unsigned)(k * 64 + lane) * 4u, 0u);
-    // top gradients: global [c][ph][pw] -> LDS [c][pw][ph] (bin rows of one column contiguous, padded to ah_pad; channel
-    // stride g_cs = 4 * odd): the DMA's per-lane source address does the transpose, pass 1 then reads a column's bin
-    // rows with ds_read_b128
+    // 16-byte pieces (the launcher checks the alignment): the per-visit cost is the number of DMA instructions, not bytes
+    for (int k = wave; k * 64 < kTabDw / 4; k += kNWaves)
+      if (k * 64 + lane < kTabDw / 4) dma_dwordx4(tsrd, tdst + (unsigned)k * 1024u, (unsigned)(k * 64 + lane) * 16u, 0u);
+    // top gradients: the [KC][bins] block is one contiguous run of KC * bins floats and lands in LDS as it lies in memory
+    // ([c][ph][pw], channel stride bins: odd for 7 x 7, 4 mod 64 for 14 x 14 -- the KC channel lanes of pass 1 hit distinct
+    // banks).  16-byte LDS-DMA pieces (the run is 16-byte aligned whenever top_grad is; the launcher checks): 7 per visit
+    // for the box head instead of the 30 dword pieces of the transposing gather used until round 4 -- the visits are bound
+    // by the DMA INSTRUCTIONS the compute unit's address path takes (profiles/r04_records_timeline.txt), and this took
+    // 5-8 us off every backward (config 2: 60.3 -> 55.3 us planned, 52.5 -> 47.1 unplanned; step RoIs 108.8 -> 103.3 / 76.1
+    // -> 67.8 us, alternating same-box runs).
     const srd_t gsrd = make_srd(top_grad + ((long long)r * channels + c0) * bins, (unsigned)(KC * bins) * 4u);
     const unsigned gdst = lds_addr_uniform(g0 + buf * g_words);
-#pragma unroll
-    for (int kk = 0; kk < kGP; kk++) {
-      const int k = wave + kNWaves * kk;
-      if (k * 64 < KC * g_cs && gsrc_off[kk] != 0xffffffffu) dma_dword(gsrd, gdst + (unsigned)k * 256u, gsrc_off[kk], 0u);
-    }
+    const int total16 = KC * bins / 4;
+    for (int k = wave; k * 64 < total16; k += kNWaves)
+      if (k * 64 + lane < total16) dma_dwordx4(gsrd, gdst + (unsigned)k * 1024u, (unsigned)(k * 64 + lane) * 16u, 0u);
   };
 
   if (nlist > 0) issue_loads(list[0], 0);
@@ -1009,7 +996,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
         const int lc = x0 + col - wx0;
         if (lc < 0 || lc >= ww) continue;
         const int k0 = cft[lc], k1 = cft[lc + 1];  // the output columns that reach this column, with their weights
-        const float* gc = g + c * g_cs;
+        const float* gc = g + c * bins;
         for (int ph0 = 0; ph0 < aligned_height; ph0 += 8) {
           v2f t[4];  // bin rows ph0 .. ph0 + 7, two per register pair: v_pk_fma_f32
 #pragma unroll
@@ -1017,13 +1004,13 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
           for (int k = k0; k < k1; k++) {
             const v2f wgt = {wxt[k], wxt[k]};
             const int pw = pxt[k];
-            const float4* gp = reinterpret_cast<const float4*>(gc + pw * ah_pad + ph0);
-            const float4 ga = gp[0];
-            const float4 gb = (ph0 + 4 < ah_pad) ? gp[1] : float4{0.f, 0.f, 0.f, 0.f};
-            t[0] = __builtin_elementwise_fma(wgt, v2f{ga.x, ga.y}, t[0]);
-            t[1] = __builtin_elementwise_fma(wgt, v2f{ga.z, ga.w}, t[1]);
-            t[2] = __builtin_elementwise_fma(wgt, v2f{gb.x, gb.y}, t[2]);
-            t[3] = __builtin_elementwise_fma(wgt, v2f{gb.z, gb.w}, t[3]);
+            const float* gq = gc + ph0 * aligned_width + pw;  // bin rows of output column pw: stride aligned_width
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const float a = (ph0 + 2 * j < aligned_height) ? gq[(2 * j) * aligned_width] : 0.f;
+              const float b = (ph0 + 2 * j + 1 < aligned_height) ? gq[(2 * j + 1) * aligned_width] : 0.f;
+              t[j] = __builtin_elementwise_fma(wgt, v2f{a, b}, t[j]);
+            }
           }
 #pragma unroll
           for (int j = 0; j < 8; j++)
@@ -1249,9 +1236,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   const int g_ablate_p = tuning().ablate;
   // channels per workgroup: 32 accumulators per lane while the g block and T fit LDS comfortably, else 16
   const int kc = (bins <= 64) ? 32 : 16;
-  const int ah_pad = (aligned_height + 3) & ~3;
-  const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);  // channel stride of the transposed g block: 4 * odd
-  const int g_words = kc * g_cs;
+  const int g_words = (kc * bins + 3) & ~3;  // the gradient block of one RoI and kc channels, natural layout
   const int tab_dw = kBwdTabDw;
   const size_t lds = (32 + (size_t)(((num_rois + 1) / 2 + 3) & ~3) + 2 * tab_dw + 2 * g_words + (size_t)aligned_height * kTW * (kc + 4)) * 4;
   const int tiles = bwd_tile_count(lv, batch, th);
@@ -1280,7 +1265,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
     roi_align_bwd_tiles<SR, KC, TH, A><<<grid, TH * 32, lds, stream>>>(                                              \
         top_grad, lv, ws, num_rois, batch, channels, aligned_height, aligned_width,                                   \
-        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, g_words, ah_pad, g_cs, planned ? tiles : 0, plan_cap); \
+        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, planned ? tiles : 0, plan_cap);                        \
   } while (0)
 #define MI_LAUNCH_TILES_TH(SR, KC, TH)                                                                                \
   do {                                                                                                                \
@@ -1339,13 +1324,10 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
   const int bins = aligned_height * aligned_width;
   const int kc = (bins <= 64) ? 32 : 16;
   const int tab_dw = kBwdTabDw;
-  const int ah_pad = (aligned_height + 3) & ~3;
-  const int g_cs = 4 * ((aligned_width * ah_pad / 4) | 1);
-  const size_t lds = (32 + (size_t)(((num_rois + 1) / 2 + 3) & ~3) + 2 * tab_dw + 2 * (size_t)kc * g_cs +
+  const size_t lds = (32 + (size_t)(((num_rois + 1) / 2 + 3) & ~3) + 2 * tab_dw + 2 * (size_t)((kc * bins + 3) & ~3) +
                       (size_t)aligned_height * kTW * (kc + 4)) * 4;
   return channels > 0 && channels % 32 == 0 && aligned_height > 0 && aligned_width > 0 &&
-         aligned_height <= kMaxStages && num_rois <= kMaxRois && lds <= 160 * 1024 - 4096 &&
-         kc * g_cs <= 64 * 64;
+         aligned_height <= kMaxStages && num_rois <= kMaxRois && lds <= 160 * 1024 - 4096;
 }
 
 int launch_roi_align_prepare(const float* rois, void* workspace, int batch, int height, int width, int num_rois,

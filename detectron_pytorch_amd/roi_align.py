@@ -99,12 +99,18 @@ def _backward_workspace_bytes(sizes, batch, num_rois):
     return int(_lib.lib().mi_roi_align_backward_workspace_bytes(ctypes.byref(t), int(batch), int(num_rois)))
 
 
+def _aligned16(t):
+    """The backward kernels fetch gradient blocks in 16-byte pieces: a contiguous view that starts in the middle of an
+    allocation (possible for a slice along the channel / bin axes flattened by the caller) is copied once."""
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 def roi_align_backward(grad_output, rois, feature_size, aligned_height, aligned_width, spatial_scale,
                        sampling_ratio, variant=_lib.ROI_ALIGN_CAFFE2, channels_last=False, workspace=None):
     """Raw backward: returns grad w.r.t. features, shape `feature_size` (zero-filled then accumulated,
     functions/roi_align.py:39-44)."""
     _lib.require_cuda(grad_output, "grad_output")
-    grad_output = grad_output.contiguous()
+    grad_output = _aligned16(grad_output.contiguous())
     rois = rois.contiguous()
     n, c, h, w = feature_size
     fmt = torch.channels_last if (channels_last and variant == _lib.ROI_ALIGN_CAFFE2) else torch.contiguous_format
@@ -234,7 +240,7 @@ class _RoIAlignFPN(Function):
         lib = _lib.lib()
         rois, roi_levels, workspace = ctx.saved_tensors
         ah, aw, sr, scales = ctx.cfg
-        grad_output = grad_output.contiguous()
+        grad_output = _aligned16(grad_output.contiguous())
         fmt = torch.channels_last if ctx.layout == _lib.LAYOUT_NHWC else torch.contiguous_format
         grads = [torch.empty(shape, dtype=torch.float32, device=grad_output.device, memory_format=fmt)
                  for shape in ctx.shapes]

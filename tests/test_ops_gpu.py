@@ -110,6 +110,47 @@ def _roi_align_gpu(feat, rois, res, scale, sr, gtop=None, channels_last=False):
     return out, grad
 
 
+@pytest.mark.parametrize("res,sr,channels,channels_last", [(16, 2, 64, False), (10, 0, 32, False), (3, 2, 96, False),
+                                                         (16, 2, 64, True), (21, 2, 32, False)])
+def test_roi_align_backward_pooled_sizes_beyond_the_heads(oracle_mod, res, sr, channels, channels_last):
+    """The tile backward takes a RoI's gradient block as it lies in memory (16-byte LDS-DMA pieces); pooled sizes other
+    than the heads' 7 x 7 / 14 x 14 -- 16 x 16 and 21 x 21 could not take the tile kernel at all before -- run the generic
+    (run-time size) instance: gradients against the oracle, two images, RoIs from tiny to map-sized."""
+    h, w, scale = 50, 84, 1.0 / 16
+    feat = syn.feature_map(2, channels, h, w, seed=res)
+    rois = syn.rois_adversarial(96, 2, h, w, scale, seed=res + 1)
+    gtop = np.random.RandomState(res).randn(96, channels, res, res).astype(np.float32)
+    out, grad = _roi_align_gpu(feat, rois, res, scale, sr, gtop, channels_last=channels_last)
+    assert_fwd(out, oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=8), "fwd %d" % res, exact=False)
+    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, sr, threads=8), "bwd %d" % res)
+
+
+def test_roi_align_backward_with_a_misaligned_top_gradient(oracle_mod):
+    """The tile backward fetches gradient blocks in 16-byte pieces: the C-ABI refuses a top_grad that is not 16-byte aligned
+    (an error code, no launch) and the autograd Function copies such a gradient once instead of failing."""
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import roi_align_backward
+
+    h, w, scale = 50, 84, 1.0 / 16
+    rois = syn.rois_canonical(40, 1, seed=3, side=(32.0, 300.0))
+    shape = (40, 64, 7, 7)
+    gtop = np.random.RandomState(4).randn(*shape).astype(np.float32)
+    flat = torch.zeros(int(np.prod(shape)) + 1, device=dev())
+    flat[1:] = to_dev(gtop).reshape(-1)
+    odd = flat[1:].view(shape)                      # contiguous, 4 bytes past a 16-byte boundary
+    assert odd.is_contiguous() and odd.data_ptr() % 16 == 4
+    grad = roi_align_backward(odd, to_dev(rois), (1, 64, h, w), 7, 7, scale, 2)
+    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, (1, 64, h, w), scale, 2, threads=8), "misaligned top_grad")
+    lib = _lib.lib()
+    ws = torch.empty(lib.mi_roi_align_forward_workspace_bytes(40), dtype=torch.uint8, device=dev())
+    gin = torch.zeros((1, 64, h, w), device=dev())
+    rc = lib.mi_roi_align_backward_ws(odd.data_ptr(), to_dev(rois).data_ptr(), gin.data_ptr(), 1, 64, h, w, 40, 7, 7, scale, 2,
+                                      0, 0, ws.data_ptr(), ws.numel(), 0, _lib.current_stream_handle(dev()))
+    assert rc == 1 and b"16-byte aligned" in lib.mi_last_error()
+    torch.cuda.synchronize()
+    assert float(gin.abs().sum()) == 0.0
+
+
 def test_roi_align_golden():
     g = load_golden("roi_align.npz")
     feat, rois, scale = g["feat"], g["rois"], float(g["scale"])
