@@ -169,7 +169,7 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
       yhw = hw / count;
       ylw = lw / count;
       int4 e;
-      e.x = ylo * ww * 4;
+      e.x = ylo * ((ww + 3) & ~3) * 4;  // the NCHW forward lays a window row out on a pitch of whole 16-byte groups
       e.y = __float_as_int(yhw);
       e.z = __float_as_int(ylw);
       e.w = ylo;
@@ -259,7 +259,7 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
       int row1 = row0;
       while (e < aligned_height && e < ph0 + max_rows_tile) {
         const int hi = __builtin_amdgcn_readlane(ylo, e * gh + gh - 1) + 1;
-        const int px = (hi - row0 + 1) * ww;
+        const int px = (hi - row0 + 1) * ((ww + 3) & ~3);
         if (px > (e == ph0 ? cap_px : half)) break;
         row1 = hi;
         e++;
@@ -290,7 +290,7 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
     h0.y = batch_ind;
     h0.z = wx0;
     h0.w = ww;
-    h1.x = (int)((1u << 20) / (unsigned)ww + 1u);
+    h1.x = (int)((1u << 20) / (((unsigned)ww + 3u) >> 2) + 1u);  // divides a lane's group index by the groups per row
     h1.y = nstages;
     h1.z = gh;
     h1.w = gw;
@@ -381,7 +381,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
   // table between the record and the first DMA
   const uintptr_t img_base = ((uintptr_t)(unsigned)rec[17] << 32) | (unsigned)rec[16];
   const int rec_h = rec[18], rec_w = rec[19];
-  const unsigned pmagic = (unsigned)rec[4];  // 2^20 / ww + 1
+  const unsigned gmagic = (unsigned)rec[4];  // 2^20 / (groups of 4 pixels per window row) + 1
   // the feature map of the RoI's level (one entry unless the call is an FPN-fused one)
   const int height = rec_h, width = rec_w;
   const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
@@ -439,7 +439,8 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
   const srd_t srd = make_srd(reinterpret_cast<const char*>(img_base) + (size_t)(c0 + wave * kChPerWave) * plane_bytes,
                              (unsigned)kChPerWave * plane_bytes);
   const unsigned plane0 = lds_addr_uniform(s.img + wave * kChPerWave * kPlane);
-  const unsigned pitch_px = (unsigned)ww;
+  // a window row lies in LDS on a pitch of whole 16-byte groups: the copy moves 4 pixels per lane
+  const unsigned pitch_px = ((unsigned)ww + 3u) & ~3u;
   const int pitch = (int)pitch_px * 4;
   const int gh = kSR > 0 ? kSR : rgh, gw = kSR > 0 ? kSR : rgw;
   const TabEntry* ty = s.tab;
@@ -451,23 +452,27 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     const int ph0 = pp & 0xffff, ph1 = pp >> 16;
     if (k > 0) __syncthreads();  // image and tile are reused
     if (!(ablate & 1)) {
-      // lanes flattened over the window's (row, column): every piece moves 64 useful pixels of one channel; the per-lane
-      // offset uses 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter).  Measured against it inside one run, per
-      // config-2 call / two-image box head: rows on a pitch of whole 16-byte groups 38.9 / 64.8 us against 38.5 / 63.6;
-      // that pitch with 4 pixels per lane (buffer_load_dwordx4 ... lds, a quarter of the DMA instructions) 38.8 / 65.2
-      // against 37.6 / 61.5.
-      const unsigned npp = (unsigned)nrows * pitch_px;
-      for (int kk = 0; kk * 64 < (int)npp; kk++) {
-        const unsigned p = (unsigned)(kk * 64 + lane);
-        const unsigned q = __umul24(p, pmagic) >> 20;  // p / pitch
-        const unsigned col = p - __umul24(q, pitch_px);
-        // the window may end one row / column past the map (border samples, axis_taps): those read the last one again
-        const unsigned voff = (__umul24(min((unsigned)row0 + q, (unsigned)height - 1u), (unsigned)width) +
-                               min((unsigned)wx0 + col, (unsigned)width - 1u)) * 4u;
-        if (p < npp) {
+      // lanes flattened over the window's (row, group of 4 pixels): buffer_load_dwordx4 ... lds, a quarter of the DMA
+      // instructions of a pixel-per-lane copy (neither side needs more than dword alignment) -- what the compute unit's
+      // address path charges for is instructions (profiles/r04_records_timeline.txt).  NO branch around the pieces: a
+      // group that runs past the end of a map row drags in the first pixels of the next row (or zeros behind the wave's
+      // channels), which land in padding columns nobody reads -- except the column one past the map of a window that touches
+      // the right edge, which is patched below.  Rows past the map read the last row again through the clamp.
+      // Config 2, alternating runs: 37.9 -> 37.1 us per call (two-image box head 69.3 -> 68.4, pyramid 67.0 -> 65.8): the
+      // pieces still touch the same cache lines, so the gain is the instruction count only.  (Round 4 first measured this
+      // with a run-time choice between 16-byte and 4-byte pieces per window and found it slower: the branch around the
+      // pieces cost more than the pieces saved.)
+      const unsigned gpr = pitch_px >> 2, groups = (unsigned)nrows * gpr;
+      for (int kk = 0; kk * 64 < (int)groups; kk++) {
+        const unsigned g = (unsigned)(kk * 64 + lane);
+        const unsigned q = __umul24(g, gmagic) >> 20;  // g / gpr
+        const unsigned gc = g - __umul24(q, gpr);
+        const unsigned voff = (__umul24(min((unsigned)row0 + q, (unsigned)height - 1u), (unsigned)width) + (unsigned)wx0 +
+                               gc * 4u) * 4u;
+        if (g < groups) {
 #pragma unroll
           for (int c = 0; c < kChPerWave; c++)
-            dma_dword(srd, plane0 + (unsigned)(c * kPlane + kk * 64) * 4u, voff, (unsigned)c * plane_bytes);
+            dma_dwordx4(srd, plane0 + (unsigned)(c * kPlane + kk * 256) * 4u, voff, (unsigned)c * plane_bytes);
         }
       }
     }
@@ -481,6 +486,17 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (k == 0) MI_STAMP(3);  // landed, published
+    if (wx0 + ww > width) {
+      // the window ends one column past the map (a border sample's upper tap, weight 0: axis_taps): that column has to hold
+      // the border pixel again -- the reference reads it twice -- not what followed it in memory
+      const int edge = width - 1 - wx0;  // window column of the map's last pixel
+      for (int i = tid; i < kCT * nrows; i += kThreads) {
+        const int c = i / nrows, rr = i - c * nrows;
+        float* rowp = s.img + c * kPlane + rr * (int)pitch_px;
+        rowp[edge + 1] = rowp[edge];
+      }
+      __syncthreads();
+    }
 
     const int base_off = row0 * pitch;
     const int nb = (ph1 - ph0) * aligned_width;
