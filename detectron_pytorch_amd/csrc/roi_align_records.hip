@@ -872,7 +872,7 @@ __global__ void __launch_bounds__(kTH * 32)
     __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
 roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, const int* __restrict__ ws,
                     int num_rois, int batch, int channels, int aligned_height_arg, int aligned_width_arg, int overwrite,
-                    int ablate_arg, int plan_tiles, int plan_cap) {
+                    int ablate_arg, int plan_tiles, int plan_cap MI_TL_PARAM) {
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   // the block of top gradients of one RoI and KC channels, as it lies in memory: [c][ph][pw], KC * bins floats
   const int g_words = (KC * aligned_height * aligned_width + 3) & ~3;
@@ -986,7 +986,23 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
       if (k * 64 + lane < total16) dma_dwordx4(gsrd, gdst + (unsigned)k * 1024u, (unsigned)(k * 64 + lane) * 16u, 0u);
   };
 
+#if MI_TUNING
+  // tuning builds: wave 0 sums clock64() differences per phase over the visits of this workgroup (tools/timeline_bwd.py)
+  long long tl_t = clock64(), tl_acc[5] = {0, 0, 0, 0, 0};
+  const long long tl_start = tl_t;
+#define MI_TL_LAP(k)                          \
+  do {                                        \
+    const long long tl_now = clock64();       \
+    tl_acc[k] += tl_now - tl_t;               \
+    tl_t = tl_now;                            \
+  } while (0)
+#else
+#define MI_TL_LAP(k) \
+  do {               \
+  } while (0)
+#endif
   if (nlist > 0) issue_loads(list[0], 0);
+  MI_TL_LAP(4);  // list + first issue (not per visit)
   for (int li = 0; li < nlist; li++) {
     const int buf = li & 1;
     const int pos = uniform(list[li]);
@@ -994,7 +1010,9 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
     const int wx0 = rec[2], ww = rec[3], wy0 = rec[9], wy1 = rec[10];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // B1: buffers of this RoI have landed; everybody is done with the previous RoI (T, other buffer)
+    MI_TL_LAP(0);  // wait for the landing + barrier B1
     if (li + 1 < nlist) issue_loads(list[li + 1], buf ^ 1);
+    MI_TL_LAP(1);  // issue of the next RoI's pieces
     const char* blk = reinterpret_cast<const char*>(tab0 + buf * kTabDw);
     const float* wxt = reinterpret_cast<const float*>(blk + kBwdWx);
     const float* wyt = reinterpret_cast<const float*>(blk + kBwdWy);
@@ -1035,6 +1053,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
       }
     }
     __syncthreads();  // B2: T complete
+    MI_TL_LAP(2);  // pass 1 + barrier B2
 
     // ---- pass 2: this lane's pixel, all KC channels ----
     if (!(ablate & 2)) {
@@ -1056,8 +1075,16 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
         }
       }
     }
+    MI_TL_LAP(3);  // pass 2
   }
 
+#if MI_TUNING
+  if (timeline != nullptr && threadIdx.x == 0) {
+    long long* o = timeline + (long long)blockIdx.x * 8;
+    o[0] = tl_acc[0]; o[1] = tl_acc[1]; o[2] = tl_acc[2]; o[3] = tl_acc[3]; o[4] = tl_acc[4];
+    o[5] = clock64() - tl_start; o[6] = nlist; o[7] = nslices;
+  }
+#endif
   // ---- the tile leaves as 128-byte rows (NCHW) or as one 4*KC-byte run per pixel (channels-last) ----
   float acc[KC];
 #pragma unroll
@@ -1281,7 +1308,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
     roi_align_bwd_tiles<SR, KC, TH, A><<<grid, TH * 32, lds, stream>>>(                                              \
         top_grad, lv, ws, num_rois, batch, channels, aligned_height, aligned_width,                                   \
-        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, planned ? tiles : 0, plan_cap);                        \
+        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, planned ? tiles : 0, plan_cap MI_TL_ARG);              \
   } while (0)
 #define MI_LAUNCH_TILES_TH(SR, KC, TH)                                                                                \
   do {                                                                                                                \
