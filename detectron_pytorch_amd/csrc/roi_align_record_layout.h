@@ -32,7 +32,9 @@ constexpr int kBwdTabDw = (kBwdRf + 64) / 4;           // 352 dwords = 1408 B
 constexpr int kRecDwords = kRecB + kBwdTabDw;          // 752 dwords = 3008 B
 // after the records: one int4 per rank {x0, x1, batch*H + y0, batch*H + y1} = window of a backward-capable RoI
 // ({0x3fffffff, -1, ..} otherwise), read by the backward tiles to find the RoIs that touch them
-constexpr int kCounterDwords = 64;                     // counters in front of the records, zeroed by prepare
+constexpr int kCounterDwords = 512;                    // counters in front of the records, zeroed by prepare
+constexpr int kTicketStride = 64;                      // the forward's 8 work counters lie 256 B apart: atomics on one
+                                                       // 128-byte line serialise (~11 ns each, whichever word they hit)
 constexpr int kNoItem = 0x7fffffff;
 
 // forward LDS path / no such image / backward tile path / y and x tables valid

@@ -84,7 +84,9 @@ __device__ __forceinline__ int level_of(const int* __restrict__ levels, int i, c
   return levels != nullptr ? min(max(levels[i], 0), lv.count - 1) : 0;
 }
 
-// level (2 bits) | image (6 bits) | band (8) | x (16): RoIs of one level and image are contiguous in the sweep
+// level (2 bits) | image (6 bits) | band (8) | x (16): RoIs of one level and image are contiguous in the sweep.
+// (Round 5 measured "expensive RoIs first" -- a cost class in front of the key, each class swept on its own -- to shorten the
+// tail of the forward: the classes' windows no longer meet in L2, config 2 went 35.9 -> 40.4 us, channels-last 30.5 -> 44.6.)
 __device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int lvl, float spatial_scale, int height) {
   const float cy = (roi[2] + roi[4]) * 0.5f * spatial_scale, cx = (roi[1] + roi[3]) * 0.5f * spatial_scale;
   const int b = (lvl << 6) | min(max((int)roi[0], 0), 63);
@@ -100,7 +102,8 @@ roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels
                   int stage_px, int max_rows_tile, int bwd_tables, int channels, int* __restrict__ ws) {
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
-  if (blockIdx.x == 0 && threadIdx.x < kCounterDwords) ws[threadIdx.x] = 0;
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < kCounterDwords; i += 256) ws[i] = 0;
   // This wave's RoI: its five floats and its level are fetched FIRST (wave-uniform address -> scalar loads), so that
   // their latency passes under the key phase below instead of after the barrier.
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -336,95 +339,313 @@ __device__ __forceinline__ const float* lds_at(const float* base, int byte_off) 
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// roi_align_fwd_records: one workgroup per (rank, channel tile).  Data movement and arithmetic of
-// roi_align_fwd_tile.hip; its per-RoI prologue (geometry, tables, window) is replaced by one scalar load of the
-// record, and workgroups are dispatched in sweep order.
+// Forward over the records.  Two launch forms share the stage pieces below (window DMA, axis tables, border patch, bins,
+// tile store):
+//   roi_align_fwd_records   one workgroup per (rank, channel tile), dispatched in sweep order;
+//   roi_align_fwd_persist   a resident grid (LDS-limited slots x compute units) whose workgroups walk the items of
+//                           their XCD: item k + 1's record header is in SGPRs and its window pieces are issued BEFORE the
+//                           stores of item k, so the store drain, the record latency and the per-workgroup launch /
+//                           teardown of the per-item form disappear from the chain.  Every wave still does DMA -> bins ->
+//                           store (no roles on waves, no second window in LDS).
 // -------------------------------------------------------------------------------------------------------------------
+// What a workgroup needs of a record's header -- wave-uniform, fetched with scalar loads.
+struct FwdRec {
+  int flags, wx0, ww, nstages, gh, gw, r, lvl, height, width;
+  unsigned gmagic;        // 2^20 / (groups of 4 pixels per window row) + 1
+  uintptr_t img;          // address of channel 0 of the RoI's image in its level's map
+  int st_pp, st_row0, st_nrows;  // stage 0: ph0 | ph1 << 16, first window row, rows
+};
+__device__ __forceinline__ FwdRec fwd_load_rec(const int* __restrict__ records, int pos) {
+  const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)pos * kRecDwords);
+  FwdRec h;
+  h.flags = rec[0];
+  h.wx0 = rec[2];
+  h.ww = rec[3];
+  h.gmagic = (unsigned)rec[4];
+  h.nstages = rec[5];
+  h.gh = rec[6];
+  h.gw = rec[7];
+  h.r = rec[8];
+  h.lvl = rec[11];
+  h.st_pp = rec[12];
+  h.st_row0 = rec[13];
+  h.st_nrows = rec[14];
+  h.img = ((uintptr_t)(unsigned)rec[17] << 32) | (unsigned)rec[16];
+  h.height = rec[18];
+  h.width = rec[19];
+  return h;
+}
+
+// The window rows [row0, row0 + nrows) of this wave's kChPerWave channels -> LDS planes, lanes flattened over the
+// window's (row, group of 4 pixels): buffer_load_dwordx4 ... lds, a quarter of the DMA instructions of a pixel-per-lane
+// copy (neither side needs more than dword alignment) -- what the compute unit's address path charges for is
+// instructions (profiles/r04_records_timeline.txt).  NO branch around the pieces: a group that runs past the end of a map
+// row drags in the first pixels of the next row (or zeros behind the wave's channels: the descriptor ends with them),
+// which land in padding columns nobody reads -- except the column one past the map of a window that touches the right
+// edge, which fwd_patch_edge rewrites.  Rows past the map read the last row again through the clamp.
+// Config 2, alternating runs: 37.9 -> 37.1 us per call (two-image box head 69.3 -> 68.4, pyramid 67.0 -> 65.8): the
+// pieces still touch the same cache lines, so the gain is the instruction count only.
+template <int kChPerWave, int kPlane>
+__device__ __forceinline__ void fwd_issue_window(const FwdRec& h, int first_channel, unsigned plane0, int lane, int row0,
+                                                 int nrows) {
+  const unsigned plane_bytes = (unsigned)h.height * (unsigned)h.width * 4u;
+  const srd_t srd = make_srd(reinterpret_cast<const char*>(h.img) + (size_t)first_channel * plane_bytes,
+                             (unsigned)kChPerWave * plane_bytes);
+  const unsigned pitch_px = ((unsigned)h.ww + 3u) & ~3u;
+  const unsigned gpr = pitch_px >> 2, groups = (unsigned)nrows * gpr;
+  for (int kk = 0; kk * 64 < (int)groups; kk++) {
+    const unsigned g = (unsigned)(kk * 64 + lane);
+    const unsigned q = __umul24(g, h.gmagic) >> 20;  // g / gpr
+    const unsigned gc = g - __umul24(q, gpr);
+    const unsigned voff = (__umul24(min((unsigned)row0 + q, (unsigned)h.height - 1u), (unsigned)h.width) +
+                           (unsigned)h.wx0 + gc * 4u) * 4u;
+    if (g < groups) {
+#pragma unroll
+      for (int c = 0; c < kChPerWave; c++)
+        dma_dwordx4(srd, plane0 + (unsigned)(c * kPlane + kk * 256) * 4u, voff, (unsigned)c * plane_bytes);
+    }
+  }
+}
+
+// axis tables: record -> LDS (wave 0: y, wave 1: x)
+__device__ __forceinline__ void fwd_issue_tables(const int* __restrict__ records, int pos, int wave, int lane,
+                                                 TabEntry* tab, int nsy, int nsx) {
+  if (wave >= 2) return;
+  const int n = (wave == 0 ? nsy : nsx) * 4;
+  const srd_t tsrd = make_srd(records + (long long)pos * kRecDwords + (wave == 0 ? kRecY : kRecX), 4 * kMaxS * 4);
+  const unsigned dstl = lds_addr_uniform(tab + wave * kMaxS);
+  for (int kk = 0; kk * 64 < n; kk++) dma_dword(tsrd, dstl + (unsigned)kk * 256u, (unsigned)(kk * 64 + lane) * 4u, 0u);
+}
+
+// A window that ends one column past the map (a border sample's upper tap, weight 0: axis_taps): that column has to hold
+// the border pixel again -- the reference reads it twice -- not what followed it in memory.  Wave-uniform condition; the
+// caller puts a barrier behind it.
+template <int kCT, int kThreads, int kPlane>
+__device__ __forceinline__ bool fwd_patch_edge(const FwdRec& h, float* img, int tid, int nrows) {
+  if (h.wx0 + h.ww <= h.width) return false;
+  const int edge = h.width - 1 - h.wx0;  // window column of the map's last pixel
+  const int pitch_px = (h.ww + 3) & ~3;
+  for (int i = tid; i < kCT * nrows; i += kThreads) {
+    const int c = i / nrows, rr = i - c * nrows;
+    float* rowp = img + c * kPlane + rr * pitch_px;
+    rowp[edge + 1] = rowp[edge];
+  }
+  return true;
+}
+
+// Bins [pa, pb) x aligned_width of this lane's channel -> the LDS tile.  Half-wave = output column; taps of 4 bin rows in
+// flight before the first use; 0.25 * sum_iy (hy * R(y) + ly * R(y + 1)), R(row) = sum_ix (hx * F[x] + lx * F[x + 1]).
+template <int kSR, int kNSlots>
+__device__ __forceinline__ void fwd_bins(const TabEntry* ty, const TabEntry* tx, const float* img_c, float* tile_c,
+                                         int slot, int pa, int pb, int ph0, int base_off, int pitch, int aligned_width,
+                                         int gh, int gw) {
+  if (kSR > 0) {
+    constexpr int kS = kSR > 0 ? kSR : 1;
+    for (int pw = slot; pw < aligned_width; pw += kNSlots) {
+      float hx[kS], lx[kS];
+      unsigned xa[kS];
+#pragma unroll
+      for (int i = 0; i < kS; i++) {
+        const TabEntry ex = tx[pw * kS + i];
+        hx[i] = ex.hw;
+        lx[i] = ex.lw;
+        xa[i] = lds_addr_opaque(lds_at(img_c, ex.off - base_off));
+      }
+      auto rows = [&](int ph, auto kn) {
+        constexpr int kN = decltype(kn)::value;
+        float v[kN][kS][2][kS][2];
+        float wy[kN][kS][2];
+#pragma unroll
+        for (int b = 0; b < kN; b++) {
+#pragma unroll
+          for (int iy = 0; iy < kS; iy++) {
+            const TabEntry ey = ty[(ph + b) * kS + iy];
+            wy[b][iy][0] = ey.hw;
+            wy[b][iy][1] = ey.lw;
+#pragma unroll
+            for (int ix = 0; ix < kS; ix++) {
+              const unsigned a = xa[ix] + (unsigned)ey.off;
+              lds_pair(a, v[b][iy][0][ix][0], v[b][iy][0][ix][1]);
+              lds_pair(a + (unsigned)pitch, v[b][iy][1][ix][0], v[b][iy][1][ix][1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < kN; b++) {
+          float acc = 0.f;
+#pragma unroll
+          for (int iy = 0; iy < kS; iy++) {
+#pragma unroll
+            for (int kx = 0; kx < 2; kx++) {
+              float rsum = hx[0] * v[b][iy][kx][0][0];
+              rsum = __builtin_fmaf(lx[0], v[b][iy][kx][0][1], rsum);
+#pragma unroll
+              for (int ix = 1; ix < kS; ix++) {
+                rsum = __builtin_fmaf(hx[ix], v[b][iy][kx][ix][0], rsum);
+                rsum = __builtin_fmaf(lx[ix], v[b][iy][kx][ix][1], rsum);
+              }
+              acc = __builtin_fmaf(wy[b][iy][kx], rsum, acc);
+            }
+          }
+          tile_c[(ph + b - ph0) * aligned_width + pw] = acc;
+        }
+      };
+      int ph = pa;
+      for (; ph + 4 <= pb; ph += 4) rows(ph, std::integral_constant<int, 4>());
+      switch (pb - ph) {
+        case 3: rows(ph, std::integral_constant<int, 3>()); break;
+        case 2: rows(ph, std::integral_constant<int, 2>()); break;
+        case 1: rows(ph, std::integral_constant<int, 1>()); break;
+        default: break;
+      }
+    }
+  } else {
+    for (int pw = slot; pw < aligned_width; pw += kNSlots) {
+      for (int ph = pa; ph < pb; ph++) {
+        float acc = 0.f;
+        for (int iy = 0; iy < gh; iy++) {
+          const TabEntry ey = ty[ph * gh + iy];
+          float r0s = 0.f, r1s = 0.f;
+          for (int ix = 0; ix < gw; ix++) {
+            const TabEntry ex = tx[pw * gw + ix];
+            const float* a = lds_at(img_c, ey.off + ex.off - base_off);
+            const float* b = lds_at(a, pitch);
+            r0s = __builtin_fmaf(ex.hw, a[0], r0s);
+            r0s = __builtin_fmaf(ex.lw, a[1], r0s);
+            r1s = __builtin_fmaf(ex.hw, b[0], r1s);
+            r1s = __builtin_fmaf(ex.lw, b[1], r1s);
+          }
+          acc = __builtin_fmaf(ey.hw, r0s, acc);
+          acc = __builtin_fmaf(ey.lw, r1s, acc);
+        }
+        tile_c[(ph - ph0) * aligned_width + pw] = acc;
+      }
+    }
+  }
+}
+
+// LDS tile (kCT channels x nb bins, channel stride ts) -> out[r][c0 ..][ph0 * aligned_width ..]: contiguous 16-byte pieces
+// when the stage covers the RoI's whole [kCT][bins] block.
+template <int kCT, int kThreads>
+__device__ __forceinline__ void fwd_store(const float* tile, float* __restrict__ dst, int tid, int ph0, int nb, int ts,
+                                          int bins, int aligned_width) {
+  if (nb == bins && ts == nb && ((kCT * nb) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    // non-temporal: the pooled features are read next by another kernel, and a streaming store lets the workgroup's LDS go
+    // ~1 % earlier (38.55 -> 38.25 us per config-2 call, three alternating runs)
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < kCT * nb / 4; i += kThreads)
+      __builtin_nontemporal_store(reinterpret_cast<const v4f_t*>(tile)[i], reinterpret_cast<v4f_t*>(dst) + i);
+  } else {
+    float* gdst = dst + ph0 * aligned_width;
+    const unsigned nb_magic = (1u << 20) / (unsigned)nb + 1u;
+    for (int i = tid; i < kCT * nb; i += kThreads) {
+      const int c = (int)(((unsigned)i * nb_magic) >> 20), b = i - c * nb;
+      gdst[(long long)c * bins + b] = tile[c * ts + b];
+    }
+  }
+}
+
+// store instructions fwd_store issues in one wave (its first lane runs the most trips of the loop)
+template <int CT, int NT>
+__device__ __forceinline__ int fwd_store_count(const float* dst, int wave, int nb, int ts, int bins) {
+  const bool whole = nb == bins && ts == nb && ((CT * nb) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  const int n = whole ? CT * nb / 4 : CT * nb;
+  return n > wave * 64 ? (n - wave * 64 + NT - 1) / NT : 0;
+}
+
+__device__ __forceinline__ void wait_vmcnt_at_most(int n) {
+  // s_waitcnt takes an immediate; n is wave-uniform.  Waiting for MORE than asked (a smaller immediate) is always safe.
+  if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// A RoI the LDS image cannot serve (flagged by roi_align_prepare): zeros for a RoI of no image, otherwise the reference's
+// operation order straight from memory (bit-exact).
+template <int kCT, int kThreads>
+__device__ __forceinline__ void fwd_direct_item(const FwdRec& h, const LevelTable& lv, const float* __restrict__ rois,
+                                                float* __restrict__ dst, int tid, int c0, int channels,
+                                                int aligned_height, int aligned_width, int sampling_ratio) {
+  const int bins = aligned_height * aligned_width;
+  if (h.flags & kFlagZero) {
+    for (int i = tid; i < kCT * bins; i += kThreads) dst[i] = 0.f;
+    return;
+  }
+  const int height = h.height, width = h.width;
+  const RoiGeom g = roi_geometry(rois + (long long)h.r * 5, lv.scale[h.lvl], aligned_height, aligned_width, sampling_ratio);
+  const float* src = lv.feat[h.lvl] + ((long long)g.batch_ind * channels + c0) * height * width;
+  for (int i = tid; i < kCT * bins; i += kThreads) {
+    const int c = i / bins, bin = i - c * bins;
+    const int ph = bin / aligned_width, pw = bin - ph * aligned_width;
+    const float* plane = src + (long long)c * height * width;
+    float output_val = 0.f;
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const float y = sample_y(g, ph, iy);
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const float x = sample_x(g, pw, ix);
+        const Taps t = sample_taps(height, width, y, x);
+        float val = 0.f;
+        if (t.y_low >= 0) {
+          const float v1 = plane[t.y_low * width + t.x_low], v2 = plane[t.y_low * width + t.x_high];
+          const float v3 = plane[t.y_high * width + t.x_low], v4 = plane[t.y_high * width + t.x_high];
+          val = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t.w1, v1), __fmul_rn(t.w2, v2)), __fmul_rn(t.w3, v3)),
+                          __fmul_rn(t.w4, v4));
+        }
+        output_val = __fadd_rn(output_val, val);
+      }
+    }
+    dst[i] = output_val / g.count;
+  }
+}
+
+// One ticket of a work counter (agent scope, relaxed).  The address goes through an opaque per-lane zero: with a provably
+// wave-uniform address hipcc's atomic optimizer rewrites the instruction into "first lane adds popcount(exec), readfirstlane,
+// + lane prefix", and the readfirstlane waits for the return on the spot -- the caller wants the ~1 us of a device-scope
+// atomic under load to pass under its arithmetic, the wait at the first USE of the result.
+__device__ __forceinline__ int fetch_ticket(int* counter) {
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  return __hip_atomic_fetch_add(counter + z, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // kA > 0: aligned_height == aligned_width == kA at compile time (7: box head, 14: mask / keypoint heads).
-template <int kSR, int kCap, int kCTt, int kHalves, int kA = 0>
-__global__ void __launch_bounds__(kCTt * 8 * kHalves)
+template <int kSR, int kCap, int kA = 0>
+__global__ void __launch_bounds__(kCT * 8)
 roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
                       const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height_arg,
                       int aligned_width_arg, int sampling_ratio, int ablate_arg MI_TL_PARAM) {
   MI_STAMP(0);
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   const int ablate = MI_ABLATE(ablate_arg);
-  // kCTt channels per workgroup (32: half-waves own output columns; 16: quarter-waves do, twice as many workgroups
-  // fit a CU -- the per-workgroup chain record load -> DMA -> landing -> arithmetic -> store drain is latency, and
-  // what hides it is the number of workgroups in flight)
-  // kHalves = 2: twice the lanes per workgroup, the two halves take the upper / lower bin rows of a stage
-  constexpr int kCT = kCTt, kThreads = kCTt * 8 * kHalves, kChPerWave = kCT / (kThreads / 64);
+  constexpr int kChPerWave = kCT / (kThreads / 64);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kPlane = kCap | 1;
   constexpr int kTileWords = kCT * (kTileBins + 1);
-  struct {
-    TabEntry* tab;
-    float* tile;
-    float* img;
-  } s;
-  s.tab = reinterpret_cast<TabEntry*>(smem);
-  s.tile = reinterpret_cast<float*>(s.tab + 2 * kMaxS);
-  s.img = s.tile + kTileWords;
+  TabEntry* tab = reinterpret_cast<TabEntry*>(smem);
+  float* tile = reinterpret_cast<float*>(tab + 2 * kMaxS);
+  float* img = tile + kTileWords;
   const int tid = threadIdx.x;
   const int bins = aligned_height * aligned_width;
   const int tiles = channels / kCT;
   const int pos = blockIdx.x / tiles;
   const int c0 = (blockIdx.x - pos * tiles) * kCT;
   const int wave = uniform(tid >> 6), lane = tid & 63;
-  const int cl = tid % kCT, slot = (tid / kCT) & 7, half = tid / (kCT * 8);
-  const float* img_c = s.img + cl * kPlane;
+  const int cl = tid % kCT, slot = (tid / kCT) & 7;
   const int* __restrict__ records = ws + kCounterDwords;
-  const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)pos * kRecDwords);
-  const int flags = rec[0], wx0 = rec[2], ww = rec[3], nstages = rec[5];
-  const int rgh = rec[6], rgw = rec[7], r = rec[8], lvl = rec[11];
-  // address of channel 0 of the RoI's image and the size of its map: the record carries them, no indexed walk of the level
-  // table between the record and the first DMA
-  const uintptr_t img_base = ((uintptr_t)(unsigned)rec[17] << 32) | (unsigned)rec[16];
-  const int rec_h = rec[18], rec_w = rec[19];
-  const unsigned gmagic = (unsigned)rec[4];  // 2^20 / (groups of 4 pixels per window row) + 1
-  // the feature map of the RoI's level (one entry unless the call is an FPN-fused one)
-  const int height = rec_h, width = rec_w;
-  const unsigned plane_bytes = (unsigned)height * (unsigned)width * 4u;
-  float* __restrict__ dst = out + ((long long)r * channels + c0) * bins;
-  if (flags != 0x7fffffff) MI_STAMP(1);  // the record header has arrived
+  const FwdRec h = fwd_load_rec(records, pos);
+  float* __restrict__ dst = out + ((long long)h.r * channels + c0) * bins;
+  if (h.flags != 0x7fffffff) MI_STAMP(1);  // the record header has arrived
 #if MI_TUNING
   if (timeline != nullptr && threadIdx.x == 0)  // where it ran (XCC_ID, HW_ID) and how many stages
-    timeline[(long long)blockIdx.x * 8 + 7] = ((long long)nstages << 48) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+    timeline[(long long)blockIdx.x * 8 + 7] = ((long long)h.nstages << 48) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                               (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
-
-  if (!(flags & kFlagFast)) {
-    if (flags & kFlagZero) {
-      for (int i = tid; i < kCT * bins; i += kThreads) dst[i] = 0.f;
-      return;
-    }
-    const RoiGeom g = roi_geometry(rois + (long long)r * 5, lv.scale[lvl], aligned_height, aligned_width, sampling_ratio);
-    const float* src = lv.feat[lvl] + ((long long)g.batch_ind * channels + c0) * height * width;
-    for (int i = tid; i < kCT * bins; i += kThreads) {
-      const int c = i / bins, bin = i - c * bins;
-      const int ph = bin / aligned_width, pw = bin - ph * aligned_width;
-      const float* plane = src + (long long)c * height * width;
-      float output_val = 0.f;
-      for (int iy = 0; iy < g.grid_h; iy++) {
-        const float y = sample_y(g, ph, iy);
-        for (int ix = 0; ix < g.grid_w; ix++) {
-          const float x = sample_x(g, pw, ix);
-          const Taps t = sample_taps(height, width, y, x);
-          float val = 0.f;
-          if (t.y_low >= 0) {
-            const float v1 = plane[t.y_low * width + t.x_low], v2 = plane[t.y_low * width + t.x_high];
-            const float v3 = plane[t.y_high * width + t.x_low], v4 = plane[t.y_high * width + t.x_high];
-            val = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(t.w1, v1), __fmul_rn(t.w2, v2)), __fmul_rn(t.w3, v3)),
-                            __fmul_rn(t.w4, v4));
-          }
-          output_val = __fadd_rn(output_val, val);
-        }
-      }
-      dst[i] = output_val / g.count;
-    }
+  if (!(h.flags & kFlagFast)) {
+    fwd_direct_item<kCT, kThreads>(h, lv, rois, dst, tid, c0, channels, aligned_height, aligned_width, sampling_ratio);
     return;
   }
-
   {
     // Warm this XCD's L2 with the record a later workgroup of this XCD starts from: XCD x runs the ranks in order (block
     // 8 j + x pools rank j), ~96 at a time, and a record written by roi_align_prepare sits in the Infinity Cache at best.
@@ -434,182 +655,249 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     constexpr int kAhead = 64;
     const int ahead = pos + kAhead;
     if (wave == kThreads / 64 - 1 && ahead < num_rois && lane < 13)
-      dma_dword(make_srd(records + (long long)ahead * kRecDwords, 13 * 128), lds_addr_uniform(s.tile), (unsigned)lane * 128u, 0u);
+      dma_dword(make_srd(records + (long long)ahead * kRecDwords, 13 * 128), lds_addr_uniform(tile), (unsigned)lane * 128u, 0u);
   }
-  const srd_t srd = make_srd(reinterpret_cast<const char*>(img_base) + (size_t)(c0 + wave * kChPerWave) * plane_bytes,
-                             (unsigned)kChPerWave * plane_bytes);
-  const unsigned plane0 = lds_addr_uniform(s.img + wave * kChPerWave * kPlane);
-  // a window row lies in LDS on a pitch of whole 16-byte groups: the copy moves 4 pixels per lane
-  const unsigned pitch_px = ((unsigned)ww + 3u) & ~3u;
-  const int pitch = (int)pitch_px * 4;
-  const int gh = kSR > 0 ? kSR : rgh, gw = kSR > 0 ? kSR : rgw;
-  const TabEntry* ty = s.tab;
-  const TabEntry* tx = s.tab + kMaxS;
-
-  for (int k = 0; k < nstages; k++) {
-    const const_int_ptr st = k == 0 ? rec + 12 : rec + kRecStages + 4 * k;
-    const int pp = st[0], row0 = st[1], nrows = st[2];
+  const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kPlane);
+  const int pitch = ((h.ww + 3) & ~3) * 4;  // a window row lies in LDS on a pitch of whole 16-byte groups
+  const int gh = kSR > 0 ? kSR : h.gh, gw = kSR > 0 ? kSR : h.gw;
+  const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)pos * kRecDwords);
+  // Stages are pipelined inside the item (round 5, from the resident form below): the window pieces of stage k + 1 are issued
+  // BEFORE the tile of stage k is stored, and the landing wait is vmcnt(stores of stage k) -- window pieces are older than
+  // those stores and vmcnt retires in order, so the stores drain under the next stage's bins instead of in front of its copy.
+  int pp = h.st_pp, row0 = h.st_row0, nrows = h.st_nrows;
+  if (!(ablate & 1)) fwd_issue_window<kChPerWave, kPlane>(h, c0 + wave * kChPerWave, plane0, lane, row0, nrows);
+  fwd_issue_tables(records, pos, wave, lane, tab, aligned_height * gh, aligned_width * gw);
+  MI_STAMP(2);  // window and table pieces issued
+  int stores_out = 0;
+  for (int k = 0; k < h.nstages; k++) {
+    int n_pp = 0, n_row0 = 0, n_nrows = 0;
+    if (k + 1 < h.nstages) {  // the next stage's descriptor arrives under the bins
+      const const_int_ptr st = rec + kRecStages + 4 * (k + 1);
+      n_pp = st[0];
+      n_row0 = st[1];
+      n_nrows = st[2];
+    }
     const int ph0 = pp & 0xffff, ph1 = pp >> 16;
-    if (k > 0) __syncthreads();  // image and tile are reused
-    if (!(ablate & 1)) {
-      // lanes flattened over the window's (row, group of 4 pixels): buffer_load_dwordx4 ... lds, a quarter of the DMA
-      // instructions of a pixel-per-lane copy (neither side needs more than dword alignment) -- what the compute unit's
-      // address path charges for is instructions (profiles/r04_records_timeline.txt).  NO branch around the pieces: a
-      // group that runs past the end of a map row drags in the first pixels of the next row (or zeros behind the wave's
-      // channels), which land in padding columns nobody reads -- except the column one past the map of a window that touches
-      // the right edge, which is patched below.  Rows past the map read the last row again through the clamp.
-      // Config 2, alternating runs: 37.9 -> 37.1 us per call (two-image box head 69.3 -> 68.4, pyramid 67.0 -> 65.8): the
-      // pieces still touch the same cache lines, so the gain is the instruction count only.  (Round 4 first measured this
-      // with a run-time choice between 16-byte and 4-byte pieces per window and found it slower: the branch around the
-      // pieces cost more than the pieces saved.)
-      const unsigned gpr = pitch_px >> 2, groups = (unsigned)nrows * gpr;
-      for (int kk = 0; kk * 64 < (int)groups; kk++) {
-        const unsigned g = (unsigned)(kk * 64 + lane);
-        const unsigned q = __umul24(g, gmagic) >> 20;  // g / gpr
-        const unsigned gc = g - __umul24(q, gpr);
-        const unsigned voff = (__umul24(min((unsigned)row0 + q, (unsigned)height - 1u), (unsigned)width) + (unsigned)wx0 +
-                               gc * 4u) * 4u;
-        if (g < groups) {
-#pragma unroll
-          for (int c = 0; c < kChPerWave; c++)
-            dma_dwordx4(srd, plane0 + (unsigned)(c * kPlane + kk * 256) * 4u, voff, (unsigned)c * plane_bytes);
-        }
-      }
-    }
-    if (k == 0 && wave < 2) {  // axis tables: record -> LDS (wave 0: y, wave 1: x); every variant has >= 2 waves
-      const int n = (wave == 0 ? aligned_height * gh : aligned_width * gw) * 4;
-      const srd_t tsrd = make_srd(records + (long long)pos * kRecDwords + (wave == 0 ? kRecY : kRecX), 4 * kMaxS * 4);
-      const unsigned dstl = lds_addr_uniform(s.tab + wave * kMaxS);
-      for (int kk = 0; kk * 64 < n; kk++) dma_dword(tsrd, dstl + (unsigned)kk * 256u, (unsigned)(kk * 64 + lane) * 4u, 0u);
-    }
-    if (k == 0) MI_STAMP(2);  // window and table pieces issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wait_vmcnt_at_most((ablate & 16) ? 0 : stores_out);
+    __syncthreads();  // this stage's window has landed; the previous tile is out of LDS
     if (k == 0) MI_STAMP(3);  // landed, published
-    if (wx0 + ww > width) {
-      // the window ends one column past the map (a border sample's upper tap, weight 0: axis_taps): that column has to hold
-      // the border pixel again -- the reference reads it twice -- not what followed it in memory
-      const int edge = width - 1 - wx0;  // window column of the map's last pixel
-      for (int i = tid; i < kCT * nrows; i += kThreads) {
-        const int c = i / nrows, rr = i - c * nrows;
-        float* rowp = s.img + c * kPlane + rr * (int)pitch_px;
-        rowp[edge + 1] = rowp[edge];
-      }
-      __syncthreads();
-    }
-
-    const int base_off = row0 * pitch;
+    if (fwd_patch_edge<kCT, kThreads, kPlane>(h, img, tid, nrows)) __syncthreads();
     const int nb = (ph1 - ph0) * aligned_width;
     const int ts = nb | 1;
-    // this half's share of the stage's bin rows
-    const int phm = ph0 + (ph1 - ph0 + kHalves - 1) / kHalves;
-    const int pa = half == 0 ? ph0 : phm, pb = (kHalves == 1 || half == 1) ? ph1 : phm;
-    if (ablate & 2) {
-    } else if (kSR > 0) {
-      constexpr int kS = kSR > 0 ? kSR : 1;
-      for (int pw = slot; pw < aligned_width; pw += kSlots) {
-        float hx[kS], lx[kS];
-        unsigned xa[kS];
-#pragma unroll
-        for (int i = 0; i < kS; i++) {
-          const TabEntry ex = tx[pw * kS + i];
-          hx[i] = ex.hw;
-          lx[i] = ex.lw;
-          xa[i] = lds_addr_opaque(lds_at(img_c, ex.off - base_off));
-        }
-        auto rows = [&](int ph, auto kn) {
-          constexpr int kN = decltype(kn)::value;
-          float v[kN][kS][2][kS][2];
-          float wy[kN][kS][2];
-#pragma unroll
-          for (int b = 0; b < kN; b++) {
-#pragma unroll
-            for (int iy = 0; iy < kS; iy++) {
-              const TabEntry ey = ty[(ph + b) * kS + iy];
-              wy[b][iy][0] = ey.hw;
-              wy[b][iy][1] = ey.lw;
-#pragma unroll
-              for (int ix = 0; ix < kS; ix++) {
-                const unsigned a = xa[ix] + (unsigned)ey.off;
-                lds_pair(a, v[b][iy][0][ix][0], v[b][iy][0][ix][1]);
-                lds_pair(a + (unsigned)pitch, v[b][iy][1][ix][0], v[b][iy][1][ix][1]);
-              }
-            }
-          }
-#pragma unroll
-          for (int b = 0; b < kN; b++) {
-            float acc = 0.f;
-#pragma unroll
-            for (int iy = 0; iy < kS; iy++) {
-#pragma unroll
-              for (int kx = 0; kx < 2; kx++) {
-                float rsum = hx[0] * v[b][iy][kx][0][0];
-                rsum = __builtin_fmaf(lx[0], v[b][iy][kx][0][1], rsum);
-#pragma unroll
-                for (int ix = 1; ix < kS; ix++) {
-                  rsum = __builtin_fmaf(hx[ix], v[b][iy][kx][ix][0], rsum);
-                  rsum = __builtin_fmaf(lx[ix], v[b][iy][kx][ix][1], rsum);
-                }
-                acc = __builtin_fmaf(wy[b][iy][kx], rsum, acc);
-              }
-            }
-            s.tile[cl * ts + (ph + b - ph0) * aligned_width + pw] = acc;
-          }
-        };
-        int ph = pa;
-        for (; ph + 4 <= pb; ph += 4) rows(ph, std::integral_constant<int, 4>());
-        switch (pb - ph) {
-          case 3: rows(ph, std::integral_constant<int, 3>()); break;
-          case 2: rows(ph, std::integral_constant<int, 2>()); break;
-          case 1: rows(ph, std::integral_constant<int, 1>()); break;
-          default: break;
-        }
-      }
-    } else {
-      for (int pw = slot; pw < aligned_width; pw += kSlots) {
-        for (int ph = pa; ph < pb; ph++) {
-          float acc = 0.f;
-          for (int iy = 0; iy < gh; iy++) {
-            const TabEntry ey = ty[ph * gh + iy];
-            float r0s = 0.f, r1s = 0.f;
-            for (int ix = 0; ix < gw; ix++) {
-              const TabEntry ex = tx[pw * gw + ix];
-              const float* a = lds_at(img_c, ey.off + ex.off - base_off);
-              const float* b = lds_at(a, pitch);
-              r0s = __builtin_fmaf(ex.hw, a[0], r0s);
-              r0s = __builtin_fmaf(ex.lw, a[1], r0s);
-              r1s = __builtin_fmaf(ex.hw, b[0], r1s);
-              r1s = __builtin_fmaf(ex.lw, b[1], r1s);
-            }
-            acc = __builtin_fmaf(ey.hw, r0s, acc);
-            acc = __builtin_fmaf(ey.lw, r1s, acc);
-          }
-          s.tile[cl * ts + (ph - ph0) * aligned_width + pw] = acc;
-        }
-      }
-    }
+    if (!(ablate & 2))
+      fwd_bins<kSR, kSlots>(tab, tab + kMaxS, img + cl * kPlane, tile + cl * ts, slot, ph0, ph1, ph0, row0 * pitch, pitch,
+                            aligned_width, gh, gw);
     MI_STAMP(4);  // this wave's bins are in the tile
-    __syncthreads();
+    __syncthreads();  // the tile is complete, the image is free
     MI_STAMP(5);
-    float* gdst = dst + ph0 * aligned_width;
-    if (ablate & 4) {
-    } else if (nb == bins && ts == nb && ((kCT * nb) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-      const float4* t4 = reinterpret_cast<const float4*>(s.tile);
-      float4* d4 = reinterpret_cast<float4*>(dst);
-      // non-temporal: the pooled features are read next by another kernel, and a streaming store lets the workgroup's LDS go
-      // ~1 % earlier (38.55 -> 38.25 us per config-2 call, three alternating runs)
-      typedef float v4f_t __attribute__((ext_vector_type(4)));
-      for (int i = tid; i < kCT * nb / 4; i += kThreads)
-        __builtin_nontemporal_store(reinterpret_cast<const v4f_t*>(t4)[i], reinterpret_cast<v4f_t*>(d4) + i);
-    } else {
-      const unsigned nb_magic = (1u << 20) / (unsigned)nb + 1u;
-      for (int i = tid; i < kCT * nb; i += kThreads) {
-        const int c = (int)(((unsigned)i * nb_magic) >> 20), b = i - c * nb;
-        gdst[(long long)c * bins + b] = s.tile[c * ts + b];
-      }
+    if (k + 1 < h.nstages && !(ablate & 1))
+      fwd_issue_window<kChPerWave, kPlane>(h, c0 + wave * kChPerWave, plane0, lane, n_row0, n_nrows);
+    stores_out = 0;
+    if (!(ablate & 4)) {
+      fwd_store<kCT, kThreads>(tile, dst, tid, ph0, nb, ts, bins, aligned_width);
+      stores_out = fwd_store_count<kCT, kThreads>(dst, wave, nb, ts, bins);
     }
     MI_STAMP(6);  // stores issued
+    pp = n_pp;
+    row0 = n_row0;
+    nrows = n_nrows;
   }
+}
+
+// roi_align_fwd_persist: the resident form.  Items = (rank, channel tile), item i -> tile i % tiles, rank i / tiles; the
+// workgroup with blockIdx b owns items b and b + gridDim (no ticket needed for its first two), every further item is a
+// ticket of the counter of its "virtual XCD" b % 8 (ws[(b % 8) * kTicketStride], zeroed by roi_align_prepare): item = 2 * gridDim +
+// ticket * 8 + b % 8, so that with 8 channel tiles a workgroup keeps its tile and one XCD's L2 serves one 32-channel slab,
+// ranks in sweep order.  Three items are in flight per workgroup:
+//     k      its window is in LDS (or landing), its record front (header, stages, y / x tables) in rec[k & 1]
+//     k + 1  its record front is landing in rec[(k + 1) & 1] (LDS-DMA, issued a whole item before its first use: no scalar
+//            load, no record latency anywhere in the steady state)
+//     k + 2  its ticket is in flight (wave 0; the atomic returns under the bins of k)
+// Per unit (= one stage of one item):
+//     s_waitcnt vmcnt(stores of the previous unit); barrier    window pieces are older than those stores and vmcnt retires
+//                                                              in order: the window has landed, the stores may still drain
+//     bins -> LDS tile; barrier                                image and tables are free
+//     record front of k + 2, window pieces of the NEXT unit    <- they land while ...
+//     the tile is stored                                       <- ... the stores of this unit drain, under the next bins
+// One window in LDS, one tile, two barriers per unit: the same instructions per byte as the per-item kernel.
+// Tuning builds: wave 0 sums clock64() differences per phase (tools/timeline_persist.py); MI_ROI_ALIGN_ABLATE bit 8 replaces
+// the tickets by a static stride, bit 16 waits for everything (vmcnt(0)) at the top of a unit.
+constexpr int kRecFront = (kRecX + 4 * kMaxS + 3) & ~3;  // dwords of a record the forward needs: header, stages, y, x tables
+
+// the record front of rank `pos` -> LDS, as it lies in memory (16-byte pieces; waves 0 and 1)
+__device__ __forceinline__ void fwd_issue_record(const int* __restrict__ records, int pos, int wave, int lane, int* dst) {
+  constexpr int kPieces = kRecFront / 4;  // 16-byte pieces
+  if (wave * 64 < kPieces && wave * 64 + lane < kPieces)
+    dma_dwordx4(make_srd(records + (long long)pos * kRecDwords, kRecFront * 4), lds_addr_uniform(dst) + (unsigned)wave * 1024u,
+                (unsigned)(wave * 64 + lane) * 16u, 0u);
+}
+// header of a record front in LDS -> SGPRs: one ds_read per lane, the fields by v_readlane
+__device__ __forceinline__ FwdRec fwd_rec_from_lds(const int* rec, int lane) {
+  const int v = rec[lane < kRecHeader ? lane : 0];
+  FwdRec h;
+  h.flags = __builtin_amdgcn_readlane(v, 0);
+  h.wx0 = __builtin_amdgcn_readlane(v, 2);
+  h.ww = __builtin_amdgcn_readlane(v, 3);
+  h.gmagic = (unsigned)__builtin_amdgcn_readlane(v, 4);
+  h.nstages = __builtin_amdgcn_readlane(v, 5);
+  h.gh = __builtin_amdgcn_readlane(v, 6);
+  h.gw = __builtin_amdgcn_readlane(v, 7);
+  h.r = __builtin_amdgcn_readlane(v, 8);
+  h.lvl = __builtin_amdgcn_readlane(v, 11);
+  h.st_pp = __builtin_amdgcn_readlane(v, 12);
+  h.st_row0 = __builtin_amdgcn_readlane(v, 13);
+  h.st_nrows = __builtin_amdgcn_readlane(v, 14);
+  h.img = ((uintptr_t)(unsigned)__builtin_amdgcn_readlane(v, 17) << 32) | (unsigned)__builtin_amdgcn_readlane(v, 16);
+  h.height = __builtin_amdgcn_readlane(v, 18);
+  h.width = __builtin_amdgcn_readlane(v, 19);
+  return h;
+}
+
+template <int kSR, int kCap, int kA = 0>
+__global__ void __launch_bounds__(kCT * 8)
+roi_align_fwd_persist(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out, int* __restrict__ ws,
+                      int num_rois, int batch, int channels, int aligned_height_arg, int aligned_width_arg,
+                      int sampling_ratio, int ablate_arg MI_TL_PARAM) {
+  const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
+  const int ablate = MI_ABLATE(ablate_arg);
+  constexpr int kChPerWave = kCT / (kThreads / 64);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kPlane = kCap | 1;
+  constexpr int kTileWords = kCT * (kTileBins + 1);
+  int* recbuf = reinterpret_cast<int*>(smem);                    // [2][kRecFront]
+  float* tile = reinterpret_cast<float*>(recbuf + 2 * kRecFront);
+  float* img = tile + kTileWords;
+  int* ctl = reinterpret_cast<int*>(img + kCT * kPlane);  // [0]: the item after next, handed from wave 0 to the workgroup
+  const int tid = threadIdx.x;
+  const int bins = aligned_height * aligned_width;
+  const int tiles = channels / kCT;
+  const int total = num_rois * tiles, grid = (int)gridDim.x;
+  const int wave = uniform(tid >> 6), lane = tid & 63;
+  const int cl = tid % kCT, slot = (tid / kCT) & 7;
+  const int* __restrict__ records = ws + kCounterDwords;
+  const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kPlane);
+  const int vx = (int)(blockIdx.x & 7);
+#if MI_TUNING
+  long long tl_t = clock64(), tl_acc[5] = {0, 0, 0, 0, 0};
+  const long long tl_start = tl_t;
+  int tl_units = 0, tl_items = 0;
+#define MI_PL_LAP(k)                          \
+  do {                                        \
+    const long long tl_now = clock64();       \
+    tl_acc[k] += tl_now - tl_t;               \
+    tl_t = tl_now;                            \
+  } while (0)
+#else
+#define MI_PL_LAP(k) \
+  do {               \
+  } while (0)
+#endif
+
+  int cur_item = (int)blockIdx.x, nxt_item = cur_item + grid;
+  if (cur_item >= total) return;
+  int par = 0;  // rec[par]: the current item's record front
+  fwd_issue_record(records, cur_item / tiles, wave, lane, recbuf);
+  if (nxt_item < total) fwd_issue_record(records, nxt_item / tiles, wave, lane, recbuf + kRecFront);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  FwdRec cur = fwd_rec_from_lds(recbuf, lane);
+  int c0 = (cur_item % tiles) * kCT;
+  int stage = 0, pp = cur.st_pp, row0 = cur.st_row0, nrows = cur.st_nrows;
+  if ((cur.flags & kFlagFast) && !(ablate & 1))
+    fwd_issue_window<kChPerWave, kPlane>(cur, c0 + wave * kChPerWave, plane0, lane, row0, nrows);
+  int ticket = 0;      // wave 0, lane 0: the returned ticket of the item after next
+  int stores_out = 0;  // store instructions this wave issued behind its last window piece
+  for (;;) {
+    const bool fast = (cur.flags & kFlagFast) != 0;
+    const bool last = !fast || stage + 1 >= cur.nstages;
+    const int* rec = recbuf + par * kRecFront;
+    if (ablate & 16) stores_out = 0;
+    wait_vmcnt_at_most(stores_out);
+    __syncthreads();  // B1: this unit's window has landed (and the next item's record front); the previous tile is out of LDS
+    MI_PL_LAP(0);
+    if (stage == 0 && wave == 0 && nxt_item < total && !(ablate & 8)) {
+      if (lane == 0) ticket = fetch_ticket(ws + vx * kTicketStride);
+    }
+    const int ph0 = pp & 0xffff, ph1 = pp >> 16;
+    const int nb = (ph1 - ph0) * aligned_width;
+    const int ts = nb | 1;
+    float* __restrict__ dst = out + ((long long)cur.r * channels + c0) * bins;
+    if (fast) {
+      const int pitch = ((cur.ww + 3) & ~3) * 4;
+      if (fwd_patch_edge<kCT, kThreads, kPlane>(cur, img, tid, nrows)) __syncthreads();
+      const TabEntry* ty = reinterpret_cast<const TabEntry*>(rec + kRecY);
+      const TabEntry* tx = reinterpret_cast<const TabEntry*>(rec + kRecX);
+      if (!(ablate & 2))
+        fwd_bins<kSR, kSlots>(ty, tx, img + cl * kPlane, tile + cl * ts, slot, ph0, ph1, ph0, row0 * pitch, pitch,
+                              aligned_width, kSR > 0 ? kSR : cur.gh, kSR > 0 ? kSR : cur.gw);
+    } else {
+      fwd_direct_item<kCT, kThreads>(cur, lv, rois, dst, tid, c0, channels, aligned_height, aligned_width, sampling_ratio);
+    }
+    if (last && wave == 0) {
+      int nn = kNoItem;
+      if (nxt_item < total) nn = (ablate & 8) ? nxt_item + grid : 2 * grid + uniform(ticket) * 8 + vx;  // waits for the atomic
+      if (lane == 0) ctl[0] = nn;
+    }
+    MI_PL_LAP(1);
+    __syncthreads();  // B2: the tile is complete; image and tables are free
+    MI_PL_LAP(2);
+    int nn_item = kNoItem;
+    FwdRec nxt = cur;
+    if (last) {
+      nn_item = uniform(ctl[0]);
+      // the record front of the item after next replaces this item's (its tables are done with)
+      if (nn_item < total) fwd_issue_record(records, nn_item / tiles, wave, lane, recbuf + par * kRecFront);
+      if (nxt_item < total) {
+        nxt = fwd_rec_from_lds(recbuf + (par ^ 1) * kRecFront, lane);
+        if ((nxt.flags & kFlagFast) && !(ablate & 1))
+          fwd_issue_window<kChPerWave, kPlane>(nxt, (nxt_item % tiles) * kCT + wave * kChPerWave, plane0, lane, nxt.st_row0,
+                                               nxt.st_nrows);
+      }
+    } else {
+      pp = uniform(rec[kRecStages + 4 * (stage + 1)]);
+      row0 = uniform(rec[kRecStages + 4 * (stage + 1) + 1]);
+      nrows = uniform(rec[kRecStages + 4 * (stage + 1) + 2]);
+      if (!(ablate & 1)) fwd_issue_window<kChPerWave, kPlane>(cur, c0 + wave * kChPerWave, plane0, lane, row0, nrows);
+    }
+    MI_PL_LAP(3);
+    // ... then this unit's tile leaves, draining while they land and while the next bins run
+    stores_out = 0;
+    if (fast && !(ablate & 4)) {
+      fwd_store<kCT, kThreads>(tile, dst, tid, ph0, nb, ts, bins, aligned_width);
+      stores_out = fwd_store_count<kCT, kThreads>(dst, wave, nb, ts, bins);
+    }
+    MI_PL_LAP(4);
+#if MI_TUNING
+    tl_units++;
+#endif
+    if (!last) {
+      stage++;
+      continue;
+    }
+#if MI_TUNING
+    tl_items++;
+#endif
+    if (nxt_item >= total) break;
+    cur = nxt;
+    cur_item = nxt_item;
+    nxt_item = nn_item;
+    c0 = (cur_item % tiles) * kCT;
+    stage = 0;
+    pp = cur.st_pp;
+    row0 = cur.st_row0;
+    nrows = cur.st_nrows;
+    par ^= 1;
+  }
+#if MI_TUNING
+  if (timeline != nullptr && threadIdx.x == 0) {
+    long long* o = timeline + (long long)blockIdx.x * 8;
+    o[0] = tl_acc[0]; o[1] = tl_acc[1]; o[2] = tl_acc[2]; o[3] = tl_acc[3]; o[4] = tl_acc[4];
+    o[5] = clock64() - tl_start;
+    o[6] = ((long long)tl_items << 32) | (unsigned)tl_units;
+    o[7] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
+#endif
+#undef MI_PL_LAP
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -1184,7 +1472,8 @@ roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__
 }
 
 size_t records_lds_bytes(int cap, int ct) {
-  return 2 * kMaxS * sizeof(TabEntry) + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4;
+  // the resident form holds two record fronts (the per-item form: the y / x tables only) and a control word
+  return (size_t)2 * kRecFront * 4 + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4 + 16;
 }
 
 int launch_prepare(const float* rois, const int* levels, int* ws, int batch, const LevelTable& lv, int num_rois,
@@ -1201,6 +1490,19 @@ int launch_prepare(const float* rois, const int* levels, int* ws, int batch, con
 long long* g_records_timeline = nullptr;
 #endif
 
+// compute units of the current device (the resident grid of roi_align_fwd_persist); asked once
+int compute_units() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    (void)hipGetLastError();
+    return cus;
+  }();
+  return n;
+}
+
 template <int kCap>
 int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float* output, int* ws, int batch,
                int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio, bool bwd_tables,
@@ -1208,16 +1510,40 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
   int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio, kCap,
                           bwd_tables, stream, channels);
   if (rc != MI_OK) return rc;
+  const size_t lds = records_lds_bytes(kCap, kCT);
+  const int items = num_rois * (channels / kCT);
+  // resident form: as many workgroups as the LDS lets live on the chip at once (a multiple of 8: blockIdx % 8 is the XCD)
+  int slots = tuning().fwd_slots > 0 ? tuning().fwd_slots : (int)((160 * 1024) / lds);
+  if (slots < 1) slots = 1;
+  int resident = (compute_units() * slots) & ~7;
+  if (resident > ((items + 7) & ~7)) resident = (items + 7) & ~7;
+  // Which form: the resident one where every item has several stages by construction (more bins than the LDS tile holds:
+  // the 14 x 14 mask / keypoint heads), the per-item one otherwise.  Measured on one box (tools/fwd_ab.py, us per call,
+  // per-item / resident): config 2 34.8 / 39.3, 1024 RoIs on two images 58.0 / 63.4, a step's box RoIs over the pyramid
+  // 68.9 / 74.3, 128 RoIs x 14 x 14 32.5 / 30.7.  The resident form's unit chain is 11 % shorter (profiles/
+  // r05_persist_timeline.txt), but a workgroup is committed to its next two items, and behind the last ticket that costs
+  // a tail of ~1.5 items (8-10 us at 7 x 7) where the hardware's dispatch of 4096 small workgroups leaves ~half an item.
+  // MI_ROI_ALIGN_FWD_PERSIST=0 / 1 forces a form.
+  const int want = tuning().fwd_persist;
+  const bool persist = resident >= 8 && (want == 1 || (want < 0 && aligned_height * aligned_width > kTileBins));
   // the LDS images of MI_ROI_ALIGN_CAP >= 448 exceed the 64 KB a kernel may ask for without opting in
 #define MI_LAUNCH_REC(SR, A)                                                                                          \
   do {                                                                                                                \
-    if (records_lds_bytes(kCap, kCT) > 64 * 1024)                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_records<SR, kCap, kCT, 1, A>),          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)records_lds_bytes(kCap, kCT));       \
-    roi_align_fwd_records<SR, kCap, kCT, 1, A>                                                                        \
-        <<<num_rois * (channels / kCT), kCT * 8, records_lds_bytes(kCap, kCT), stream>>>(                             \
-            lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio,           \
-            tuning().ablate MI_TL_ARG);                                                                                         \
+    if (persist) {                                                                                                    \
+      if (lds > 64 * 1024)                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_persist<SR, kCap, A>),                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+      roi_align_fwd_persist<SR, kCap, A><<<resident, kThreads, lds, stream>>>(                                        \
+          lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio,             \
+          tuning().ablate MI_TL_ARG);                                                                                 \
+    } else {                                                                                                          \
+      if (lds > 64 * 1024)                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_records<SR, kCap, A>),                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+      roi_align_fwd_records<SR, kCap, A><<<items, kThreads, lds, stream>>>(                                           \
+          lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio,             \
+          tuning().ablate MI_TL_ARG);                                                                                 \
+    }                                                                                                                 \
   } while (0)
   const int a = aligned_height == aligned_width ? aligned_height : 0;
   if (sampling_ratio == 2 && kCap == 336 && a == 7)
@@ -1229,7 +1555,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
   else
     MI_LAUNCH_REC(0, 0);
 #undef MI_LAUNCH_REC
-  return check_launch("roi_align_fwd_records");
+  return check_launch(persist ? "roi_align_fwd_persist" : "roi_align_fwd_records");
 }
 
 }  // namespace
