@@ -9,12 +9,14 @@ constexpr int kMaxS = 32;                  // samples per axis on the fast path
 constexpr int kMaxStages = 32;             // == max aligned_height on the fast path
 
 // ---- per-RoI record (dwords), stored at the RoI's rank along the sweep ---------------------------------------------
-constexpr int kRecHeader = 24;  // [0] flags [1] batch_ind [2] wx0 [3] ww [4] magic [5] nstages [6] gh [7] gw [8] roi
+constexpr int kRecHeader = 24;  // [0] flags [1] batch_ind [2] wx0 [3] ww [4] 2^20 / ((ww + 3) / 4) + 1 (divides a lane index by the 16-byte
+                                // groups per window row) [5] nstages [6] gh [7] gw [8] roi
                                 // [9] wy0 [10] wy1 (last window row) [11] level [12..15] stage 0
                                 // [16..17] address of channel 0 of the RoI's image in its level's map (forward calls)
                                 // [18] height [19] width of that map [20..23] spare
 constexpr int kRecStages = kRecHeader;                 // kMaxStages x {ph0 | ph1 << 16, row0, nrows, 0}
-constexpr int kRecY = kRecStages + 4 * kMaxStages;     // kMaxS x {row_lo * ww * 4, hw / count, lw / count, row_lo}
+constexpr int kRecY = kRecStages + 4 * kMaxStages;     // kMaxS x {row_lo * ((ww + 3) & ~3) * 4 (the NCHW forward's LDS row
+                                                       // pitch), hw / count, lw / count, row_lo}
 constexpr int kRecX = kRecY + 4 * kMaxS;               // kMaxS x {(col_lo - wx0) * 4, hw, lw, col_lo}
 constexpr int kMaxWin = 63;                            // window rows / columns the backward tables cover
 // backward block: the weights of the tile kernel's two passes, merged per window column / row by roi_align_prepare.
@@ -29,12 +31,19 @@ constexpr int kBwdPy = kBwdPx + kBwdEnt;               // u8 ph of entry k
 constexpr int kBwdCf = kBwdPy + kBwdEnt;               // u8 cf[64]: first entry of window column c (cf[ww] = number of entries)
 constexpr int kBwdRf = kBwdCf + 64;                    // u8 rf[64]: first entry of window row r
 constexpr int kBwdTabDw = (kBwdRf + 64) / 4;           // 352 dwords = 1408 B
-constexpr int kRecDwords = kRecB + kBwdTabDw;          // 752 dwords = 3008 B
+constexpr int kRecDwords = kRecB + kBwdTabDw;          // 760 dwords = 3040 B
+static_assert(kRecDwords % 4 == 0 && kRecB % 4 == 0, "records and their backward block are fetched in 16-byte pieces");
 // after the records: one int4 per rank {x0, x1, batch*H + y0, batch*H + y1} = window of a backward-capable RoI
 // ({0x3fffffff, -1, ..} otherwise), read by the backward tiles to find the RoIs that touch them
-constexpr int kCounterDwords = 512;                    // counters in front of the records, zeroed by prepare
-constexpr int kTicketStride = 64;                      // the forward's 8 work counters lie 256 B apart: atomics on one
-                                                       // 128-byte line serialise (~11 ns each, whichever word they hit)
+// counters in front of the records, zeroed by roi_align_prepare.  Every live counter has a 128-byte line to itself: device-
+// scope atomics on one line serialise at ~11 ns apiece whichever word they hit (round 5: eight ticket words in one line made
+// the resident forward 20 us slower).
+constexpr int kCounterDwords = 1024;
+constexpr int kTicketStride = 64;                      // resident forward: work counter of virtual XCD v at [v * 64], v < 8
+constexpr int kBwdClasses = 6;                         // planned backward: cost classes of the tile entries
+constexpr int kBwdCounterStride = 32;
+constexpr int kBwdBucket = 512;                        // [kBwdBucket + 32 c]: entries filed in class c (roi_align_bwd_plan adds,
+                                                       // roi_align_bwd_tiles reads, roi_align_bwd_slow zeroes for the next call)
 constexpr int kNoItem = 0x7fffffff;
 
 // forward LDS path / no such image / backward tile path / y and x tables valid

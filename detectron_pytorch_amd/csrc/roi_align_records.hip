@@ -937,19 +937,45 @@ struct BwdLds {
   static constexpr int kGWords = KC * kTileBins * 4;               // g block: up to 224 bins per channel
 };
 
-// roi_align_bwd_plan: one 1024-lane workgroup per tile, in front of roi_align_bwd_tiles when the caller's workspace has
-// room for the plan (roi_align_bwd_workspace_bytes).  It finds the RoIs whose window touches the tile ONCE (the tile kernel
-// used to repeat the scan in each of its channel groups) and leaves their ranks and their number in the workspace; the
-// tile kernel then cuts long lists into slices.  Why slices: the RoIs of a training step cluster on the ground-truth boxes (a few 16 x 32
-// tiles of P4 see 100-200 of the 1024 RoIs, most tiles none), and one workgroup per tile then works for 300 us while
-// the rest of the chip is idle.
-constexpr int kPlanThreads = 1024, kPlanWaves = kPlanThreads / 64;
+// roi_align_bwd_plan: one 256-lane workgroup per tile, in front of roi_align_bwd_tiles when the caller's workspace has
+// room for the plan (roi_align_bwd_workspace_bytes).  It finds the RoIs whose window touches the tile ONCE (the unplanned
+// tile kernel repeats the scan in each of its channel groups), leaves their ranks and their number in the workspace, and
+// files the tile's work as ENTRIES {tile, first, length, slices} in one of six cost classes:
+//   class 0   the slices of a list longer than `slice_len` (even slices of <= slice_len RoIs) -- while the budget of extra
+//             entries lasts (sum of slices - 1 <= `extra`: the tile kernel's grid is tiles + extra rows); then whole
+//   class 1-4 whole lists of >= 20, 10-19, 5-9, 1-4 RoIs
+//   class 5   (OVERWRITE contract only) tiles without RoIs: their item stores zeros
+// A class is an array filled through one atomic counter (ws[kBwdBucket + 32 c]: one 128-byte line each -- atomics on one line
+// serialise at ~11 ns apiece); the order inside a class is the order of arrival and only decides WHO sums a tile, never
+// in which order (a list is summed in rank order by one workgroup, or slice-wise with atomics as before).  The resident
+// tile kernel walks class 0, 1, ... 5: longest processing time first, so that what is left for the end of the launch are
+// the one-visit items and the zero stores.  (Rounds 3-4 built the same table with a single sorting workgroup in a launch
+// of its own -- roi_align_bwd_items, 5.6 us + a launch boundary per call -- and dispatched one workgroup per table row.)
+// Why slices: the RoIs of a training step cluster on the ground-truth boxes (a few 16 x 32 tiles of P4 see 100-200 of the
+// 1024 RoIs, most tiles none), and one workgroup per tile then works for 300 us while the rest of the chip is idle.
+// A sliced tile is zero-filled here (OVERWRITE contract: its slices ADD): under that contract every tile has kZeroParts
+// more workgroups in this launch, which repeat the count and, if the list is long, zero their share of the channels (one
+// workgroup zero-filling a whole 512 KB tile made this launch 35 us long on a step's clustered RoIs).
+constexpr int kPlanThreads = 256, kPlanWaves = kPlanThreads / 64;  // (1024 lanes: 9 roles x 402 tiles of 16-wave workgroups took 20 us to dispatch)
+constexpr int kMaxPlanTiles = 8192;
+constexpr int kZeroParts = 8;
+__host__ __device__ inline int bwd_plan_extra(int num_rois) {  // entries beyond one per tile
+  return num_rois / 4 < 64 ? 64 : (num_rois / 4 > 2048 ? 2048 : num_rois / 4);
+}
+__host__ __device__ inline int bwd_class_cap0(int tiles, int num_rois) { return (tiles + bwd_plan_extra(num_rois) + 3) & ~3; }
+__host__ __device__ inline int bwd_class_base(int c, int tiles, int num_rois) {  // first entry of class c
+  return c == 0 ? 0 : bwd_class_cap0(tiles, num_rois) + (c - 1) * tiles;
+}
+__device__ __forceinline__ int bwd_class_of(int len) { return len >= 20 ? 1 : len >= 10 ? 2 : len >= 5 ? 3 : len >= 1 ? 4 : 5; }
 __global__ void __launch_bounds__(kPlanThreads)
-roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int batch, int th, int plan_tiles, int plan_cap,
-                   int items_max) {
+roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int batch, int channels, int th, int plan_tiles,
+                   int plan_cap, int slice_len, int overwrite) {
   __shared__ int wave_hits[kPlanWaves];
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-  const int tile_global = blockIdx.x;
+  // role 0 plans the tile, roles 1.. zero a share of a sliced tile; a tile's roles are neighbours in the grid (planners
+  // first and 4 larger shares measured 4-10 us slower on a step's RoIs)
+  const int roles = (overwrite & 1) ? 1 + kZeroParts : 1;
+  const int tile_global = blockIdx.x / roles, role = blockIdx.x - tile_global * roles;
   int tile_lin = tile_global, lvl = 0;
   while (lvl + 1 < lv.count && tile_lin >= lv.tile_base[lvl + 1]) lvl++;
   tile_lin -= lv.tile_base[lvl];
@@ -963,8 +989,9 @@ roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int 
   const int gy0 = img_row0 + y0;
   const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
   int* __restrict__ counts = ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4);
-  int4* __restrict__ items = reinterpret_cast<int4*>(counts + ((plan_tiles + 3) & ~3));
-  unsigned short* __restrict__ list = reinterpret_cast<unsigned short*>(items + items_max) + (long long)tile_global * plan_cap;
+  int4* __restrict__ entries = reinterpret_cast<int4*>(counts + ((plan_tiles + 3) & ~3));
+  const int entries_total = bwd_class_base(kBwdClasses - 1, plan_tiles, num_rois) + plan_tiles;
+  unsigned short* __restrict__ list = reinterpret_cast<unsigned short*>(entries + entries_total) + (long long)tile_global * plan_cap;
   // each wave owns a contiguous share of the ranks: count, one barrier, then write at the wave's offset (rank order)
   const int share = (((num_rois + kPlanWaves - 1) / kPlanWaves) + 63) & ~63;
   const int r0 = wave * share, r1 = min(num_rois, r0 + share);
@@ -982,6 +1009,40 @@ roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int 
     off += w < wave ? wave_hits[w] : 0;
     total += wave_hits[w];
   }
+  if (role > 0) {
+    // ---- zero this workgroup's share of the channels if the tile's list will be cut (a list that does not get its slices
+    // any more -- budget used up -- is summed by one workgroup that overwrites: the zeros are then wasted, not wrong) ----
+    if (total <= slice_len) return;
+    float* __restrict__ grad = lv.grad[lvl];
+    const int rows = min(th, height - y0), cols = min(kTW, width - x0);
+    const int cz = channels / kZeroParts, c_lo = (role - 1) * cz;  // channels % 32 == 0
+    if (overwrite & 2) {
+      // channels-last: `channels` contiguous floats per pixel
+      const int c4 = cz / 4;
+      for (int i = tid; i < rows * cols * c4; i += kPlanThreads) {
+        const int px = i / c4, q = i - px * c4;
+        const int rr = px / cols, cc = px - rr * cols;
+        reinterpret_cast<float4*>(grad + (((long long)n * height + y0 + rr) * width + x0 + cc) * channels + c_lo)[q] =
+            make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else if (cols == kTW && (width & 3) == 0) {
+      // 128-byte row pieces, 16-byte aligned: eight lanes per piece
+      for (int i = tid; i < cz * rows * 8; i += kPlanThreads) {
+        const int seg = i >> 3, q = i & 7;
+        const int c = seg / rows, rr = seg - c * rows;
+        reinterpret_cast<float4*>(grad + (((long long)n * channels + c_lo + c) * height + y0 + rr) * width + x0)[q] =
+            make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      const int col = tid & 31;
+      if (col < cols)
+        for (int i = tid >> 5; i < cz * rows; i += kPlanThreads / 32) {
+          const int c = i / rows, rr = i - c * rows;
+          grad[(((long long)n * channels + c_lo + c) * height + y0 + rr) * width + x0 + col] = 0.f;
+        }
+    }
+    return;
+  }
   if (mine > 0)
     for (int base = r0; base < r1; base += 64) {
       const bool hit = hit_of(base + lane);
@@ -989,165 +1050,23 @@ roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int 
       if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(base + lane);
       off += __popcll(m);
     }
-  if (tid == 0) counts[tile_global] = total;
-}
-
-// roi_align_bwd_items: workgroup 0, between roi_align_bwd_plan and roi_align_bwd_tiles, turns the per-tile counts into the
-// item table the tile kernel's workgroups index with blockIdx / ncg (a release fence + ticket in the plan kernel, so that
-// its last workgroup could do this, cost 350 us: an agent-scope fence writes the whole L2 back, once per tile).
-// Items, in dispatch order: (0) the slices of the long lists, (1) the short lists, (2) under the OVERWRITE contract the
-// tiles without RoIs (their workgroups only store zeros, and do so on the compute units the long items leave idle).
-// Slice length: the first of {1, 2, 4, 8, 32} * slice_min (a power of two), "whole list" whose item total fits the table.
-constexpr int kMaxPlanTiles = 8192;
-constexpr int kItemThreads = 256, kItemWaves = kItemThreads / 64;  // the zero-fill workgroups are launched at this size too
-__global__ void __launch_bounds__(kItemThreads)
-roi_align_bwd_items(const LevelTable lv, int* __restrict__ ws, int num_rois, int batch, int channels, int th,
-                    int slice_shift, int plan_tiles, int items_max, int overwrite) {
-  if (blockIdx.x > 0) {
-    // ---- workgroups 1..: (tile, group of 32 channels) -- zero-fill the tiles whose list may be cut into slices (their
-    // sums arrive by atomics); launched under the OVERWRITE contract only, next to the table builder ----
-    const int nzg = channels / kCT;
-    const int zg = (blockIdx.x - 1) % nzg, tile_global = (blockIdx.x - 1) / nzg;
-    const const_int_ptr cnt_p =
-        (const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4) + tile_global);
-    if (cnt_p[0] <= (1 << slice_shift)) return;
-    const int tid = threadIdx.x;
-    int tile_lin = tile_global, lvl = 0;
-    while (lvl + 1 < lv.count && tile_lin >= lv.tile_base[lvl + 1]) lvl++;
-    tile_lin -= lv.tile_base[lvl];
-    const int height = lv.height[lvl], width = lv.width[lvl];
-    const int tiles_x = (width + kTW - 1) / kTW, tiles_y = (height + th - 1) / th;
-    const int n = tile_lin / (tiles_x * tiles_y);
-    const int trem = tile_lin - n * tiles_x * tiles_y;
-    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
-    const int x0 = txi * kTW, y0 = tyi * th;
-    float* __restrict__ grad = lv.grad[lvl];
-    const int rows = min(th, height - y0), cols = min(kTW, width - x0), c0 = zg * kCT;
-    if (overwrite & 2) {
-      // channels-last: kCT contiguous floats per pixel
-      for (int i = tid; i < rows * cols * (kCT / 4); i += kItemThreads) {
-        const int px = i / (kCT / 4), q = i - px * (kCT / 4);
-        const int rr = px / cols, cc = px - rr * cols;
-        reinterpret_cast<float4*>(grad + (((long long)n * height + y0 + rr) * width + x0 + cc) * channels + c0)[q] =
-            make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid == 0) {
+    counts[tile_global] = total;
+    bool whole = true;
+    if (total > slice_len) {
+      const int v = (total + slice_len - 1) / slice_len, per = (total + v - 1) / v;  // even slices: (v - 1) * per < total
+      if (atomicAdd(ws + kBwdBucket + kBwdClasses * kBwdCounterStride, v - 1) + v - 1 <= bwd_plan_extra(num_rois)) {
+        whole = false;
+        const int slot = atomicAdd(ws + kBwdBucket, v);
+        for (int sl = 0; sl < v; sl++) entries[slot + sl] = make_int4(tile_global, sl * per, min(per, total - sl * per), v);
       }
-    } else if (cols == kTW && (width & 3) == 0) {
-      // 128-byte row pieces, 16-byte aligned: eight lanes per piece
-      for (int i = tid; i < kCT * rows * 8; i += kItemThreads) {
-        const int seg = i >> 3, q = i & 7;
-        const int c = seg / rows, rr = seg - c * rows;
-        reinterpret_cast<float4*>(grad + (((long long)n * channels + c0 + c) * height + y0 + rr) * width + x0)[q] =
-            make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    } else {
-      const int col = tid & 31;
-      if (col < cols)
-        for (int i = tid >> 5; i < kCT * rows; i += kItemThreads / 32) {
-          const int c = i / rows, rr = i - c * rows;
-          grad[(((long long)n * channels + c0 + c) * height + y0 + rr) * width + x0 + col] = 0.f;
-        }
     }
-    return;
-  }
-  __shared__ int cnts[kMaxPlanTiles];
-  __shared__ int ladder[6];
-  __shared__ int wsum[3][kItemWaves];
-  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-  const int* __restrict__ counts = ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4);
-  int4* __restrict__ items = reinterpret_cast<int4*>(const_cast<int*>(counts) + ((plan_tiles + 3) & ~3));
-  auto wave_sum = [&](int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-  };
-  for (int t = tid; t < plan_tiles; t += kItemThreads) cnts[t] = counts[t];
-  if (tid < 6) ladder[tid] = 0;
-  __syncthreads();
-  const int empty_items = (overwrite & 1) ? 1 : 0;
-  {
-    int sums[6] = {0, 0, 0, 0, 0, 0};
-    for (int t = tid; t < plan_tiles; t += kItemThreads) {
-      const int cnt = cnts[t];
-      const int empty = cnt == 0 ? empty_items : 0;
-#pragma unroll
-      for (int k = 0; k < 5; k++) {
-        const int sh = slice_shift + (k < 4 ? k : 5);
-        sums[k] += ((cnt + (1 << sh) - 1) >> sh) + empty;
-      }
-      sums[5] += (cnt > 0 ? 1 : 0) + empty;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const int v = wave_sum(sums[k]);
-      if (lane == 0 && v != 0) atomicAdd(&ladder[k], v);
+    if (whole && (total > 0 || (overwrite & 1))) {
+      const int c = bwd_class_of(total);
+      const int slot = atomicAdd(ws + kBwdBucket + c * kBwdCounterStride, 1);
+      entries[bwd_class_base(c, plan_tiles, num_rois) + slot] = make_int4(tile_global, 0, total, 1);
     }
   }
-  __syncthreads();
-  int shift = 30, nitems = ladder[5];
-#pragma unroll
-  for (int k = 4; k >= 0; k--)
-    if (ladder[k] <= items_max) {
-      shift = slice_shift + (k < 4 ? k : 5);
-      nitems = ladder[k];
-    }
-  auto classify = [&](int t, int& cnt, int& v) {
-    cnt = t < plan_tiles ? cnts[t] : -1;
-    v = cnt > 0 ? ((cnt - 1) >> shift) + 1 : (cnt == 0 ? empty_items : 0);
-    return v == 0 ? 3 : cnt == 0 ? 2 : (v > 1 || (cnt >> (shift - 1)) > 0) ? 0 : 1;
-  };
-  // class totals -> class bases
-  int base[3];
-  {
-    int tot[3] = {0, 0, 0};
-    for (int t = tid; t < plan_tiles; t += kItemThreads) {
-      int cnt, v;
-      const int cls = classify(t, cnt, v);
-#pragma unroll
-      for (int c = 0; c < 3; c++) tot[c] += cls == c ? v : 0;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const int v = wave_sum(tot[c]);
-      if (lane == 0) wsum[c][wave] = v;
-    }
-    __syncthreads();
-    int run = 0;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      base[c] = run;
-      for (int w = 0; w < kItemWaves; w++) run += wsum[c][w];
-    }
-    __syncthreads();
-  }
-  // positions: exclusive scan of the slice counts inside each class, tile order
-  for (int chunk = 0; chunk < plan_tiles; chunk += kItemThreads) {
-    int cnt, v;
-    const int cls = classify(chunk + tid, cnt, v);
-    int incl[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      int x = cls == c ? v : 0;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(x, d);
-        if (lane >= d) x += o;
-      }
-      incl[c] = x;
-      if (lane == 63) wsum[c][wave] = x;
-    }
-    __syncthreads();
-    if (cls < 3) {
-      int pos = base[cls] + (cls == 0 ? incl[0] : cls == 1 ? incl[1] : incl[2]) - v;
-      for (int w = 0; w < wave; w++) pos += wsum[cls][w];
-      const int per = (cnt + v - 1) / v;  // even slices: (v - 1) * per < cnt; an empty tile is one item of length 0
-      for (int sl = 0; sl < v; sl++) items[pos + sl] = make_int4(chunk + tid, sl * per, min(per, cnt - sl * per), v);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-      for (int w = 0; w < kItemWaves; w++) base[c] += wsum[c][w];
-    __syncthreads();
-  }
-  for (int i = nitems + tid; i < items_max; i += kItemThreads) items[i] = make_int4(-1, 0, 0, 0);
 }
 
 // 16-row tiles with 32 channels: 84 VGPRs would cap a SIMD at 5 waves = two 8-wave workgroups per CU; pinning the
@@ -1183,20 +1102,50 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
   const int wave = uniform(tid >> 6);
   const int bins = aligned_height * aligned_width;
   const int ncg = channels / KC;
+  const int* __restrict__ records = ws + kCounterDwords;
+  const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
+  // Planned launch (roi_align_bwd_plan ran before): blockIdx / ncg is the e-th ENTRY in class order (longest lists first:
+  // the hardware hands out workgroups in blockIdx order); the grid is an upper bound of the entry count.
   const int cg = blockIdx.x % ncg;
   int tile_lin = blockIdx.x / ncg;
   int nslices = 1, planned_len = 0, planned_first = 0;
+  const int4* __restrict__ entries =
+      reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4) + ((plan_tiles + 3) & ~3));
   if (plan_tiles > 0) {
-    // ---- planned launch (roi_align_bwd_plan ran before): blockIdx / ncg is an ITEM = one slice of one tile's list; the
-    // grid is an upper bound of the item count, the entries behind the last item hold -1 ----
-    const const_int_ptr it = (const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4) +
-                                                         ((plan_tiles + 3) & ~3) + 4 * (blockIdx.x / ncg));
+    const const_int_ptr bc = (const_int_ptr)(uintptr_t)(ws + kBwdBucket);
+    const int e = tile_lin;
+    int c = 0, first = 0, run = 0;
+#pragma unroll
+    for (int k = 0; k < kBwdClasses; k++) {
+      const int cnt = bc[k * kBwdCounterStride];
+      run += cnt;
+      if (k + 1 < kBwdClasses && e >= run) {
+        c = k + 1;
+        first = run;
+      }
+    }
+    if (e >= run) return;
+    const const_int_ptr it = (const_int_ptr)(uintptr_t)(entries + bwd_class_base(c, plan_tiles, num_rois) + (e - first));
     tile_lin = it[0];
-    if (tile_lin < 0) return;
     planned_first = it[1];
     planned_len = it[2];
     nslices = it[3];
   }
+#if MI_TUNING
+  // tuning builds: wave 0 sums clock64() differences per phase over the visits of this workgroup (tools/timeline_bwd.py)
+  long long tl_t = clock64(), tl_acc[5] = {0, 0, 0, 0, 0};
+  const long long tl_start = tl_t;
+#define MI_TL_LAP(k)                          \
+  do {                                        \
+    const long long tl_now = clock64();       \
+    tl_acc[k] += tl_now - tl_t;               \
+    tl_t = tl_now;                            \
+  } while (0)
+#else
+#define MI_TL_LAP(k) \
+  do {               \
+  } while (0)
+#endif
   const int tile_global = tile_lin;
   int lvl = 0;  // the level this tile belongs to (tiles of all levels share the grid in an FPN-fused call)
   while (lvl + 1 < lv.count && tile_lin >= lv.tile_base[lvl + 1]) lvl++;
@@ -1211,14 +1160,12 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
   const int img_row0 = lv.row_base[lvl] + n * height;  // "global rows": levels and images stacked
   const int gy0 = img_row0 + y0;
   const int c0 = cg * KC;
-  const int* __restrict__ records = ws + kCounterDwords;
-  const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
 
   // ---- RoIs whose window touches this tile, in rank order ----
   if (tid == 0) list_len = planned_len;
   if (plan_tiles > 0) {
-    const unsigned short* __restrict__ lists = reinterpret_cast<const unsigned short*>(
-        ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4) + ((plan_tiles + 3) & ~3) + 4 * (gridDim.x / ncg));
+    const unsigned short* __restrict__ lists =
+        reinterpret_cast<const unsigned short*>(entries + bwd_class_base(kBwdClasses - 1, plan_tiles, num_rois) + plan_tiles);
     for (int i = tid; i < planned_len; i += kThreads) list[i] = lists[(long long)tile_global * plan_cap + planned_first + i];
   }
   __syncthreads();
@@ -1274,21 +1221,6 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
       if (k * 64 + lane < total16) dma_dwordx4(gsrd, gdst + (unsigned)k * 1024u, (unsigned)(k * 64 + lane) * 16u, 0u);
   };
 
-#if MI_TUNING
-  // tuning builds: wave 0 sums clock64() differences per phase over the visits of this workgroup (tools/timeline_bwd.py)
-  long long tl_t = clock64(), tl_acc[5] = {0, 0, 0, 0, 0};
-  const long long tl_start = tl_t;
-#define MI_TL_LAP(k)                          \
-  do {                                        \
-    const long long tl_now = clock64();       \
-    tl_acc[k] += tl_now - tl_t;               \
-    tl_t = tl_now;                            \
-  } while (0)
-#else
-#define MI_TL_LAP(k) \
-  do {               \
-  } while (0)
-#endif
   if (nlist > 0) issue_loads(list[0], 0);
   MI_TL_LAP(4);  // list + first issue (not per visit)
   for (int li = 0; li < nlist; li++) {
@@ -1414,6 +1346,7 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
       }
     }
   }
+#undef MI_TL_LAP
 }
 
 // RoIs the tile kernel does not cover: reference mapping, arithmetic and atomics (roi_align_kernel.cu:195-270).
@@ -1423,19 +1356,26 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
 constexpr int kSlowGroup = 64;
 __global__ void __launch_bounds__(256)
 roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__ rois, const LevelTable lv,
-                   const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height,
+                   int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height,
                    int aligned_width, int sampling_ratio, int nhwc) {
   const int tiles = channels / kCT;
   const int group = blockIdx.x / tiles;
   const int c0 = (blockIdx.x - group * tiles) * kCT;
   const int bins = aligned_height * aligned_width;
   const int tid = threadIdx.x;
-  // the flags of the group's ranks in one vector load (lane = rank), then only the flagged ranks are visited
+  // The tile kernel of this call has finished: the plan's class counters go back to zero for the next backward over this
+  // workspace (a forward in between rewrites the whole counter block in roi_align_prepare).
+  if (blockIdx.x == 0 && tid <= kBwdClasses) ws[kBwdBucket + tid * kBwdCounterStride] = 0;  // classes + the slice budget
+  // Candidates from the window table (16 bytes per rank, contiguous: the record flags lie 3 KB apart and cost this launch
+  // 64 cache lines per workgroup to find nothing): a RoI without backward tables has the empty window; of those, the ranks
+  // that are not "RoI of no image" are visited.
   unsigned long long todo;
   {
     const int p = group * kSlowGroup + (tid & 63);
-    const int f = p < num_rois ? ws[kCounterDwords + (long long)p * kRecDwords] : (int)kFlagZero;
-    todo = __ballot((f & (kFlagBwd | kFlagZero)) == 0);
+    const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
+    bool cand = p < num_rois && bounds[p].y < 0;
+    if (cand) cand = (ws[kCounterDwords + (long long)p * kRecDwords] & (kFlagBwd | kFlagZero)) == 0;
+    todo = __ballot(cand);
   }
   while (todo != 0ull) {
   const int pos = group * kSlowGroup + (int)__builtin_ctzll(todo);
@@ -1518,7 +1458,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
   int resident = (compute_units() * slots) & ~7;
   if (resident > ((items + 7) & ~7)) resident = (items + 7) & ~7;
   // Which form: the resident one where every item has several stages by construction (more bins than the LDS tile holds:
-  // the 14 x 14 mask / keypoint heads), the per-item one otherwise.  Measured on one box (tools/fwd_ab.py, us per call,
+  // the 14 x 14 mask / keypoint heads), the per-item one otherwise.  Measured on one box (tools/roi_align_ab.py, us per call,
   // per-item / resident): config 2 34.8 / 39.3, 1024 RoIs on two images 58.0 / 63.4, a step's box RoIs over the pyramid
   // 68.9 / 74.3, 128 RoIs x 14 x 14 32.5 / 30.7.  The resident form's unit chain is 11 % shorter (profiles/
   // r05_persist_timeline.txt), but a workgroup is committed to its next two items, and behind the last ticket that costs
@@ -1569,11 +1509,11 @@ int bwd_tile_count(LevelTable& lv, int batch, int th) {
     lv.tile_base[l + 1] = lv.tile_base[l] + ((lv.width[l] + kTW - 1) / kTW) * ((lv.height[l] + th - 1) / th) * batch;
   return lv.tile_base[lv.count];
 }
-// the plan region behind the records and bounds: one count per tile, the item table (int4 {tile, first, length,
-// slices of the tile}; the grid of the tile kernel is its capacity), one list of 16-bit ranks per tile
-int bwd_plan_items(int tiles, int num_rois) { return tiles + std::min(std::max(num_rois / 4, 64), 2048); }
+// the plan region behind the records and bounds: one count per tile, the entry arrays of the six cost classes (int4 {tile,
+// first, length, slices of the tile}: roi_align_bwd_plan), one list of 16-bit ranks per tile
+int bwd_plan_entries(int tiles, int num_rois) { return bwd_class_base(kBwdClasses - 1, tiles, num_rois) + tiles; }
 size_t bwd_plan_bytes(int tiles, int num_rois) {
-  return (size_t)((tiles + 3) & ~3) * 4 + (size_t)bwd_plan_items(tiles, num_rois) * 16 +
+  return (size_t)((tiles + 3) & ~3) * 4 + (size_t)bwd_plan_entries(tiles, num_rois) * 16 +
          (size_t)tiles * ((num_rois + 7) & ~7) * 2;
 }
 }  // namespace
@@ -1612,20 +1552,17 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   // planned launch (see roi_align_bwd_plan) when the workspace has room for the plan: the grid is an upper bound of the
   // number of list slices (every tile once + room for extra slices of the long lists)
   const int slice_min = tuning().bwd_slice;
-  const bool planned = slice_min > 0 && tiles <= kMaxPlanTiles &&
+  const bool planned = slice_min > 0 && tiles <= kMaxPlanTiles && tiles < 65536 &&
                        workspace_bytes >= roi_align_records_workspace_bytes(num_rois) + bwd_plan_bytes(tiles, num_rois);
   const int plan_cap = (num_rois + 7) & ~7;
-  const int items = planned ? bwd_plan_items(tiles, num_rois) : tiles;
-  const int grid = items * (channels / kc);
+  int grid = tiles * (channels / kc);
   if (planned) {
-    roi_align_bwd_plan<<<tiles, kPlanThreads, 0, stream>>>(lv, ws, num_rois, batch, th, tiles, plan_cap, items);
+    roi_align_bwd_plan<<<tiles * (overwrite ? 1 + kZeroParts : 1), kPlanThreads, 0, stream>>>(lv, ws, num_rois, batch, channels, th, tiles, plan_cap, slice_min,
+                                                           (overwrite ? 1 : 0) | (nhwc ? 2 : 0));
     int rc = check_launch("roi_align_bwd_plan");
     if (rc != MI_OK) return rc;
-    roi_align_bwd_items<<<overwrite ? 1 + tiles * (channels / kCT) : 1, kItemThreads, 0, stream>>>(
-        lv, ws, num_rois, batch, channels, th, 31 - __builtin_clz((unsigned)slice_min), tiles, items,
-        (overwrite ? 1 : 0) | (nhwc ? 2 : 0));
-    rc = check_launch("roi_align_bwd_items");
-    if (rc != MI_OK) return rc;
+    // upper bound of the entries: every tile once + the budget of extra slices
+    grid = (tiles + bwd_plan_extra(num_rois)) * (channels / kc);
   }
 #define MI_LAUNCH_TILES_A(SR, KC, TH, A)                                                                              \
   do {                                                                                                                \

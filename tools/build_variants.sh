@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds the A/B arms of tools/fwd_ab.py / tools/bwd_ab.py into .ab_r5/ (git-ignored, travels with gpurun):
+# Builds the A/B arms of tools/roi_align_ab.py / tools/bwd_ab.py into .ab_r5/ (git-ignored, travels with gpurun):
 #   libmi_head.so    the library of the last commit (git archive HEAD)
 #   libmi_tuning.so  the working tree with -DMI_TUNING=1 (ablation switches, timeline stamps)
 # and the release library of the working tree in place.   usage: bash tools/build_variants.sh [head] [tuning]

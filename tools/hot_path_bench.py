@@ -194,10 +194,11 @@ def roofline_roi_align_forward(device, iters):
                         "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
                         "algorithmic_bytes": int(bwd_bytes), "planned": bws_bytes > ws_bytes,
                         "unplanned_us": round(sec_unplanned * 1e6, 2),
-                        "what": "planned = roi_align_bwd_plan + _items + _tiles + _slow with the workspace the autograd "
-                                "Function allocates (pays ~10 us on these uniformly spread RoIs, halves the backward on "
-                                "the clustered RoIs of a training step: roi_align_step_rois); unplanned = the same call "
-                                "under MI_ROI_ALIGN_BWD_SLICE=0 (one workgroup per tile walks the whole list)"}
+                        "what": "planned = roi_align_bwd_plan + _tiles + _slow with the workspace the autograd Function "
+                                "allocates (the plan files every tile's list in a cost class -- longest first -- and cuts the "
+                                "long lists of a training step's clustered RoIs into slices: roi_align_step_rois); unplanned = "
+                                "the same call under MI_ROI_ALIGN_BWD_SLICE=0 (one workgroup per tile scans the RoIs itself and "
+                                "walks the whole list: no atomics, bit-reproducible)"}
     info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
     if layout == _lib.LAYOUT_NCHW:
         info["channels_last"] = channels_last_variant(device, lib, stream, feat, rois, out, ws, alg_bytes, gtop, iters)
