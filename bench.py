@@ -139,6 +139,11 @@ class TrainHarness:
         if layout == "channels_last":
             self.net = self.net.to(memory_format=torch.channels_last)
         self.net.train()
+        # replicas start equal by construction (same seed) -- and by one broadcast from rank 0, which is what keeps a loaded
+        # checkpoint or a rank-dependent initialisation from diverging silently (the reference re-broadcasts every forward,
+        # nn/parallel/replicate.py:12); no-ops on one rank
+        self.synced_bytes = parallel.sync_parameters(self.net)
+        parallel.assert_replicas_equal(self.net)
         self.autocast = torch.bfloat16 if dtype == "bf16" else None
         batch = rdata.synthetic_minibatch(cfg, images_per_rank, seed=rank)      # per-rank images (weak scaling)
         self.data, self.im_info, self.roidb, self.rpn_targets = rdata.to_device(batch, device,
@@ -715,6 +720,12 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = IMAGES_PER_RANK * world * args.steps / elapsed
     comm = allreduce_bandwidth(work.reducer, world, device)
+    # outside the timed region: the replicas are still bit-identical after the timed steps, and what a logger would print --
+    # the step's loss averaged over the ranks (utils/training_stats.py:84) in one all-reduce of a scalar
+    from detectron_pytorch_amd import parallel as _par
+
+    _par.assert_replicas_equal(work.net)
+    mean_loss = _par.reduce_losses({"total_loss": work.last})["total_loss"]
 
     if rank == 0:
         line = {
@@ -728,7 +739,8 @@ def main():
                        "global_batch": IMAGES_PER_RANK * world, "images_per_rank": IMAGES_PER_RANK,
                        "parallelism": "dp%d" % world, "launch": work.mode, "layout": work.layout,
                        "trainable_params": work.params, "gradient_payload_bytes": work.params * 4,
-                       "loss_first": round(first_loss, 4), "loss_last": round(last_loss, 4)},
+                       "loss_first": round(first_loss, 4), "loss_last": round(last_loss, 4),
+                       "loss_last_mean_over_ranks": round(mean_loss, 4)},
         }
         if comm is not None:
             # everything needed to read a scaling curve from this record alone: the group the collectives really ran in,

@@ -42,6 +42,7 @@ Tuning read_tuning() {
   t.nhwc_order_mul = om > 0 ? om : 1;
   t.nhwc_zigzag = env_int("MI_ROI_ALIGN_NHWC_ZIGZAG", 1);
   t.ablate = MI_ABLATE(env_int("MI_ROI_ALIGN_ABLATE", 0));
+  t.copy_variant = env_int("MI_COPY_VARIANT", 411);
   return t;
 }
 }  // namespace
@@ -50,6 +51,19 @@ namespace {
 Tuning g_tuning;
 std::once_flag g_tuning_once;
 }  // namespace
+
+// compute units of the current device (resident grids, the copy-ceiling kernel); asked once
+int compute_units() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    (void)hipGetLastError();
+    return cus;
+  }();
+  return n;
+}
 
 const Tuning& tuning() {
   std::call_once(g_tuning_once, [] { g_tuning = read_tuning(); });
@@ -92,13 +106,13 @@ extern "C" int mi_dbg_copy_float4(const void* src, void* dst, size_t bytes, mi_s
                  (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
              "mi_dbg_copy_float4: 16-byte aligned buffers of a multiple of 16 bytes");
   const size_t n4 = bytes / 16;
-  // MI_COPY_VARIANT = blocks_per_cu * 100 + unroll * 10 + nontemporal (tools/copy_sweep.py).  Default: 4 workgroups per CU,
-  // one 16-byte load in flight per lane and loop trip, non-temporal loads and stores -- 6.48 TB/s on a 256 MiB buffer, the
-  // best of the sweep (2..64 workgroups per CU x unroll 1 / 4 / 8 x nt: 4.1-6.5 TB/s; torch's copy_: 5.40)
-  const char* var = std::getenv("MI_COPY_VARIANT");
-  const int v = var != nullptr ? std::atoi(var) : 411;
+  // MI_COPY_VARIANT = blocks_per_cu * 100 + unroll * 10 + nontemporal (tools/copy_sweep.py; read with the other tuning
+  // variables, i.e. once, or again through mi_dbg_reload_tuning).  Default: 4 workgroups per CU, one 16-byte load in flight
+  // per lane and loop trip, non-temporal loads and stores -- 6.48 TB/s on a 256 MiB buffer, the best of the sweep (2..64
+  // workgroups per CU x unroll 1 / 4 / 8 x nt: 4.1-6.5 TB/s; torch's copy_: 5.40)
+  const int v = mi::tuning().copy_variant;
   const int per_cu = v / 100 > 0 ? v / 100 : 8, unroll = (v / 10) % 10, nt = v % 10;
-  size_t blocks = (size_t)256 * per_cu;
+  size_t blocks = (size_t)mi::compute_units() * per_cu;
   const size_t want = (n4 + 255) / 256;
   if (blocks > want) blocks = want ? want : 1;
   const v4f_t* s4 = static_cast<const v4f_t*>(src);

@@ -65,8 +65,10 @@ struct Tuning {
   int fwd_persist, fwd_slots;
   int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag;
   int ablate;
+  int copy_variant;  // MI_COPY_VARIANT of mi_dbg_copy_float4 (tools/copy_sweep.py)
 };
 const Tuning& tuning();
+int compute_units();  // of the current device; asked once
 void reload_tuning();  // mi_dbg_reload_tuning() only
 
 #ifdef MI_TUNING

@@ -352,9 +352,9 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
                "roi_align: workspace of %zu bytes, %zu needed", workspace_bytes,
                mi::roi_align_records_workspace_bytes(num_rois));
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "roi_align: workspace must be 16-byte aligned");
-    // the tile kernel takes a RoI's block of top gradients in 16-byte pieces
-    MI_REQUIRE((reinterpret_cast<uintptr_t>(top_grad) & 15) == 0, "roi_align: top_grad must be 16-byte aligned");
-    if (!force_direct() && !no_ws() &&
+    // the tile kernel takes a RoI's block of top gradients in 16-byte pieces: a dword-aligned gradient view (legal at this
+    // boundary) goes to the generic kernel below instead of being refused
+    if (!force_direct() && !no_ws() && (reinterpret_cast<uintptr_t>(top_grad) & 15) == 0 &&
         mi::roi_align_bwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
       return mi::launch_roi_align_bwd_records(top_grad, rois, bottom_grad, workspace, workspace_bytes,
                                               (records_ready & 1) != 0,
@@ -362,6 +362,11 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
                                               height, width, num_rois, aligned_height, aligned_width, spatial_scale,
                                               sampling_ratio, ring_words(), s);
   }
+  // the generic kernel accumulates: under the OVERWRITE contract (only reachable here with a workspace and a gradient
+  // view the tile kernel cannot take) the zeros are ours to write
+  if ((records_ready & 2) != 0 &&
+      hipMemsetAsync(bottom_grad, 0, (size_t)batch * channels * height * width * sizeof(float), s) != hipSuccess)
+    return mi::check_launch("roi_align_backward: zero fill");
   FeatStrides st = make_strides(layout, channels, height, width);
   roi_align_bwd_direct<<<mi::grid_for(total, block), block, 0, s>>>(
       total, top_grad, rois, bottom_grad, batch, channels, height, width, aligned_height,

@@ -79,9 +79,13 @@ roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* _
                    int chunks, int tile_stride, int order_mul, int zigzag,
                    long long* __restrict__ timeline) {
   extern __shared__ float tile[];  // [V][64][tile_stride]
-  // tuning aid (tools/timeline_nhwc.py): s_memtime stamps of wave 0 of every workgroup, null in normal operation
+  // tuning builds only (tools/timeline_nhwc.py): clock stamps of wave 0 of every workgroup; the release kernel has none
   const auto stamp = [&](int k) {
+#if MI_TUNING
     if (timeline != nullptr && threadIdx.x == 0) timeline[(long long)blockIdx.x * 8 + k] = (long long)clock64();
+#else
+    (void)k;
+#endif
   };
   stamp(0);
   const int lane = threadIdx.x & 63;
@@ -117,11 +121,13 @@ roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* _
   const float spatial_scale = lv.scale[lvl];
   const int gh = kSR > 0 ? kSR : rec[6], gw = kSR > 0 ? kSR : rec[7];
   if (flags >= 0) stamp(1);  // record words have arrived
+#if MI_TUNING
   if (timeline != nullptr && threadIdx.x == 0) {  // where the workgroup ran (XCC_ID, HW_ID) and which RoI it pooled
     timeline[(long long)blockIdx.x * 8 + 6] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                               (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     timeline[(long long)blockIdx.x * 8 + 7] = r;
   }
+#endif
   const int cl = c0 + lane * V;
   // lanes past the last channel read channel 0 (valid memory); their results are never copied out
   const unsigned lane_off = (unsigned)(cl < channels ? cl : 0) * 4u;  // bytes

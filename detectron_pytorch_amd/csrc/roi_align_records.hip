@@ -1430,19 +1430,6 @@ int launch_prepare(const float* rois, const int* levels, int* ws, int batch, con
 long long* g_records_timeline = nullptr;
 #endif
 
-// compute units of the current device (the resident grid of roi_align_fwd_persist); asked once
-int compute_units() {
-  static const int n = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-    (void)hipGetLastError();
-    return cus;
-  }();
-  return n;
-}
-
 template <int kCap>
 int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float* output, int* ws, int batch,
                int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio, bool bwd_tables,

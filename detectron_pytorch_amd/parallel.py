@@ -165,7 +165,9 @@ class GradientAllReducer(object):
         hipGraph launch, no hook ran).  Returns the number of collectives."""
         if not self.active:
             return 0
-        assert not self.detect_unused, "detect_unused reads the autograd hooks' flags: incompatible with a replayed backward"
+        if self.detect_unused:
+            raise RuntimeError("GradientAllReducer.reduce_now(): detect_unused reads the autograd hooks' flags, and a "
+                               "replayed (hipGraph) backward runs no hook")
         handles = [dist.all_reduce(flat, op=self._op, group=self.group, async_op=True) for flat, _ in self.buckets]
         for h in handles:
             h.wait()
@@ -200,16 +202,22 @@ class GradientAllReducer(object):
             for flat, _ in self.buckets:
                 flat.div_(self.world)
         if self.detect_unused:
-            # every rank issues this collective: agree on the parameters that got no gradient on any rank
-            if not any(self._fired_host):
-                # no hook ran at all: the backward was replayed from a hipGraph (hooks do not run on replay) or begin_step()
-                # was skipped -- every flag would read "unused" and the whole model's gradients would be dropped silently
-                raise RuntimeError("GradientAllReducer(detect_unused=True): no gradient hook fired in this step; "
-                                   "detect_unused needs an eagerly executed backward between begin_step() and finish_step()")
-            flags = torch.tensor([1.0 if f else 0.0 for f in self._fired_host], device=self.buckets[0][0].device)
+            # Every rank issues this collective: agree on the parameters that got no gradient on any rank.  The last element
+            # carries "no hook ran at all on some rank" (MAX): the backward was replayed from a hipGraph (hooks do not run on
+            # replay) or begin_step() was skipped -- every flag of that rank would read "unused" and gradients would be
+            # dropped silently.  It travels IN the collective, so that every rank raises after it; raising before it on the
+            # one rank that noticed would leave the others blocked in the all-reduce.
+            none_fired = 0.0 if any(self._fired_host) else 1.0
+            flags = torch.tensor([1.0 if f else 0.0 for f in self._fired_host] + [none_fired],
+                                 device=self.buckets[0][0].device)
             if self.world > 1:
                 dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
-            dead = set(k for k, v in enumerate(flags.tolist()) if v == 0.0)
+            flags = flags.tolist()
+            if flags[-1] != 0.0:
+                raise RuntimeError("GradientAllReducer(detect_unused=True): no gradient hook fired in this step on at least "
+                                   "one rank; detect_unused needs an eagerly executed backward between begin_step() and "
+                                   "finish_step()")
+            dead = set(k for k, v in enumerate(flags[:-1]) if v == 0.0)
             for p in self.params:
                 if self._index[id(p)] in dead:
                     p.grad = None
@@ -229,6 +237,129 @@ class GradientAllReducer(object):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+def _state_tensors(model):
+    """Parameters and buffers of a module (or an iterable of tensors), in registration order -- the same on every rank."""
+    if isinstance(model, torch.nn.Module):
+        return [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
+    return [t.data if isinstance(t, torch.nn.Parameter) else t for t in model]
+
+
+def sync_parameters(model, src=0, group=None, bucket_bytes=BUCKET_BYTES):
+    """One broadcast of every parameter and buffer from rank `src`: after it all replicas are bit-identical.
+
+    The reference re-broadcasts the parameters from GPU 0 in EVERY forward (nn/parallel/replicate.py:12 ->
+    _functions.py:6-24, 176.5 MB per step for e2e_mask_rcnn_R-50-FPN); with one process per GPU the replicas only have to
+    start equal -- identical averaged gradients and a deterministic optimizer keep them equal -- so this is called once,
+    after the model is built or a checkpoint is loaded (a checkpoint read on one rank only, or any rank-dependent
+    initialisation, would otherwise diverge silently).  Tensors travel in flat buckets of one dtype (few large messages:
+    xGMI is point-to-point).  Returns the number of bytes broadcast; a no-op returning 0 without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    sent = 0
+    pending, size = [], 0
+
+    def flush():
+        nonlocal pending, size, sent
+        if not pending:
+            return
+        flat = torch.cat([t.reshape(-1) for t in pending])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in pending:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        sent += flat.numel() * flat.element_size()
+        pending, size = [], 0
+
+    by_type = {}
+    for t in _state_tensors(model):
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    for (_, _), tensors in by_type.items():
+        for t in tensors:
+            nbytes = t.numel() * t.element_size()
+            if pending and size + nbytes > bucket_bytes:
+                flush()
+            pending.append(t)
+            size += nbytes
+        flush()
+    return sent
+
+
+def replica_checksum(model):
+    """A 64-bit checksum of every parameter and buffer: the wrapping int64 sum of the tensors' bit patterns, each weighted
+    by its position (so that swapped tensors do not cancel).  Cheap enough to run every K steps: one pass over the
+    state, no host copy until `.item()`."""
+    total = None
+    for k, t in enumerate(_state_tensors(model)):
+        if t.numel() == 0:
+            continue
+        flat = t.contiguous().reshape(-1)
+        if flat.element_size() == 4:
+            bits = flat.view(torch.int32).to(torch.int64)
+        elif flat.element_size() == 8:
+            bits = flat.view(torch.int64)
+        elif flat.element_size() == 2:
+            bits = flat.view(torch.int16).to(torch.int64)
+        else:
+            bits = flat.view(torch.uint8).to(torch.int64)
+        s = (bits * (2 * k + 1)).sum()
+        total = s if total is None else total + s
+    return total if total is not None else torch.zeros((), dtype=torch.int64)
+
+
+def assert_replicas_equal(model, group=None):
+    """Raises on every rank when the replicas' parameters / buffers differ (two all-reduces of one int64: MIN and MAX of
+    replica_checksum).  The reference cannot diverge -- it re-broadcasts every forward; here this is the assertion to run
+    after sync_parameters() and every K steps."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return True
+    mine = replica_checksum(model).reshape(1)
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if int(lo.item()) != int(hi.item()):
+        raise RuntimeError("data-parallel replicas have diverged: parameter checksum %d on this rank, range [%d, %d]"
+                           % (int(mine.item()), int(lo.item()), int(hi.item())))
+    return True
+
+
+def reduce_losses(values, group=None):
+    """The ~15 loss / metric scalars of a step, averaged over the ranks with ONE all-reduce -- what the reference logs
+    (utils/training_stats.py:84 takes the mean over GPUs of every loss and metric of `ret`).  `values`: a dict (of dicts)
+    of 0-d / 1-element tensors or floats, e.g. the `losses` / `metrics` of a training forward.  Returns the same structure
+    with plain floats.  Logging only: it is not on the step's critical path (call it after finish_step(); it synchronises
+    with the host once, for the `.tolist()`)."""
+    names, scalars = [], []
+
+    def walk(prefix, v):
+        if isinstance(v, dict):
+            for k in v:
+                walk(prefix + (k,), v[k])
+        else:
+            names.append(prefix)
+            scalars.append(v.detach().reshape(-1)[:1].float() if isinstance(v, torch.Tensor) else torch.tensor([float(v)]))
+
+    walk((), values)
+    if not scalars:
+        return {}
+    device = next((t.device for t in scalars if t.is_cuda), scalars[0].device)
+    stacked = torch.cat([t.to(device) for t in scalars])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        w = dist.get_world_size(group)
+        if dist.get_backend(group) == "nccl" and hasattr(dist.ReduceOp, "AVG"):
+            dist.all_reduce(stacked, op=dist.ReduceOp.AVG, group=group)
+        else:
+            dist.all_reduce(stacked, op=dist.ReduceOp.SUM, group=group)
+            stacked = stacked / w
+    out = {}
+    for path, v in zip(names, stacked.tolist()):
+        d = out
+        for k in path[:-1]:
+            d = d.setdefault(k, {})
+        d[path[-1]] = v
+    return out
 
 
 def max_over_ranks(seconds, device=None):

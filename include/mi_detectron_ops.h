@@ -112,8 +112,9 @@ int mi_roi_align_backward(const float* top_grad, const float* rois, float* botto
  *                               mi_roi_align_backward_overwrites() before relying on it.
  * The tile path is a gather over tiles of bottom_grad: a fixed summation order per tile; with a workspace of
  * mi_roi_align_backward_workspace_bytes() lists of more than 32 RoIs are cut into slices whose sums are added with fp32
- * atomics (see there).  With a workspace, `top_grad` has to be 16-byte aligned (MI_ERR_BAD_ARGUMENT otherwise): the tile
- * kernel fetches a RoI's block of gradients in 16-byte pieces. */
+ * atomics (see there).  The tile kernel fetches a RoI's block of gradients in 16-byte pieces: a `top_grad` that is only
+ * dword-aligned takes the generic kernel instead (reference mapping and atomics; under MI_ROI_ALIGN_OVERWRITE the zero fill
+ * is then done here). */
 #define MI_ROI_ALIGN_RECORDS_READY 1
 #define MI_ROI_ALIGN_OVERWRITE 2
 int mi_roi_align_backward_ws(const float* top_grad, const float* rois, float* bottom_grad,

@@ -531,6 +531,30 @@ def _same_detections(a_scores, a_boxes, b_scores, b_boxes, score_atol, box_atol=
     return int((~ok.any(dim=1)).sum()) <= flips and int((~ok.any(dim=0)).sum()) <= flips
 
 
+def _strict_postprocess_equality(gpu, cfg, inference, blob, im_info):
+    """The tolerant comparisons below absorb the network's run-to-run rounding; an off-by-one or a dropped row of the static
+    post-processing must not hide in that tolerance.  So the head runs ONCE, and the same score / box tensors go through the
+    static sequence (what the hipGraph replays) and through the dynamic one: rows, order, scores, boxes and the per-class
+    counts must be EQUAL, bit for bit."""
+    from detectron_pytorch_amd import detection
+
+    t = cfg.TEST
+    scores, boxes, _, valid = inference.im_detect_bbox(gpu, blob, im_info.to(dev()), None, None, static=True)
+    opts = dict(soft_nms=t.SOFT_NMS.ENABLED, soft_nms_sigma=t.SOFT_NMS.SIGMA, soft_nms_method=t.SOFT_NMS.METHOD,
+                bbox_vote=t.BBOX_VOTE.ENABLED, bbox_vote_thresh=t.BBOX_VOTE.VOTE_TH, bbox_vote_method=t.BBOX_VOTE.SCORING_METHOD)
+    if t.SOFT_NMS.ENABLED or t.BBOX_VOTE.ENABLED:
+        res = detection.box_results_static_general(scores, boxes, t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, roi_valid=valid, **opts)
+    else:
+        res = detection.box_results_static(scores, boxes, t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, roi_valid=valid)
+    stat = detection._results_from_static(res, False)
+    assert stat is not None, "more ties at the detections_per_im cut than the static result holds"
+    rows = valid.nonzero().flatten()          # the dynamic path never sees the padding rows of the static RoI blob
+    dyn = detection.box_results_with_nms_and_limit(scores[rows], boxes[rows], t.SCORE_THRESH, t.NMS, t.DETECTIONS_PER_IM, **opts)
+    assert torch.equal(stat[0], dyn[0]) and torch.equal(stat[1], dyn[1]), "static and dynamic post-processing differ"
+    assert [len(c) for c in stat[2]] == [len(c) for c in dyn[2]]
+    assert all(torch.equal(a, b) for a, b in zip(stat[2][1:], dyn[2][1:]))
+
+
 def _check_static_detection(gpu, cfg, inference):
     graph, seen = None, 0
     # Soft-NMS re-scores a row with a function of its IoU with the rows picked before it: boxes that differ by 1e-3 px move
@@ -541,6 +565,7 @@ def _check_static_detection(gpu, cfg, inference):
         blob = torch.from_numpy(data_np[:1]).to(dev())
         im_info = torch.tensor([[float(H), float(W), scale]])
         want = inference.im_detect_all(gpu, blob, im_info)
+        _strict_postprocess_equality(gpu, cfg, inference, blob, im_info)
         res = inference.im_detect_all_static(gpu, blob, im_info.to(dev()))
         count = int(res["count"])
         assert count == int(res["total"]) and abs(count - want[0].numel()) <= 2

@@ -126,8 +126,9 @@ def test_roi_align_backward_pooled_sizes_beyond_the_heads(oracle_mod, res, sr, c
 
 
 def test_roi_align_backward_with_a_misaligned_top_gradient(oracle_mod):
-    """The tile backward fetches gradient blocks in 16-byte pieces: the C-ABI refuses a top_grad that is not 16-byte aligned
-    (an error code, no launch) and the autograd Function copies such a gradient once instead of failing."""
+    """The tile backward fetches gradient blocks in 16-byte pieces.  A top_grad that is only dword-aligned is a legal argument
+    at the C boundary: such a call takes the generic kernel (reference mapping, atomics) instead of being refused, with and
+    without the OVERWRITE contract; the autograd Function copies such a gradient once and stays on the tile kernel."""
     from detectron_pytorch_amd import _lib
     from detectron_pytorch_amd.roi_align import roi_align_backward
 
@@ -139,16 +140,17 @@ def test_roi_align_backward_with_a_misaligned_top_gradient(oracle_mod):
     flat[1:] = to_dev(gtop).reshape(-1)
     odd = flat[1:].view(shape)                      # contiguous, 4 bytes past a 16-byte boundary
     assert odd.is_contiguous() and odd.data_ptr() % 16 == 4
+    want = oracle_mod.roi_align_backward(gtop, rois, (1, 64, h, w), scale, 2, threads=8)
     grad = roi_align_backward(odd, to_dev(rois), (1, 64, h, w), 7, 7, scale, 2)
-    assert_close(grad, oracle_mod.roi_align_backward(gtop, rois, (1, 64, h, w), scale, 2, threads=8), "misaligned top_grad")
+    assert_close(grad, want, "misaligned top_grad through the autograd wrapper")
     lib = _lib.lib()
     ws = torch.empty(lib.mi_roi_align_forward_workspace_bytes(40), dtype=torch.uint8, device=dev())
-    gin = torch.zeros((1, 64, h, w), device=dev())
-    rc = lib.mi_roi_align_backward_ws(odd.data_ptr(), to_dev(rois).data_ptr(), gin.data_ptr(), 1, 64, h, w, 40, 7, 7, scale, 2,
-                                      0, 0, ws.data_ptr(), ws.numel(), 0, _lib.current_stream_handle(dev()))
-    assert rc == 1 and b"16-byte aligned" in lib.mi_last_error()
-    torch.cuda.synchronize()
-    assert float(gin.abs().sum()) == 0.0
+    for flags, fill in ((0, 0.0), (_lib.ROI_ALIGN_OVERWRITE, float("nan"))):   # accumulate into zeros / overwrite garbage
+        gin = torch.full((1, 64, h, w), fill, device=dev())
+        rc = lib.mi_roi_align_backward_ws(odd.data_ptr(), to_dev(rois).data_ptr(), gin.data_ptr(), 1, 64, h, w, 40, 7, 7, scale,
+                                          2, 0, 0, ws.data_ptr(), ws.numel(), flags, _lib.current_stream_handle(dev()))
+        assert rc == 0, lib.mi_last_error()
+        assert_close(gin, want, "misaligned top_grad at the C-ABI, flags %d" % flags)
 
 
 def test_roi_align_golden():
@@ -279,6 +281,88 @@ def test_roi_align_non_finite_border_pixels_propagate_as_in_the_reference(oracle
     fin = np.isfinite(ref)
     assert np.array_equal(np.sign(out[~fin & ~np.isnan(ref)]), np.sign(ref[~fin & ~np.isnan(ref)]))
     assert np.abs(out[fin] - ref[fin]).max() <= FAST_ATOL
+
+
+def _edge_rois(batch, height, width, scale, seed):
+    """RoIs inside the image whose windows reach the last row, the last column and the bottom-right corner of the LAST image
+    (where a 16-byte group of the window copy runs past the row end, the map and the allocation), a few interior ones
+    around, fractional coordinates throughout (no tap with weight exactly 0)."""
+    rng = np.random.RandomState(seed)
+    im_w, im_h = width / scale, height / scale
+    last = batch - 1
+    rows = [[last, im_w - 0.37 / scale - rng.uniform(3, 9) / scale, im_h * 0.31, im_w - 0.37 / scale, im_h * 0.31 + rng.uniform(4, 9) / scale],
+            [last, im_w * 0.27, im_h - 0.41 / scale - rng.uniform(3, 8) / scale, im_w * 0.27 + rng.uniform(4, 9) / scale, im_h - 0.41 / scale],
+            [last, im_w - 0.23 / scale - 5.3 / scale, im_h - 0.29 / scale - 4.7 / scale, im_w - 0.23 / scale, im_h - 0.29 / scale],
+            [last, im_w - 1.0 - 2.6 / scale, im_h - 1.0 - 2.2 / scale, im_w - 1.0, im_h - 1.0],     # the reference's clamped last sample
+            [0, 0.19 / scale, 0.23 / scale, 6.6 / scale, 5.4 / scale]]
+    for _ in range(11):
+        x1, y1 = rng.uniform(1.1, width - 12.3) / scale, rng.uniform(1.1, height - 12.3) / scale
+        rows.append([rng.randint(0, batch), x1, y1, x1 + rng.uniform(2.3, 10.7) / scale, y1 + rng.uniform(2.3, 10.7) / scale])
+    return np.asarray(rows, np.float32)
+
+
+@pytest.mark.parametrize("path", ["records", "resident", "channels_last", "direct"])
+@pytest.mark.parametrize("channels,height,width", [(32, 25, 42), (256, 50, 84), (32, 200, 336)])
+def test_roi_align_consumes_nothing_outside_its_windows(oracle_mod, tuning_env, path, channels, height, width):
+    """The NCHW forward copies window rows in 16-byte groups that run past the row end (into the next row, the next channel,
+    or behind the descriptor) and lays them out on a padded pitch.  Nothing of that may reach a sum: every feature pixel
+    no sample taps is NaN here, the features are the TAIL of a NaN-filled allocation (the last channel of the last image
+    ends with the buffer) with NaN guards in front, and the RoIs sit on the last row / column / corner of the last image.
+    Forward and backward through the C-ABI on caller-placed buffers; the gradient map sits between sentinel guards."""
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import _backward_workspace_bytes
+
+    n, res, sr, scale = 2, 7, 2, 0.25
+    rois = _edge_rois(n, height, width, scale, seed=channels + width)
+    r = rois.shape[0]
+    # pixels some sample taps: where the gradient of an all-ones top gradient is non-zero (one channel is enough)
+    tapped = oracle_mod.roi_align_backward(np.ones((r, 1, res, res), np.float32), rois, (n, 1, height, width), scale, sr,
+                                           threads=4)[:, 0] != 0
+    assert tapped[n - 1, height - 1, width - 1] and tapped[n - 1, height - 1].any() and tapped[n - 1, :, width - 1].any()
+    feat = syn.feature_map(n, channels, height, width, seed=7)
+    feat[np.broadcast_to(~tapped[:, None], feat.shape)] = np.nan
+    gtop = np.random.RandomState(3).randn(r, channels, res, res).astype(np.float32)
+    ref = oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=4)
+    ref_grad = oracle_mod.roi_align_backward(gtop, rois, feat.shape, scale, sr, threads=4)
+    assert np.isfinite(ref).all()
+
+    tuning_env(MI_ROI_ALIGN_IMPL="direct" if path == "direct" else None,
+               MI_ROI_ALIGN_FWD_PERSIST={"records": 0, "resident": 1}.get(path))
+    lib, d = _lib.lib(), dev()
+    layout = _lib.LAYOUT_NHWC if path == "channels_last" else _lib.LAYOUT_NCHW
+    f_np = np.ascontiguousarray(feat.transpose(0, 2, 3, 1)) if path == "channels_last" else feat
+    guard = 4096
+    fbuf = torch.full((guard + feat.size,), float("nan"), device=d)
+    fbuf[guard:] = to_dev(f_np).reshape(-1)                                   # features = the tail of the allocation
+    gbuf = torch.full((guard + gtop.size,), float("nan"), device=d)
+    gbuf[guard:] = to_dev(gtop).reshape(-1)
+    sentinel = 12345.0
+    dbuf = torch.full((guard + feat.size + guard,), sentinel, device=d)       # gradient map between two guards
+    obuf = torch.full((guard + ref.size + guard,), sentinel, device=d)
+    rois_d = to_dev(rois)
+    ws = torch.empty(_backward_workspace_bytes([(height, width)], n, r), dtype=torch.uint8, device=d)
+    stream = _lib.current_stream_handle(d)
+    f_ptr, g_ptr = fbuf.data_ptr() + 4 * guard, gbuf.data_ptr() + 4 * guard
+    o_ptr, d_ptr = obuf.data_ptr() + 4 * guard, dbuf.data_ptr() + 4 * guard
+    _lib.check(lib.mi_roi_align_forward_ws(f_ptr, rois_d.data_ptr(), o_ptr, n, channels, height, width, r, res, res, scale,
+                                           sr, _lib.ROI_ALIGN_CAFFE2, layout, ws.data_ptr(), ws.numel(), stream), "forward")
+    flags = _lib.ROI_ALIGN_OVERWRITE if lib.mi_roi_align_backward_overwrites(channels, height, width, r, res, res,
+                                                                            _lib.ROI_ALIGN_CAFFE2, layout) else 0
+    if not flags:
+        dbuf[guard:guard + feat.size] = 0
+    _lib.check(lib.mi_roi_align_backward_ws(g_ptr, rois_d.data_ptr(), d_ptr, n, channels, height, width, r, res, res, scale,
+                                            sr, _lib.ROI_ALIGN_CAFFE2, layout, ws.data_ptr(), ws.numel(), flags, stream),
+               "backward")
+    torch.cuda.synchronize()
+    out = obuf[guard:guard + ref.size].cpu().numpy().reshape(ref.shape)
+    grad = dbuf[guard:guard + feat.size].cpu().numpy().reshape(f_np.shape)
+    if path == "channels_last":
+        grad = grad.transpose(0, 3, 1, 2)
+    assert np.isfinite(out).all(), "%d outputs took a value from outside their windows" % int((~np.isfinite(out)).sum())
+    assert_fwd(out, ref, "forward on the map's last row / column / corner", exact=(path == "direct"))
+    assert_close(grad, ref_grad, "backward on the map's last row / column / corner")
+    for buf, size in ((obuf, ref.size), (dbuf, feat.size)):
+        assert bool((buf[:guard] == sentinel).all()) and bool((buf[guard + size:] == sentinel).all()), "guard overwritten"
 
 
 @pytest.mark.parametrize("variant", ["records", "channels_last"])

@@ -162,6 +162,73 @@ def test_reduce_now_averages_bucket_views():
     assert out[0] == out[1] == (1, [1.5, 1.5])
 
 
+def _sync_and_losses_job(rank, world_size):
+    """sync_parameters / assert_replicas_equal / reduce_losses: what is left of the reference's per-forward parameter
+    broadcast (nn/parallel/replicate.py:12) and of its mean-over-GPUs logging (utils/training_stats.py:84)."""
+    torch.manual_seed(11)   # every rank builds the same net ...
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.Linear(16, 4))
+    net[1].running_mean.add_(0.25)                      # ... a buffer too
+    reference = [t.clone() for t in parallel._state_tensors(net)]
+    if rank == 1:                                       # ... and rank 1 then diverges: weights, a buffer, an integer buffer
+        with torch.no_grad():
+            net[0].weight.add_(torch.randn(16, 8))
+            net[2].bias.mul_(3.0)
+            net[1].running_var.add_(1.0)
+            net[1].num_batches_tracked.add_(7)
+    diverged = False
+    try:
+        parallel.assert_replicas_equal(net)
+    except RuntimeError:
+        diverged = True                                 # raised on BOTH ranks (the verdict travels in the collective)
+    sent = parallel.sync_parameters(net, src=0, bucket_bytes=256)   # tiny buckets: several broadcasts per dtype
+    parallel.assert_replicas_equal(net)
+    same_as_rank0 = all(torch.equal(a, b) for a, b in zip(parallel._state_tensors(net), reference))
+    # the losses of this rank's shard; the logged value is the mean over the ranks
+    ret = {"losses": {"loss_cls": torch.tensor(1.0 + rank), "loss_bbox": torch.tensor([0.5 * (rank + 1)])},
+           "metrics": {"accuracy_cls": 0.25 + 0.5 * rank}, "total_loss": torch.tensor(3.0 * (rank + 1))}
+    logged = parallel.reduce_losses(ret)
+    return diverged, same_as_rank0, sent, logged, int(parallel.replica_checksum(net).item())
+
+
+def test_sync_parameters_makes_a_perturbed_replica_bit_identical_and_losses_are_averaged():
+    out = _run(_sync_and_losses_job)
+    assert out[0][0] and out[1][0]                       # the divergence was seen on both ranks
+    assert out[0][1] and out[1][1]                       # afterwards both hold rank 0's state, bit for bit
+    assert out[0][2] == out[1][2] > 0 and out[0][4] == out[1][4]
+    want = {"losses": {"loss_cls": 1.5, "loss_bbox": 0.75}, "metrics": {"accuracy_cls": 0.5}, "total_loss": 4.5}
+    assert out[0][3] == out[1][3] == want                # = the mean of the shard values (training_stats.py:84)
+
+
+def _no_hook_job(rank, world_size):
+    """detect_unused with a step in which no hook ran on ONE rank only: every rank must raise (after the collective) instead
+    of one rank raising in front of it and the other hanging in the all-reduce."""
+    torch.manual_seed(2)
+    net = torch.nn.Linear(4, 2)
+    red = parallel.GradientAllReducer(net.parameters(), overlap=False, detect_unused=True)
+    red.begin_step()
+    if rank == 0:
+        net(torch.ones(3, 4)).sum().backward()
+    try:
+        red.finish_step()
+    except RuntimeError as exc:
+        return "no gradient hook fired" in str(exc)
+    return False
+
+
+def test_detect_unused_without_hooks_on_one_rank_raises_on_every_rank():
+    assert _run(_no_hook_job) == [True, True]
+
+
+def test_replica_helpers_without_a_process_group():
+    net = torch.nn.Linear(3, 3)
+    assert parallel.sync_parameters(net) == 0 and parallel.assert_replicas_equal(net)
+    assert parallel.reduce_losses({"a": torch.tensor(2.0), "b": {"c": 1}}) == {"a": 2.0, "b": {"c": 1.0}}
+    c0 = int(parallel.replica_checksum(net).item())
+    with torch.no_grad():
+        net.weight[0, 0] += 1e-3
+    assert int(parallel.replica_checksum(net).item()) != c0
+
+
 def test_single_process_is_a_no_op():
     net = torch.nn.Linear(3, 3)
     red = parallel.GradientAllReducer(net.parameters())

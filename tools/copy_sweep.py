@@ -13,5 +13,6 @@ for per_cu in (2, 4, 8, 16, 32, 64):
     for unroll in (1, 4, 8):
         for nt in (0, 1):
             os.environ["MI_COPY_VARIANT"] = str(per_cu * 100 + unroll * 10 + nt)
+            lib.mi_dbg_reload_tuning()  # the library reads its tuning variables once
             sec = time_kernel(lambda: lib.mi_dbg_copy_float4(a.data_ptr(), b.data_ptr(), n, stream), 20)
             print("blocks/CU %2d unroll %d nt %d: %.0f GB/s" % (per_cu, unroll, nt, 2 * n / sec / 1e9), flush=True)
