@@ -445,10 +445,11 @@ extern "C" int mi_roi_align_fpn_supported(const mi_fpn_levels* levels, int chann
   return 1;
 }
 
-extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels,
-                                        float* output, int batch, int channels, int num_rois, int aligned_height,
-                                        int aligned_width, int sampling_ratio, int layout, void* workspace,
-                                        size_t workspace_bytes, mi_stream_t stream) {
+namespace {
+int roi_align_forward_fpn_impl(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels, float* output,
+                               int batch, int channels, int num_rois, int aligned_height, int aligned_width,
+                               int sampling_ratio, int layout, void* workspace, size_t workspace_bytes, bool records_ready,
+                               mi_stream_t stream) {
   mi::begin_call();
   MI_REQUIRE(batch > 0 && channels > 0 && num_rois >= 0 && aligned_height > 0 && aligned_width > 0,
              "roi_align_fpn: bad size");
@@ -466,15 +467,64 @@ extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float
              mi::roi_align_records_workspace_bytes(num_rois));
   const bool bwd_tables = workspace_bytes >= mi::roi_align_bwd_workspace_bytes(lv, batch, num_rois);
   if (layout == MI_LAYOUT_NHWC) {
-    int rc = mi::launch_roi_align_prepare_levels(lv, rois, roi_levels, workspace, batch, num_rois, aligned_height,
-                                                 aligned_width, sampling_ratio, bwd_tables, mi::as_stream(stream), channels);
-    if (rc != MI_OK) return rc;
+    if (!records_ready) {
+      int rc = mi::launch_roi_align_prepare_levels(lv, rois, roi_levels, workspace, batch, num_rois, aligned_height,
+                                                   aligned_width, sampling_ratio, bwd_tables, mi::as_stream(stream), channels);
+      if (rc != MI_OK) return rc;
+    }
     return mi::launch_roi_align_fwd_nhwc_levels(lv, rois, output, workspace, batch, channels, num_rois, aligned_height,
                                                 aligned_width, sampling_ratio, mi::as_stream(stream));
   }
   return mi::launch_roi_align_fwd_records_levels(lv, rois, roi_levels, output, workspace, batch, channels, num_rois,
                                                  aligned_height, aligned_width, sampling_ratio, cap, bwd_tables,
-                                                 mi::as_stream(stream));
+                                                 mi::as_stream(stream), records_ready);
+}
+}  // namespace
+
+extern "C" int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels,
+                                        float* output, int batch, int channels, int num_rois, int aligned_height,
+                                        int aligned_width, int sampling_ratio, int layout, void* workspace,
+                                        size_t workspace_bytes, mi_stream_t stream) {
+  return roi_align_forward_fpn_impl(levels, rois, roi_levels, output, batch, channels, num_rois, aligned_height,
+                                    aligned_width, sampling_ratio, layout, workspace, workspace_bytes, false, stream);
+}
+
+extern "C" int mi_roi_align_forward_fpn_records(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels,
+                                                float* output, int batch, int channels, int num_rois, int aligned_height,
+                                                int aligned_width, int sampling_ratio, int layout, void* workspace,
+                                                size_t workspace_bytes, mi_stream_t stream) {
+  return roi_align_forward_fpn_impl(levels, rois, roi_levels, output, batch, channels, num_rois, aligned_height,
+                                    aligned_width, sampling_ratio, layout, workspace, workspace_bytes, true, stream);
+}
+
+extern "C" int mi_rpn_collect_finish_records(const float* top_scores, const int64_t* top_indices, const float* cand_rois,
+                                             int rows, int mark_invalid, int k_min, int k_max, float canonical_scale,
+                                             float canonical_level, float* rois, uint8_t* valid, int32_t* roi_fpn_levels,
+                                             const mi_fpn_levels* levels, int batch, int channels, int aligned_height,
+                                             int aligned_width, int sampling_ratio, int layout, void* workspace,
+                                             size_t workspace_bytes, mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(rows >= 0 && k_min <= k_max, "rpn_collect_finish_records: bad size");
+  if (rows == 0) return MI_OK;
+  MI_REQUIRE(top_scores != nullptr && top_indices != nullptr && cand_rois != nullptr && rois != nullptr &&
+                 valid != nullptr && roi_fpn_levels != nullptr && workspace != nullptr,
+             "rpn_collect_finish_records: null pointer");
+  MI_REQUIRE(batch > 0 && channels > 0 && aligned_height > 0 && aligned_width > 0, "rpn_collect_finish_records: bad size");
+  mi::LevelTable lv;
+  MI_REQUIRE(to_level_table(levels, batch, true, &lv), "rpn_collect_finish_records: malformed level table");
+  MI_REQUIRE(lv.count == k_max - k_min + 1,
+             "rpn_collect_finish_records: %d maps for FPN levels %d..%d (coarsest first)", lv.count, k_min, k_max);
+  MI_REQUIRE(mi_roi_align_fpn_supported(levels, channels, rows, aligned_height, aligned_width, layout) == 1,
+             "rpn_collect_finish_records: shapes not served by the fused RoIAlign (mi_roi_align_fpn_supported() == 0)");
+  MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
+                 workspace_bytes >= mi::roi_align_records_workspace_bytes(rows),
+             "rpn_collect_finish_records: workspace of %zu bytes (16-byte aligned), %zu needed", workspace_bytes,
+             mi::roi_align_records_workspace_bytes(rows));
+  const bool bwd_tables = workspace_bytes >= mi::roi_align_bwd_workspace_bytes(lv, batch, rows);
+  return mi::launch_roi_align_prepare_collected(lv, top_scores, reinterpret_cast<const long long*>(top_indices), cand_rois,
+                                                mark_invalid, k_min, k_max, canonical_scale, canonical_level, rois, valid,
+                                                roi_fpn_levels, workspace, batch, rows, aligned_height, aligned_width,
+                                                sampling_ratio, ring_words(), bwd_tables, mi::as_stream(stream), channels);
 }
 
 extern "C" int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const float* top_grad, const float* rois,

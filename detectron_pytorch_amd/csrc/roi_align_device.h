@@ -133,7 +133,14 @@ bool roi_align_bwd_records_supported(int channels, int height, int width, int nu
 int launch_roi_align_fwd_records_levels(const LevelTable& lv, const float* rois, const int* levels, float* output,
                                         void* workspace, int batch, int channels, int num_rois, int aligned_height,
                                         int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables,
-                                        hipStream_t stream);
+                                        hipStream_t stream, bool records_ready = false);
+// the records of RoIs that are still candidates of the proposal stage: row r = candidate top_idx[r]; also writes the RoI
+// blob, its validity bytes and FPN levels (what mi_rpn_collect_finish writes) -- roi_align_records.hip, CollectedRois
+int launch_roi_align_prepare_collected(const LevelTable& lv, const float* top_scores, const long long* top_idx,
+                                       const float* cand_rois, int mark_invalid, int k_min, int k_max, float s0, float lvl0,
+                                       float* rois, unsigned char* valid, int* levels, void* workspace, int batch,
+                                       int num_rois, int aligned_height, int aligned_width, int sampling_ratio, int cap_px,
+                                       bool bwd_tables, hipStream_t stream, int channels);
 // workspace_bytes >= roi_align_bwd_workspace_bytes(): the planned backward (roi_align_bwd_plan + list slices);
 // a workspace of roi_align_records_workspace_bytes() only: every tile's workgroups scan the RoIs themselves
 size_t roi_align_bwd_workspace_bytes(LevelTable lv, int batch, int num_rois);

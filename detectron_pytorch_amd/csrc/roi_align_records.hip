@@ -96,26 +96,81 @@ __device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int
   return ((unsigned)b << 24) | ((unsigned)band << 16) | (unsigned)x;
 }
 
+// Where roi_align_prepare takes its RoIs from.
+//   PlainRois      the caller's [R, 5] blob and (pyramid calls) the level-table index of every RoI;
+//   CollectedRois  the LAST step of the device-side proposal stage folded in (modeling/collect_and_distribute_fpn_rpn_
+//                  proposals.py:101-119; mi_rpn_collect_finish without a launch of its own): row r of the RoI blob is candidate
+//                  top_idx[r], its FPN level comes from utils/fpn.py:11-28 (fp32, the reference's operation order), and the
+//                  owner wave of a RoI also writes the blob row, the validity byte and the level the model consumes -- the
+//                  producer of the RoIs leaves their records behind, the forward over them starts with its gather kernel.
+struct PlainRois {
+  const float* __restrict__ rois;
+  const int* __restrict__ levels;
+  __device__ __forceinline__ int get(int i, int nlevels, float (&v)[5]) const {
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = rois[(long long)i * 5 + k];
+    return levels != nullptr ? min(max(levels[i], 0), nlevels - 1) : 0;
+  }
+  __device__ __forceinline__ void emit(int, const float (&)[5]) const {}
+};
+struct CollectedRois {
+  const float* __restrict__ top_scores;
+  const long long* __restrict__ top_idx;
+  const float* __restrict__ cand_rois;
+  int mark_invalid, k_min, k_max;
+  float s0, lvl0;
+  float* __restrict__ out_rois;
+  unsigned char* __restrict__ out_valid;
+  int* __restrict__ out_levels;
+  __device__ __forceinline__ float fpn_level(const float (&v)[5]) const {
+    const float w = v[3] - v[1] + 1.f, h = v[4] - v[2] + 1.f;
+    float area = w * h;
+    area = area < 0.f ? 0.f : area;             // areas[neg_idx] = 0 (utils/boxes.py:113-121 via fpn.py:18)
+    const float lvl = floorf(lvl0 + log2f(sqrtf(area) / s0 + 1e-6f));
+    return fminf(fmaxf(lvl, (float)k_min), (float)k_max);
+  }
+  __device__ __forceinline__ int get(int i, int nlevels, float (&v)[5]) const {
+    const float* c = cand_rois + top_idx[i] * 5;
+    const bool ok = top_scores[i] > -__builtin_inff();
+    v[0] = (ok || !mark_invalid) ? c[0] : -1.f;
+#pragma unroll
+    for (int k = 1; k < 5; k++) v[k] = c[k];
+    return min(max(k_max - (int)fpn_level(v), 0), nlevels - 1);  // the level table lists the coarsest map first
+  }
+  __device__ __forceinline__ void emit(int i, const float (&v)[5]) const {
+#pragma unroll
+    for (int k = 0; k < 5; k++) out_rois[(long long)i * 5 + k] = v[k];
+    out_valid[i] = top_scores[i] > -__builtin_inff() ? 1 : 0;
+    out_levels[i] = (int)fpn_level(v);
+  }
+};
+
+template <class Src>
 __global__ void __launch_bounds__(256)
-roi_align_prepare(const float* __restrict__ rois, const int* __restrict__ levels, int num_rois, int batch,
-                  const LevelTable lv, int aligned_height, int aligned_width, int sampling_ratio, int cap_px,
-                  int stage_px, int max_rows_tile, int bwd_tables, int channels, int* __restrict__ ws) {
+roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, int aligned_height, int aligned_width,
+                  int sampling_ratio, int cap_px, int stage_px, int max_rows_tile, int bwd_tables, int channels,
+                  int* __restrict__ ws) {
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < kCounterDwords; i += 256) ws[i] = 0;
-  // This wave's RoI: its five floats and its level are fetched FIRST (wave-uniform address -> scalar loads), so that
-  // their latency passes under the key phase below instead of after the barrier.
+  // This wave's RoI: its five floats and its level are fetched FIRST (one address for the whole wave), so that their
+  // latency passes under the key phase below instead of after the barrier.
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  using const_float_ptr = const __attribute__((address_space(4))) float*;
   const int r_safe = __builtin_amdgcn_readfirstlane(min(r, num_rois - 1));
-  const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)r_safe * 5);
-  const float roi_b = roi[0], roi_x1 = roi[1], roi_y1 = roi[2], roi_x2 = roi[3], roi_y2 = roi[4];
-  const int lvl = __builtin_amdgcn_readfirstlane(level_of(levels, r_safe, lv));
+  float own[5];
+  const int lvl = __builtin_amdgcn_readfirstlane(src.get(r_safe, lv.count, own));
   for (int i = threadIdx.x; i < num_rois; i += 256) {
-    const int l = level_of(levels, i, lv);
-    keys[i] = sweep_key(rois + (long long)i * 5, l, lv.scale[l], lv.height[l]);
+    float v[5];
+    const int l = src.get(i, lv.count, v);
+    keys[i] = sweep_key(v, l, lv.scale[l], lv.height[l]);
   }
+  const float roi_b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, own[0])));
+  const float roi_x1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, own[1])));
+  const float roi_y1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, own[2])));
+  const float roi_x2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, own[3])));
+  const float roi_y2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, own[4])));
+  if (r < num_rois && lane == 0) src.emit(r, own);
   __syncthreads();
   if (r >= num_rois) return;
   // rank of this RoI in the sweep (ties by index): the record index
@@ -1416,14 +1471,20 @@ size_t records_lds_bytes(int cap, int ct) {
   return (size_t)2 * kRecFront * 4 + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4 + 16;
 }
 
+template <class Src>
+int launch_prepare_from(const Src& src, int* ws, int batch, const LevelTable& lv, int num_rois, int aligned_height,
+                        int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables, hipStream_t stream, int channels) {
+  const int max_rows_tile = kTileBins / aligned_width;
+  roi_align_prepare<Src><<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
+      src, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile,
+      bwd_tables ? 1 : 0, channels, ws);
+  return check_launch("roi_align_prepare");
+}
 int launch_prepare(const float* rois, const int* levels, int* ws, int batch, const LevelTable& lv, int num_rois,
                    int aligned_height, int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables,
                    hipStream_t stream, int channels = 0) {
-  const int max_rows_tile = kTileBins / aligned_width;
-  roi_align_prepare<<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
-      rois, levels, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile,
-      bwd_tables ? 1 : 0, channels, ws);
-  return check_launch("roi_align_prepare");
+  return launch_prepare_from(PlainRois{rois, levels}, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio,
+                             cap_px, bwd_tables, stream, channels);
 }
 
 #if MI_TUNING
@@ -1433,9 +1494,11 @@ long long* g_records_timeline = nullptr;
 template <int kCap>
 int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float* output, int* ws, int batch,
                int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio, bool bwd_tables,
-               hipStream_t stream) {
-  int rc = launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio, kCap,
-                          bwd_tables, stream, channels);
+               hipStream_t stream, bool records_ready) {
+  // records_ready: the producer of the RoIs wrote the records (launch_roi_align_prepare_collected, same LDS capacity)
+  int rc = records_ready ? MI_OK
+                         : launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio,
+                                          kCap, bwd_tables, stream, channels);
   if (rc != MI_OK) return rc;
   const size_t lds = records_lds_bytes(kCap, kCT);
   const int items = num_rois * (channels / kCT);
@@ -1638,6 +1701,18 @@ int launch_roi_align_prepare_levels(const LevelTable& lv, const float* rois, con
                         sampling_ratio, 336, bwd_tables, stream, channels);
 }
 
+int launch_roi_align_prepare_collected(const LevelTable& lv, const float* top_scores, const long long* top_idx,
+                                       const float* cand_rois, int mark_invalid, int k_min, int k_max, float s0, float lvl0,
+                                       float* rois, unsigned char* valid, int* levels, void* workspace, int batch,
+                                       int num_rois, int aligned_height, int aligned_width, int sampling_ratio, int cap_px,
+                                       bool bwd_tables, hipStream_t stream, int channels) {
+  const CollectedRois src = {top_scores, top_idx, cand_rois, mark_invalid, k_min, k_max, s0, lvl0, rois, valid, levels};
+  // the forward cuts its stages for one of five LDS capacities: the same rounding as launch_roi_align_fwd_records_levels
+  const int cap = cap_px >= 640 ? 640 : cap_px >= 448 ? 448 : cap_px >= 336 ? 336 : cap_px >= 256 ? 256 : 192;
+  return launch_prepare_from(src, static_cast<int*>(workspace), batch, lv, num_rois, aligned_height, aligned_width,
+                             sampling_ratio, cap, bwd_tables, stream, channels);
+}
+
 void roi_align_fwd_records_set_timeline(long long* device_buffer) {
 #if MI_TUNING
   g_records_timeline = device_buffer;
@@ -1660,11 +1735,11 @@ bool roi_align_fwd_records_supported(int channels, int height, int width, int nu
 int launch_roi_align_fwd_records_levels(const LevelTable& lv, const float* rois, const int* levels, float* output,
                                         void* workspace, int batch, int channels, int num_rois, int aligned_height,
                                         int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables,
-                                        hipStream_t stream) {
+                                        hipStream_t stream, bool records_ready) {
   int* ws = static_cast<int*>(workspace);
 #define MI_CAP(C)                                                                                                     \
   return launch_cap<C>(lv, rois, levels, output, ws, batch, channels, num_rois, aligned_height, aligned_width,        \
-                       sampling_ratio, bwd_tables, stream)
+                       sampling_ratio, bwd_tables, stream, records_ready)
   if (cap_px >= 640) MI_CAP(640);
   if (cap_px >= 448) MI_CAP(448);
   if (cap_px >= 336) MI_CAP(336);
@@ -1679,7 +1754,7 @@ int launch_roi_align_fwd_records(const float* features, const float* rois, float
                                  hipStream_t stream) {
   return launch_roi_align_fwd_records_levels(single_level(features, nullptr, batch, height, width, spatial_scale), rois,
                                              nullptr, output, workspace, batch, channels, num_rois, aligned_height,
-                                             aligned_width, sampling_ratio, cap_px, bwd_tables, stream);
+                                             aligned_width, sampling_ratio, cap_px, bwd_tables, stream, false);
 }
 
 }  // namespace mi

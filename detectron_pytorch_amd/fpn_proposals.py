@@ -72,7 +72,8 @@ def _fused_supported(ops, heads, post_nms_topN):
     return True
 
 
-def generate_and_collect(ops, heads, im_info, post_nms_topN, static=False, with_levels=False, k_min=2, k_max=5):
+def generate_and_collect(ops, heads, im_info, post_nms_topN, static=False, with_levels=False, k_min=2, k_max=5,
+                         records=None):
     """GenerateProposals on every RPN level followed by `collect`, as ONE asynchronous pipeline of a dozen launches:
         mi_topk_batched            pre-NMS top-k of every (level, image) score map, all side by side
         mi_rpn_decode_proposals    anchors + deltas -> boxes, clip, size filter                       (per level)
@@ -85,7 +86,10 @@ def generate_and_collect(ops, heads, im_info, post_nms_topN, static=False, with_
     rpn_bbox_pred) pairs.  Returns rois [R,5] in descending score order, R <= post_nms_topN -- what `collect` returns
     for the reference's per-level outputs.  `static=True`: (rois [k,5], valid [k]) with k = min(post_nms_topN,
     candidates) fixed by the shapes alone and no host synchronisation at all; `with_levels=True` (static only): (rois,
-    valid, levels int32 [k]) where the rows that are no proposals carry image index -1."""
+    valid, levels int32 [k]) where the rows that are no proposals carry image index -1.
+    `records` (static + with_levels only): a roi_align.PreparedRecords for the pooling call that will consume the blob --
+    the last launch then also writes the RoIAlign records of the rows (mi_rpn_collect_finish_records) and `records.rois`
+    is the returned blob; ignored when the shapes do not fit."""
     if not _fused_supported(ops, heads, post_nms_topN):
         return _generate_and_collect_torch(ops, heads, im_info, post_nms_topN, static, with_levels, k_min, k_max)
     lib = _lib.lib()
@@ -130,10 +134,21 @@ def generate_and_collect(ops, heads, im_info, post_nms_topN, static=False, with_
     rois = torch.empty((k, 5), dtype=torch.float32, device=device)
     valid = torch.empty((k,), dtype=torch.bool, device=device)
     levels = torch.empty((k,), dtype=torch.int32, device=device)
+    fuse_records = (records is not None and static and with_levels and records.supported and records.num_rois == k
+                    and len(records.features) == int(k_max) - int(k_min) + 1)
     with torch.cuda.device(device):
-        rc = lib.mi_rpn_collect_finish(best.data_ptr(), inds.data_ptr(), cand_rois.data_ptr(), k,
-                                       1 if (static and with_levels) else 0, int(k_min), int(k_max), 224.0, 4.0,
-                                       rois.data_ptr(), valid.data_ptr(), levels.data_ptr(), stream)
+        if fuse_records:
+            ah, aw, sr = records.cfg
+            rc = lib.mi_rpn_collect_finish_records(best.data_ptr(), inds.data_ptr(), cand_rois.data_ptr(), k, 1, int(k_min),
+                                                   int(k_max), 224.0, 4.0, rois.data_ptr(), valid.data_ptr(),
+                                                   levels.data_ptr(), ctypes.byref(records.table), records.batch,
+                                                   records.channels, ah, aw, sr, records.layout,
+                                                   records.workspace.data_ptr(), records.workspace.numel(), stream)
+            records.rois = rois
+        else:
+            rc = lib.mi_rpn_collect_finish(best.data_ptr(), inds.data_ptr(), cand_rois.data_ptr(), k,
+                                           1 if (static and with_levels) else 0, int(k_min), int(k_max), 224.0, 4.0,
+                                           rois.data_ptr(), valid.data_ptr(), levels.data_ptr(), stream)
     _lib.check(rc, "mi_rpn_collect_finish")
     if static:
         return (rois, valid, levels) if with_levels else (rois, valid)

@@ -19,6 +19,12 @@ import torch
 import torch.nn as nn
 
 from .. import fpn_proposals, nms, roi_xform
+from .. import roi_align as roi_align_mod
+
+import os
+
+# A/B switch of the measurement tools: 0 = the box head's pooling call writes its records itself
+PRODUCER_RECORDS = os.environ.get("MI_RCNN_PRODUCER_RECORDS", "1") != "0"
 from . import fpn as fpn_mod
 from . import heads, targets
 
@@ -81,7 +87,7 @@ class GeneralizedRCNN(nn.Module):
                                                sampling_ratio, self.cfg.FPN.ROI_MIN_LEVEL, self.cfg.FPN.ROI_MAX_LEVEL)
 
     # ---- proposals -----------------------------------------------------------------------------------------------------
-    def proposals(self, rpn_ret, im_info, static, with_levels=False):
+    def proposals(self, rpn_ret, im_info, static, with_levels=False, records=None):
         """FPN.py:390-417 without leaving the device: objectness (sigmoid / softmax), GenerateProposals on every level, collect."""
         cfg = self.cfg
         heads_ = [(fpn_mod.rpn_cls_probs(cfg, rpn_ret["rpn_cls_logits_fpn%d" % lvl].detach().float()).contiguous(),
@@ -92,7 +98,7 @@ class GeneralizedRCNN(nn.Module):
         if with_levels:
             return fpn_proposals.generate_and_collect(self.RPN.proposal_ops(self.training), heads_, im_info, post,
                                                       static=True, with_levels=True, k_min=cfg.FPN.ROI_MIN_LEVEL,
-                                                      k_max=cfg.FPN.ROI_MAX_LEVEL)
+                                                      k_max=cfg.FPN.ROI_MAX_LEVEL, records=records)
         return fpn_proposals.generate_and_collect(self.RPN.proposal_ops(self.training), heads_, im_info, post,
                                                   static=static)
 
@@ -132,8 +138,16 @@ class GeneralizedRCNN(nn.Module):
                 if self.static_inference:
                     # always RPN_POST_NMS_TOP_N rows; the rows that are no proposals get image index -1 (the RoI operators
                     # pool zeros for them) and are reported in `rois_valid`: no host synchronisation, capturable
-                    rois, valid, lvls = self.proposals(rpn_ret, im_info_d, static=True, with_levels=True)
-                    blobs = {"rois": rois, "rois_levels": lvls}
+                    # the box head's pooling call is known before its RoIs are: the proposal stage's last launch writes
+                    # the RoIAlign records of the blob it emits, and the pooling starts with its gather kernel
+                    fr = cfg.FAST_RCNN
+                    records = None
+                    if fr.ROI_XFORM_METHOD == "RoIAlign" and cfg.FPN.MULTILEVEL_ROIS and PRODUCER_RECORDS:
+                        post = int(cfg.TEST.RPN_POST_NMS_TOP_N * cfg.FPN.RPN_COLLECT_SCALE + 0.5)
+                        records = roi_align_mod.PreparedRecords(roi_blobs, self.roi_scales, fr.ROI_XFORM_RESOLUTION,
+                                                                fr.ROI_XFORM_RESOLUTION, fr.ROI_XFORM_SAMPLING_RATIO, post)
+                    rois, valid, lvls = self.proposals(rpn_ret, im_info_d, static=True, with_levels=True, records=records)
+                    blobs = {"rois": rois, "rois_levels": lvls, "rois_records": records}
                     ret["rois_valid"] = valid
                 else:
                     rois = self.proposals(rpn_ret, im_info_d, static=False)

@@ -257,11 +257,59 @@ class _RoIAlignFPN(Function):
         return (None, None, None, None, None, None) + tuple(grads)
 
 
-def roi_align_fpn(features, scales, rois, roi_levels, aligned_height, aligned_width, sampling_ratio):
+class PreparedRecords(object):
+    """The RoIAlign records of a RoI blob, written by the stage that PRODUCES the blob (mi_rpn_collect_finish_records:
+    fpn_proposals.generate_and_collect(..., records=this)) instead of by the first launch of the pooling call -- the producer
+    holds every RoI in a launch of its own, so the pooling call that follows starts with its gather kernel.
+
+    Built before the proposals exist, from what the pooling call will be: the pyramid (`features`, coarsest map first, and
+    their `scales`), the pooled size, the sampling ratio and the number of rows of the (static) RoI blob.  `matches()` is
+    what roi_align_fpn checks before it trusts the records: same maps (addresses), same geometry, and the very tensor the
+    producer wrote the RoIs into.  Inference only (no backward block is asked for)."""
+
+    def __init__(self, features, scales, aligned_height, aligned_width, sampling_ratio, num_rois):
+        self.features = list(features)
+        self.scales = tuple(float(s) for s in scales)
+        self.cfg = (int(aligned_height), int(aligned_width), int(sampling_ratio))
+        self.num_rois = int(num_rois)
+        self.layout = _common_layout(self.features)
+        self.batch, self.channels = int(features[0].size(0)), int(features[0].size(1))
+        self.supported = self.layout is not None and roi_align_fpn_supported(self.features, self.num_rois, *self.cfg[:2])
+        self.rois = None          # set by the producer: the blob these records describe
+        self.workspace = None
+        if self.supported:
+            self.table = _fpn_table(self.features, self.scales)
+            self.workspace = torch.empty(int(_lib.lib().mi_roi_align_forward_workspace_bytes(self.num_rois)),
+                                         dtype=torch.uint8, device=features[0].device)
+
+    def matches(self, features, scales, rois, aligned_height, aligned_width, sampling_ratio):
+        return (self.supported and self.rois is not None and rois is self.rois and rois.size(0) == self.num_rois
+                and (int(aligned_height), int(aligned_width), int(sampling_ratio)) == self.cfg
+                and len(features) == len(self.features)
+                and all(a.data_ptr() == b.data_ptr() and a.shape == b.shape for a, b in zip(features, self.features))
+                and tuple(float(s) for s in scales) == self.scales and _common_layout(features) == self.layout)
+
+
+def roi_align_fpn(features, scales, rois, roi_levels, aligned_height, aligned_width, sampling_ratio, prepared=None):
     """Pool `rois` [R,5] from the FPN maps `features` (list, any order; `scales` alike) in one call; roi_levels [R]
-    (int tensor on the device) indexes into `features`.  Differentiable w.r.t. every map."""
+    (int tensor on the device) indexes into `features`.  Differentiable w.r.t. every map.
+    `prepared`: a PreparedRecords whose producer already wrote the records of exactly this call (inference): the records
+    launch is skipped (mi_roi_align_forward_fpn_records); anything that does not match is ignored."""
     for f in features:
         _check_inputs(f, rois)
+    if (prepared is not None and not torch.is_grad_enabled()
+            and prepared.matches(features, scales, rois, aligned_height, aligned_width, sampling_ratio)):
+        lib = _lib.lib()
+        roi_levels = roi_levels.to(dtype=torch.int32).contiguous()
+        output = torch.empty((rois.size(0), prepared.channels, int(aligned_height), int(aligned_width)), dtype=torch.float32,
+                             device=rois.device)
+        with torch.cuda.device(rois.device):
+            rc = lib.mi_roi_align_forward_fpn_records(
+                ctypes.byref(prepared.table), rois.data_ptr(), roi_levels.data_ptr(), output.data_ptr(), prepared.batch,
+                prepared.channels, rois.size(0), int(aligned_height), int(aligned_width), int(sampling_ratio), prepared.layout,
+                prepared.workspace.data_ptr(), prepared.workspace.numel(), _lib.current_stream_handle(rois.device))
+        _lib.check(rc, "mi_roi_align_forward_fpn_records")
+        return output
     return _RoIAlignFPN.apply(rois, roi_levels, int(aligned_height), int(aligned_width), int(sampling_ratio),
                               tuple(scales), *features)
 

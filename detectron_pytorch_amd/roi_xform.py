@@ -96,8 +96,9 @@ def roi_feature_transform(blobs_in, rpn_ret, blob_rois="rois", method="RoIPoolF"
         # the FPN level of each: nothing to split, concatenate or restore -- one fused call, output in the order of the rois
         rois = _as_device_rois(rpn_ret[blob_rois], blobs_in[0].device)
         if roi_align_fpn_supported(list(blobs_in), rois.size(0), resolution, resolution):
+            # `<blob>_records`: the producer of the blob already wrote its RoIAlign records (roi_align.PreparedRecords)
             return roi_align_fpn(list(blobs_in), list(spatial_scale), rois, (k_max - levels).to(torch.int32), resolution,
-                                 resolution, sampling_ratio)
+                                 resolution, sampling_ratio, prepared=rpn_ret.get(blob_rois + "_records"))
     if levels is not None and ("%s_fpn%d" % (blob_rois, k_min)) not in rpn_ret:
         # the device-side producers emit only `<blob>` + `<blob>_levels`; when the fused call is not available (RoIPool /
         # RoICrop, MI_ROI_ALIGN_IMPL=direct, MI_ROI_ALIGN_NO_WS, > 8192 RoIs, FPN.DIM not a multiple of 32, fused=False)

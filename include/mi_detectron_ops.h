@@ -39,8 +39,10 @@ extern "C" {
 /* 2: round-2/3 entry points (top-k, segmented NMS, RPN collect, affine, result formats, FPN-fused RoIAlign), RoIs of a
  * non-existent image pool zeros.  3 (round 4): the opt-in tile-centric NCHW forward and its two entry points
  * (mi_roi_align_forward_tiles_workspace_bytes, mi_roi_align_forward_fpn_writes_records) are gone -- measured slower on
- * every shape but one; every fast forward now leaves its records (mi_roi_align_forward_writes_records). */
-#define MI_ABI_VERSION 3
+ * every shape but one; every fast forward now leaves its records (mi_roi_align_forward_writes_records).  4 (round 5):
+ * mi_rpn_collect_finish_records + mi_roi_align_forward_fpn_records (the producer of the RoIs writes their records); a
+ * dword-aligned top_grad is served by the generic backward instead of refused. */
+#define MI_ABI_VERSION 4
 
 typedef void* mi_stream_t; /* hipStream_t */
 
@@ -168,6 +170,14 @@ int mi_roi_align_forward_fpn(const mi_fpn_levels* levels, const float* rois, con
                              int batch, int channels, int num_rois, int aligned_height, int aligned_width,
                              int sampling_ratio, int layout, void* workspace, size_t workspace_bytes,
                              mi_stream_t stream);
+/* The same forward over records that are ALREADY in `workspace`: written for exactly these rois / roi_levels / geometry /
+ * level table by mi_rpn_collect_finish_records (below) on the same stream -- the records launch is skipped.  The library
+ * cannot check that the records belong to the rois; a workspace sized for a backward must have been that size when the
+ * records were written (their backward block). */
+int mi_roi_align_forward_fpn_records(const mi_fpn_levels* levels, const float* rois, const int32_t* roi_levels,
+                                     float* output, int batch, int channels, int num_rois, int aligned_height,
+                                     int aligned_width, int sampling_ratio, int layout, void* workspace,
+                                     size_t workspace_bytes, mi_stream_t stream);
 int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const float* top_grad, const float* rois,
                               const int32_t* roi_levels, int batch, int channels, int num_rois, int aligned_height,
                               int aligned_width, int sampling_ratio, int layout, void* workspace,
@@ -317,6 +327,19 @@ int mi_rpn_collect_candidates(int num_problems, const float* const* dets, const 
 int mi_rpn_collect_finish(const float* top_scores, const int64_t* top_indices, const float* cand_rois, int rows,
                           int mark_invalid, int k_min, int k_max, float canonical_scale, float canonical_level,
                           float* rois, uint8_t* valid, int32_t* levels, mi_stream_t stream);
+/* mi_rpn_collect_finish that ALSO leaves the RoIAlign records of the blob it writes (same outputs, bit for bit) -- the
+ * producer of the RoIs holds every one of them in a launch of its own, so the per-RoI records of the box head's pyramid
+ * call (sweep rank, window, tap tables: what mi_roi_align_forward_fpn's first launch computes) are written here and
+ * mi_roi_align_forward_fpn_records starts with its gather kernel.  `levels`: the maps the head will pool from, COARSEST
+ * FIRST (k_max .. k_min, modeling/FPN.py:76-78), so that RoI r pools from map k_max - roi_fpn_levels[r] -- the roi_levels
+ * vector to pass on is k_max - roi_fpn_levels.  batch / channels / aligned size / sampling ratio / layout / workspace: those
+ * of the forward call that will follow (mi_roi_align_fpn_supported(...) must be 1).
+ * Replaces collect (:91-98), the level half of distribute (:101-119) and the record launch of the RoIAlign that follows. */
+int mi_rpn_collect_finish_records(const float* top_scores, const int64_t* top_indices, const float* cand_rois, int rows,
+                                  int mark_invalid, int k_min, int k_max, float canonical_scale, float canonical_level,
+                                  float* rois, uint8_t* valid, int32_t* roi_fpn_levels, const mi_fpn_levels* levels,
+                                  int batch, int channels, int aligned_height, int aligned_width, int sampling_ratio,
+                                  int layout, void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* Bounding-box voting (lib/utils/boxes.py:268-317 box_voting; call site lib/core/test.py:766-773, TEST.BBOX_VOTE): every
  * row of top_dets [num_top, 5] (x1, y1, x2, y2, score: the detections that survived NMS) is refined by the rows of its

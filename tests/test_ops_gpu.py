@@ -1110,6 +1110,58 @@ def test_roi_align_fpn_fused_matches_per_level_loop_and_oracle(oracle_mod):
                      "adv bwd %d" % k)
 
 
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_records_written_by_the_proposal_stage_equal_the_pooling_calls_own(channels_last):
+    """mi_rpn_collect_finish_records: the last launch of the proposal stage writes the RoI blob (bit-equal to
+    mi_rpn_collect_finish) AND the RoIAlign records of its rows; mi_roi_align_forward_fpn_records over them returns exactly
+    what mi_roi_align_forward_fpn returns for the same blob (same records, same kernel).  Rows that are no proposals (score
+    -inf) carry image index -1 and pool zeros."""
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import PreparedRecords, roi_align_fpn
+
+    d, lib = dev(), _lib.lib()
+    rng = np.random.RandomState(17)
+    n, c, k_min, k_max, rows, total = 2, 64, 2, 5, 300, 420
+    sizes = {5: (13, 21), 4: (25, 42), 3: (50, 84), 2: (100, 168)}                       # a 400 x 672 image
+    feats = [to_dev(syn.feature_map(n, c, *sizes[l], seed=l)) for l in (5, 4, 3, 2)]     # coarsest first
+    if channels_last:
+        feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+    scales = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4]
+    side = np.exp(rng.uniform(np.log(12.0), np.log(380.0), total))
+    x1, y1 = rng.uniform(0, 672 - 8, total), rng.uniform(0, 400 - 8, total)
+    cand = np.stack([rng.randint(0, n, total), x1, y1, np.minimum(x1 + side, 671), np.minimum(y1 + side * rng.uniform(0.5, 2, total), 399)], 1)
+    cand_rois = to_dev(cand.astype(np.float32))
+    scores = rng.rand(total).astype(np.float32)
+    scores[rng.rand(total) < 0.45] = -np.inf            # fewer proposals than rows: padding rows at the end of the blob
+    best, inds = torch.topk(to_dev(scores), rows)
+    inds = inds.to(torch.int64).contiguous()
+    stream = _lib.current_stream_handle(d)
+
+    def blob():
+        return (torch.empty((rows, 5), device=d), torch.empty((rows,), dtype=torch.bool, device=d),
+                torch.empty((rows,), dtype=torch.int32, device=d))
+
+    rois_a, valid_a, lv_a = blob()
+    _lib.check(lib.mi_rpn_collect_finish(best.data_ptr(), inds.data_ptr(), cand_rois.data_ptr(), rows, 1, k_min, k_max, 224.0,
+                                         4.0, rois_a.data_ptr(), valid_a.data_ptr(), lv_a.data_ptr(), stream), "finish")
+    rec = PreparedRecords(feats, scales, 7, 7, 2, rows)
+    assert rec.supported
+    rois_b, valid_b, lv_b = blob()
+    _lib.check(lib.mi_rpn_collect_finish_records(best.data_ptr(), inds.data_ptr(), cand_rois.data_ptr(), rows, 1, k_min, k_max,
+                                                 224.0, 4.0, rois_b.data_ptr(), valid_b.data_ptr(), lv_b.data_ptr(),
+                                                 ctypes.byref(rec.table), rec.batch, rec.channels, 7, 7, 2, rec.layout,
+                                                 rec.workspace.data_ptr(), rec.workspace.numel(), stream), "finish_records")
+    rec.rois = rois_b
+    assert torch.equal(rois_a, rois_b) and torch.equal(valid_a, valid_b) and torch.equal(lv_a, lv_b)
+    assert 0 < int(valid_a.sum()) < rows and bool((rois_a[~valid_a, 0] == -1).all())
+    with torch.no_grad():
+        want = roi_align_fpn(feats, scales, rois_a, (k_max - lv_a), 7, 7, 2)
+        got = roi_align_fpn(feats, scales, rois_b, (k_max - lv_b), 7, 7, 2, prepared=rec)
+        assert rec.matches(feats, scales, rois_b, 7, 7, 2) and not rec.matches(feats, scales, rois_a, 7, 7, 2)
+    assert torch.equal(got, want)
+    assert bool((got[~valid_a] == 0).all()) and float(got[valid_a].abs().sum()) > 0
+
+
 def _clustered_rois(num, batch, height, width, scale, boxes_per_image, seed):
     """RoIs jittered around a few boxes per image (what a training step samples around its ground truth)."""
     rng = np.random.RandomState(seed)

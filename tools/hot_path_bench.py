@@ -149,7 +149,8 @@ def roofline_roi_align_forward(device, iters):
     traffic, traffic_src = pmc_traffic("forward")
     info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
+            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call; the 14x14 shapes below run the "
+                      "resident form roi_align_fwd_persist)",
             "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
             "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
     # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
@@ -205,6 +206,10 @@ def roofline_roi_align_forward(device, iters):
     if layout == _lib.LAYOUT_NCHW:
         info["cold_cache"] = cold_cache_variant(device, lib, stream, feat, rois, ws, ws_bytes, alg_bytes, r, c, h, w, res,
                                                 scale, sr, max(iters // 2, 20))
+        # `frac` above is measured on ONE map visited back to back (it stays in the 256 MB Infinity Cache); a step that
+        # pools a map a convolution has just written sees something between the two
+        info["cold_cache_frac"] = info["cold_cache"]["frac"]
+        info["frac_is"] = "warm: the same feature map every call; cold_cache_frac: six maps round-robin"
     copy_gbs, torch_gbs = copy_ceiling(device)
     info["copy_ceiling"] = {"measured": round(copy_gbs, 1), "unit": "GB/s", "frac_of_copy": round(achieved / copy_gbs, 4),
                             "ceiling_frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 3),
@@ -321,7 +326,17 @@ def other_shapes(device, lib, stream, iters):
             assert lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), n, c, h, w, r, res, res,
                                                 scale, sr, 0, 0, ws.data_ptr(), ws_bytes, flags, stream) == 0
 
-        out[name] = {"fwd_us": round(time_kernel(fwd, iters) * 1e6, 1), "bwd_us": round(time_kernel(bwd, iters) * 1e6, 1)}
+        fwd_s, bwd_s = time_kernel(fwd, iters), time_kernel(bwd, iters)
+        # the same algorithmic-bytes formulas as the headline shape: forward 4 R C PH PW + 4 C U + 20 R
+        # with U = distinct tapped pixels of THIS RoI set, backward 4 R C PH PW + 4 N C H W + 20 R
+        u = touched_pixels(rois.cpu().numpy(), n, h, w, res, res, scale, sr)
+        fwd_bytes = 4 * r * c * res * res + 4 * c * u + 20 * r
+        bwd_bytes = 4 * r * c * res * res + 4 * n * c * h * w + 20 * r
+        out[name] = {"fwd_us": round(fwd_s * 1e6, 1), "bwd_us": round(bwd_s * 1e6, 1),
+                     "touched_pixels": int(u), "fwd_algorithmic_bytes": int(fwd_bytes),
+                     "fwd_achieved": round(fwd_bytes / fwd_s / 1e9, 1), "fwd_frac": round(fwd_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
+                     "bwd_algorithmic_bytes": int(bwd_bytes), "bwd_achieved": round(bwd_bytes / bwd_s / 1e9, 1),
+                     "bwd_frac": round(bwd_bytes / bwd_s / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s"}
     out["fpn_1000rois_P2-P5_7x7"] = fpn_variant(device, iters)
     return out
 
@@ -354,9 +369,21 @@ def fpn_variant(device, iters):
         with torch.no_grad():
             roi_align_fpn(feats, scales, rois_d, lvl_d, 7, 7, 2)
 
+    # algorithmic bytes of the pyramid call: every level's RoIs tap their own map
+    u_total = 0
+    for lvl in (2, 3, 4, 5):
+        hh, ww_, sc = syn.FPN_LEVELS[lvl]
+        sel = rois[lvls == lvl]
+        if len(sel):
+            u_total += touched_pixels(sel, 1, hh, ww_, 7, 7, sc, 2)
+    alg = 4 * len(rois) * syn.FPN_DIM * 49 + 4 * syn.FPN_DIM * u_total + 20 * len(rois)
+    fused_s = time_kernel(fused_direct, iters)
     return {"fwd_us": round(time_kernel(lambda: fwd(True), iters) * 1e6, 1),
             "fwd_us_per_level_loop": round(time_kernel(lambda: fwd(False), iters) * 1e6, 1),
-            "fwd_us_fused_call_only": round(time_kernel(fused_direct, iters) * 1e6, 1),
+            "fwd_us_fused_call_only": round(fused_s * 1e6, 1),
+            "touched_pixels": int(u_total), "fwd_algorithmic_bytes": int(alg),
+            "fwd_achieved": round(alg / fused_s / 1e9, 1), "fwd_frac": round(alg / fused_s / 1e9 / HBM_PEAK_GBS, 4),
+            "unit": "GB/s (of the fused call)",
             "rois_per_level": {int(l): int((lvls == l).sum()) for l in (2, 3, 4, 5)}}
 
 
@@ -532,4 +559,51 @@ def inference_path(device, iters=10):
                what="GenerateProposals P2-P6 + collect + fused RoIAlign P2-P5 + per-class NMS (mi_nms_segmented) + top-100, "
                     "one image, static shapes, captured once and replayed; eager_dynamic_ms_per_image = the same work "
                     "launched from Python with the reference's variable-length results")
+    out["records_by_producer"] = producer_records_pair(device, feats, scales)
     return out
+
+
+def producer_records_pair(device, feats, scales, rows=1000, iters=200):
+    """The last launch of the proposal stage + the box head's pooling call, as two C-ABI calls on resident buffers:
+    mi_rpn_collect_finish + mi_roi_align_forward_fpn (three launches: blob, records, gather) against
+    mi_rpn_collect_finish_records + mi_roi_align_forward_fpn_records (two: blob + records, gather)."""
+    import ctypes
+
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import PreparedRecords
+
+    lib, stream = _lib.lib(), _lib.current_stream_handle(device)
+    rois_np, _ = syn.rois_fpn_distributed(rows + 200, batch=1, seed=4)
+    cand = torch.from_numpy(rois_np).to(device)
+    best, inds = torch.topk(torch.rand(rows + 200, generator=torch.Generator().manual_seed(1)).to(device), rows)
+    inds = inds.to(torch.int64).contiguous()
+    rois = torch.empty((rows, 5), device=device)
+    valid = torch.empty((rows,), dtype=torch.bool, device=device)
+    lv = torch.empty((rows,), dtype=torch.int32, device=device)
+    idx = torch.empty((rows,), dtype=torch.int32, device=device)
+    out = torch.empty((rows, syn.FPN_DIM, 7, 7), device=device)
+    rec = PreparedRecords(feats, scales, 7, 7, 2, rows)
+    ws = rec.workspace
+
+    def plain():
+        assert lib.mi_rpn_collect_finish(best.data_ptr(), inds.data_ptr(), cand.data_ptr(), rows, 1, 2, 5, 224.0, 4.0,
+                                         rois.data_ptr(), valid.data_ptr(), lv.data_ptr(), stream) == 0
+        torch.sub(5, lv, out=idx)
+        assert lib.mi_roi_align_forward_fpn(ctypes.byref(rec.table), rois.data_ptr(), idx.data_ptr(), out.data_ptr(), 1,
+                                            syn.FPN_DIM, rows, 7, 7, 2, rec.layout, ws.data_ptr(), ws.numel(), stream) == 0
+
+    def fused():
+        assert lib.mi_rpn_collect_finish_records(best.data_ptr(), inds.data_ptr(), cand.data_ptr(), rows, 1, 2, 5, 224.0, 4.0,
+                                                 rois.data_ptr(), valid.data_ptr(), lv.data_ptr(), ctypes.byref(rec.table), 1,
+                                                 syn.FPN_DIM, 7, 7, 2, rec.layout, ws.data_ptr(), ws.numel(), stream) == 0
+        torch.sub(5, lv, out=idx)
+        assert lib.mi_roi_align_forward_fpn_records(ctypes.byref(rec.table), rois.data_ptr(), idx.data_ptr(), out.data_ptr(),
+                                                    1, syn.FPN_DIM, rows, 7, 7, 2, rec.layout, ws.data_ptr(), ws.numel(),
+                                                    stream) == 0
+
+    a = [time_kernel(plain, iters) * 1e6, 0.0]
+    b = [time_kernel(fused, iters) * 1e6, 0.0]
+    a[1], b[1] = time_kernel(plain, iters) * 1e6, time_kernel(fused, iters) * 1e6
+    return {"collect_finish_plus_forward_fpn_us": [round(x, 1) for x in a],
+            "collect_finish_records_plus_forward_fpn_records_us": [round(x, 1) for x in b],
+            "what": "1000-row blob over P2-P5, 7x7, alternating runs of %d call pairs" % iters}
