@@ -27,7 +27,7 @@ class _RoIAlignOracle(torch.autograd.Function):
         return torch.from_numpy(g), None, None, None, None, None
 
 
-def roi_align_fpn(features, scales, rois, roi_levels, ah, aw, sr):
+def roi_align_fpn(features, scales, rois, roi_levels, ah, aw, sr, prepared=None):
     """Same contract as roi_align.roi_align_fpn: output rows in the order of `rois`."""
     out = torch.zeros((rois.size(0), features[0].size(1), ah, aw))
     pieces, index = [], []
