@@ -149,7 +149,8 @@ template <class Src>
 __global__ void __launch_bounds__(256)
 roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, int aligned_height, int aligned_width,
                   int sampling_ratio, int cap_px, int stage_px, int max_rows_tile, int bwd_tables, int channels,
-                  int* __restrict__ ws) {
+                  int* __restrict__ ws, int ablate_arg) {
+  const int ablate = MI_ABLATE(ablate_arg);  // tuning builds: 32 = no sweep keys / rank, 64 = no tables, 128 = no stage loop
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
   if (blockIdx.x == 0)
@@ -160,7 +161,7 @@ roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, i
   const int r_safe = __builtin_amdgcn_readfirstlane(min(r, num_rois - 1));
   float own[5];
   const int lvl = __builtin_amdgcn_readfirstlane(src.get(r_safe, lv.count, own));
-  for (int i = threadIdx.x; i < num_rois; i += 256) {
+  for (int i = threadIdx.x; i < num_rois && !(ablate & 32); i += 256) {
     float v[5];
     const int l = src.get(i, lv.count, v);
     keys[i] = sweep_key(v, l, lv.scale[l], lv.height[l]);
@@ -175,7 +176,8 @@ roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, i
   if (r >= num_rois) return;
   // rank of this RoI in the sweep (ties by index): the record index
   int rank = 0;
-  {
+  if (ablate & 32) rank = r;
+  else {
     const unsigned mine = keys[r];
     for (int j = lane; j < num_rois; j += 64) {
       const unsigned k = keys[j];
@@ -218,7 +220,7 @@ roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, i
   // this lane's y sample (lane < nsy) and x sample (lane < nsx)
   int ylo = wy0, xlo = wx0;
   float yhw = 0.f, ylw = 0.f, xhw = 0.f, xlw = 0.f;  // this lane's sample: weights of (lo, lo + 1); y: divided by count
-  if (fast) {
+  if (fast && !(ablate & 64)) {
     float hw = 0.f, lw = 0.f;
     if (lane < nsy) {
       const int ph = lane / gh;
@@ -308,7 +310,7 @@ roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, i
   // stages: consecutive bin rows whose window fits half the LDS image (so that the next stage can be prefetched while
   // this one is computed), the whole image if a single bin row needs it; at most max_rows_tile output rows
   int nstages = 0;
-  if (fast) {
+  if (fast && !(ablate & 128)) {
     const int half = stage_px;
     int ph0 = 0;
     while (ph0 < aligned_height) {
@@ -1477,7 +1479,7 @@ int launch_prepare_from(const Src& src, int* ws, int batch, const LevelTable& lv
   const int max_rows_tile = kTileBins / aligned_width;
   roi_align_prepare<Src><<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
       src, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile,
-      bwd_tables ? 1 : 0, channels, ws);
+      bwd_tables ? 1 : 0, channels, ws, tuning().ablate);
   return check_launch("roi_align_prepare");
 }
 int launch_prepare(const float* rois, const int* levels, int* ws, int batch, const LevelTable& lv, int num_rois,
