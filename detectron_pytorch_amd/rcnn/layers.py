@@ -1,7 +1,6 @@
 """Small layers and initialisers of the reference's `lib/nn` that the graph needs."""
 import math
 
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.init as init
@@ -44,19 +43,19 @@ class BilinearInterpolation2d(nn.Module):
     def __init__(self, in_channels, out_channels, up_scale):
         super().__init__()
         assert in_channels == out_channels and up_scale % 2 == 0
-        self.up_scale = int(up_scale)
-        size = self.up_scale * 2
-        factor = (size + 1) // 2
-        centre = factor - 1 if size % 2 == 1 else factor - 0.5
-        og = np.ogrid[:size, :size]
-        filt = (1 - abs(og[0] - centre) / factor) * (1 - abs(og[1] - centre) / factor)
-        kernel = np.zeros((in_channels, out_channels, size, size), dtype=np.float32)
-        kernel[range(in_channels), range(out_channels), :, :] = filt
-        self.upconv = nn.ConvTranspose2d(in_channels, out_channels, size, stride=self.up_scale, padding=self.up_scale // 2)
-        self.upconv.weight.data.copy_(torch.from_numpy(kernel))
-        self.upconv.bias.data.fill_(0)
-        self.upconv.weight.requires_grad = False
-        self.upconv.bias.requires_grad = False
+        self.up_scale = s = int(up_scale)
+        # A transposed convolution of stride s with the separable triangle filter of support 2 s is bilinear up-sampling
+        # by s: tap k of the 1-D filter weighs 1 - |k - (s - 1/2)| / s, i.e. (1, 3, 5, ..., 5, 3, 1) / (2 s); the 2-D
+        # kernel is its outer product, on the diagonal of the [C, C] channel pairs (every channel is up-sampled on its own).
+        tri = 1.0 - (torch.arange(2 * s, dtype=torch.float64) - (s - 0.5)).abs() / s
+        self.upconv = nn.ConvTranspose2d(in_channels, out_channels, 2 * s, stride=s, padding=s // 2)
+        with torch.no_grad():
+            self.upconv.weight.zero_()
+            diag = torch.arange(in_channels)
+            self.upconv.weight[diag, diag] = torch.outer(tri, tri).to(self.upconv.weight.dtype)
+            self.upconv.bias.zero_()
+        for p in self.upconv.parameters():   # frozen: the checkpoint name `upconv.*` is what the weight mapping expects
+            p.requires_grad = False
 
     def forward(self, x):
         return self.upconv(x)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 profiles: the judged bench line; rocprofv3 kernel statistics of the training step (steady-state window); the
+# The round's profiles (ROUND=r05 bash tools/gpu_profiles.sh ...): the judged bench line; rocprofv3 kernel statistics of the training step (steady-state window); the
 # MFMA utilisation (PMC pass) of the training step AND of BASELINE config 5 (X-101-64x4d: grouped convolutions); the
 # config-2 kernel durations of every RoIAlign forward / backward variant.  Run on the GPU box through gpurun; output
-# gpurun_out/prof_r04/, copy what is judged into profiles/.   usage: bash tools/gpu_profiles_r04.sh [all|bench|trace|mfma|config2|pmc]
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r04; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+# gpurun_out/prof_$ROUND/, copy what is judged into profiles/.   usage: [ROUND=r05] bash tools/gpu_profiles.sh [all|bench|trace|mfma|config2|pmc]
+ROUND=${ROUND:-r05}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$ROUND; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 STAGE=${1:-all}
 if [ $STAGE = all ] || [ $STAGE = bench ]; then
 (cd $R && timeout 1200 python bench.py 2> $O/bench_plain.err | grep '^{' | tail -1 > $O/bench_line.json)

@@ -25,7 +25,7 @@ def section(path):
 
 doc = {
     "source": "rocprofv3 --kernel-trace --pmc <group> -- python tools/run_one_kernel.py roi_align_fwd|roi_align_bwd 5 "
-              "(tools/gpu_profiles_r04.sh pmc, %s; one pass per counter group; per-kernel averages over the 5 launches)" % tag,
+              "(tools/gpu_profiles.sh pmc, %s; one pass per counter group; per-kernel averages over the 5 launches)" % tag,
     "corrections": "FETCH_SIZE doubled (gfx950: reports 1/2 of the bytes of wide coalesced reads, MI355X_MICROARCH.md "
                    "section HBM); WRITE_SIZE as reported (calibrated on a 68.8 MB torch fill: 67200 KB); units KB = 1024 B",
     "shape": "R=512 C=256 7x7 sr=2 on 200x336 (config 2)",
