@@ -34,8 +34,6 @@ Tuning read_tuning() {
   const int sl = env_int("MI_ROI_ALIGN_BWD_SLICE", 32);
   t.bwd_slice = 0;  // a power of two in [2, 256], or 0 (no plan)
   for (int p2 = 2; p2 <= 256 && p2 <= sl; p2 *= 2) t.bwd_slice = p2;
-  t.fwd_persist = env_int("MI_ROI_ALIGN_FWD_PERSIST", -1);
-  t.fwd_slots = env_int("MI_ROI_ALIGN_FWD_SLOTS", 0);
   t.nhwc_vec = env_int("MI_ROI_ALIGN_NHWC_V", 0);
   t.nhwc_pb = env_int("MI_ROI_ALIGN_NHWC_PB", 0);
   const int om = env_int("MI_ROI_ALIGN_NHWC_ORDER_MUL", 1);

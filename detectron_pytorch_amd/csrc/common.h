@@ -52,9 +52,6 @@ inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
 //   MI_ROI_ALIGN_IMPL=direct   generic one-lane-per-output kernels only (tests of the generic path, A/B baselines)
 //   MI_ROI_ALIGN_NO_WS=1       ignore the caller's workspace (no records path)
 //   MI_ROI_ALIGN_CAP=192|256|336|448|640   window pixels per channel of the NCHW forward LDS image
-//   MI_ROI_ALIGN_FWD_PERSIST=0|1           NCHW forward: force the per-item launch / the resident grid walking the items
-//                                          (default: resident where bins > LDS tile, i.e. the 14 x 14 heads)
-//   MI_ROI_ALIGN_FWD_SLOTS=n               resident workgroups per compute unit of that grid (default: what the LDS allows)
 //   MI_ROI_ALIGN_BWD_TH=8|16|32            rows per backward tile
 //   MI_ROI_ALIGN_BWD_SLICE=n   RoIs per list slice of the planned backward (32; 0: no plan, no atomics)
 //   MI_ROI_ALIGN_NHWC_V / _PB / _ORDER_MUL / _ZIGZAG   channels-last forward variants
@@ -62,7 +59,6 @@ inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
 struct Tuning {
   bool force_direct, no_ws;
   int cap_px, bwd_tile_rows, bwd_slice;
-  int fwd_persist, fwd_slots;
   int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag;
   int ablate;
   int copy_variant;  // MI_COPY_VARIANT of mi_dbg_copy_float4 (tools/copy_sweep.py)

@@ -36,10 +36,9 @@ static_assert(kRecDwords % 4 == 0 && kRecB % 4 == 0, "records and their backward
 // after the records: one int4 per rank {x0, x1, batch*H + y0, batch*H + y1} = window of a backward-capable RoI
 // ({0x3fffffff, -1, ..} otherwise), read by the backward tiles to find the RoIs that touch them
 // counters in front of the records, zeroed by roi_align_prepare.  Every live counter has a 128-byte line to itself: device-
-// scope atomics on one line serialise at ~11 ns apiece whichever word they hit (round 5: eight ticket words in one line made
-// the resident forward 20 us slower).
+// scope atomics on one line serialise at ~11 ns apiece whichever word they hit (round 5: the eight ticket words of a resident
+// forward in one line cost 20 us per call).
 constexpr int kCounterDwords = 1024;
-constexpr int kTicketStride = 64;                      // resident forward: work counter of virtual XCD v at [v * 64], v < 8
 constexpr int kBwdClasses = 6;                         // planned backward: cost classes of the tile entries
 constexpr int kBwdCounterStride = 32;
 constexpr int kBwdBucket = 512;                        // [kBwdBucket + 32 c]: entries filed in class c (roi_align_bwd_plan adds,

@@ -12,9 +12,10 @@
 //       60 MB of distinct bytes -- in arrival order the gather is bound by the Infinity-Cache -> L2 rate.
 //   roi_align_fwd_records   one 256-lane workgroup per (rank, 32-channel tile); tile index = blockIdx % 8, i.e. the
 //       slab of the feature map a tile reads is served by one XCD's L2.  Record by scalar load -> window by LDS-DMA ->
-//       one vmcnt(0) + barrier -> bins -> LDS tile -> contiguous 16-byte stores.  (A persistent variant that
-//       prefetched the next window under the arithmetic of the current one measured 66 us against 40 us -- per-stage
-//       overheads -- and was removed; so were 16-channel workgroups, which gained nothing.)
+//       vmcnt + barrier -> bins (packed FMAs) -> LDS tile -> contiguous 16-byte stores; the stages of an item are pipelined
+//       (next window issued before the tile is stored).  (Removed after measurement: a variant that prefetched the next
+//       window under the current arithmetic, 16-channel workgroups, roles on waves, a resident ticketed grid -- see
+//       DESIGN.md section 5 and docs/history.md.)
 //   roi_align_bwd_tiles / roi_align_bwd_slow   the backward over the same records (see below).
 //
 // Data movement and arithmetic are those of roi_align_fwd_tile.hip (see its header): LDS-DMA of the compact
@@ -386,24 +387,22 @@ __device__ __forceinline__ unsigned lds_addr_opaque(const void* p) {
   asm volatile("" : "+v"(a));
   return a;
 }
-__device__ __forceinline__ void lds_pair(unsigned a, float& v0, float& v1) {
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+// the tap pair (F[x], F[x + 1]) of one row: one ds_read2_b32 into a register pair
+__device__ __forceinline__ v2f_t lds_pair2(unsigned a) {
   const lds_cfloat_t q = (lds_cfloat_t)(uintptr_t)a;
-  v0 = q[0];
-  v1 = q[1];
+  return v2f_t{q[0], q[1]};
 }
 __device__ __forceinline__ const float* lds_at(const float* base, int byte_off) {
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// Forward over the records.  Two launch forms share the stage pieces below (window DMA, axis tables, border patch, bins,
-// tile store):
-//   roi_align_fwd_records   one workgroup per (rank, channel tile), dispatched in sweep order;
-//   roi_align_fwd_persist   a resident grid (LDS-limited slots x compute units) whose workgroups walk the items of
-//                           their XCD: item k + 1's record header is in SGPRs and its window pieces are issued BEFORE the
-//                           stores of item k, so the store drain, the record latency and the per-workgroup launch /
-//                           teardown of the per-item form disappear from the chain.  Every wave still does DMA -> bins ->
-//                           store (no roles on waves, no second window in LDS).
+// Forward over the records: roi_align_fwd_records, one workgroup per (rank, channel tile), dispatched in sweep order.  The
+// stage pieces (window DMA, axis tables, border patch, bins, tile store) are functions of their own.  (Round 5 also built a
+// RESIDENT form -- 768 workgroups walking the items by ticket, record fronts and next windows in flight across items --
+// whose unit chain was 11 % shorter and whose 2-item commitment cost a tail of 8-10 us: profiles/r05_persist_timeline.txt.
+// Its stage pipelining lives on below; the kernel itself lost on every shape once the bins used packed FMAs, and is gone.)
 // -------------------------------------------------------------------------------------------------------------------
 // What a workgroup needs of a record's header -- wave-uniform, fetched with scalar loads.
 struct FwdRec {
@@ -499,18 +498,22 @@ __device__ __forceinline__ void fwd_bins(const TabEntry* ty, const TabEntry* tx,
   if (kSR > 0) {
     constexpr int kS = kSR > 0 ? kSR : 1;
     for (int pw = slot; pw < aligned_width; pw += kNSlots) {
-      float hx[kS], lx[kS];
+      v2f_t hxl[kS];
       unsigned xa[kS];
 #pragma unroll
       for (int i = 0; i < kS; i++) {
         const TabEntry ex = tx[pw * kS + i];
-        hx[i] = ex.hw;
-        lx[i] = ex.lw;
+        hxl[i] = v2f_t{ex.hw, ex.lw};
         xa[i] = lds_addr_opaque(lds_at(img_c, ex.off - base_off));
       }
       auto rows = [&](int ph, auto kn) {
         constexpr int kN = decltype(kn)::value;
-        float v[kN][kS][2][kS][2];
+        // A tap pair (F[x], F[x + 1]) arrives in an even-aligned register pair and so do its weights (hx, lx): the row sums
+        // run as v_pk_fma_f32 on (even, odd) partial sums -- S = sum_ix (hx, lx) * (F[x], F[x + 1]), acc += (wy, wy) * S --
+        // and the two halves meet once per bin: 13 instead of 20 FMA-class instructions per bin (the bins are bound by
+        // VALU issue: ~170 instructions per batch of four bin rows before this).  Same taps and weights; the summation
+        // order differs from the scalar chain in the last bits (contract 1e-4, asserted 1e-5).
+        v2f_t v[kN][kS][2][kS];
         float wy[kN][kS][2];
 #pragma unroll
         for (int b = 0; b < kN; b++) {
@@ -522,29 +525,25 @@ __device__ __forceinline__ void fwd_bins(const TabEntry* ty, const TabEntry* tx,
 #pragma unroll
             for (int ix = 0; ix < kS; ix++) {
               const unsigned a = xa[ix] + (unsigned)ey.off;
-              lds_pair(a, v[b][iy][0][ix][0], v[b][iy][0][ix][1]);
-              lds_pair(a + (unsigned)pitch, v[b][iy][1][ix][0], v[b][iy][1][ix][1]);
+              v[b][iy][0][ix] = lds_pair2(a);
+              v[b][iy][1][ix] = lds_pair2(a + (unsigned)pitch);
             }
           }
         }
 #pragma unroll
         for (int b = 0; b < kN; b++) {
-          float acc = 0.f;
+          v2f_t acc = {0.f, 0.f};
 #pragma unroll
           for (int iy = 0; iy < kS; iy++) {
 #pragma unroll
             for (int kx = 0; kx < 2; kx++) {
-              float rsum = hx[0] * v[b][iy][kx][0][0];
-              rsum = __builtin_fmaf(lx[0], v[b][iy][kx][0][1], rsum);
+              v2f_t rsum = hxl[0] * v[b][iy][kx][0];
 #pragma unroll
-              for (int ix = 1; ix < kS; ix++) {
-                rsum = __builtin_fmaf(hx[ix], v[b][iy][kx][ix][0], rsum);
-                rsum = __builtin_fmaf(lx[ix], v[b][iy][kx][ix][1], rsum);
-              }
-              acc = __builtin_fmaf(wy[b][iy][kx], rsum, acc);
+              for (int ix = 1; ix < kS; ix++) rsum = __builtin_elementwise_fma(hxl[ix], v[b][iy][kx][ix], rsum);
+              acc = __builtin_elementwise_fma(v2f_t{wy[b][iy][kx], wy[b][iy][kx]}, rsum, acc);
             }
           }
-          tile_c[(ph + b - ph0) * aligned_width + pw] = acc;
+          tile_c[(ph + b - ph0) * aligned_width + pw] = acc.x + acc.y;
         }
       };
       int ph = pa;
@@ -657,16 +656,6 @@ __device__ __forceinline__ void fwd_direct_item(const FwdRec& h, const LevelTabl
   }
 }
 
-// One ticket of a work counter (agent scope, relaxed).  The address goes through an opaque per-lane zero: with a provably
-// wave-uniform address hipcc's atomic optimizer rewrites the instruction into "first lane adds popcount(exec), readfirstlane,
-// + lane prefix", and the readfirstlane waits for the return on the spot -- the caller wants the ~1 us of a device-scope
-// atomic under load to pass under its arithmetic, the wait at the first USE of the result.
-__device__ __forceinline__ int fetch_ticket(int* counter) {
-  int z = 0;
-  asm volatile("" : "+v"(z));
-  return __hip_atomic_fetch_add(counter + z, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // kA > 0: aligned_height == aligned_width == kA at compile time (7: box head, 14: mask / keypoint heads).
 template <int kSR, int kCap, int kA = 0>
 __global__ void __launch_bounds__(kCT * 8)
@@ -718,7 +707,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
   const int pitch = ((h.ww + 3) & ~3) * 4;  // a window row lies in LDS on a pitch of whole 16-byte groups
   const int gh = kSR > 0 ? kSR : h.gh, gw = kSR > 0 ? kSR : h.gw;
   const const_int_ptr rec = (const_int_ptr)(uintptr_t)(records + (long long)pos * kRecDwords);
-  // Stages are pipelined inside the item (round 5, from the resident form below): the window pieces of stage k + 1 are issued
+  // Stages are pipelined inside the item (round 5): the window pieces of stage k + 1 are issued
   // BEFORE the tile of stage k is stored, and the landing wait is vmcnt(stores of stage k) -- window pieces are older than
   // those stores and vmcnt retires in order, so the stores drain under the next stage's bins instead of in front of its copy.
   int pp = h.st_pp, row0 = h.st_row0, nrows = h.st_nrows;
@@ -759,202 +748,6 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     row0 = n_row0;
     nrows = n_nrows;
   }
-}
-
-// roi_align_fwd_persist: the resident form.  Items = (rank, channel tile), item i -> tile i % tiles, rank i / tiles; the
-// workgroup with blockIdx b owns items b and b + gridDim (no ticket needed for its first two), every further item is a
-// ticket of the counter of its "virtual XCD" b % 8 (ws[(b % 8) * kTicketStride], zeroed by roi_align_prepare): item = 2 * gridDim +
-// ticket * 8 + b % 8, so that with 8 channel tiles a workgroup keeps its tile and one XCD's L2 serves one 32-channel slab,
-// ranks in sweep order.  Three items are in flight per workgroup:
-//     k      its window is in LDS (or landing), its record front (header, stages, y / x tables) in rec[k & 1]
-//     k + 1  its record front is landing in rec[(k + 1) & 1] (LDS-DMA, issued a whole item before its first use: no scalar
-//            load, no record latency anywhere in the steady state)
-//     k + 2  its ticket is in flight (wave 0; the atomic returns under the bins of k)
-// Per unit (= one stage of one item):
-//     s_waitcnt vmcnt(stores of the previous unit); barrier    window pieces are older than those stores and vmcnt retires
-//                                                              in order: the window has landed, the stores may still drain
-//     bins -> LDS tile; barrier                                image and tables are free
-//     record front of k + 2, window pieces of the NEXT unit    <- they land while ...
-//     the tile is stored                                       <- ... the stores of this unit drain, under the next bins
-// One window in LDS, one tile, two barriers per unit: the same instructions per byte as the per-item kernel.
-// Tuning builds: wave 0 sums clock64() differences per phase (tools/timeline_persist.py); MI_ROI_ALIGN_ABLATE bit 8 replaces
-// the tickets by a static stride, bit 16 waits for everything (vmcnt(0)) at the top of a unit.
-constexpr int kRecFront = (kRecX + 4 * kMaxS + 3) & ~3;  // dwords of a record the forward needs: header, stages, y, x tables
-
-// the record front of rank `pos` -> LDS, as it lies in memory (16-byte pieces; waves 0 and 1)
-__device__ __forceinline__ void fwd_issue_record(const int* __restrict__ records, int pos, int wave, int lane, int* dst) {
-  constexpr int kPieces = kRecFront / 4;  // 16-byte pieces
-  if (wave * 64 < kPieces && wave * 64 + lane < kPieces)
-    dma_dwordx4(make_srd(records + (long long)pos * kRecDwords, kRecFront * 4), lds_addr_uniform(dst) + (unsigned)wave * 1024u,
-                (unsigned)(wave * 64 + lane) * 16u, 0u);
-}
-// header of a record front in LDS -> SGPRs: one ds_read per lane, the fields by v_readlane
-__device__ __forceinline__ FwdRec fwd_rec_from_lds(const int* rec, int lane) {
-  const int v = rec[lane < kRecHeader ? lane : 0];
-  FwdRec h;
-  h.flags = __builtin_amdgcn_readlane(v, 0);
-  h.wx0 = __builtin_amdgcn_readlane(v, 2);
-  h.ww = __builtin_amdgcn_readlane(v, 3);
-  h.gmagic = (unsigned)__builtin_amdgcn_readlane(v, 4);
-  h.nstages = __builtin_amdgcn_readlane(v, 5);
-  h.gh = __builtin_amdgcn_readlane(v, 6);
-  h.gw = __builtin_amdgcn_readlane(v, 7);
-  h.r = __builtin_amdgcn_readlane(v, 8);
-  h.lvl = __builtin_amdgcn_readlane(v, 11);
-  h.st_pp = __builtin_amdgcn_readlane(v, 12);
-  h.st_row0 = __builtin_amdgcn_readlane(v, 13);
-  h.st_nrows = __builtin_amdgcn_readlane(v, 14);
-  h.img = ((uintptr_t)(unsigned)__builtin_amdgcn_readlane(v, 17) << 32) | (unsigned)__builtin_amdgcn_readlane(v, 16);
-  h.height = __builtin_amdgcn_readlane(v, 18);
-  h.width = __builtin_amdgcn_readlane(v, 19);
-  return h;
-}
-
-template <int kSR, int kCap, int kA = 0>
-__global__ void __launch_bounds__(kCT * 8)
-roi_align_fwd_persist(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out, int* __restrict__ ws,
-                      int num_rois, int batch, int channels, int aligned_height_arg, int aligned_width_arg,
-                      int sampling_ratio, int ablate_arg MI_TL_PARAM) {
-  const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
-  const int ablate = MI_ABLATE(ablate_arg);
-  constexpr int kChPerWave = kCT / (kThreads / 64);
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kPlane = kCap | 1;
-  constexpr int kTileWords = kCT * (kTileBins + 1);
-  int* recbuf = reinterpret_cast<int*>(smem);                    // [2][kRecFront]
-  float* tile = reinterpret_cast<float*>(recbuf + 2 * kRecFront);
-  float* img = tile + kTileWords;
-  int* ctl = reinterpret_cast<int*>(img + kCT * kPlane);  // [0]: the item after next, handed from wave 0 to the workgroup
-  const int tid = threadIdx.x;
-  const int bins = aligned_height * aligned_width;
-  const int tiles = channels / kCT;
-  const int total = num_rois * tiles, grid = (int)gridDim.x;
-  const int wave = uniform(tid >> 6), lane = tid & 63;
-  const int cl = tid % kCT, slot = (tid / kCT) & 7;
-  const int* __restrict__ records = ws + kCounterDwords;
-  const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kPlane);
-  const int vx = (int)(blockIdx.x & 7);
-#if MI_TUNING
-  long long tl_t = clock64(), tl_acc[5] = {0, 0, 0, 0, 0};
-  const long long tl_start = tl_t;
-  int tl_units = 0, tl_items = 0;
-#define MI_PL_LAP(k)                          \
-  do {                                        \
-    const long long tl_now = clock64();       \
-    tl_acc[k] += tl_now - tl_t;               \
-    tl_t = tl_now;                            \
-  } while (0)
-#else
-#define MI_PL_LAP(k) \
-  do {               \
-  } while (0)
-#endif
-
-  int cur_item = (int)blockIdx.x, nxt_item = cur_item + grid;
-  if (cur_item >= total) return;
-  int par = 0;  // rec[par]: the current item's record front
-  fwd_issue_record(records, cur_item / tiles, wave, lane, recbuf);
-  if (nxt_item < total) fwd_issue_record(records, nxt_item / tiles, wave, lane, recbuf + kRecFront);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  FwdRec cur = fwd_rec_from_lds(recbuf, lane);
-  int c0 = (cur_item % tiles) * kCT;
-  int stage = 0, pp = cur.st_pp, row0 = cur.st_row0, nrows = cur.st_nrows;
-  if ((cur.flags & kFlagFast) && !(ablate & 1))
-    fwd_issue_window<kChPerWave, kPlane>(cur, c0 + wave * kChPerWave, plane0, lane, row0, nrows);
-  int ticket = 0;      // wave 0, lane 0: the returned ticket of the item after next
-  int stores_out = 0;  // store instructions this wave issued behind its last window piece
-  for (;;) {
-    const bool fast = (cur.flags & kFlagFast) != 0;
-    const bool last = !fast || stage + 1 >= cur.nstages;
-    const int* rec = recbuf + par * kRecFront;
-    if (ablate & 16) stores_out = 0;
-    wait_vmcnt_at_most(stores_out);
-    __syncthreads();  // B1: this unit's window has landed (and the next item's record front); the previous tile is out of LDS
-    MI_PL_LAP(0);
-    if (stage == 0 && wave == 0 && nxt_item < total && !(ablate & 8)) {
-      if (lane == 0) ticket = fetch_ticket(ws + vx * kTicketStride);
-    }
-    const int ph0 = pp & 0xffff, ph1 = pp >> 16;
-    const int nb = (ph1 - ph0) * aligned_width;
-    const int ts = nb | 1;
-    float* __restrict__ dst = out + ((long long)cur.r * channels + c0) * bins;
-    if (fast) {
-      const int pitch = ((cur.ww + 3) & ~3) * 4;
-      if (fwd_patch_edge<kCT, kThreads, kPlane>(cur, img, tid, nrows)) __syncthreads();
-      const TabEntry* ty = reinterpret_cast<const TabEntry*>(rec + kRecY);
-      const TabEntry* tx = reinterpret_cast<const TabEntry*>(rec + kRecX);
-      if (!(ablate & 2))
-        fwd_bins<kSR, kSlots>(ty, tx, img + cl * kPlane, tile + cl * ts, slot, ph0, ph1, ph0, row0 * pitch, pitch,
-                              aligned_width, kSR > 0 ? kSR : cur.gh, kSR > 0 ? kSR : cur.gw);
-    } else {
-      fwd_direct_item<kCT, kThreads>(cur, lv, rois, dst, tid, c0, channels, aligned_height, aligned_width, sampling_ratio);
-    }
-    if (last && wave == 0) {
-      int nn = kNoItem;
-      if (nxt_item < total) nn = (ablate & 8) ? nxt_item + grid : 2 * grid + uniform(ticket) * 8 + vx;  // waits for the atomic
-      if (lane == 0) ctl[0] = nn;
-    }
-    MI_PL_LAP(1);
-    __syncthreads();  // B2: the tile is complete; image and tables are free
-    MI_PL_LAP(2);
-    int nn_item = kNoItem;
-    FwdRec nxt = cur;
-    if (last) {
-      nn_item = uniform(ctl[0]);
-      // the record front of the item after next replaces this item's (its tables are done with)
-      if (nn_item < total) fwd_issue_record(records, nn_item / tiles, wave, lane, recbuf + par * kRecFront);
-      if (nxt_item < total) {
-        nxt = fwd_rec_from_lds(recbuf + (par ^ 1) * kRecFront, lane);
-        if ((nxt.flags & kFlagFast) && !(ablate & 1))
-          fwd_issue_window<kChPerWave, kPlane>(nxt, (nxt_item % tiles) * kCT + wave * kChPerWave, plane0, lane, nxt.st_row0,
-                                               nxt.st_nrows);
-      }
-    } else {
-      pp = uniform(rec[kRecStages + 4 * (stage + 1)]);
-      row0 = uniform(rec[kRecStages + 4 * (stage + 1) + 1]);
-      nrows = uniform(rec[kRecStages + 4 * (stage + 1) + 2]);
-      if (!(ablate & 1)) fwd_issue_window<kChPerWave, kPlane>(cur, c0 + wave * kChPerWave, plane0, lane, row0, nrows);
-    }
-    MI_PL_LAP(3);
-    // ... then this unit's tile leaves, draining while they land and while the next bins run
-    stores_out = 0;
-    if (fast && !(ablate & 4)) {
-      fwd_store<kCT, kThreads>(tile, dst, tid, ph0, nb, ts, bins, aligned_width);
-      stores_out = fwd_store_count<kCT, kThreads>(dst, wave, nb, ts, bins);
-    }
-    MI_PL_LAP(4);
-#if MI_TUNING
-    tl_units++;
-#endif
-    if (!last) {
-      stage++;
-      continue;
-    }
-#if MI_TUNING
-    tl_items++;
-#endif
-    if (nxt_item >= total) break;
-    cur = nxt;
-    cur_item = nxt_item;
-    nxt_item = nn_item;
-    c0 = (cur_item % tiles) * kCT;
-    stage = 0;
-    pp = cur.st_pp;
-    row0 = cur.st_row0;
-    nrows = cur.st_nrows;
-    par ^= 1;
-  }
-#if MI_TUNING
-  if (timeline != nullptr && threadIdx.x == 0) {
-    long long* o = timeline + (long long)blockIdx.x * 8;
-    o[0] = tl_acc[0]; o[1] = tl_acc[1]; o[2] = tl_acc[2]; o[3] = tl_acc[3]; o[4] = tl_acc[4];
-    o[5] = clock64() - tl_start;
-    o[6] = ((long long)tl_items << 32) | (unsigned)tl_units;
-    o[7] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-  }
-#endif
-#undef MI_PL_LAP
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -1469,8 +1262,7 @@ roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__
 }
 
 size_t records_lds_bytes(int cap, int ct) {
-  // the resident form holds two record fronts (the per-item form: the y / x tables only) and a control word
-  return (size_t)2 * kRecFront * 4 + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4 + 16;
+  return 2 * kMaxS * sizeof(TabEntry) + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4;
 }
 
 template <class Src>
@@ -1504,38 +1296,15 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
   if (rc != MI_OK) return rc;
   const size_t lds = records_lds_bytes(kCap, kCT);
   const int items = num_rois * (channels / kCT);
-  // resident form: as many workgroups as the LDS lets live on the chip at once (a multiple of 8: blockIdx % 8 is the XCD)
-  int slots = tuning().fwd_slots > 0 ? tuning().fwd_slots : (int)((160 * 1024) / lds);
-  if (slots < 1) slots = 1;
-  int resident = (compute_units() * slots) & ~7;
-  if (resident > ((items + 7) & ~7)) resident = (items + 7) & ~7;
-  // Which form: the resident one where every item has several stages by construction (more bins than the LDS tile holds:
-  // the 14 x 14 mask / keypoint heads), the per-item one otherwise.  Measured on one box (tools/roi_align_ab.py, us per call,
-  // per-item / resident): config 2 34.8 / 39.3, 1024 RoIs on two images 58.0 / 63.4, a step's box RoIs over the pyramid
-  // 68.9 / 74.3, 128 RoIs x 14 x 14 32.5 / 30.7.  The resident form's unit chain is 11 % shorter (profiles/
-  // r05_persist_timeline.txt), but a workgroup is committed to its next two items, and behind the last ticket that costs
-  // a tail of ~1.5 items (8-10 us at 7 x 7) where the hardware's dispatch of 4096 small workgroups leaves ~half an item.
-  // MI_ROI_ALIGN_FWD_PERSIST=0 / 1 forces a form.
-  const int want = tuning().fwd_persist;
-  const bool persist = resident >= 8 && (want == 1 || (want < 0 && aligned_height * aligned_width > kTileBins));
   // the LDS images of MI_ROI_ALIGN_CAP >= 448 exceed the 64 KB a kernel may ask for without opting in
 #define MI_LAUNCH_REC(SR, A)                                                                                          \
   do {                                                                                                                \
-    if (persist) {                                                                                                    \
-      if (lds > 64 * 1024)                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_persist<SR, kCap, A>),                \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-      roi_align_fwd_persist<SR, kCap, A><<<resident, kThreads, lds, stream>>>(                                        \
-          lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio,             \
-          tuning().ablate MI_TL_ARG);                                                                                 \
-    } else {                                                                                                          \
-      if (lds > 64 * 1024)                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_records<SR, kCap, A>),                \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-      roi_align_fwd_records<SR, kCap, A><<<items, kThreads, lds, stream>>>(                                           \
-          lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio,             \
-          tuning().ablate MI_TL_ARG);                                                                                 \
-    }                                                                                                                 \
+    if (lds > 64 * 1024)                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_records<SR, kCap, A>),                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+    roi_align_fwd_records<SR, kCap, A><<<items, kThreads, lds, stream>>>(                                             \
+        lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio,               \
+        tuning().ablate MI_TL_ARG);                                                                                   \
   } while (0)
   const int a = aligned_height == aligned_width ? aligned_height : 0;
   if (sampling_ratio == 2 && kCap == 336 && a == 7)
@@ -1547,7 +1316,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
   else
     MI_LAUNCH_REC(0, 0);
 #undef MI_LAUNCH_REC
-  return check_launch(persist ? "roi_align_fwd_persist" : "roi_align_fwd_records");
+  return check_launch("roi_align_fwd_records");
 }
 
 }  // namespace

@@ -149,8 +149,7 @@ def roofline_roi_align_forward(device, iters):
     traffic, traffic_src = pmc_traffic("forward")
     info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call; the 14x14 shapes below run the "
-                      "resident form roi_align_fwd_persist)",
+            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
             "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
             "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
     # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
