@@ -162,6 +162,19 @@ roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* _
       // request finds it in L1 (seven waves x 18 KB per step thrash a CU's L1 otherwise: 194 MB L2->L1 for 148 MB
       // of window pixels).  MI_ROI_ALIGN_NHWC_ZIGZAG=0 walks every bin row downwards.
       const int nrows = row_last - row_first + 1;
+      // the column part of every tap's address does not depend on the feature row: byte offset of the lower tap and the
+      // step to the upper one (0 at the map's last column: a border sample reads the border pixel twice), once per bin row
+      // in SGPRs instead of a v_readlane + six scalar operations per tap pair and row
+      constexpr int kNX = kSR > 0 ? PW * kSR : 1;
+      int tap_lo[kNX], tap_up[kNX];
+      if constexpr (kSR > 0) {
+#pragma unroll
+        for (int j = 0; j < kNX; j++) {
+          const int xlo = xtab(4 * j + 3);
+          tap_lo[j] = xlo * pixel_bytes;
+          tap_up[j] = xlo + 1 < width ? pixel_bytes : 0;
+        }
+      }
       for (int step = 0; step < nrows; step++) {
         const int row = (zigzag && (ph & 1)) ? row_last - step : row_first + step;
         // weight of this feature row in the bin row: sum over the y samples that tap it
@@ -191,10 +204,9 @@ roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* _
 #pragma unroll
               for (int ix = 0; ix < kSR; ix++)
                 if (pw0 + j < PW) {
-                  const int xlo = xtab(4 * ((pw0 + j) * kSR + ix) + 3);
-                  const int tap = row_bytes + xlo * pixel_bytes;
+                  const int tap = row_bytes + tap_lo[(pw0 + j) * kSR + ix];
                   load_tap<V>(img, lane_off, tap, f[j][ix][0]);
-                  load_tap<V>(img, lane_off, tap + (xlo + 1 < width ? pixel_bytes : 0), f[j][ix][1]);
+                  load_tap<V>(img, lane_off, tap + tap_up[(pw0 + j) * kSR + ix], f[j][ix][1]);
                 }
             __builtin_amdgcn_sched_barrier(0);  // every tap of the batch is in flight before the first FMA
 #pragma unroll
