@@ -85,16 +85,28 @@ __device__ __forceinline__ int level_of(const int* __restrict__ levels, int i, c
   return levels != nullptr ? min(max(levels[i], 0), lv.count - 1) : 0;
 }
 
-// level (2 bits) | image (6 bits) | band (8) | x (16): RoIs of one level and image are contiguous in the sweep.
-// (Round 5 measured "expensive RoIs first" -- a cost class in front of the key, each class swept on its own -- to shorten the
-// tail of the forward: the classes' windows no longer meet in L2, config 2 went 35.9 -> 40.4 us, channels-last 30.5 -> 44.6.)
-__device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int lvl, float spatial_scale, int height) {
+// level (2 bits) | image (6 bits) | band (8) | cost class (2) | x (14): RoIs of one level and image are contiguous in the
+// sweep.  Inside a 16-row band the RoIs whose window needs several LDS stages come first (class from the RoI's size: an
+// estimate, any order is correct): the forward's workgroups are handed out in rank order, a three-stage item lives three
+// times as long as a small one, and what the launch ends with -- the last band -- should be its cheap items.  A band is
+// ~2.3x smaller than what is resident per XCD, so the order inside it does not change what meets in L2.  Measured (one box,
+// alternating): config 2 34.6 -> 33.4 us, 1024 RoIs on two images 57.6 -> 56.7; but the channels-last tap kernel, whose
+// workgroups are all resident at once and live off their x-neighbours' lines, loses 0.65 us, and the backward over a step's
+// clustered pyramid RoIs 1.3 us (its tile lists follow the rank order): `cost_in_band` is set by the planar forward of a
+// single map only, everybody else sweeps plainly.
+// (Round 5 first put the class in FRONT of the whole key: each class then sweeps the map on its own, the windows of
+// neighbouring RoIs no longer meet in L2 -- config 2 35.9 -> 40.4 us, channels-last 30.5 -> 44.6.)
+__device__ __forceinline__ unsigned sweep_key(const float* __restrict__ roi, int lvl, float spatial_scale, int height,
+                                              int cap_px, int cost_in_band) {
   const float cy = (roi[2] + roi[4]) * 0.5f * spatial_scale, cx = (roi[1] + roi[3]) * 0.5f * spatial_scale;
   const int b = (lvl << 6) | min(max((int)roi[0], 0), 63);
   const int y = min(max((int)cy, 0), max(height - 1, 0)), band = min(y / kBandRows, 255);
-  int x = min(max((int)(cx * 16.f), 0), 65535);
-  if (band & 1) x = 65535 - x;
-  return ((unsigned)b << 24) | ((unsigned)band << 16) | (unsigned)x;
+  int x = min(max((int)(cx * 4.f), 0), 16383);
+  if (band & 1) x = 16383 - x;
+  const float rw = fmaxf((roi[3] - roi[1]) * spatial_scale, 1.f), rh = fmaxf((roi[4] - roi[2]) * spatial_scale, 1.f);
+  const int px = ((min((int)rw, 4096) + 3 + 3) & ~3) * (min((int)rh, 4096) + 3);  // padded window pitch x window rows
+  const unsigned cls = !cost_in_band ? 0u : px <= cap_px ? 2u : (px <= 2 * cap_px ? 1u : 0u);
+  return ((unsigned)b << 24) | ((unsigned)band << 16) | (cls << 14) | (unsigned)x;
 }
 
 // Where roi_align_prepare takes its RoIs from.
@@ -150,7 +162,7 @@ template <class Src>
 __global__ void __launch_bounds__(256)
 roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, int aligned_height, int aligned_width,
                   int sampling_ratio, int cap_px, int stage_px, int max_rows_tile, int bwd_tables, int channels,
-                  int* __restrict__ ws, int ablate_arg) {
+                  int* __restrict__ ws, int ablate_arg, int cost_in_band) {
   const int ablate = MI_ABLATE(ablate_arg);  // tuning builds: 32 = no sweep keys / rank, 64 = no tables, 128 = no stage loop
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
@@ -165,7 +177,7 @@ roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, i
   for (int i = threadIdx.x; i < num_rois && !(ablate & 32); i += 256) {
     float v[5];
     const int l = src.get(i, lv.count, v);
-    keys[i] = sweep_key(v, l, lv.scale[l], lv.height[l]);
+    keys[i] = sweep_key(v, l, lv.scale[l], lv.height[l], cap_px, cost_in_band);
   }
   const float roi_b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, own[0])));
   const float roi_x1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, own[1])));
@@ -1267,18 +1279,19 @@ size_t records_lds_bytes(int cap, int ct) {
 
 template <class Src>
 int launch_prepare_from(const Src& src, int* ws, int batch, const LevelTable& lv, int num_rois, int aligned_height,
-                        int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables, hipStream_t stream, int channels) {
+                        int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables, hipStream_t stream, int channels,
+                        bool cost_in_band = false) {
   const int max_rows_tile = kTileBins / aligned_width;
   roi_align_prepare<Src><<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
       src, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile,
-      bwd_tables ? 1 : 0, channels, ws, tuning().ablate);
+      bwd_tables ? 1 : 0, channels, ws, tuning().ablate, cost_in_band ? 1 : 0);
   return check_launch("roi_align_prepare");
 }
 int launch_prepare(const float* rois, const int* levels, int* ws, int batch, const LevelTable& lv, int num_rois,
                    int aligned_height, int aligned_width, int sampling_ratio, int cap_px, bool bwd_tables,
-                   hipStream_t stream, int channels = 0) {
+                   hipStream_t stream, int channels = 0, bool cost_in_band = false) {
   return launch_prepare_from(PlainRois{rois, levels}, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio,
-                             cap_px, bwd_tables, stream, channels);
+                             cap_px, bwd_tables, stream, channels, cost_in_band);
 }
 
 #if MI_TUNING
@@ -1292,7 +1305,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
   // records_ready: the producer of the RoIs wrote the records (launch_roi_align_prepare_collected, same LDS capacity)
   int rc = records_ready ? MI_OK
                          : launch_prepare(rois, levels, ws, batch, lv, num_rois, aligned_height, aligned_width, sampling_ratio,
-                                          kCap, bwd_tables, stream, channels);
+                                          kCap, bwd_tables, stream, channels, /*cost_in_band=*/levels == nullptr);
   if (rc != MI_OK) return rc;
   const size_t lds = records_lds_bytes(kCap, kCT);
   const int items = num_rois * (channels / kCT);
