@@ -673,7 +673,7 @@ template <int kSR, int kCap, int kA = 0>
 __global__ void __launch_bounds__(kCT * 8)
 roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
                       const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height_arg,
-                      int aligned_width_arg, int sampling_ratio, int ablate_arg MI_TL_PARAM) {
+                      int aligned_width_arg, int sampling_ratio, int split, int ablate_arg MI_TL_PARAM) {
   MI_STAMP(0);
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   const int ablate = MI_ABLATE(ablate_arg);
@@ -687,8 +687,12 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
   const int tid = threadIdx.x;
   const int bins = aligned_height * aligned_width;
   const int tiles = channels / kCT;
-  const int pos = blockIdx.x / tiles;
-  const int c0 = (blockIdx.x - pos * tiles) * kCT;
+  // split > 1: an item's stages are dealt to `split` workgroups (stage k to part k % split) -- launches of few, long
+  // items (the 14x14 heads: 4 stages per item) otherwise run one and a third rounds over the chip's 768 slots
+  const int pos_part = blockIdx.x / tiles;
+  const int pos = split > 1 ? pos_part / split : pos_part;
+  const int part = split > 1 ? pos_part - pos * split : 0;
+  const int c0 = (blockIdx.x - pos_part * tiles) * kCT;
   const int wave = uniform(tid >> 6), lane = tid & 63;
   const int cl = tid % kCT, slot = (tid / kCT) & 7;
   const int* __restrict__ records = ws + kCounterDwords;
@@ -701,9 +705,11 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
                                               (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
   if (!(h.flags & kFlagFast)) {
-    fwd_direct_item<kCT, kThreads>(h, lv, rois, dst, tid, c0, channels, aligned_height, aligned_width, sampling_ratio);
+    if (part == 0)
+      fwd_direct_item<kCT, kThreads>(h, lv, rois, dst, tid, c0, channels, aligned_height, aligned_width, sampling_ratio);
     return;
   }
+  if (part >= h.nstages) return;
   {
     // Warm this XCD's L2 with the record a later workgroup of this XCD starts from: XCD x runs the ranks in order (block
     // 8 j + x pools rank j), ~96 at a time, and a record written by roi_align_prepare sits in the Infinity Cache at best.
@@ -712,7 +718,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     // Config 2, three alternating runs: 38.41 -> 37.97 us per call (distances 32 / 64 / 128 were within 0.2 us of each other).
     constexpr int kAhead = 64;
     const int ahead = pos + kAhead;
-    if (wave == kThreads / 64 - 1 && ahead < num_rois && lane < 13)
+    if (wave == kThreads / 64 - 1 && ahead < num_rois && lane < 13 && part == 0)
       dma_dword(make_srd(records + (long long)ahead * kRecDwords, 13 * 128), lds_addr_uniform(tile), (unsigned)lane * 128u, 0u);
   }
   const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kPlane);
@@ -723,14 +729,21 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
   // BEFORE the tile of stage k is stored, and the landing wait is vmcnt(stores of stage k) -- window pieces are older than
   // those stores and vmcnt retires in order, so the stores drain under the next stage's bins instead of in front of its copy.
   int pp = h.st_pp, row0 = h.st_row0, nrows = h.st_nrows;
+  if (part > 0) {
+    const const_int_ptr st = rec + kRecStages + 4 * part;
+    pp = st[0];
+    row0 = st[1];
+    nrows = st[2];
+  }
+  const int step = split > 1 ? split : 1;
   if (!(ablate & 1)) fwd_issue_window<kChPerWave, kPlane>(h, c0 + wave * kChPerWave, plane0, lane, row0, nrows);
   fwd_issue_tables(records, pos, wave, lane, tab, aligned_height * gh, aligned_width * gw);
   MI_STAMP(2);  // window and table pieces issued
   int stores_out = 0;
-  for (int k = 0; k < h.nstages; k++) {
+  for (int k = part; k < h.nstages; k += step) {
     int n_pp = 0, n_row0 = 0, n_nrows = 0;
-    if (k + 1 < h.nstages) {  // the next stage's descriptor arrives under the bins
-      const const_int_ptr st = rec + kRecStages + 4 * (k + 1);
+    if (k + step < h.nstages) {  // the next stage's descriptor arrives under the bins
+      const const_int_ptr st = rec + kRecStages + 4 * (k + step);
       n_pp = st[0];
       n_row0 = st[1];
       n_nrows = st[2];
@@ -738,7 +751,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     const int ph0 = pp & 0xffff, ph1 = pp >> 16;
     wait_vmcnt_at_most((ablate & 16) ? 0 : stores_out);
     __syncthreads();  // this stage's window has landed; the previous tile is out of LDS
-    if (k == 0) MI_STAMP(3);  // landed, published
+    if (k == part) MI_STAMP(3);  // landed, published
     if (fwd_patch_edge<kCT, kThreads, kPlane>(h, img, tid, nrows)) __syncthreads();
     const int nb = (ph1 - ph0) * aligned_width;
     const int ts = nb | 1;
@@ -748,7 +761,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     MI_STAMP(4);  // this wave's bins are in the tile
     __syncthreads();  // the tile is complete, the image is free
     MI_STAMP(5);
-    if (k + 1 < h.nstages && !(ablate & 1))
+    if (k + step < h.nstages && !(ablate & 1))
       fwd_issue_window<kChPerWave, kPlane>(h, c0 + wave * kChPerWave, plane0, lane, n_row0, n_nrows);
     stores_out = 0;
     if (!(ablate & 4)) {
@@ -1308,7 +1321,15 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
                                           kCap, bwd_tables, stream, channels, /*cost_in_band=*/levels == nullptr);
   if (rc != MI_OK) return rc;
   const size_t lds = records_lds_bytes(kCap, kCT);
-  const int items = num_rois * (channels / kCT);
+  // An item has at least ceil(aligned_height / rows per output tile) stages (four at 14x14).  A launch of few such items
+  // -- the mask / keypoint heads: 128 RoIs = 1024 items over the chip's 768 slots -- deals every item's stages to two
+  // workgroups: 128 x 14x14 30.5 -> 28.7 us, a step's mask RoIs 37.4 -> 37.0 (four: 29.8 / 39.8).  Bit-equal: a stage is
+  // computed by the same code either way.  MI_ROI_ALIGN_FWD_SPLIT = 1 / 2 / 4 overrides.
+  const int min_stages = (aligned_height + kTileBins / aligned_width - 1) / (kTileBins / aligned_width);
+  int split = tuning().fwd_split;
+  if (split <= 0) split = (min_stages >= 2 && num_rois * (channels / kCT) <= 2048) ? 2 : 1;
+  if (split > min_stages) split = min_stages;
+  const int items = num_rois * (channels / kCT) * split;
   // the LDS images of MI_ROI_ALIGN_CAP >= 448 exceed the 64 KB a kernel may ask for without opting in
 #define MI_LAUNCH_REC(SR, A)                                                                                          \
   do {                                                                                                                \
@@ -1316,7 +1337,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_records<SR, kCap, A>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
     roi_align_fwd_records<SR, kCap, A><<<items, kThreads, lds, stream>>>(                                             \
-        lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio,               \
+        lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, split,        \
         tuning().ablate MI_TL_ARG);                                                                                   \
   } while (0)
   const int a = aligned_height == aligned_width ? aligned_height : 0;

@@ -495,6 +495,29 @@ def test_roi_align_forward_large_lds_caps(oracle_mod, tuning_env):
         assert_fwd(out, want14, "14x14 cap " + cap, exact=False)
 
 
+def test_roi_align_forward_stages_dealt_to_several_workgroups(oracle_mod, tuning_env):
+    """A launch of few multi-stage items deals every item's stages to two workgroups (MI_ROI_ALIGN_FWD_SPLIT forces 1 / 2 /
+    4): the same stage code runs either way, so the outputs are bit-equal between the settings and equal to the oracle --
+    pooled heights whose stage count is not a multiple of the split included, and a RoI of no image / a RoI the records
+    cannot describe among them (only part 0 of such an item may write)."""
+    for ah, hw, scale in ((14, (50, 84), 1.0 / 16), (9, (64, 96), 0.125), (21, (40, 56), 1.0 / 16)):
+        feat = syn.feature_map(2, 64, hw[0], hw[1], seed=6 + ah)
+        rois = syn.rois_canonical(40, 2, seed=7 + ah, im_h=int(hw[0] / scale), im_w=int(hw[1] / scale))
+        rois[3, 0] = 5.0                                             # no such image: zeros
+        rois[4, 1:] = np.array([-3000.0, -3000.0, 9000.0, 9000.0], np.float32)   # far wider than any LDS window
+        valid = rois[:, 0] < 2                                       # the oracle refuses rows of no image: zeros there
+        want = np.zeros((rois.shape[0], 64, ah, ah), np.float32)
+        want[valid] = oracle_mod.roi_align_forward(feat, rois[valid], ah, ah, scale, 2, threads=8)
+        outs = {}
+        for split in ("1", "2", "4", None):
+            tuning_env(MI_ROI_ALIGN_FWD_SPLIT=split)
+            out, _ = _roi_align_gpu(feat, rois, ah, scale, 2)
+            assert_fwd(out, want, "%dx%d split %s" % (ah, ah, split), exact=False)
+            outs[split] = out.detach().cpu().numpy()
+        for split in ("2", "4", None):
+            np.testing.assert_array_equal(outs[split], outs["1"], err_msg="%dx%d split %s" % (ah, ah, split))
+
+
 # ---- RoIAlign (legacy) ----------------------------------------------------------------------------
 def test_roi_align_legacy_golden_and_oracle(oracle_mod):
     from detectron_pytorch_amd.roi_align import LegacyRoIAlignFunction
