@@ -615,6 +615,19 @@ def cpu_baseline(images_per_rank):
         extra["keypoint_decode_20x17_ms"] = round((time.perf_counter() - t) * 10 * 1e3, 1)
     except Exception as e:  # pragma: no cover
         extra["result_formats_error"] = str(e)
+    try:  # mask targets from polygons (beside nms.mask_targets): 32 of the 256 RoIs, scaled up
+        import oracle
+        from oracle import segms as osegms
+
+        polys, gt_boxes, _ = syn.polygon_instances(16, seed=9)
+        rois = syn.jittered_boxes(gt_boxes, 16, seed=10)
+        inst = oracle.bbox_overlaps(rois, osegms.polys_to_boxes(polys)).argmax(axis=1)
+        t = time.perf_counter()
+        for r in range(0, 256, 8):
+            osegms.polys_to_mask_wrt_box(polys[inst[r]], rois[r], 28)
+        extra["polys_to_masks_256rois_28x28_ms"] = round((time.perf_counter() - t) * 8 * 1e3, 2)
+    except Exception as e:  # pragma: no cover
+        extra["mask_targets_error"] = str(e)
     return {"value": round(images / total, 3), "unit": "images/s (hot path only)", "cores": threads, "kind": "port",
             "sample": "%d x the hot-path step of one image: RoIAlign fwd+bwd 512x256x7x7 and 128x256x14x14 on "
                       "1x256x200x336 (OpenMP, %d threads) + 5 x cython-semantics NMS n=2000 thr=0.7 (1 thread); "

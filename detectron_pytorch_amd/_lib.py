@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_detectron_ops.so")
 
 MI_OK = 0
-ABI_VERSION = 4  # MI_ABI_VERSION of include/mi_detectron_ops.h this binding was written against
+ABI_VERSION = 5  # MI_ABI_VERSION of include/mi_detectron_ops.h this binding was written against
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 ROI_ALIGN_CAFFE2, ROI_ALIGN_LEGACY = 0, 1
 NMS_GE_ORIG_ASC, NMS_GT_SORTED_POS = 0, 1
@@ -54,6 +54,8 @@ SIGNATURES = {
     "mi_keypoint_nms_oks": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, _c_void_p, _c_void_p, _c_void_p]),
     "mi_box_voting": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_float, _c_int, _c_float,
                               _c_void_p, _c_void_p]),
+    "mi_polys_to_masks_wrt_boxes": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
+                                            _c_int, _c_void_p]),
     "mi_roi_align_backward_workspace_bytes": (_c_size_t, [_c_void_p, _c_int, _c_int]),
     "mi_roi_align_forward_fpn": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                          _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),

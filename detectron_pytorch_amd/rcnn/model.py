@@ -18,7 +18,7 @@ The training forward has no device-to-host synchronisation.
 import torch
 import torch.nn as nn
 
-from .. import fpn_proposals, nms, roi_xform
+from .. import fpn_proposals, nms, roi_xform, segms
 from .. import roi_align as roi_align_mod
 
 import os
@@ -73,6 +73,7 @@ class GeneralizedRCNN(nn.Module):
             for p in self.Conv_Body.parameters():
                 p.requires_grad = False
         self.iou_fn = nms.bbox_overlaps                 # mi_bbox_overlaps; tests on CPU tensors inject the oracle's
+        self.rasterize_fn = segms.polys_to_masks_wrt_boxes   # mi_polys_to_masks_wrt_boxes (roidb["gt_polygons"]); likewise
         self.mark = None                                # optional callable(label) invoked at stage boundaries (bench.py)
         self.static_inference = False                   # eval forward with fixed shapes and no host sync (inference.py)
 
@@ -165,7 +166,8 @@ class GeneralizedRCNN(nn.Module):
             blobs = targets.label_proposals(cfg, rois, roidb["gt_boxes"], roidb["gt_classes"], roidb["gt_image"],
                                             im_info_d[:, 2], priority, n_img, self.iou_fn, roi_valid=valid,
                                             gt_mask_boxes=roidb.get("gt_mask_boxes"),
-                                            gt_keypoints=roidb.get("gt_keypoints"))
+                                            gt_keypoints=roidb.get("gt_keypoints"),
+                                            gt_polygons=roidb.get("gt_polygons"), rasterize_fn=self.rasterize_fn)
         self._mark("proposals_labelling")
         box_feat = self.Box_Head(roi_blobs, blobs)
         cls_score, bbox_pred = self.Box_Outs(box_feat)

@@ -108,7 +108,7 @@ def keypoints_to_heatmap_labels(keypoints, rois, heatmap_size):
 
 
 def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, im_scales, priority, num_images, iou_fn,
-                    roi_valid=None, gt_mask_boxes=None, gt_keypoints=None):
+                    roi_valid=None, gt_mask_boxes=None, gt_keypoints=None, gt_polygons=None, rasterize_fn=None):
     """Label and sample the collected proposals of a minibatch.
 
     rois       [R,5] float32  (image index, x1, y1, x2, y2) in network-input coordinates, collect order
@@ -118,6 +118,9 @@ def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, im_scales, priori
     priority   [G+R] float32  sampling priority of every candidate, gt first (unique values; lower = drawn first)
     roi_valid  [R] bool       rows of `rois` that are real (static-shape collect); None = all
     gt_mask_boxes [G,4]       the rectangles that are the instances' masks (default: the gt boxes themselves)
+    gt_polygons               segms.PackedPolygons of the G instances (roidb 'segms', original image coordinates): the mask
+                              targets are rasterised from them by pycocotools' rule through `rasterize_fn(packed, roi_inst,
+                              boxes, M)` (segms.polys_to_masks_wrt_boxes: one HIP launch); takes precedence over gt_mask_boxes
     gt_keypoints [G,3,K]      (x, y, visibility) of every instance's keypoints in original image coordinates
                               (MODEL.KEYPOINTS_ON)
 
@@ -207,12 +210,21 @@ def label_proposals(cfg, rois, gt_boxes, gt_classes, gt_image, im_scales, priori
         fboxes = cand_boxes[fsrc.reshape(-1)] * has.view(-1, 1).to(f32)
         fcls = torch.where(has, max_cls[fsrc], torch.zeros_like(fsrc)).view(-1)
         if g > 0:
-            mboxes = gt_boxes if gt_mask_boxes is None else gt_mask_boxes
+            if gt_polygons is not None:
+                from .. import segms
+                mboxes = segms.polys_to_boxes(gt_polygons)                    # mask_rcnn.py:44
+            else:
+                mboxes = gt_boxes if gt_mask_boxes is None else gt_mask_boxes
             fimg = torch.arange(n_img, device=dev).view(-1, 1).expand(n_img, fg_per_image).reshape(-1)
             ov = iou_fn(fboxes.contiguous(), mboxes.contiguous())            # [N*F,G] vs the boxes enclosing the polygons
             ov = torch.where(fimg.view(-1, 1) == gt_image.long().view(1, -1), ov, torch.full_like(ov, -1.0))
             poly = ov.argmax(dim=1)                                           # mask_rcnn.py:62
-            masks = rasterize_boxes(mboxes[poly], fboxes, m)
+            if gt_polygons is not None:
+                # mask_rcnn.py:66-76, every row in one launch; padding rows name no instance
+                inst = torch.where(has.view(-1), poly, torch.full_like(poly, -1))
+                masks = (rasterize_fn or segms.polys_to_masks_wrt_boxes)(gt_polygons, inst, fboxes.contiguous(), m)
+            else:
+                masks = rasterize_boxes(mboxes[poly], fboxes, m)
         else:
             masks = torch.zeros((n_img * fg_per_image, m * m), dtype=torch.int32, device=dev)
         masks = torch.where(has.view(-1, 1), masks, torch.full_like(masks, -1))

@@ -177,6 +177,51 @@ def result_format_inputs(num_dets=100, num_person=20, mask_size=28, heat=56, see
     return masks, boxes, maps, person
 
 
+def polygon_instances(num_instances=8, seed=0, im_h=800, im_w=1333):
+    """COCO-like ground-truth instances in the roidb's `segms` format (json_dataset.py:218-262): per instance a list of 1-3
+    polygons (flat x0, y0, x1, y1, ... with two decimals, as the annotation files carry them) -- star-shaped outlines of
+    8-60 vertices around the instance's centre, concave ones, an occasional self-intersecting one, repeated vertices and
+    parts over the image border included.  Returns (segms, boxes [G, 4] float32 = the tight boxes, classes [G] int32)."""
+    rng = np.random.RandomState(seed)
+    segms, boxes = [], []
+    for _ in range(num_instances):
+        cx, cy = rng.uniform(60, im_w - 60), rng.uniform(60, im_h - 60)
+        rx, ry = rng.uniform(16, 200), rng.uniform(16, 200)
+        polys = []
+        for part in range(rng.randint(1, 4)):
+            k = rng.randint(8, 61)
+            ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+            rad = rng.uniform(0.35, 1.0, k)
+            if rng.rand() < 0.15:
+                ang = rng.permutation(ang)                       # self-intersecting
+            ox, oy = (0.0, 0.0) if part == 0 else rng.uniform(-0.8, 0.8, 2) * (rx, ry)
+            scale = 1.0 if part == 0 else rng.uniform(0.2, 0.5)
+            x = cx + ox + scale * rx * rad * np.cos(ang)
+            y = cy + oy + scale * ry * rad * np.sin(ang)
+            pts = np.round(np.stack([x, y], 1), 2)
+            if rng.rand() < 0.3:
+                pts = np.insert(pts, rng.randint(0, k), pts[rng.randint(0, k)], axis=0)   # a vertex visited twice
+            if rng.rand() < 0.3:
+                pts = np.repeat(pts, 1 + (rng.rand(pts.shape[0]) < 0.2), axis=0)           # consecutive duplicates
+            polys.append([float(v) for v in pts.reshape(-1)])
+        segms.append(polys)
+        allp = np.concatenate([np.asarray(p, np.float32).reshape(-1, 2) for p in polys])
+        boxes.append([allp[:, 0].min(), allp[:, 1].min(), allp[:, 0].max(), allp[:, 1].max()])
+    return segms, np.asarray(boxes, np.float32), rng.randint(1, 81, num_instances).astype(np.int32)
+
+
+def jittered_boxes(boxes, per_box, seed=0, jitter=0.25):
+    """Foreground-like RoIs: every box `per_box` times with its corners moved by up to `jitter` of its size (IoU with
+    the box mostly above 0.5), float32 [len(boxes) * per_box, 4]."""
+    rng = np.random.RandomState(seed)
+    b = np.repeat(np.asarray(boxes, np.float32), per_box, axis=0)
+    w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    d = rng.uniform(-jitter, jitter, b.shape) * np.stack([w, h, w, h], 1)
+    out = b + d
+    return np.stack([np.minimum(out[:, 0], out[:, 2]), np.minimum(out[:, 1], out[:, 3]),
+                     np.maximum(out[:, 0], out[:, 2]), np.maximum(out[:, 1], out[:, 3])], 1).astype(np.float32)
+
+
 def roi_align_touched_pixels(rois, batch, height, width, aligned_height, aligned_width, spatial_scale, sampling_ratio):
     """U of the algorithmic-bytes formula: the number of distinct feature pixels (n, y, x) that
     any sample of any RoI references with a non-zero weight.  float32 sampling arithmetic of roi_align_kernel.cu:74-110

@@ -42,7 +42,7 @@ extern "C" {
  * every shape but one; every fast forward now leaves its records (mi_roi_align_forward_writes_records).  4 (round 5):
  * mi_rpn_collect_finish_records + mi_roi_align_forward_fpn_records (the producer of the RoIs writes their records); a
  * dword-aligned top_grad is served by the generic backward instead of refused. */
-#define MI_ABI_VERSION 4
+#define MI_ABI_VERSION 5
 
 typedef void* mi_stream_t; /* hipStream_t */
 
@@ -352,6 +352,22 @@ int mi_rpn_collect_finish_records(const float* top_scores, const int64_t* top_in
 int mi_box_voting(const float* top_dets, const int32_t* top_segments, int num_top, const float* all_dets,
                   const int32_t* all_offsets, int num_segments, float thresh, int scoring_method, float beta, float* out,
                   mi_stream_t stream);
+
+/* Mask R-CNN training targets from polygons (lib/roi_data/mask_rcnn.py:66-76: the per-RoI host loop over
+ * lib/utils/segms.py:93-119 polys_to_mask_wrt_box = pycocotools 2.0 mask_util.frPyObjects + mask_util.decode,
+ * common/maskApi.c rleFrPoly / rleDecode), every RoI of a step in one launch.  Ground truth as ragged arrays:
+ *   poly_xy    float32 [points, 2]        the vertices (x, y) of all polygons, image coordinates (roidb['segms'])
+ *   poly_start int32  [polygons + 1]      first vertex of every polygon
+ *   inst_start int32  [num_instances + 1] first polygon of every instance (an instance = a list of polygons)
+ * roi_inst int32 [num_rois] names the instance of every RoI (mask_rcnn.py:62 fg_polys_inds; < 0 or >= num_instances: no
+ * instance, the row is zero-filled); rois float32 [num_rois, 4] (x1, y1, x2, y2, image coordinates -- before `*= im_scale`,
+ * mask_rcnn.py:99).  masks int32 [num_rois, m * m], row-major [y][x] as mask_rcnn.py:76 reshapes them: 1 where any polygon
+ * of the instance, moved into the RoI's frame and scaled to m x m (float32, segms.py:104-112), covers the pixel by
+ * pycocotools' rule.  m <= 64 (MI_ERR_UNSUPPORTED above).  Asynchronous, no workspace, bit-exact against the oracle's
+ * sequential restatement of maskApi.c. */
+int mi_polys_to_masks_wrt_boxes(const float* poly_xy, const int32_t* poly_start, const int32_t* inst_start,
+                                const int32_t* roi_inst, const float* rois, int32_t* masks, int num_rois, int num_instances,
+                                int m, mi_stream_t stream);
 
 /* Independent NMS problems in one call (no reference counterpart: the reference runs one cython_nms per FPN level and
  * image on the host, modeling/generate_proposals.py:91-99,161).  `dets`, `n`, `keep`, `num_keep` are HOST arrays of

@@ -759,6 +759,116 @@ void oracle_bbox_overlaps(const float* boxes, int N, const float* query_boxes, i
   }
 }
 
+/* ---- polygon -> binary mask: pycocotools 2.0, common/maskApi.c rleFrPoly followed by rleDecode ------------------------
+ * THIRD-PARTY ALGORITHM, RESTATED (pycocotools is not installed here and is not part of /root/reference; the reference
+ * calls it through mask_util.frPyObjects / mask_util.decode in lib/utils/segms.py:66-67,114-115).  PARITY UNPINNED against
+ * the real package; pinned are the call sites around it (oracle/segms.py) and hand-derived vectors (tests/test_oracle_cpu.py).
+ * The published procedure, in its own order:
+ *   1. vertices are scaled by 5 and rounded with (int)(5 v + .5) -- a C cast, i.e. truncation towards zero;
+ *   2. every edge (closed polygon) is walked along its longer axis, one point per unit step, the other coordinate
+ *      (int)(start + slope * t + .5) in double precision; the points are emitted from the edge's first vertex to its second;
+ *   3. wherever two consecutive points of the whole chain differ in x, a crossing is recorded at the down-sampled column
+ *      x = ((min(u, u') side) + .5) / 5 - .5 when that is a whole number inside [0, w - 1], at row
+ *      ceil(clamp((min(v, v') + .5) / 5 - .5, 0, h));
+ *   4. the crossings, as column-major positions x h + y, are sorted; consecutive differences are the run lengths (first
+ *      run = zeros), zero-length runs are merged away (two crossings at one position cancel);
+ *   5. rleDecode paints the runs into a column-major h x w image.
+ * `mask_cm` [h * w] (column-major, uint8) receives this polygon OR-ed over what it holds (segms.py:117-118 sums the
+ * per-polygon masks of an instance and thresholds at > 0). */
+static int oracle_cmp_u32(const void* a, const void* b) {
+  const uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+  return x > y ? 1 : x < y ? -1 : 0;
+}
+
+void oracle_poly_to_mask(const double* xy, int k, int h, int w, uint8_t* mask_cm) {
+  if (k <= 0) return;
+  const double scale = 5;
+  int* px = (int*)malloc(sizeof(int) * (size_t)(k + 1));
+  int* py = (int*)malloc(sizeof(int) * (size_t)(k + 1));
+  for (int j = 0; j < k; j++) {
+    px[j] = (int)(scale * xy[2 * j] + .5);
+    py[j] = (int)(scale * xy[2 * j + 1] + .5);
+  }
+  px[k] = px[0];
+  py[k] = py[0];
+  size_t total = 0;
+  for (int j = 0; j < k; j++) {
+    const int ax = abs(px[j] - px[j + 1]), ay = abs(py[j] - py[j + 1]);
+    total += (size_t)(ax > ay ? ax : ay) + 1;
+  }
+  int* u = (int*)malloc(sizeof(int) * total);
+  int* v = (int*)malloc(sizeof(int) * total);
+  size_t m = 0;
+  for (int j = 0; j < k; j++) {
+    int xs = px[j], xe = px[j + 1], ys = py[j], ye = py[j + 1];
+    const int dx = abs(xe - xs), dy = abs(ys - ye);
+    const int flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+    if (flip) {
+      int t = xs; xs = xe; xe = t;
+      t = ys; ys = ye; ye = t;
+    }
+    const double slope = dx >= dy ? (double)(ye - ys) / dx : (double)(xe - xs) / dy;
+    if (dx >= dy) {
+      for (int d = 0; d <= dx; d++) {
+        const int t = flip ? dx - d : d;
+        u[m] = t + xs;
+        v[m] = (int)(ys + slope * t + .5);
+        m++;
+      }
+    } else {
+      for (int d = 0; d <= dy; d++) {
+        const int t = flip ? dy - d : d;
+        v[m] = t + ys;
+        u[m] = (int)(xs + slope * t + .5);
+        m++;
+      }
+    }
+  }
+  uint32_t* pos = (uint32_t*)malloc(sizeof(uint32_t) * (total + 1));
+  size_t n = 0;
+  for (size_t j = 1; j < m; j++) {
+    if (u[j] == u[j - 1]) continue;
+    double xd = (double)(u[j] < u[j - 1] ? u[j] : u[j] - 1);
+    xd = (xd + .5) / scale - .5;
+    if (floor(xd) != xd || xd < 0 || xd > w - 1) continue;
+    double yd = (double)(v[j] < v[j - 1] ? v[j] : v[j - 1]);
+    yd = (yd + .5) / scale - .5;
+    if (yd < 0) yd = 0;
+    else if (yd > h) yd = h;
+    yd = ceil(yd);
+    pos[n++] = (uint32_t)((int)xd * h + (int)yd);
+  }
+  pos[n++] = (uint32_t)(h * w);
+  qsort(pos, n, sizeof(uint32_t), oracle_cmp_u32);
+  /* differences = run lengths; a zero difference (other than a leading one) is dropped together with the toggle before it */
+  uint32_t* runs = (uint32_t*)malloc(sizeof(uint32_t) * n);
+  uint32_t prev = 0;
+  for (size_t j = 0; j < n; j++) {
+    const uint32_t t = pos[j];
+    pos[j] = t - prev;
+    prev = t;
+  }
+  size_t nr = 0, j = 0;
+  runs[nr++] = pos[j++];
+  while (j < n) {
+    if (pos[j] > 0) {
+      runs[nr++] = pos[j++];
+    } else {
+      j++;
+      if (j < n) runs[nr - 1] += pos[j++];
+    }
+  }
+  /* rleDecode: runs alternate 0 / 1, column-major */
+  size_t at = 0;
+  uint8_t value = 0;
+  for (size_t r = 0; r < nr; r++) {
+    for (uint32_t c = 0; c < runs[r] && at < (size_t)h * w; c++, at++)
+      if (value) mask_cm[at] = 1;
+    value = !value;
+  }
+  free(px); free(py); free(u); free(v); free(pos); free(runs);
+}
+
 int oracle_num_threads_available(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

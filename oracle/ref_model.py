@@ -17,6 +17,7 @@ is shimmed, and only that (no arithmetic of the reference is replaced):
   * `.cuda(device_id)` on CPU tensors (model_builder.py:276,302; *_heads.py losses) -> identity, `get_device()` -> 0.
 """
 import collections.abc
+import contextlib
 import os
 import sys
 import types
@@ -179,9 +180,58 @@ def bind_rect_rasterizer(fn):
     segm_utils.polys_to_mask_wrt_box = fn
 
 
+@contextlib.contextmanager
+def pycocotools_polygon_calls():
+    """While active, the stand-in `pycocotools.mask` answers the two calls utils/segms.py:114-115 (and :66-67) makes for
+    polygons -- frPyObjects, decode -- with the restatement of maskApi.c in oracle/segms.py; everything else of the
+    reference's polygon handling then runs from its own source."""
+    load()
+    import utils.segms as segm_utils
+
+    from . import segms as oracle_segms
+
+    mu = segm_utils.mask_util
+    keep = (mu.__dict__.get("frPyObjects"), mu.__dict__.get("decode"))
+    mu.frPyObjects = lambda polys, h, w: (list(polys), h, w)
+    mu.decode = lambda rle: oracle_segms.fr_poly_decode(rle[0], rle[1], rle[2])
+    try:
+        yield
+    finally:
+        for k, v in zip(("frPyObjects", "decode"), keep):
+            if v is None:
+                mu.__dict__.pop(k, None)
+            else:
+                setattr(mu, k, v)
+
+
+def mask_rcnn_blobs_from_polygons(labels_int32, sampled_boxes, segms, gt_classes, im_scale=1.0, batch_idx=0, resolution=28):
+    """The reference's OWN `add_mask_rcnn_blobs` (roi_data/mask_rcnn.py:34-107) and `utils/segms.py` executed on a roidb
+    entry with polygon `segms` (pycocotools_polygon_calls() active).  Returns the blobs dict (mask_rois,
+    roi_has_mask_int32, masks_int32 -- class-agnostic [n_fg, M * M]) and the boxes enclosing the polygons (:44)."""
+    import numpy as np
+
+    cfg = load()
+    import roi_data.mask_rcnn as mrcnn
+    import utils.segms as segm_utils
+
+    keep = (cfg.MRCNN.RESOLUTION, cfg.MRCNN.CLS_SPECIFIC_MASK)
+    cfg.MRCNN.RESOLUTION, cfg.MRCNN.CLS_SPECIFIC_MASK = resolution, False
+    try:
+        with pycocotools_polygon_calls():
+            entry = {"gt_classes": np.asarray(gt_classes, dtype=np.int32), "is_crowd": np.zeros(len(segms), dtype=bool),
+                     "segms": segms}
+            blobs = {"labels_int32": np.asarray(labels_int32, dtype=np.int32)}
+            mrcnn.add_mask_rcnn_blobs(blobs, np.array(sampled_boxes, dtype=np.float32), entry, im_scale, batch_idx)
+            blobs["boxes_from_polys"] = segm_utils.polys_to_boxes(segms)
+    finally:
+        cfg.MRCNN.RESOLUTION, cfg.MRCNN.CLS_SPECIFIC_MASK = keep
+    return blobs
+
+
 # ---- executing the reference's training forward on the CPU --------------------------------------------------------------
-def roidb_entry(height, width, boxes, classes, num_classes, keypoints=None):
-    """A ground-truth-only roidb entry as datasets/json_dataset.py:178-262 builds it (rectangular polygon masks)."""
+def roidb_entry(height, width, boxes, classes, num_classes, keypoints=None, segms=None):
+    """A ground-truth-only roidb entry as datasets/json_dataset.py:178-262 builds it (rectangular polygon masks unless
+    `segms` -- per instance a list of polygons -- is given)."""
     import numpy as np
     import scipy.sparse
 
@@ -190,8 +240,9 @@ def roidb_entry(height, width, boxes, classes, num_classes, keypoints=None):
     n = boxes.shape[0]
     ov = np.zeros((n, num_classes), dtype=np.float32)
     ov[np.arange(n), classes] = 1.0
-    segms = [[[float(b[0]), float(b[1]), float(b[2]), float(b[1]), float(b[2]), float(b[3]), float(b[0]), float(b[3])]]
-             for b in boxes]
+    if segms is None:
+        segms = [[[float(b[0]), float(b[1]), float(b[2]), float(b[1]), float(b[2]), float(b[3]), float(b[0]), float(b[3])]]
+                 for b in boxes]
     entry = dict(height=height, width=width, flipped=False, boxes=boxes, segms=segms,
                  seg_areas=((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).astype(np.float32),
                  gt_classes=classes, gt_overlaps=scipy.sparse.csr_matrix(ov), is_crowd=np.zeros(n, dtype=bool),
@@ -219,7 +270,8 @@ def train_forward(model, data, blobs, priority, rasterizer):
     """`Generalized_RCNN.forward` in training mode on CPU tensors, with the two things that cannot run here replaced:
     `npr.choice(inds, size, replace=False)` in roi_data/fast_rcnn.py:146,160 draws "the first `size` of the permutation
     given by `priority`" (global candidate numbering: all gt boxes, then the collected proposals in collect order), and
-    pycocotools' polygon rasteriser is `rasterizer(polygons, box, M)`.
+    pycocotools' polygon rasteriser is `rasterizer(polygons, box, M)` (None: the reference's own polys_to_mask_wrt_box
+    with pycocotools_polygon_calls() active -- polygon `segms` in the roidb entries).
     Returns (return_dict, captured) with captured['rois'] = the collected proposals and captured['blobs'] = the
     labelled RoI blobs (numpy)."""
     import pickle
@@ -264,7 +316,8 @@ def train_forward(model, data, blobs, priority, rasterizer):
         return out
 
     json_dataset.add_proposals, frcn._sample_rois, frcn.npr = add_proposals, sample_rois, Npr
-    segm_utils.polys_to_mask_wrt_box, frcn.add_fast_rcnn_blobs = rasterizer, add_blobs
+    segm_utils.polys_to_mask_wrt_box, frcn.add_fast_rcnn_blobs = rasterizer or orig_rast, add_blobs
+    polygon_calls = pycocotools_polygon_calls() if rasterizer is None else contextlib.nullcontext()
     # roi_data/keypoint_rcnn.py:52-54 calls np.random.choice directly: same permutation rule
     import roi_data.keypoint_rcnn as kprcnn
 
@@ -281,7 +334,8 @@ def train_forward(model, data, blobs, priority, rasterizer):
     try:
         roidb_in = [np.frombuffer(pickle.dumps([e]), dtype=np.uint8).astype(np.float32) for e in minimal]   # blob.py:165-169
         kwargs = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in blobs.items() if k.startswith("rpn_")}
-        ret = model(data, torch.from_numpy(blobs["im_info"]), roidb_in, **kwargs)
+        with polygon_calls:
+            ret = model(data, torch.from_numpy(blobs["im_info"]), roidb_in, **kwargs)
     finally:
         kprcnn.np = orig_kp_np
         json_dataset.add_proposals, frcn._sample_rois, frcn.npr = orig_add, orig_sample, orig_npr

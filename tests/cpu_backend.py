@@ -65,6 +65,19 @@ def bbox_overlaps(boxes, query):
     return torch.from_numpy(oracle.bbox_overlaps(boxes.numpy(), query.numpy()))
 
 
+def polys_to_masks_wrt_boxes(packed, roi_inst, boxes, m):
+    """segms.polys_to_masks_wrt_boxes through the oracle's restatement of utils/segms.py + pycocotools."""
+    from oracle import segms as oracle_segms
+
+    pts, ps, ins = packed.points.numpy(), packed.poly_start.numpy(), packed.inst_start.numpy()
+    out = np.zeros((boxes.size(0), m * m), dtype=np.int32)
+    for r, i in enumerate(roi_inst.numpy()):
+        if 0 <= i < len(ins) - 1:
+            polys = [pts[ps[p]:ps[p + 1]].reshape(-1) for p in range(ins[i], ins[i + 1])]
+            out[r] = oracle_segms.polys_to_mask_wrt_box(polys, boxes[r].numpy(), m).reshape(-1) > 0
+    return torch.from_numpy(out)
+
+
 @contextlib.contextmanager
 def cpu_ops(model=None):
     from detectron_pytorch_amd import fpn_proposals, roi_xform
@@ -75,6 +88,7 @@ def cpu_ops(model=None):
     roi_xform.roi_align_fpn_supported = lambda *a, **k: True
     if model is not None:
         model.iou_fn = bbox_overlaps
+        model.rasterize_fn = polys_to_masks_wrt_boxes
     try:
         yield
     finally:

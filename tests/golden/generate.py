@@ -316,6 +316,38 @@ def gen_fpn():
     save("fpn.npz", rois=rois, levels=lvls, **blobs)
 
 
+def gen_mask_targets():
+    """Mask targets from polygon ground truth: the reference's own add_mask_rcnn_blobs (roi_data/mask_rcnn.py:34-107) and
+    utils/segms.py executed from source on synthetic COCO-like polygons (oracle/ref_model.py); of pycocotools (absent) only
+    frPyObjects / decode are bound, to the restatement of its maskApi.c in oracle/oracle.c -- the fixture pins everything
+    around the rasteriser to the reference, the rasteriser itself to that restatement."""
+    from oracle import ref_model
+
+    out = {}
+    for tag, m, seed, n_inst, per in (("a", 28, 41, 10, 6), ("b", 14, 43, 5, 4)):
+        segms, boxes, classes = syn.polygon_instances(n_inst, seed=seed)
+        rois = syn.jittered_boxes(boxes, per, seed=seed + 1, jitter=0.3)
+        # RoIs the sampler can also hand over: thinner than a pixel, a point, one far from its polygon, one over the border
+        extra = np.array([[boxes[0, 0], boxes[0, 1], boxes[0, 0] + 0.4, boxes[0, 3]], [boxes[1, 0], boxes[1, 1], boxes[1, 0], boxes[1, 1]],
+                          [0, 0, 30, 30], [-40, -30, boxes[2, 2], boxes[2, 3]]], np.float32)
+        rois = np.vstack([rois, extra]).astype(np.float32)
+        labels = np.concatenate([np.repeat(classes, per), classes[:4]]).astype(np.int32)
+        # background rows in between, as the sampled blob has them (the fg rows are picked out by label > 0)
+        bg = syn.jittered_boxes(boxes[:3], 2, seed=seed + 2, jitter=0.9)
+        sampled = np.vstack([rois[:7], bg, rois[7:]]).astype(np.float32)
+        lab = np.concatenate([labels[:7], np.zeros(len(bg), np.int32), labels[7:]])
+        blobs = ref_model.mask_rcnn_blobs_from_polygons(lab, sampled, segms, classes, im_scale=1.5, batch_idx=1, resolution=m)
+        pts = np.concatenate([np.asarray(p, np.float32).reshape(-1, 2) for polys in segms for p in polys])
+        counts = [len(p) // 2 for polys in segms for p in polys]
+        out.update({tag + "_points": pts, tag + "_poly_start": np.concatenate([[0], np.cumsum(counts)]).astype(np.int32),
+                    tag + "_inst_start": np.concatenate([[0], np.cumsum([len(polys) for polys in segms])]).astype(np.int32),
+                    tag + "_classes": classes, tag + "_sampled_boxes": sampled, tag + "_labels": lab,
+                    tag + "_resolution": np.int32(m), tag + "_boxes_from_polys": blobs["boxes_from_polys"],
+                    tag + "_mask_rois": blobs["mask_rois"], tag + "_masks_int32": blobs["masks_int32"].astype(np.int8),
+                    tag + "_roi_has_mask": blobs["roi_has_mask_int32"]})
+    save("mask_targets.npz", **out)
+
+
 def main():
     if not ref.available():
         sys.exit("oracle/_ref is not built: run `python oracle/build_ref.py` in the build container first")
@@ -329,6 +361,7 @@ def main():
     gen_proposals()
     gen_fpn()
     gen_box_voting()
+    gen_mask_targets()
 
 
 if __name__ == "__main__":

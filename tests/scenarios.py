@@ -18,6 +18,26 @@ def scenario(seed=5):
     return boxes, classes, data
 
 
+def polygons_for_boxes(boxes, seed=23):
+    """Per gt box a COCO-style instance (list of 1-2 polygons, flat x0, y0, ... with two decimals) drawn inside the box:
+    a star-shaped outline of 6-40 vertices, sometimes a second small part.  The polygons' tight box is smaller than the gt
+    box, as in real annotations (mask_rcnn.py:44 matches the RoIs against the boxes of the POLYGONS)."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for b in boxes:
+        cx, cy, rx, ry = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2, (b[2] - b[0]) / 2, (b[3] - b[1]) / 2
+        polys = []
+        for part in range(1 + (rng.rand() < 0.4)):
+            k = rng.randint(6, 41)
+            ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+            rad = rng.uniform(0.4, 1.0, k) * (1.0 if part == 0 else 0.3)
+            ox, oy = (0.0, 0.0) if part == 0 else rng.uniform(-0.6, 0.6, 2) * (rx, ry)
+            pts = np.round(np.stack([cx + ox + rx * rad * np.cos(ang), cy + oy + ry * rad * np.sin(ang)], 1), 2)
+            polys.append([float(v) for v in pts.reshape(-1)])
+        out.append(polys)
+    return out
+
+
 def synthetic_conv_outputs(seed, n, h=H, w=W):
     """Seeded stand-ins for the outputs of the convolutions: pyramid blobs [P6, P5, P4, P3, P2] (256 channels), and per
     RPN level 2..6 the objectness logits [n,3,h,w] and box deltas [n,12,h,w]."""

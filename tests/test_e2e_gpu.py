@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
-from scenarios import H, W, NUM_GT, scenario, synthetic_conv_outputs  # noqa: E402
+from scenarios import H, W, NUM_GT, polygons_for_boxes, scenario, synthetic_conv_outputs  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model.npz")
 
@@ -53,6 +53,45 @@ def by_rows(a):
 def rel_err(got, want):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def test_labelling_with_polygon_ground_truth_on_the_device(nets, golden):
+    """targets.label_proposals with COCO-style polygon ground truth (roidb 'segms'): on the device -- mi_bbox_overlaps, the
+    boxes enclosing the polygons, one mi_polys_to_masks_wrt_boxes launch for every mask row of the minibatch -- against
+    the same function on CPU tensors with the oracle's stand-ins (tests/cpu_backend.py), which tests/test_model_cpu.py
+    compares with the reference's own data layer.  Every blob bit for bit; padding rows stay -1."""
+    import cpu_backend
+    from detectron_pytorch_amd import nms, segms
+    from detectron_pytorch_amd.rcnn import targets
+
+    _, _, cfg = nets
+    boxes, classes, _ = scenario()
+    polys = polygons_for_boxes(boxes[0], seed=23) + polygons_for_boxes(boxes[1], seed=24)
+    packed = segms.PackedPolygons.from_lists(polys)
+    rois = torch.from_numpy(golden["train_collected_rois"])
+    args = dict(gt_boxes=torch.from_numpy(np.concatenate(boxes)), gt_classes=torch.from_numpy(np.concatenate(classes)).long(),
+                gt_image=torch.tensor([0] * NUM_GT + [1] * NUM_GT), im_scales=torch.tensor([1.0, 1.0]),
+                priority=torch.from_numpy(np.random.RandomState(7).permutation(2 * NUM_GT + rois.size(0)).astype(np.float32)))
+    want = targets.label_proposals(cfg, rois, args["gt_boxes"], args["gt_classes"], args["gt_image"], args["im_scales"],
+                                   args["priority"], 2, cpu_backend.bbox_overlaps, gt_polygons=packed,
+                                   rasterize_fn=cpu_backend.polys_to_masks_wrt_boxes)
+    d = dev()
+    got = targets.label_proposals(cfg, rois.to(d), args["gt_boxes"].to(d), args["gt_classes"].to(d), args["gt_image"].to(d),
+                                  args["im_scales"].to(d), args["priority"].to(d), 2, nms.bbox_overlaps,
+                                  gt_polygons=packed.to(d))
+    assert set(got) == set(want)
+    for k in want:
+        if k == "bbox_targets":                      # log / division: the device's last bit (3e-6 as in the test below)
+            np.testing.assert_allclose(got[k].cpu().numpy(), want[k].numpy(), rtol=0, atol=3e-6)
+        else:
+            assert np.array_equal(got[k].cpu().numpy(), want[k].numpy()), k
+    fg = want["mask_class"] > 0
+    assert int(fg.sum()) >= 2 * NUM_GT and 0.1 < float(want["masks_int32"][fg].float().mean()) < 0.9
+    assert (want["masks_int32"][~fg] == -1).all()
+    # ... and differ from the rectangle ground truth of the same boxes (the polygons are star-shaped outlines inside them)
+    rect = targets.label_proposals(cfg, rois.to(d), args["gt_boxes"].to(d), args["gt_classes"].to(d), args["gt_image"].to(d),
+                                   args["im_scales"].to(d), args["priority"].to(d), 2, nms.bbox_overlaps)
+    assert (rect["masks_int32"].cpu() != want["masks_int32"]).any()
 
 
 @pytest.mark.parametrize("layout", ["nchw", "channels_last"])

@@ -27,7 +27,7 @@ from oracle import ref_model  # noqa: E402
 
 pytestmark = pytest.mark.skipif(not ref_model.available(), reason="needs /root/reference and oracle/_ref")
 
-from scenarios import H, W, NUM_GT, scenario  # noqa: E402
+from scenarios import H, W, NUM_GT, polygons_for_boxes, scenario  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -124,25 +124,36 @@ GRAD_PARAMS = ["Box_Head.fc1.weight", "Box_Outs.bbox_pred.weight", "Mask_Head.co
                "Conv_Body.conv_body.res5.2.conv3.weight", "Conv_Body.conv_body.res3.0.conv1.weight"]
 
 
-def test_training_forward_and_backward_equal_the_reference(ref_cfg, models):
+@pytest.mark.parametrize("ground_truth", ["rectangles", "polygons"])
+def test_training_forward_and_backward_equal_the_reference(ref_cfg, models, ground_truth):
+    """ground_truth "rectangles": every instance's mask is its gt box; the reference's
+    pycocotools rasteriser is replaced by the rectangle rasteriser of rcnn/targets.py.  "polygons": COCO-style polygon
+    lists per instance; the reference runs its own polys_to_boxes / polys_to_mask_wrt_box with only pycocotools'
+    frPyObjects / decode bound to the oracle's restatement of maskApi.c, this side rasterises through
+    segms.polys_to_masks_wrt_boxes (here: its oracle stand-in, tests/cpu_backend.py; the HIP kernel is compared with the
+    same oracle in tests/test_ops_gpu.py)."""
     import cpu_backend
     from detectron_pytorch_amd.rcnn import targets
+    from detectron_pytorch_amd.segms import PackedPolygons
 
     ref, mine, cfg = models
     ref.train()
     mine.train()
     boxes, classes, data_np = scenario()
-    entries = [ref_model.roidb_entry(H, W, b, c, 81) for b, c in zip(boxes, classes)]
+    polys = [polygons_for_boxes(b, seed=23 + i) for i, b in enumerate(boxes)] if ground_truth == "polygons" else [None, None]
+    entries = [ref_model.roidb_entry(H, W, b, c, 81, segms=p) for b, c, p in zip(boxes, classes, polys)]
     blobs = ref_model.rpn_blobs(entries, [1.0, 1.0], seed=11)
     data = torch.from_numpy(data_np)
     g = 2 * NUM_GT
     priority = np.random.RandomState(7).permutation(g + 2000).astype(np.float32)
     ref.zero_grad()
-    ret_ref, cap = ref_model.train_forward(ref, data, blobs, priority, rect_rasterizer)
+    ret_ref, cap = ref_model.train_forward(ref, data, blobs, priority, rect_rasterizer if ground_truth == "rectangles" else None)
     sum(v.sum() for v in ret_ref["losses"].values()).backward()
 
     roidb = {"gt_boxes": torch.from_numpy(np.concatenate(boxes)), "gt_classes": torch.from_numpy(np.concatenate(classes)).long(),
              "gt_image": torch.tensor([0] * NUM_GT + [1] * NUM_GT)}
+    if ground_truth == "polygons":
+        roidb["gt_polygons"] = PackedPolygons.from_lists(polys[0] + polys[1])
     rpn_t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in blobs.items() if k.startswith("rpn_")}
     mine.zero_grad()
     with cpu_backend.cpu_ops(mine):

@@ -1571,3 +1571,80 @@ def test_generate_and_collect_matches_per_level_ops_then_collect(oracle_mod):
     assert np.array_equal(got.cpu().numpy(), want)
     few = fpn_proposals.generate_and_collect(ops, heads, to_dev(im_info), 100000)   # fewer proposals than asked for
     assert np.array_equal(few.cpu().numpy(), all_rois[np.argsort(-all_probs)])
+
+
+# ---- mask targets from polygon ground truth (roi_data/mask_rcnn.py:34-107, utils/segms.py) ---------------------------
+def _packed(points, poly_start, inst_start, device):
+    from detectron_pytorch_amd.segms import PackedPolygons
+
+    return PackedPolygons(torch.from_numpy(np.ascontiguousarray(points)).to(device),
+                          torch.from_numpy(np.ascontiguousarray(poly_start)).to(device),
+                          torch.from_numpy(np.ascontiguousarray(inst_start)).to(device))
+
+
+def test_polygon_mask_targets_equal_the_references_blobs():
+    """Golden: the reference's own add_mask_rcnn_blobs + utils/segms.py executed from source on COCO-like polygons
+    (tests/golden/generate.py gen_mask_targets; pycocotools' two calls bound to the restatement of its maskApi.c).  The
+    device path -- boxes enclosing the polygons, IoU matrix, argmax, one rasterising launch for all foreground rows --
+    reproduces the enclosing boxes, the mask RoIs and every mask bit for bit."""
+    from detectron_pytorch_amd import nms, segms
+
+    g = load_golden("mask_targets.npz")
+    for tag in ("a", "b"):
+        m = int(g[tag + "_resolution"])
+        packed = _packed(g[tag + "_points"], g[tag + "_poly_start"], g[tag + "_inst_start"], dev())
+        boxes_from_polys = segms.polys_to_boxes(packed)
+        assert np.array_equal(boxes_from_polys.cpu().numpy(), g[tag + "_boxes_from_polys"])
+        fg = g[tag + "_labels"] > 0
+        rois_fg = to_dev(g[tag + "_sampled_boxes"][fg])
+        inst = nms.bbox_overlaps(rois_fg, boxes_from_polys).argmax(dim=1)
+        masks = segms.polys_to_masks_wrt_boxes(packed, inst, rois_fg, m)
+        assert masks.dtype == torch.int32 and tuple(masks.shape) == (int(fg.sum()), m * m)
+        assert np.array_equal(masks.cpu().numpy().astype(np.int8), g[tag + "_masks_int32"]), tag
+        mask_rois = torch.cat([torch.full((rois_fg.size(0), 1), 1.0, device=dev()), rois_fg * 1.5], dim=1)
+        assert np.array_equal(mask_rois.cpu().numpy(), g[tag + "_mask_rois"])
+
+
+@pytest.mark.parametrize("m", [7, 14, 28, 56, 64])
+def test_polygon_rasteriser_against_the_oracle(oracle_mod, m):
+    """mi_polys_to_masks_wrt_boxes (a parallel form of pycocotools' rleFrPoly: crossings toggle column-major positions, a
+    parity scan decodes) against the oracle's sequential restatement (sort, run-length merge, decode), bit for bit:
+    instances of 1-3 polygons (concave, self-intersecting, repeated vertices, parts outside the image), RoIs jittered
+    around them, a point, slivers, far away, larger than the image; rows of no instance stay zero."""
+    import cpu_backend
+    from detectron_pytorch_amd import segms
+    from detectron_pytorch_amd.segms import PackedPolygons
+
+    polys, boxes, _ = syn.polygon_instances(12, seed=100 + m)
+    rois = syn.jittered_boxes(boxes, 8, seed=m, jitter=0.4)
+    inst = np.repeat(np.arange(12), 8)
+    special = np.array([[boxes[0, 0], boxes[0, 1], boxes[0, 0], boxes[0, 1]], [boxes[1, 0] + 3, boxes[1, 1], boxes[1, 0] + 3.3, boxes[1, 3]],
+                        [boxes[2, 0], boxes[2, 1] + 5, boxes[2, 2], boxes[2, 1] + 5.2], [5, 5, 20, 20], [-200, -200, 1600, 1000],
+                        [boxes[5, 0] + 0.37, boxes[5, 1] + 0.61, boxes[5, 2] - 0.13, boxes[5, 3] - 0.29], boxes[6], boxes[7]], np.float32)
+    rois = np.vstack([rois, special]).astype(np.float32)
+    inst = np.concatenate([inst, [0, 1, 2, 3, 4, 5, 6, -1]]).astype(np.int64)
+    packed_cpu = PackedPolygons.from_lists(polys)
+    want = cpu_backend.polys_to_masks_wrt_boxes(packed_cpu, torch.from_numpy(inst), torch.from_numpy(rois), m).numpy()
+    got = segms.polys_to_masks_wrt_boxes(packed_cpu.to(dev()), to_dev(inst), to_dev(rois), m).cpu().numpy()
+    assert np.array_equal(got, want), "rows that differ: %s" % np.nonzero((got != want).any(1))[0]
+    assert 0.05 < want[:96].mean() < 0.9 and not got[-1].any()
+    # rectangles in the polygon format (SURVEY section 8d config 4's ground truth): whole pixels of an aligned rectangle
+    rect = PackedPolygons.from_boxes(torch.from_numpy(boxes))
+    want = cpu_backend.polys_to_masks_wrt_boxes(rect, torch.from_numpy(inst[:96]), torch.from_numpy(rois[:96]), m).numpy()
+    got = segms.polys_to_masks_wrt_boxes(rect.to(dev()), to_dev(inst[:96]), to_dev(rois[:96]), m).cpu().numpy()
+    assert np.array_equal(got, want)
+    whole = segms.polys_to_masks_wrt_boxes(rect.to(dev()), to_dev(np.arange(12)), to_dev(boxes), m).cpu().numpy()
+    assert whole.all()                                                        # a RoI that is its instance's rectangle
+
+
+def test_polygon_rasteriser_contract():
+    from detectron_pytorch_amd import _lib, segms
+    from detectron_pytorch_amd.segms import PackedPolygons
+
+    polys, boxes, _ = syn.polygon_instances(3, seed=5)
+    packed = PackedPolygons.from_lists(polys, device=dev())
+    with pytest.raises(_lib.MiOpsError, match="resolution"):
+        segms.polys_to_masks_wrt_boxes(packed, to_dev(np.zeros(3, np.int64)), to_dev(boxes), 65)
+    assert tuple(segms.polys_to_masks_wrt_boxes(packed, to_dev(np.zeros(0, np.int64)), to_dev(np.zeros((0, 4), np.float32)), 28).shape) == (0, 784)
+    with pytest.raises(NotImplementedError):
+        segms.polys_to_masks_wrt_boxes(packed, torch.zeros(3, dtype=torch.int64), torch.from_numpy(boxes), 28)

@@ -349,3 +349,93 @@ def test_generate_proposals_oracle_matches_reference_fixture(oracle_mod):
         rois, probs = proposals.generate_proposals(scores, deltas, g["im_info_" + name], anchors, 1.0 / stride, pre, post,
                                                    0.7, min_size)
         assert np.array_equal(rois, g["rois_" + name]) and np.array_equal(probs, g["probs_" + name]), name
+
+
+# ---- mask targets from polygons (roi_data/mask_rcnn.py:34-107, utils/segms.py; pycocotools' rasteriser restated) ------
+def _segms_from_fixture(g, tag):
+    pts, ps, ins = g[tag + "_points"], g[tag + "_poly_start"], g[tag + "_inst_start"]
+    return [[pts[ps[p]:ps[p + 1]].reshape(-1) for p in range(ins[i], ins[i + 1])] for i in range(len(ins) - 1)]
+
+
+def test_mask_targets_from_polygons_match_golden(oracle_mod):
+    """The line-by-line restatement of utils/segms.py in oracle/segms.py (what the GPU tests compare the HIP kernel with)
+    against the fixture the reference's own add_mask_rcnn_blobs + segms.py produced."""
+    from oracle import segms
+
+    g = load_golden("mask_targets.npz")
+    for tag in ("a", "b"):
+        m, polys = int(g[tag + "_resolution"]), _segms_from_fixture(g, tag)
+        boxes_from_polys = segms.polys_to_boxes(polys)
+        assert np.array_equal(boxes_from_polys, g[tag + "_boxes_from_polys"])
+        fg = g[tag + "_labels"] > 0
+        rois = g[tag + "_sampled_boxes"][fg]
+        inst = oracle_mod.bbox_overlaps(rois, boxes_from_polys).argmax(axis=1)
+        masks = np.stack([segms.polys_to_mask_wrt_box(polys[i], r, m).reshape(-1) for r, i in zip(rois, inst)])
+        assert np.array_equal(masks.astype(np.int8), g[tag + "_masks_int32"])
+        assert np.array_equal(g[tag + "_roi_has_mask"], fg.astype(np.int32))
+
+
+def test_polygon_rasteriser_known_answers(oracle_mod):
+    """pycocotools' rule, derived by hand from maskApi.c rleFrPoly: vertices go to a grid of 5 samples per pixel, a pixel
+    column is crossed where the boundary passes its centre sample (5 x + 2), rows likewise -- "the pixels whose centres
+    the polygon covers", on that grid."""
+    from oracle import segms
+
+    def rect(x0, y0, x1, y1):
+        return [x0, y0, x1, y0, x1, y1, x0, y1]
+
+    want = np.zeros((5, 5), np.float32)
+    want[1:3, 1:3] = 1
+    assert np.array_equal(segms.polys_to_mask([rect(1, 1, 3, 3)], 5, 5), want)             # whole pixels of an aligned rectangle
+    assert segms.polys_to_mask([rect(0, 0, 7, 5)], 5, 7).all()                              # the whole image
+    assert segms.polys_to_mask([rect(-10, -3, 40, 30)], 5, 7).all()                         # ... and beyond its border
+    want[:] = 0
+    want[1:4, 1:4] = 1
+    assert np.array_equal(segms.polys_to_mask([rect(0.5, 0.5, 3.5, 3.5)], 5, 5), want)     # centres 1.5, 2.5 (, 3.5: the 5x grid
+    want[:] = 0                                                                            # rounds 17.5 + .5 up) inside
+    want[1:3, 1:3] = 1
+    assert np.array_equal(segms.polys_to_mask([rect(0.6, 0.6, 2.9, 2.9)], 5, 5), want)
+    assert not segms.polys_to_mask([rect(1.6, 1.6, 2.4, 2.4)], 5, 5).any()                  # covers no pixel centre
+    tri = segms.polys_to_mask([[0.5, 0.5, 4.5, 0.5, 2.5, 4.5]], 6, 6).astype(int)          # worked through by hand
+    assert np.array_equal(tri, np.array([[0, 0, 0, 0, 0, 0], [0, 1, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 1, 0, 0, 0],
+                                         [0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0]]))
+    # two polygons of one instance are OR-ed (segms.py:117-118), overlapping or not
+    both = segms.polys_to_mask([rect(0, 0, 2, 2), rect(1, 1, 4, 4)], 5, 5)
+    assert both.sum() == 4 + 9 - 1 and both.max() == 1
+    # in the frame of a box: the reference's float32 shift-and-scale (segms.py:104-112)
+    m = segms.polys_to_mask_wrt_box([rect(10, 10, 30, 30)], np.array([5, 5, 25, 25], np.float32), 8)
+    want8 = np.zeros((8, 8), np.float32)
+    want8[2:, 2:] = 1
+    assert np.array_equal(m, want8)
+
+
+def test_polygon_rasteriser_properties(oracle_mod):
+    """Size-independent properties of the published algorithm: the mask does not depend on the vertex the outline starts
+    from nor on its orientation, repeated vertices change nothing, the area equals the polygon's up to its perimeter, and it
+    agrees with an exact even-odd test of the pixel centres except on boundary pixels."""
+    from oracle import segms
+
+    rng = np.random.RandomState(0)
+    for trial in range(12):
+        k = rng.randint(5, 40)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+        rad = rng.uniform(0.5, 1.0, k) * rng.uniform(20, 120)
+        x, y = 150 + rad * np.cos(ang), 140 + 0.8 * rad * np.sin(ang)
+        pts = np.round(np.stack([x, y], 1), 2)
+        base = segms.polys_to_mask([pts.reshape(-1)], 300, 310)
+        assert np.array_equal(segms.polys_to_mask([np.roll(pts, rng.randint(1, k), axis=0).reshape(-1)], 300, 310), base)
+        assert np.array_equal(segms.polys_to_mask([pts[::-1].reshape(-1)], 300, 310), base)
+        assert np.array_equal(segms.polys_to_mask([np.repeat(pts, 1 + (rng.rand(k) < 0.3), axis=0).reshape(-1)], 300, 310), base)
+        xs, ys = pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64)
+        area = 0.5 * abs(np.dot(xs, np.roll(ys, -1)) - np.dot(ys, np.roll(xs, -1)))
+        perimeter = np.hypot(xs - np.roll(xs, -1), ys - np.roll(ys, -1)).sum()
+        assert abs(base.sum() - area) <= 0.25 * perimeter, (trial, base.sum(), area, perimeter)
+        cy, cx = np.mgrid[0:300, 0:310] + 0.5                                  # even-odd rule at the pixel centres
+        inside = np.zeros((300, 310), bool)
+        for j in range(k):
+            x0, y0, x1, y1 = xs[j], ys[j], xs[(j + 1) % k], ys[(j + 1) % k]
+            hit = ((y0 <= cy) != (y1 <= cy))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                xc = x0 + (cy - y0) * (x1 - x0) / (y1 - y0)
+            inside ^= hit & (cx < xc)
+        assert (inside != (base > 0)).sum() <= 0.75 * perimeter, (trial, (inside != (base > 0)).sum(), perimeter)

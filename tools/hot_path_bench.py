@@ -485,6 +485,16 @@ def nms_latency(device, iters):
                                      num[0].data_ptr(), 4096, strs.data_ptr(), num[1].data_ptr(),
                                      _lib_mod.current_stream_handle(device)) == 0
 
+    # mask targets of a step's foreground RoIs from polygon ground truth (roi_data/mask_rcnn.py:66-76 in one launch)
+    from detectron_pytorch_amd import segms as segms_mod
+    polys, gt_boxes, _ = syn.polygon_instances(16, seed=9)
+    packed = segms_mod.PackedPolygons.from_lists(polys, device=device)
+    fg_rois = torch.from_numpy(syn.jittered_boxes(gt_boxes, 16, seed=10)).to(device)
+    fg_inst = torch.arange(16, device=device).repeat_interleave(16)
+    out["mask_targets"] = {
+        "polys_to_masks_256rois_28x28_us": round(time_kernel(lambda: segms_mod.polys_to_masks_wrt_boxes(packed, fg_inst, fg_rois, 28), 20, warmup=3) * 1e6, 1),
+        "what": "mi_polys_to_masks_wrt_boxes: 256 foreground RoIs (16 around each of 16 instances of 1-3 polygons, %d vertices "
+                "in all) rasterised to 28x28 by pycocotools' rule in one launch" % int(packed.points.size(0))}
     out["result_formats"] = {
         "segm_100_masks_800x1333_ms": round(host_sec * 1e3, 3),
         "mask_paste_rle_kernel_us": round(time_kernel(paste_kernel, 20, warmup=3) * 1e6, 1),
