@@ -57,6 +57,25 @@ class PackedPolygons(object):
         return PackedPolygons(self.points.to(device), self.poly_start.to(device), self.inst_start.to(device))
 
 
+def flip_segms(segms, height, width):
+    """segms.py:33-60 for polygon ground truth: the horizontally flipped roidb entry's `segms` (host lists in, host lists
+    out, float64 as there; pack afterwards).  RLE (crowd) masks never become mask targets (mask_rcnn.py:40-41 takes the
+    non-crowd instances) and are not handled."""
+    import numpy as np
+
+    flipped = []
+    for segm in segms:
+        if not isinstance(segm, list):
+            raise NotImplementedError("flip_segms: RLE ground truth is outside the training targets' path")
+        out = []
+        for poly in segm:
+            p = np.array(poly)
+            p[0::2] = width - np.array(poly[0::2]) - 1
+            out.append(p.tolist())
+        flipped.append(out)
+    return flipped
+
+
 def polys_to_boxes(packed):
     """segms.py:121-132: the tight box of every instance's polygons, [G, 4] float32."""
     g = packed.num_instances

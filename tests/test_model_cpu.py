@@ -209,6 +209,26 @@ def test_training_forward_and_backward_equal_the_reference(ref_cfg, models, grou
         assert err <= 2e-4, (name, err)
 
 
+def test_polygon_helpers_equal_the_references_segms_module(ref_cfg):
+    """The host-side polygon helpers against utils/segms.py imported from the reference: flip_segms (:33-60), and
+    PackedPolygons + polys_to_boxes against polys_to_boxes (:121-132) on the packed form."""
+    import utils.segms as ref_segms
+    from detectron_pytorch_amd import segms
+    from detectron_pytorch_amd import synthetic as syn
+
+    polys, boxes, _ = syn.polygon_instances(9, seed=12)
+    assert segms.flip_segms(polys, 800, 1333) == ref_segms.flip_segms(polys, 800, 1333)
+    packed = segms.PackedPolygons.from_lists(polys)
+    assert packed.num_instances == 9 and int(packed.poly_start[-1]) == packed.points.size(0)
+    assert np.array_equal(segms.polys_to_boxes(packed).numpy(), ref_segms.polys_to_boxes(polys))
+    flipped = segms.PackedPolygons.from_lists(segms.flip_segms(polys, 800, 1333))
+    assert np.array_equal(segms.polys_to_boxes(flipped).numpy(), ref_segms.polys_to_boxes(ref_segms.flip_segms(polys, 800, 1333)))
+    rect = segms.PackedPolygons.from_boxes(torch.from_numpy(boxes))
+    assert np.array_equal(segms.polys_to_boxes(rect).numpy(), boxes)
+    with pytest.raises(NotImplementedError):
+        segms.flip_segms([{"counts": [1, 2], "size": [3, 1]}], 3, 1)
+
+
 def test_optimizer_update_equals_the_reference(ref_cfg, models):
     """The UPDATE of a training iteration: the reference's own source text of the parameter-group construction
     (tools/train_net_step.py:262-307: weights with decay, biases at twice the learning rate without decay, frozen
