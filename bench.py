@@ -617,7 +617,7 @@ def cpu_baseline(images_per_rank):
         extra["result_formats_error"] = str(e)
     try:  # mask targets from polygons (beside nms.mask_targets): 32 of the 256 RoIs, scaled up
         import oracle
-        from oracle import segms as osegms
+        from oracle import mask_targets as osegms
 
         polys, gt_boxes, _ = syn.polygon_instances(16, seed=9)
         rois = syn.jittered_boxes(gt_boxes, 16, seed=10)

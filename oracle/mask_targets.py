@@ -5,8 +5,8 @@ Test infrastructure: only tests/ may import this.
 PARITY PARTLY PINNED.  The reference rasterises through pycocotools 2.0 (`mask_util.frPyObjects` + `mask_util.decode`,
 segms.py:66-67,114-115), which is not installed here, is not part of /root/reference and cannot be fetched: its published
 algorithm (common/maskApi.c rleFrPoly, rleDecode) is restated in oracle.c `oracle_poly_to_mask` and checked against
-hand-derived vectors only.  Pinned to the reference: everything around it -- the functions below follow segms.py line by
-line, and tests/test_model_cpu.py executes the reference's OWN add_mask_rcnn_blobs with polygon `segms` and only
+hand-derived vectors and properties only.  Pinned to the reference: everything around it -- the functions below restate
+segms.py's arithmetic (checked against the fixture its own text produced), and tests/test_model_cpu.py executes the reference's OWN add_mask_rcnn_blobs with polygon `segms` and only
 `polys_to_mask_wrt_box`'s two pycocotools calls bound to this restatement.
 """
 import ctypes
@@ -32,38 +32,35 @@ def fr_poly_decode(polygons, height, width):
     return out
 
 
+def _union(stack):
+    """segms.py:68-70 / :116-118: the per-polygon images summed over the polygon axis and thresholded at > 0."""
+    return (stack.astype(np.float32).sum(axis=2) > 0).astype(np.float32)
+
+
 def polys_to_mask(polygons, height, width):
-    """segms.py:60-71."""
-    mask = np.array(fr_poly_decode(polygons, height, width), dtype=np.float32)
-    mask = np.sum(mask, axis=2)
-    return np.array(mask > 0, dtype=np.float32)
+    """segms.py:60-71: the polygons of one instance in a height x width image."""
+    return _union(fr_poly_decode(polygons, height, width))
 
 
 def polys_to_mask_wrt_box(polygons, box, M):
-    """segms.py:93-119: the polygons of one instance, moved into `box`'s frame and scaled to M x M (float32 arithmetic, as
-    numpy does it there), rasterised, OR-ed."""
-    w = box[2] - box[0]
-    h = box[3] - box[1]
-    w = np.maximum(w, 1)
-    h = np.maximum(h, 1)
-    polygons_norm = []
+    """segms.py:93-119: the polygons of one instance moved into `box`'s frame and scaled to M x M, rasterised, OR-ed.
+    The shift and scale run in float32 exactly as numpy evaluates :108-111 -- (x - box_x1) * M / w with a float32 box and
+    w, h = max(box side, 1) -- before pycocotools widens to float64."""
+    box = np.asarray(box, dtype=np.float32)
+    side = np.maximum(box[2:4] - box[0:2], 1)                       # :99-103
+    moved = []
     for poly in polygons:
-        p = np.array(poly, dtype=np.float32)
-        p[0::2] = (p[0::2] - box[0]) * M / w
-        p[1::2] = (p[1::2] - box[1]) * M / h
-        polygons_norm.append(p)
-    mask = np.array(fr_poly_decode(polygons_norm, M, M), dtype=np.float32)
-    mask = np.sum(mask, axis=2)
-    return np.array(mask > 0, dtype=np.float32)
+        p = np.array(poly, dtype=np.float32)                         # :106
+        for axis in (0, 1):
+            p[axis::2] = (p[axis::2] - box[axis]) * M / side[axis]
+        moved.append(p)
+    return _union(fr_poly_decode(moved, M, M))
 
 
 def polys_to_boxes(polys):
-    """segms.py:121-132: tight box of every instance's polygons."""
-    boxes = np.zeros((len(polys), 4), dtype=np.float32)
-    for i, poly in enumerate(polys):
-        x0 = min(min(p[::2]) for p in poly)
-        x1 = max(max(p[::2]) for p in poly)
-        y0 = min(min(p[1::2]) for p in poly)
-        y1 = max(max(p[1::2]) for p in poly)
-        boxes[i, :] = [x0, y0, x1, y1]
-    return boxes
+    """segms.py:121-132: per instance the tight box (x_min, y_min, x_max, y_max) over all of its polygons, float32."""
+    out = np.zeros((len(polys), 4), dtype=np.float32)
+    for i, instance in enumerate(polys):
+        pts = np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in instance])
+        out[i] = np.concatenate([pts.min(axis=0), pts.max(axis=0)])
+    return out

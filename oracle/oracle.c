@@ -762,7 +762,7 @@ void oracle_bbox_overlaps(const float* boxes, int N, const float* query_boxes, i
 /* ---- polygon -> binary mask: pycocotools 2.0, common/maskApi.c rleFrPoly followed by rleDecode ------------------------
  * THIRD-PARTY ALGORITHM, RESTATED (pycocotools is not installed here and is not part of /root/reference; the reference
  * calls it through mask_util.frPyObjects / mask_util.decode in lib/utils/segms.py:66-67,114-115).  PARITY UNPINNED against
- * the real package; pinned are the call sites around it (oracle/segms.py) and hand-derived vectors (tests/test_oracle_cpu.py).
+ * the real package; pinned are the call sites around it (oracle/mask_targets.py) and hand-derived vectors (tests/test_oracle_cpu.py).
  * The published procedure, in its own order:
  *   1. vertices are scaled by 5 and rounded with (int)(5 v + .5) -- a C cast, i.e. truncation towards zero;
  *   2. every edge (closed polygon) is walked along its longer axis, one point per unit step, the other coordinate

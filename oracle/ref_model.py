@@ -183,12 +183,12 @@ def bind_rect_rasterizer(fn):
 @contextlib.contextmanager
 def pycocotools_polygon_calls():
     """While active, the stand-in `pycocotools.mask` answers the two calls utils/segms.py:114-115 (and :66-67) makes for
-    polygons -- frPyObjects, decode -- with the restatement of maskApi.c in oracle/segms.py; everything else of the
+    polygons -- frPyObjects, decode -- with the restatement of maskApi.c in oracle/mask_targets.py; everything else of the
     reference's polygon handling then runs from its own source."""
     load()
     import utils.segms as segm_utils
 
-    from . import segms as oracle_segms
+    from . import mask_targets as oracle_segms
 
     mu = segm_utils.mask_util
     keep = (mu.__dict__.get("frPyObjects"), mu.__dict__.get("decode"))

@@ -67,7 +67,7 @@ def bbox_overlaps(boxes, query):
 
 def polys_to_masks_wrt_boxes(packed, roi_inst, boxes, m):
     """segms.polys_to_masks_wrt_boxes through the oracle's restatement of utils/segms.py + pycocotools."""
-    from oracle import segms as oracle_segms
+    from oracle import mask_targets as oracle_segms
 
     pts, ps, ins = packed.points.numpy(), packed.poly_start.numpy(), packed.inst_start.numpy()
     out = np.zeros((boxes.size(0), m * m), dtype=np.int32)

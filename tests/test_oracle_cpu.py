@@ -358,9 +358,9 @@ def _segms_from_fixture(g, tag):
 
 
 def test_mask_targets_from_polygons_match_golden(oracle_mod):
-    """The line-by-line restatement of utils/segms.py in oracle/segms.py (what the GPU tests compare the HIP kernel with)
+    """The line-by-line restatement of utils/segms.py in oracle/mask_targets.py (what the GPU tests compare the HIP kernel with)
     against the fixture the reference's own add_mask_rcnn_blobs + segms.py produced."""
-    from oracle import segms
+    from oracle import mask_targets as segms
 
     g = load_golden("mask_targets.npz")
     for tag in ("a", "b"):
@@ -379,7 +379,7 @@ def test_polygon_rasteriser_known_answers(oracle_mod):
     """pycocotools' rule, derived by hand from maskApi.c rleFrPoly: vertices go to a grid of 5 samples per pixel, a pixel
     column is crossed where the boundary passes its centre sample (5 x + 2), rows likewise -- "the pixels whose centres
     the polygon covers", on that grid."""
-    from oracle import segms
+    from oracle import mask_targets as segms
 
     def rect(x0, y0, x1, y1):
         return [x0, y0, x1, y0, x1, y1, x0, y1]
@@ -413,7 +413,7 @@ def test_polygon_rasteriser_properties(oracle_mod):
     """Size-independent properties of the published algorithm: the mask does not depend on the vertex the outline starts
     from nor on its orientation, repeated vertices change nothing, the area equals the polygon's up to its perimeter, and it
     agrees with an exact even-odd test of the pixel centres except on boundary pixels."""
-    from oracle import segms
+    from oracle import mask_targets as segms
 
     rng = np.random.RandomState(0)
     for trial in range(12):
