@@ -10,8 +10,9 @@
 //     within an edge, or the last point of one edge and the first of the next;
 //   * the sorted, zero-run-merged run lengths say "the pixel at column-major position i is set iff an odd number of
 //     crossings lie at positions <= i": crossings TOGGLE, two at one position cancel.
-// So: one workgroup per RoI; per polygon, a wavefront per edge with lanes striding over the edge's steps XORs crossings
-// into an LDS array of M*M + 1 toggles; a parity prefix scan over that array is the polygon's mask; the polygons of the
+// So: one workgroup per RoI; per polygon, the up-sampled vertices go to LDS (a lane per vertex), then a lane per edge
+// walks its steps (edges of more than 16 steps are queued and walked by a wavefront each) and XORs crossings into an
+// LDS array of M*M + 1 toggles; a parity prefix scan over that array is the polygon's mask; the polygons of the
 // instance are OR-ed (segms.py:117-118 sums and thresholds).  All coordinate arithmetic in the precision and order of
 // the originals: float32 for the move into the RoI's frame (numpy, segms.py:104-112), then double with C casts.
 // Bit-exact against the oracle (tests/test_ops_gpu.py).  Work is tiny (a few thousand boundary points per RoI): the
@@ -22,6 +23,8 @@ namespace {
 
 constexpr int kMaxM = 64;  // LDS: (M*M + 1) toggles + M*M accumulated mask words
 constexpr int kThreads = 256;
+constexpr int kChunk = 1024;     // edges of a polygon handled per pass (their up-sampled vertices sit in LDS)
+constexpr int kShortEdge = 16;  // steps one lane walks by itself; longer edges are walked by a wavefront
 
 struct Edge {
   int xs, ys, dx, dy, flip, n;  // start AFTER the flip; n = points on the edge
@@ -81,12 +84,26 @@ __device__ __forceinline__ void crossing(int up, int vp, int u, int v, int m, un
   atomicXor(&toggles[(int)xd * m + (int)yd], 1u);
 }
 
+// crossings of edge `e` between its points [d0, d1), walked by one lane; (up, vp) = the point in front of d0
+__device__ __forceinline__ void walk(const Edge& e, int d0, int d1, int up, int vp, int m, unsigned* toggles) {
+  for (int d = d0; d < d1; d++) {
+    int u, v;
+    point(e, d, u, v);
+    crossing(up, vp, u, v, m, toggles);
+    up = u;
+    vp = v;
+  }
+}
+
 __global__ void __launch_bounds__(kThreads)
 polys_to_masks_kernel(const float* __restrict__ poly_xy, const int* __restrict__ poly_start,
                       const int* __restrict__ inst_start, const int* __restrict__ roi_inst,
                       const float* __restrict__ rois, int* __restrict__ masks, int num_instances, int m) {
   __shared__ unsigned toggles[kMaxM * kMaxM + 1];
   __shared__ unsigned acc[kMaxM * kMaxM];
+  __shared__ int vx[kChunk + 2], vy[kChunk + 2];  // up-sampled vertices c0 - 1 .. c0 + kChunk of the polygon
+  __shared__ int long_edges[kThreads];
+  __shared__ int num_long;
   __shared__ unsigned wave_parity[kThreads / 64];
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int mm = m * m;
@@ -105,28 +122,54 @@ polys_to_masks_kernel(const float* __restrict__ poly_xy, const int* __restrict__
     const float* pts = poly_xy + 2LL * poly_start[p];
     const int k = poly_start[p + 1] - poly_start[p];
     for (int i = tid; i <= mm; i += kThreads) toggles[i] = 0u;
-    __syncthreads();
-    for (int e = wave; e < k; e += kThreads / 64) {
-      int x0, y0, x1, y1;
-      vertex(pts, e, bx, by, fm, w, h, x0, y0);
-      vertex(pts, e + 1 < k ? e + 1 : 0, bx, by, fm, w, h, x1, y1);
-      const Edge edge = make_edge(x0, y0, x1, y1);
-      for (int d = lane; d < edge.n; d += 64) {
-        int u, v, up, vp;
-        point(edge, d, u, v);
-        if (d > 0) {
-          point(edge, d - 1, up, vp);
-        } else {
-          if (e == 0) continue;  // the chain starts here: no point in front of it
-          int xb, yb;
-          vertex(pts, e - 1, bx, by, fm, w, h, xb, yb);
-          const Edge before = make_edge(xb, yb, x0, y0);
-          point(before, before.n - 1, up, vp);
-        }
-        crossing(up, vp, u, v, m, toggles);
+    for (int c0 = 0; c0 < k; c0 += kChunk) {
+      const int cnt = k - c0 < kChunk ? k - c0 : kChunk;  // edges c0 .. c0 + cnt - 1 of the closed outline
+      if (tid == 0) num_long = 0;
+      for (int i = tid; i < cnt + 2; i += kThreads) {     // slot i = vertex c0 - 1 + i (vertex k = vertex 0)
+        const int j = c0 - 1 + i;
+        if (j >= 0) vertex(pts, j < k ? j : 0, bx, by, fm, w, h, vx[i], vy[i]);
       }
+      __syncthreads();
+      // a lane per edge: most edges are a few steps long (a 28 x 28 target is 140 samples wide); the long ones queue up
+      for (int i = tid; i < cnt; i += kThreads) {
+        const Edge edge = make_edge(vx[i + 1], vy[i + 1], vx[i + 2], vy[i + 2]);
+        if (edge.n > kShortEdge) {
+          const int q = atomicAdd(&num_long, 1);
+          if (q < kThreads) {
+            long_edges[q] = i;
+            continue;
+          }
+        }
+        int u0, v0;
+        point(edge, 0, u0, v0);
+        if (c0 + i > 0) {  // the point in front of the edge's first: the last point of the edge before (none at the chain's start)
+          const Edge before = make_edge(vx[i], vy[i], vx[i + 1], vy[i + 1]);
+          int up, vp;
+          point(before, before.n - 1, up, vp);
+          crossing(up, vp, u0, v0, m, toggles);
+        }
+        walk(edge, 1, edge.n, u0, v0, m, toggles);
+      }
+      __syncthreads();
+      const int nl = num_long < kThreads ? num_long : kThreads;
+      for (int q = wave; q < nl; q += kThreads / 64) {  // long edges: a wavefront each, lanes stride over the steps
+        const int i = long_edges[q];
+        const Edge edge = make_edge(vx[i + 1], vy[i + 1], vx[i + 2], vy[i + 2]);
+        for (int d = lane; d < edge.n; d += 64) {
+          int u, v, up, vp;
+          point(edge, d, u, v);
+          if (d > 0) {
+            point(edge, d - 1, up, vp);
+          } else {
+            if (c0 + i == 0) continue;
+            const Edge before = make_edge(vx[i], vy[i], vx[i + 1], vy[i + 1]);
+            point(before, before.n - 1, up, vp);
+          }
+          crossing(up, vp, u, v, m, toggles);
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // parity prefix over the column-major positions: every lane owns `per` consecutive ones
     const int lo = tid * per, hi = lo + per < mm ? lo + per : mm;
     unsigned mine = 0u;

@@ -1616,6 +1616,12 @@ def test_polygon_rasteriser_against_the_oracle(oracle_mod, m):
     from detectron_pytorch_amd.segms import PackedPolygons
 
     polys, boxes, _ = syn.polygon_instances(12, seed=100 + m)
+    # an outline of 2500 vertices (the kernel takes a polygon's edges 1024 at a time) in place of instance 11
+    ang = np.linspace(0, 2 * np.pi, 2500, endpoint=False)
+    rad = 90 + 25 * np.sin(9 * ang) + np.random.RandomState(m).uniform(-2, 2, 2500)
+    dense = np.round(np.stack([600 + rad * np.cos(ang), 400 + 0.7 * rad * np.sin(ang)], 1), 2)
+    polys[11] = [[float(v) for v in dense.reshape(-1)]]
+    boxes[11] = [dense[:, 0].min(), dense[:, 1].min(), dense[:, 0].max(), dense[:, 1].max()]
     rois = syn.jittered_boxes(boxes, 8, seed=m, jitter=0.4)
     inst = np.repeat(np.arange(12), 8)
     special = np.array([[boxes[0, 0], boxes[0, 1], boxes[0, 0], boxes[0, 1]], [boxes[1, 0] + 3, boxes[1, 1], boxes[1, 0] + 3.3, boxes[1, 3]],
