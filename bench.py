@@ -61,6 +61,10 @@ def parse_args():
     ap.add_argument("--layout", default="nchw", choices=["nchw", "channels_last"],
                     help="memory format of the model and the image blob of the training step (the RoI operators take "
                          "both; MIOpen picks other fp32 solvers for channels_last)")
+    ap.add_argument("--masks", default="rectangles", choices=["rectangles", "polygons"],
+                    help="ground-truth masks of the training step: the instances' boxes rasterised by tensor operations "
+                         "(default; SURVEY section 8d config 4), or the same rectangles as COCO polygon lists rasterised by "
+                         "pycocotools' rule in one HIP launch per step (mi_polys_to_masks_wrt_boxes, the roidb 'segms' path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no roofline / breakdown / inference objects)")
     ap.add_argument("--kernel-iters", type=int, default=200, help="back-to-back launches per roofline timing")
@@ -123,7 +127,8 @@ class TrainHarness:
     """One rank of the data-parallel job: model, resident minibatch, optimizer, gradient reducer, and the step in its
     two launch forms."""
 
-    def __init__(self, device, rank, world, dtype, launch, cfg=None, images_per_rank=IMAGES_PER_RANK, layout="nchw"):
+    def __init__(self, device, rank, world, dtype, launch, cfg=None, images_per_rank=IMAGES_PER_RANK, layout="nchw",
+                 masks="rectangles"):
         from detectron_pytorch_amd import parallel
         from detectron_pytorch_amd.rcnn import config, data as rdata, model as rmodel, train as rtrain
 
@@ -148,6 +153,10 @@ class TrainHarness:
         batch = rdata.synthetic_minibatch(cfg, images_per_rank, seed=rank)      # per-rank images (weak scaling)
         self.data, self.im_info, self.roidb, self.rpn_targets = rdata.to_device(batch, device,
                                                                                 channels_last=layout == "channels_last")
+        self.masks = masks
+        if masks == "polygons":
+            from detectron_pytorch_amd.segms import PackedPolygons
+            self.roidb["gt_polygons"] = PackedPolygons.from_boxes(self.roidb["gt_boxes"])
         # the reference's learning-rate rule: the yaml's BASE_LR is for NUM_GPUS x IMS_PER_BATCH = 16 images and is
         # rescaled linearly to the actual batch (tools/train_net_step.py:166-201); first iteration of the warm-up
         # (SOLVER.WARM_UP_FACTOR = 1/3, config.py:560)
@@ -719,7 +728,7 @@ def main():
     if args.only_config5:
         print(json.dumps({"config5_x101_mask_keypoint": config5(device, rank, args, steps=args.steps)}), flush=True)
         return
-    work = TrainHarness(device, rank, world, args.dtype, args.launch, layout=args.layout)
+    work = TrainHarness(device, rank, world, args.dtype, args.launch, layout=args.layout, masks=args.masks)
     if args.launch == "graph":
         work.capture()
     else:
@@ -750,7 +759,7 @@ def main():
                                    "512 RoIs/image, <=128 mask RoIs/image, 8 gt boxes/image, random-init weights (seed 3)"
                                    % IMAGES_PER_RANK,
                        "global_batch": IMAGES_PER_RANK * world, "images_per_rank": IMAGES_PER_RANK,
-                       "parallelism": "dp%d" % world, "launch": work.mode, "layout": work.layout,
+                       "parallelism": "dp%d" % world, "launch": work.mode, "layout": work.layout, "masks": work.masks,
                        "trainable_params": work.params, "gradient_payload_bytes": work.params * 4,
                        "loss_first": round(first_loss, 4), "loss_last": round(last_loss, 4),
                        "loss_last_mean_over_ranks": round(mean_loss, 4)},
