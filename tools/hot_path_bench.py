@@ -152,6 +152,30 @@ def roofline_roi_align_forward(device, iters):
             "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
             "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
             "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
+    # the gather alone: the same call over records that are already in the workspace (the launch above has just written
+    # them) -- what a caller pays whose RoI producer writes the records (mi_rpn_collect_finish_records: rcnn's static
+    # inference path; the producer is measured as long as before, inference_path.producer_records_pair)
+    if ready_fwd and not os.environ.get("MI_BENCH_NHWC"):
+        import ctypes
+
+        lvt = _lib.FpnLevels()
+        lvt.num_levels = 1
+        lvt.features[0], lvt.height[0], lvt.width[0], lvt.spatial_scale[0] = feat.data_ptr(), h, w, scale
+        level0 = torch.zeros(r, dtype=torch.int32, device=device)
+        first = out.clone()
+
+        def launch_ready():
+            rc = lib.mi_roi_align_forward_fpn_records(ctypes.byref(lvt), rois.data_ptr(), level0.data_ptr(), out.data_ptr(), 1, c,
+                                                      r, res, res, sr, layout, ws.data_ptr(), ws_bytes, stream)
+            assert rc == 0
+
+        sec_ready = time_kernel(launch_ready, iters)
+        assert torch.equal(out, first), "the records-ready forward must reproduce the full call bit for bit"
+        info["records_ready"] = {"avg_launch_us": round(sec_ready * 1e6, 2), "achieved": round(alg_bytes / sec_ready / 1e9, 1),
+                                 "unit": "GB/s", "frac": round(alg_bytes / sec_ready / 1e9 / HBM_PEAK_GBS, 4),
+                                 "what": "roi_align_fwd_records alone (mi_roi_align_forward_fpn_records over the records the "
+                                         "full call has just written): the call of a consumer whose RoI producer writes the "
+                                         "records; NOT the headline fraction, which includes the records launch"}
     # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
     gtop = torch.randn(r, c, res, res, device=device)
     gin = torch.zeros(1, c, h, w, device=device)
