@@ -33,16 +33,27 @@ constexpr int kBwdRf = kBwdCf + 64;                    // u8 rf[64]: first entry
 constexpr int kBwdTabDw = (kBwdRf + 64) / 4;           // 352 dwords = 1408 B
 constexpr int kRecDwords = kRecB + kBwdTabDw;          // 760 dwords = 3040 B
 static_assert(kRecDwords % 4 == 0 && kRecB % 4 == 0, "records and their backward block are fetched in 16-byte pieces");
-// after the records: one int4 per rank {x0, x1, batch*H + y0, batch*H + y1} = window of a backward-capable RoI
-// ({0x3fffffff, -1, ..} otherwise), read by the backward tiles to find the RoIs that touch them
+// after the records: one int4 per rank {x0, x1 | flag, batch*H + y0, batch*H + y1} = the window columns / "global" rows the
+// backward of the RoI can touch ({0x3fffffff, 0, ..}: a RoI of no image), read by the backward to find the RoIs of a tile;
+// flag kBoundsNoTables: the record has no backward tables (kFlagBwd clear), the RoI takes the per-sample path
+constexpr int kBoundsNoTables = 1 << 30;
 // counters in front of the records, zeroed by roi_align_prepare.  Every live counter has a 128-byte line to itself: device-
 // scope atomics on one line serialise at ~11 ns apiece whichever word they hit (round 5: the eight ticket words of a resident
 // forward in one line cost 20 us per call).
 constexpr int kCounterDwords = 1024;
 constexpr int kBwdClasses = 6;                         // planned backward: cost classes of the tile entries
 constexpr int kBwdCounterStride = 32;
-constexpr int kBwdBucket = 512;                        // [kBwdBucket + 32 c]: entries filed in class c (roi_align_bwd_plan adds,
-                                                       // roi_align_bwd_tiles reads, roi_align_bwd_slow zeroes for the next call)
+constexpr int kBwdBucket = 512;                        // [kBwdBucket + 256 s + 32 c]: entries filed in class c of counter SET s
+                                                       // (c == kBwdClasses: the slice budget used).  Two sets, so that no launch
+                                                       // has to zero them: a backward files into set P = ws[kBwdParity], its
+                                                       // plan kernel's first workgroup zeroes the OTHER set and publishes P in
+                                                       // ws[kBwdInUse]; the tile kernel reads set ws[kBwdInUse] and its first
+                                                       // workgroup flips ws[kBwdParity] -- each word is read by all workgroups
+                                                       // of one launch and written by one workgroup of the other.
+constexpr int kBwdSetStride = 256;
+constexpr int kBwdParity = kBwdBucket + 7 * 32;        // 736
+constexpr int kBwdInUse = kBwdBucket + kBwdSetStride + 7 * 32;  // 992
+static_assert(kBwdClasses + 1 <= 7 && kBwdInUse + 32 <= kCounterDwords, "counter block layout");
 constexpr int kNoItem = 0x7fffffff;
 
 // forward LDS path / no such image / backward tile path / y and x tables valid

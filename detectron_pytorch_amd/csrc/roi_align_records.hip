@@ -16,7 +16,7 @@
 //       (next window issued before the tile is stored).  (Removed after measurement: a variant that prefetched the next
 //       window under the current arithmetic, 16-channel workgroups, roles on waves, a resident ticketed grid -- see
 //       DESIGN.md section 5 and docs/history.md.)
-//   roi_align_bwd_tiles / roi_align_bwd_slow   the backward over the same records (see below).
+//   roi_align_bwd_plan / roi_align_bwd_tiles   the backward over the same records (see below).
 //
 // Data movement and arithmetic are those of roi_align_fwd_tile.hip (see its header): LDS-DMA of the compact
 // [row][ww] window into one odd-stride plane per channel, lane & 31 = channel, conflict-free ds_read2_b32 tap pairs,
@@ -313,11 +313,25 @@ roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, i
     merge_axis(ylo, yhw, ylw, nsy, gh, wy0, nrows_win, kBwdWy, kBwdPy, kBwdRf);
   }
   if (lane == 0) {
+    // A RoI the backward tables cannot describe is found by every tile its samples can tap -- rows / columns
+    // [(int)max(first, 0), (int)max(last, 0) + 1] clamped to the map, a superset of roi_align_kernel.cu:150-190's taps --
+    // marked kBoundsNoTables, and whoever finds it adds its share of the tile with the reference's per-sample arithmetic
+    // (bwd_slow_in_tile).  A RoI of no image keeps the interval that overlaps no tile.
+    int bx0 = wx0, bx1 = wx1, by0 = wy0, by1 = wy1;
+    if (!fast) {
+      by0 = min((int)fminf(fmaxf(yf, 0.f), (float)height), max(height - 1, 0));
+      by1 = min((int)fminf(fmaxf(yl, 0.f), (float)height) + 1, max(height - 1, 0));
+      bx0 = min((int)fminf(fmaxf(xf, 0.f), (float)width), max(width - 1, 0));
+      bx1 = min((int)fminf(fmaxf(xl, 0.f), (float)width) + 1, max(width - 1, 0));
+      by0 = min(by0, by1);
+      bx0 = min(bx0, bx1);
+    }
+    const bool listed = !(flags & kFlagZero);
     int4 bnd;
-    bnd.x = bwd_ok ? wx0 : 0x3fffffff;  // an interval that overlaps no tile
-    bnd.y = bwd_ok ? wx1 : -1;
-    bnd.z = lv.row_base[lvl] + batch_ind * height + wy0;  // "global rows": levels and images stacked
-    bnd.w = lv.row_base[lvl] + batch_ind * height + wy1;
+    bnd.x = listed ? bx0 : 0x3fffffff;  // an interval that overlaps no tile
+    bnd.y = listed ? (bx1 | (bwd_ok ? 0 : kBoundsNoTables)) : 0;
+    bnd.z = lv.row_base[lvl] + batch_ind * height + by0;  // "global rows": levels and images stacked
+    bnd.w = lv.row_base[lvl] + batch_ind * height + by1;
     reinterpret_cast<int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords)[rank] = bnd;
   }
   // stages: consecutive bin rows whose window fits half the LDS image (so that the next stage can be prefetched while
@@ -798,7 +812,8 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
 // one is processed.
 // At the end each lane stores its KC sums as 128-byte rows (or adds them to what the caller supplied).
 // RoIs the tables cannot describe (a sample outside the [-1, size] band, window > 63 rows or columns, > 32 samples
-// per axis) are added afterwards by roi_align_bwd_slow with the reference's arithmetic and atomics.
+// per axis) are listed like the others and added by the same workgroup behind its store, with the reference's
+// arithmetic and atomics restricted to the tile (bwd_slow_in_tile; a launch of its own until round 5).
 // Weights: g * (hy / count) * hx instead of the reference's g * (hy * hx) / count -- fp32 rounding only (the
 // accumulation order of the reference's atomics is unspecified; contract 1e-4).
 // -------------------------------------------------------------------------------------------------------------------
@@ -842,10 +857,68 @@ __host__ __device__ inline int bwd_class_base(int c, int tiles, int num_rois) { 
   return c == 0 ? 0 : bwd_class_cap0(tiles, num_rois) + (c - 1) * tiles;
 }
 __device__ __forceinline__ int bwd_class_of(int len) { return len >= 20 ? 1 : len >= 10 ? 2 : len >= 5 ? 3 : len >= 1 ? 4 : 5; }
+// One RoI without backward tables, its contribution to `nch` channels of ONE tile of the gradient map:
+// roi_align_kernel.cu:195-270 -- the reference's lane mapping (one lane per output element), sample coordinates, weights and
+// atomics -- restricted to the taps that lie in rows [y0, y0 + th) x columns [x0, x0 + tw); the tiles of the map partition
+// its pixels, so every tap is added exactly once.  Bins and sample rows that cannot reach the tile are skipped before
+// their inner loops (a RoI of 100 x 100 window pixels is found by 28 tiles; without the test each of them would walk all
+// of its samples).  Rare: windows wider than kMaxWin, more than kMaxS samples per axis, samples outside the [-1, size] band.
+__device__ __noinline__ void bwd_slow_in_tile(const float* __restrict__ top_grad, const float* __restrict__ roi,
+                                              float* __restrict__ bottom_grad, float spatial_scale, int height, int width,
+                                              int channels, int c0, int nch, int aligned_height, int aligned_width,
+                                              int sampling_ratio, bool nhwc, int x0, int y0, int th, int tw, int r, int tid,
+                                              int nthreads) {
+  const int bins = aligned_height * aligned_width;
+  const RoiGeom g = roi_geometry(roi, spatial_scale, aligned_height, aligned_width, sampling_ratio);
+  const float* __restrict__ gsrc = top_grad + ((long long)r * channels + c0) * bins;
+  // element strides of (channel, pixel) in the gradient map: NCHW or channels-last
+  const int cs = nhwc ? 1 : height * width, ps = nhwc ? channels : 1;
+  float* gdst = bottom_grad + (long long)g.batch_ind * channels * height * width + (long long)c0 * cs;
+  // rows / columns a sample at coordinate v can tap: (int)max(v, 0) and the next one, clamped to the map
+  auto first_tap = [](float v, int size) { return min((int)fminf(fmaxf(v, 0.f), (float)size), size - 1); };
+#pragma nounroll
+  for (int i = tid; i < nch * bins; i += nthreads) {
+    const int c = i / bins, bin = i - c * bins;
+    const int ph = bin / aligned_width, pw = bin - ph * aligned_width;
+    // the bin's samples lie in [start + p * bin, start + (p + 1) * bin] (one more pixel of margin for fp32 rounding)
+    const float by = g.start_h + (float)ph * g.bin_h, bx = g.start_w + (float)pw * g.bin_w;
+    if (first_tap(by + g.bin_h, height) + 2 < y0 || first_tap(by, height) - 1 >= y0 + th) continue;
+    if (first_tap(bx + g.bin_w, width) + 2 < x0 || first_tap(bx, width) - 1 >= x0 + tw) continue;
+    float* plane = gdst + (long long)c * cs;
+    const float top_diff_this_bin = gsrc[i];
+#pragma nounroll
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const float y = sample_y(g, ph, iy);
+      const int ty = first_tap(y, height);
+      if (ty + 1 < y0 || ty >= y0 + th) continue;
+#pragma nounroll
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const float x = sample_x(g, pw, ix);
+        const Taps t = sample_taps(height, width, y, x);
+        if (t.y_low < 0) continue;
+        const bool yl_in = t.y_low >= y0 && t.y_low < y0 + th, yh_in = t.y_high >= y0 && t.y_high < y0 + th;
+        const bool xl_in = t.x_low >= x0 && t.x_low < x0 + tw, xh_in = t.x_high >= x0 && t.x_high < x0 + tw;
+        if (yl_in && xl_in) atomicAdd(plane + (t.y_low * width + t.x_low) * ps, top_diff_this_bin * t.w1 / g.count);
+        if (yl_in && xh_in) atomicAdd(plane + (t.y_low * width + t.x_high) * ps, top_diff_this_bin * t.w2 / g.count);
+        if (yh_in && xl_in) atomicAdd(plane + (t.y_high * width + t.x_low) * ps, top_diff_this_bin * t.w3 / g.count);
+        if (yh_in && xh_in) atomicAdd(plane + (t.y_high * width + t.x_high) * ps, top_diff_this_bin * t.w4 / g.count);
+      }
+    }
+  }
+}
+
+// RoIs WITHOUT backward tables (kBoundsNoTables) never enter a list: this kernel adds their share of the tile.  Planned
+// launches: BEFORE the tile kernel runs, and the tile's entry is filed in "add" mode (slices = 2: the tile kernel then adds
+// its sums atomically instead of storing them); under the OVERWRITE contract the tile is zero-filled first by the role
+// workgroups, each of which then adds the RoIs' share of the channels it zeroed; without it the planner adds into the
+// caller's values.  (The unplanned tile kernel, which has no launch in front of it, is followed by roi_align_bwd_untabled.)
+// (Until round 5 a launch of its own behind the tile kernel -- roi_align_bwd_slow, 4.7 us + a launch boundary per call,
+// nearly always to find nothing -- did this and reset the counters.)
 __global__ void __launch_bounds__(kPlanThreads)
 roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int batch, int channels, int th, int plan_tiles,
-                   int plan_cap, int slice_len, int overwrite) {
-  __shared__ int wave_hits[kPlanWaves];
+                   int plan_cap, int slice_len, int overwrite, const float* __restrict__ top_grad,
+                   const float* __restrict__ rois, int aligned_height, int aligned_width, int sampling_ratio) {
+  __shared__ int wave_hits[2 * kPlanWaves];
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   // role 0 plans the tile, roles 1.. zero a share of a sliced tile; a tile's roles are neighbours in the grid (planners
   // first and 4 larger shares measured 4-10 us slower on a step's RoIs)
@@ -867,30 +940,58 @@ roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int 
   int4* __restrict__ entries = reinterpret_cast<int4*>(counts + ((plan_tiles + 3) & ~3));
   const int entries_total = bwd_class_base(kBwdClasses - 1, plan_tiles, num_rois) + plan_tiles;
   unsigned short* __restrict__ list = reinterpret_cast<unsigned short*>(entries + entries_total) + (long long)tile_global * plan_cap;
+  // Counter set of this call (roi_align_record_layout.h): the set the parity word names; the first workgroup zeroes the
+  // other one for the next call and tells the tile kernel which set to read -- no launch exists only to reset counters.
+  const int set = ((const_int_ptr)(uintptr_t)(ws + kBwdParity))[0] & 1;
+  int* __restrict__ bucket = ws + kBwdBucket + set * kBwdSetStride;
+  if (blockIdx.x == 0 && tid <= kBwdClasses) ws[kBwdBucket + (set ^ 1) * kBwdSetStride + tid * kBwdCounterStride] = 0;
+  if (blockIdx.x == 0 && tid == 0) ws[kBwdInUse] = set;
   // each wave owns a contiguous share of the ranks: count, one barrier, then write at the wave's offset (rank order)
   const int share = (((num_rois + kPlanWaves - 1) / kPlanWaves) + 63) & ~63;
   const int r0 = wave * share, r1 = min(num_rois, r0 + share);
+  // 0: the RoI at rank i does not touch the tile, 1: it does (listed), 2: it does and has no tables (added here)
   auto hit_of = [&](int i) {
-    if (i >= r1) return false;
+    if (i >= r1) return 0;
     const int4 b = bounds[i];
-    return b.y >= x0 && b.x < x0 + kTW && b.w >= gy0 && b.z < gy0 + th && b.z >= img_row0 && b.z < img_row0 + height;
+    const int bx1 = b.y & (kBoundsNoTables - 1);
+    const bool hit = bx1 >= x0 && b.x < x0 + kTW && b.w >= gy0 && b.z < gy0 + th && b.z >= img_row0 && b.z < img_row0 + height;
+    return !hit ? 0 : (b.y & kBoundsNoTables) ? 2 : 1;
   };
-  int mine = 0;
-  for (int base = r0; base < r1; base += 64) mine += __popcll(__ballot(hit_of(base + lane)));
-  if (lane == 0) wave_hits[wave] = mine;
+  int mine = 0, mine_slow = 0;
+  for (int base = r0; base < r1; base += 64) {
+    const int h = hit_of(base + lane);
+    mine += __popcll(__ballot(h == 1));
+    mine_slow += __popcll(__ballot(h == 2));
+  }
+  if (lane == 0) {
+    wave_hits[wave] = mine;
+    wave_hits[kPlanWaves + wave] = mine_slow;
+  }
   __syncthreads();
-  int off = 0, total = 0;
+  int off = 0, total = 0, nslow = 0;
   for (int w = 0; w < kPlanWaves; w++) {
     off += w < wave ? wave_hits[w] : 0;
     total += wave_hits[w];
+    nslow += wave_hits[kPlanWaves + w];
   }
-  if (role > 0) {
-    // ---- zero this workgroup's share of the channels if the tile's list will be cut (a list that does not get its slices
-    // any more -- budget used up -- is summed by one workgroup that overwrites: the zeros are then wasted, not wrong) ----
-    if (total <= slice_len) return;
-    float* __restrict__ grad = lv.grad[lvl];
+  float* __restrict__ grad = lv.grad[lvl];
+  // the RoIs without tables, for channels [c_lo, c_lo + nch): every wave walks its own share of the ranks
+  auto add_slow = [&](int c_lo, int nch) {
+    if (mine_slow == 0) return;
+    for (int base = r0; base < r1; base += 64) {
+      unsigned long long m = __ballot(hit_of(base + lane) == 2);
+      while (m != 0ull) {
+        const int pos = base + (int)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const int r = ((const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)pos * kRecDwords))[8];
+        bwd_slow_in_tile(top_grad, rois + (long long)r * 5, grad, lv.scale[lvl], height, width, channels, c_lo, nch,
+                         aligned_height, aligned_width, sampling_ratio, (overwrite & 2) != 0, x0, y0, th, kTW, r, lane, 64);
+      }
+    }
+  };
+  // zeros into channels [c_lo, c_lo + cz) of the tile
+  auto zero_share = [&](int c_lo, int cz) {
     const int rows = min(th, height - y0), cols = min(kTW, width - x0);
-    const int cz = channels / kZeroParts, c_lo = (role - 1) * cz;  // channels % 32 == 0
     if (overwrite & 2) {
       // channels-last: `channels` contiguous floats per pixel
       const int c4 = cz / 4;
@@ -916,31 +1017,72 @@ roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int 
           grad[(((long long)n * channels + c_lo + c) * height + y0 + rr) * width + x0 + col] = 0.f;
         }
     }
+  };
+  if (role > 0) {
+    // ---- zero this workgroup's share of the channels if the tile's sums will be ADDED: its list is cut into slices (a
+    // list that does not get its slices any more -- budget used up -- is summed by one workgroup that overwrites: the
+    // zeros are then wasted, not wrong), or RoIs without tables add to it ----
+    if (total <= slice_len && nslow == 0) return;
+    const int cz = channels / kZeroParts, c_lo = (role - 1) * cz;  // channels % 32 == 0
+    zero_share(c_lo, cz);
+    if (nslow > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // the zeros have reached the L2 the atomics execute in
+      add_slow(c_lo, cz);
+    }
     return;
   }
   if (mine > 0)
     for (int base = r0; base < r1; base += 64) {
-      const bool hit = hit_of(base + lane);
+      const bool hit = hit_of(base + lane) == 1;
       const unsigned long long m = __ballot(hit);
       if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(base + lane);
       off += __popcll(m);
     }
   if (tid == 0) {
     counts[tile_global] = total;
+    const int add_mode = nslow > 0 ? 2 : 1;  // slices = 2 on a whole list: the tile kernel adds atomically
     bool whole = true;
     if (total > slice_len) {
       const int v = (total + slice_len - 1) / slice_len, per = (total + v - 1) / v;  // even slices: (v - 1) * per < total
-      if (atomicAdd(ws + kBwdBucket + kBwdClasses * kBwdCounterStride, v - 1) + v - 1 <= bwd_plan_extra(num_rois)) {
+      if (atomicAdd(bucket + kBwdClasses * kBwdCounterStride, v - 1) + v - 1 <= bwd_plan_extra(num_rois)) {
         whole = false;
-        const int slot = atomicAdd(ws + kBwdBucket, v);
+        const int slot = atomicAdd(bucket, v);
         for (int sl = 0; sl < v; sl++) entries[slot + sl] = make_int4(tile_global, sl * per, min(per, total - sl * per), v);
       }
     }
-    if (whole && (total > 0 || (overwrite & 1))) {
+    // a tile without listed RoIs is stored as zeros under the OVERWRITE contract -- unless RoIs without tables add to it:
+    // then the role workgroups have zeroed it already
+    if (whole && (total > 0 || ((overwrite & 1) && nslow == 0))) {
       const int c = bwd_class_of(total);
-      const int slot = atomicAdd(ws + kBwdBucket + c * kBwdCounterStride, 1);
-      entries[bwd_class_base(c, plan_tiles, num_rois) + slot] = make_int4(tile_global, 0, total, 1);
+      const int slot = atomicAdd(bucket + c * kBwdCounterStride, 1);
+      entries[bwd_class_base(c, plan_tiles, num_rois) + slot] = make_int4(tile_global, 0, total, add_mode);
     }
+  }
+  if (!(overwrite & 1) && nslow > 0) add_slow(0, channels);  // accumulate contract: into the caller's values, all channels
+}
+
+// Behind the UNPLANNED tile kernel (MI_ROI_ALIGN_BWD_SLICE=0, forward-sized workspaces, deterministic mode), whose lists
+// skip the RoIs without backward tables: those RoIs, whole, with the reference's mapping and atomics -- bwd_slow_in_tile with
+// the map as the tile.  One workgroup per (64 ranks, channel tile) looks at the 64 window entries and leaves at once when
+// none is marked, which is nearly always.  The default (planned) path has no such launch: roi_align_bwd_plan serves them.
+__global__ void __launch_bounds__(256)
+roi_align_bwd_untabled(const float* __restrict__ top_grad, const float* __restrict__ rois, const LevelTable lv,
+                       const int* __restrict__ ws, int num_rois, int channels, int aligned_height, int aligned_width,
+                       int sampling_ratio, int nhwc) {
+  const int tiles = channels / kCT;
+  const int group = blockIdx.x / tiles, c0 = (blockIdx.x - group * tiles) * kCT;
+  const int p = group * 64 + (threadIdx.x & 63);
+  const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
+  unsigned long long todo = __ballot(p < num_rois && (bounds[min(p, num_rois - 1)].y & kBoundsNoTables) != 0);
+  while (todo != 0ull) {
+    const int pos = group * 64 + (int)__builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const const_int_ptr rec = (const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)pos * kRecDwords);
+    const int r = rec[8], lvl = rec[11];
+    bwd_slow_in_tile(top_grad, rois + (long long)r * 5, lv.grad[lvl], lv.scale[lvl], lv.height[lvl], lv.width[lvl], channels,
+                     c0, kCT, aligned_height, aligned_width, sampling_ratio, nhwc != 0, 0, 0, lv.height[lvl], lv.width[lvl], r,
+                     threadIdx.x, 256);
   }
 }
 
@@ -952,7 +1094,7 @@ roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int 
 template <int kSR, int KC, int kTH, int kA = 0>
 __global__ void __launch_bounds__(kTH * 32)
     __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
-roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, const int* __restrict__ ws,
+roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, int* __restrict__ ws,
                     int num_rois, int batch, int channels, int aligned_height_arg, int aligned_width_arg, int overwrite,
                     int ablate_arg, int plan_tiles, int plan_cap MI_TL_PARAM) {
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
@@ -987,12 +1129,17 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
   const int4* __restrict__ entries =
       reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * (kRecDwords + 4) + ((plan_tiles + 3) & ~3));
   if (plan_tiles > 0) {
+    // both counter sets and the word that says which one this call filed into arrive together (no dependent scalar load);
+    // the first workgroup hands the OTHER set to the next backward over this workspace
     const const_int_ptr bc = (const_int_ptr)(uintptr_t)(ws + kBwdBucket);
+    const int set = bc[kBwdInUse - kBwdBucket] & 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws[kBwdParity] = set ^ 1;
     const int e = tile_lin;
     int c = 0, first = 0, run = 0;
 #pragma unroll
     for (int k = 0; k < kBwdClasses; k++) {
-      const int cnt = bc[k * kBwdCounterStride];
+      const int cnt0 = bc[k * kBwdCounterStride], cnt1 = bc[kBwdSetStride + k * kBwdCounterStride];
+      const int cnt = set ? cnt1 : cnt0;
       run += cnt;
       if (k + 1 < kBwdClasses && e >= run) {
         c = k + 1;
@@ -1049,7 +1196,10 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
     bool hit = false;
     if (i < num_rois) {
       const int4 b = bounds[i];
-      hit = b.y >= x0 && b.x < x0 + kTW && b.w >= gy0 && b.z < gy0 + kTH && b.z >= img_row0 && b.z < img_row0 + height;
+      hit = (b.y & (kBoundsNoTables - 1)) >= x0 && b.x < x0 + kTW && b.w >= gy0 && b.z < gy0 + kTH && b.z >= img_row0 &&
+            b.z < img_row0 + height;
+      // a RoI without tables is not listed: the launch behind this one (roi_align_bwd_untabled) adds it to what the tiles store
+      if (b.y & kBoundsNoTables) hit = false;
     }
     const unsigned long long m = __ballot(hit);
     if (lane == 0) wave_count[wave] = __popcll(m);
@@ -1224,68 +1374,6 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, con
 #undef MI_TL_LAP
 }
 
-// RoIs the tile kernel does not cover: reference mapping, arithmetic and atomics (roi_align_kernel.cu:195-270).
-// They are rare (windows wider than kMaxWin, more than kMaxS samples per axis), so the grid is small: one workgroup per
-// (group of kSlowGroup ranks, channel tile) walks its ranks and leaves at once when none of them is flagged -- a launch
-// of num_rois x tiles workgroups that all return took 4.8 us at config 2.
-constexpr int kSlowGroup = 64;
-__global__ void __launch_bounds__(256)
-roi_align_bwd_slow(const float* __restrict__ top_grad, const float* __restrict__ rois, const LevelTable lv,
-                   int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height,
-                   int aligned_width, int sampling_ratio, int nhwc) {
-  const int tiles = channels / kCT;
-  const int group = blockIdx.x / tiles;
-  const int c0 = (blockIdx.x - group * tiles) * kCT;
-  const int bins = aligned_height * aligned_width;
-  const int tid = threadIdx.x;
-  // The tile kernel of this call has finished: the plan's class counters go back to zero for the next backward over this
-  // workspace (a forward in between rewrites the whole counter block in roi_align_prepare).
-  if (blockIdx.x == 0 && tid <= kBwdClasses) ws[kBwdBucket + tid * kBwdCounterStride] = 0;  // classes + the slice budget
-  // Candidates from the window table (16 bytes per rank, contiguous: the record flags lie 3 KB apart and cost this launch
-  // 64 cache lines per workgroup to find nothing): a RoI without backward tables has the empty window; of those, the ranks
-  // that are not "RoI of no image" are visited.
-  unsigned long long todo;
-  {
-    const int p = group * kSlowGroup + (tid & 63);
-    const int4* __restrict__ bounds = reinterpret_cast<const int4*>(ws + kCounterDwords + (long long)num_rois * kRecDwords);
-    bool cand = p < num_rois && bounds[p].y < 0;
-    if (cand) cand = (ws[kCounterDwords + (long long)p * kRecDwords] & (kFlagBwd | kFlagZero)) == 0;
-    todo = __ballot(cand);
-  }
-  while (todo != 0ull) {
-  const int pos = group * kSlowGroup + (int)__builtin_ctzll(todo);
-  todo &= todo - 1ull;
-  const const_int_ptr rec = (const_int_ptr)(uintptr_t)(ws + kCounterDwords + (long long)pos * kRecDwords);
-  const int r = rec[8], lvl = rec[11];
-  float* __restrict__ bottom_grad = lv.grad[lvl];
-  const int height = lv.height[lvl], width = lv.width[lvl];
-  const float spatial_scale = lv.scale[lvl];
-  const float* __restrict__ gsrc = top_grad + ((long long)r * channels + c0) * bins;
-  const RoiGeom g = roi_geometry(rois + (long long)r * 5, spatial_scale, aligned_height, aligned_width, sampling_ratio);
-  // element strides of (channel, pixel) in the gradient map: NCHW or channels-last
-  const long long cs = nhwc ? 1 : (long long)height * width, ps = nhwc ? channels : 1;
-  float* gdst = bottom_grad + (long long)g.batch_ind * channels * height * width + c0 * cs;
-  for (int i = tid; i < kCT * bins; i += 256) {
-    const int c = i / bins, bin = i - c * bins;
-    const int ph = bin / aligned_width, pw = bin - ph * aligned_width;
-    float* plane = gdst + (long long)c * cs;
-    const float top_diff_this_bin = gsrc[i];
-    for (int iy = 0; iy < g.grid_h; iy++) {
-      const float y = sample_y(g, ph, iy);
-      for (int ix = 0; ix < g.grid_w; ix++) {
-        const float x = sample_x(g, pw, ix);
-        const Taps t = sample_taps(height, width, y, x);
-        if (t.y_low < 0) continue;
-        atomicAdd(plane + (t.y_low * width + t.x_low) * ps, top_diff_this_bin * t.w1 / g.count);
-        atomicAdd(plane + (t.y_low * width + t.x_high) * ps, top_diff_this_bin * t.w2 / g.count);
-        atomicAdd(plane + (t.y_high * width + t.x_low) * ps, top_diff_this_bin * t.w3 / g.count);
-        atomicAdd(plane + (t.y_high * width + t.x_high) * ps, top_diff_this_bin * t.w4 / g.count);
-      }
-    }
-  }
-  }
-}
-
 size_t records_lds_bytes(int cap, int ct) {
   return 2 * kMaxS * sizeof(TabEntry) + (size_t)(ct * (kTileBins + 1) + ct * (cap | 1)) * 4;
 }
@@ -1412,12 +1500,14 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
   const int plan_cap = (num_rois + 7) & ~7;
   int grid = tiles * (channels / kc);
   if (planned) {
-    roi_align_bwd_plan<<<tiles * (overwrite ? 1 + kZeroParts : 1), kPlanThreads, 0, stream>>>(lv, ws, num_rois, batch, channels, th, tiles, plan_cap, slice_min,
-                                                           (overwrite ? 1 : 0) | (nhwc ? 2 : 0));
+    // files every tile's list AND adds the RoIs without backward tables (rare, but only the device knows whether there are
+    // any): the trailing roi_align_bwd_slow launch of rounds 1-5 is gone from this, the default, path
+    roi_align_bwd_plan<<<tiles * (overwrite ? 1 + kZeroParts : 1), kPlanThreads, 0, stream>>>(
+        lv, ws, num_rois, batch, channels, th, tiles, plan_cap, slice_min, (overwrite ? 1 : 0) | (nhwc ? 2 : 0), top_grad, rois,
+        aligned_height, aligned_width, sampling_ratio);
     int rc = check_launch("roi_align_bwd_plan");
     if (rc != MI_OK) return rc;
-    // upper bound of the entries: every tile once + the budget of extra slices
-    grid = (tiles + bwd_plan_extra(num_rois)) * (channels / kc);
+    grid = (tiles + bwd_plan_extra(num_rois)) * (channels / kc);  // upper bound of the entries: every tile once + the budget of extra slices
   }
 #define MI_LAUNCH_TILES_A(SR, KC, TH, A)                                                                              \
   do {                                                                                                                \
@@ -1460,12 +1550,10 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
 #undef MI_LAUNCH_TILES_TH
 #undef MI_LAUNCH_TILES_A
   int rc = check_launch("roi_align_bwd_tiles");
-  if (rc != MI_OK) return rc;
-  if (!(g_ablate_p & 16))
-    roi_align_bwd_slow<<<((num_rois + kSlowGroup - 1) / kSlowGroup) * (channels / kCT), 256, 0, stream>>>(top_grad, rois, lv, ws, num_rois, batch, channels,
-                                                                    aligned_height, aligned_width, sampling_ratio,
-                                                                    nhwc ? 1 : 0);
-  return check_launch("roi_align_bwd_slow");
+  if (rc != MI_OK || planned) return rc;
+  roi_align_bwd_untabled<<<((num_rois + 63) / 64) * (channels / kCT), 256, 0, stream>>>(
+      top_grad, rois, lv, ws, num_rois, channels, aligned_height, aligned_width, sampling_ratio, nhwc ? 1 : 0);
+  return check_launch("roi_align_bwd_untabled");
 }
 
 int launch_roi_align_bwd_records(const float* top_grad, const float* rois, float* bottom_grad, void* workspace,

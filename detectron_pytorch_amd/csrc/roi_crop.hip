@@ -7,86 +7,214 @@
 // (:92-93, caller zero-fills); image of RoI r is r / (R / N) (:64,:217); the backward never
 // writes a grid gradient.
 //
-// Mapping: one lane per (roi, y, x) grid point x channel; the grid coordinates and the four
-// weights are per-(roi,y,x) quantities, so lanes iterate channels in the outer grid-stride
-// dimension and consecutive lanes take consecutive x (coalesced output rows).
+// Round 6 (until then the reference's one-thread-per-output-element loops re-typed): one 256-lane workgroup per (RoI,
+// 32-channel tile), tile = blockIdx % tiles (one XCD's L2 serves one channel slab).  A grid point's top-left tap, its four
+// weights and which of its taps lie in the image do not depend on the channel: they are computed ONCE per workgroup --
+// 64 points at a time, one per lane of wave 0 -- into an LDS table (the reference recomputes them in every thread: 32 x
+// per point here), with the bounding box of the group's taps reduced across the wave.
+//   forward   the box's rows arrive in LDS by LDS-DMA (buffer_load_dwordx4 ... lds; one odd-stride plane per channel,
+//             lane & 31 = channel: 32 banks), in chunks of as many rows as the image holds (consecutive chunks share a row,
+//             so the two tap rows of a point always lie in one chunk); half-wave = point, four ds_reads and the reference's
+//             expression per (point, channel); the [32][points] tile leaves as contiguous runs, points without a tap in
+//             the image left unwritten.  A box wider than the image's capacity is sampled from memory by the same lanes.
+//   backward  lanes flattened over (channel, point) with the point fastest -- the gradient block is read as it lies in
+//             memory -- and the reference's four atomics per element with the table's weights.  (A sampler's taps are
+//             sparse in its box -- 4 x 49 of ~1000 pixels at 7 x 7 -- so accumulating the box in LDS and flushing it would
+//             issue MORE atomics than the taps themselves; the scatter stays a scatter.)
+// Bit-exact forward: the same fp32 products and sums in the reference's order (-ffp-contract=off).
 #include "common.h"
+#include "lds_dma.h"
 
 namespace {
 
+using namespace mi;
+
+constexpr int kCropCT = 32;        // channels per workgroup
+constexpr int kCropThreads = 256;
+constexpr int kCropSlots = kCropThreads / kCropCT;
+constexpr int kCropCap = 336;      // box pixels per channel of the LDS image
+constexpr int kCropPlane = kCropCap | 1;
+constexpr int kCropPts = 64;       // grid points per group: one per lane of the wave that builds the table
+
+// roi_crop_cuda_kernel.cu:17-23
 __device__ __forceinline__ void get_top_left(float x, int width, int& point, float& weight) {
-  float xcoord = (x + 1) * (width - 1) / 2;  // :19
-  point = (int)floorf(xcoord);               // :20
-  weight = 1 - (xcoord - point);             // :21
+  float xcoord = (x + 1) * (width - 1) / 2;
+  point = (int)floorf(xcoord);
+  weight = 1 - (xcoord - point);
 }
 __device__ __forceinline__ bool between(int value, int lo, int hi) { return value >= lo && value <= hi; }
 
-struct CropTaps {
-  long long tl;
-  bool tl_in, tr_in, bl_in, br_in;
-  float xw, yw;
+// What is identical for all channels of a grid point.
+struct PointTab {
+  int x[kCropPts], y[kCropPts];          // top-left tap
+  float w_tl[kCropPts], w_tr[kCropPts], w_bl[kCropPts], w_br[kCropPts];  // xw*yw, (1-xw)*yw, xw*(1-yw), (1-xw)*(1-yw)
+  int in[kCropPts];                      // bit 0..3: top-left, top-right, bottom-left, bottom-right tap lies in the image
+  int box[4];                            // rows [y0, y1], columns [x0, x1] of the taps of the group that lie in the image
 };
 
-__device__ __forceinline__ CropTaps crop_taps(const float* __restrict__ grids, long long gidx, int b,
-                                              int cOut, int channels, int height, int width,
-                                              int roiPerImage) {
-  CropTaps t;
-  const int b_input = b / roiPerImage;  // :64
-  float yf = grids[gidx * 2];           // :66
-  float xf = grids[gidx * 2 + 1];       // :67
-  int yTL, xTL;
-  get_top_left(xf, width, xTL, t.xw);
-  get_top_left(yf, height, yTL, t.yw);
-  t.tl = ((long long)(b_input * channels + cOut) * height + yTL) * width + xTL;
-  t.tl_in = between(xTL, 0, width - 1) && between(yTL, 0, height - 1);
-  t.tr_in = between(xTL + 1, 0, width - 1) && between(yTL, 0, height - 1);
-  t.bl_in = between(xTL, 0, width - 1) && between(yTL + 1, 0, height - 1);
-  t.br_in = between(xTL + 1, 0, width - 1) && between(yTL + 1, 0, height - 1);
-  return t;
-}
-
-__global__ void __launch_bounds__(256)
-roi_crop_fwd(long long total, const float* __restrict__ input, const float* __restrict__ grids,
-             float* __restrict__ output, int channels, int height, int width, int gh, int gw,
-             int roiPerImage) {
-  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
-       index += (long long)gridDim.x * blockDim.x) {
-    const int xOut = (int)(index % gw);
-    const int yOut = (int)((index / gw) % gh);
-    const int cOut = (int)((index / gw / gh) % channels);
-    const int b = (int)(index / gw / gh / channels);
-    CropTaps t = crop_taps(grids, ((long long)b * gh + yOut) * gw + xOut, b, cOut, channels, height,
-                           width, roiPerImage);
-    if (!t.tl_in && !t.tr_in && !t.bl_in && !t.br_in) continue;  // :92-93
-    float inTopLeft = 0, inTopRight = 0, inBottomLeft = 0, inBottomRight = 0;
-    if (t.tl_in) inTopLeft = input[t.tl];
-    if (t.tr_in) inTopRight = input[t.tl + 1];
-    if (t.bl_in) inBottomLeft = input[t.tl + width];
-    if (t.br_in) inBottomRight = input[t.tl + width + 1];
-    float v = t.xw * t.yw * inTopLeft  // :100-103
-              + (1 - t.xw) * t.yw * inTopRight + t.xw * (1 - t.yw) * inBottomLeft +
-              (1 - t.xw) * (1 - t.yw) * inBottomRight;
-    output[index] = v;
+// wave 0: the table of points [p0, p0 + np) of RoI r and the bounding box of their in-image taps
+__device__ __forceinline__ void crop_build_table(PointTab* tab, const float* __restrict__ grids, long long gbase, int np,
+                                                 int lane, int height, int width, bool image_ok) {
+  int xTL = 0, yTL = 0, in = 0;
+  float xw = 0.f, yw = 0.f;
+  if (lane < np) {
+    const float yf = grids[(gbase + lane) * 2];      // :66
+    const float xf = grids[(gbase + lane) * 2 + 1];  // :67
+    get_top_left(xf, width, xTL, xw);
+    get_top_left(yf, height, yTL, yw);
+    const bool xl = between(xTL, 0, width - 1), xr = between(xTL + 1, 0, width - 1);
+    const bool yt = between(yTL, 0, height - 1), yb = between(yTL + 1, 0, height - 1);
+    in = image_ok ? ((xl && yt) ? 1 : 0) | ((xr && yt) ? 2 : 0) | ((xl && yb) ? 4 : 0) | ((xr && yb) ? 8 : 0) : 0;
+  }
+  tab->x[lane] = xTL;
+  tab->y[lane] = yTL;
+  tab->w_tl[lane] = xw * yw;              // the products of :100-103 / :169-172, formed as the reference forms them
+  tab->w_tr[lane] = (1 - xw) * yw;
+  tab->w_bl[lane] = xw * (1 - yw);
+  tab->w_br[lane] = (1 - xw) * (1 - yw);
+  tab->in[lane] = in;
+  // rows / columns of the in-image taps: a point with a tap in the image has its rows in [max(y, 0), min(y + 1, H - 1)]
+  int ylo = in ? max(yTL, 0) : 0x3fffffff, yhi = in ? min(yTL + 1, height - 1) : -1;
+  int xlo = in ? max(xTL, 0) : 0x3fffffff, xhi = in ? min(xTL + 1, width - 1) : -1;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    ylo = min(ylo, __shfl_xor(ylo, d));
+    yhi = max(yhi, __shfl_xor(yhi, d));
+    xlo = min(xlo, __shfl_xor(xlo, d));
+    xhi = max(xhi, __shfl_xor(xhi, d));
+  }
+  if (lane == 0) {
+    tab->box[0] = ylo;
+    tab->box[1] = yhi;
+    tab->box[2] = xlo;
+    tab->box[3] = xhi;
   }
 }
 
-__global__ void __launch_bounds__(256)
-roi_crop_bwd(long long total, const float* __restrict__ grids, const float* __restrict__ grad_output,
-             float* __restrict__ grad_input, int channels, int height, int width, int gh, int gw,
-             int roiPerImage) {
-  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
-       index += (long long)gridDim.x * blockDim.x) {
-    const int xOut = (int)(index % gw);
-    const int yOut = (int)((index / gw) % gh);
-    const int cOut = (int)((index / gw / gh) % channels);
-    const int b = (int)(index / gw / gh / channels);
-    CropTaps t = crop_taps(grids, ((long long)b * gh + yOut) * gw + xOut, b, cOut, channels, height,
-                           width, roiPerImage);
-    float gradOutValue = grad_output[index];
-    if (t.tl_in) atomicAdd(grad_input + t.tl, t.xw * t.yw * gradOutValue);  // :169
-    if (t.tr_in) atomicAdd(grad_input + t.tl + 1, (1 - t.xw) * t.yw * gradOutValue);
-    if (t.bl_in) atomicAdd(grad_input + t.tl + width, t.xw * (1 - t.yw) * gradOutValue);
-    if (t.br_in) atomicAdd(grad_input + t.tl + width + 1, (1 - t.xw) * (1 - t.yw) * gradOutValue);
+__global__ void __launch_bounds__(kCropThreads)
+roi_crop_fwd(const float* __restrict__ input, const float* __restrict__ grids, float* __restrict__ output, int batch,
+             int channels, int height, int width, int gh, int gw, int roiPerImage) {
+  __shared__ PointTab tab;
+  __shared__ float tile[kCropCT * (kCropPts + 1)];
+  extern __shared__ __attribute__((aligned(16))) float img[];  // [kCropCT][kCropPlane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int cl = tid % kCropCT, slot = tid / kCropCT;
+  const int tiles = (channels + kCropCT - 1) / kCropCT;
+  const int r = blockIdx.x / tiles, c0 = (blockIdx.x - r * tiles) * kCropCT;
+  const int points = gh * gw;
+  const int b_input = r / roiPerImage;  // :64
+  const bool image_ok = b_input < batch;  // (the reference would read past its input)
+  const int cvalid = min(kCropCT, channels - c0);
+  const long long plane_px = (long long)height * width;
+  const float* __restrict__ src = input + ((long long)(image_ok ? b_input : 0) * channels + c0) * plane_px;
+  constexpr int kChPerWave = kCropCT / (kCropThreads / 64);
+  const int wave_ch = max(0, min(kChPerWave, cvalid - wave * kChPerWave));
+  const srd_t srd = make_srd(src + (long long)wave * kChPerWave * plane_px, (unsigned)(wave_ch * plane_px * 4));
+  const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kCropPlane);
+  constexpr int ts = kCropPts + 1;
+
+  for (int p0 = 0; p0 < points; p0 += kCropPts) {
+    const int np = min(kCropPts, points - p0);
+    __syncthreads();  // the previous group's table and tile are no longer read
+    if (wave == 0) crop_build_table(&tab, grids, (long long)r * points + p0, np, lane, height, width, image_ok);
+    __syncthreads();
+    const int y0 = uniform(tab.box[0]), y1 = uniform(tab.box[1]), x0 = uniform(tab.box[2]), x1 = uniform(tab.box[3]);
+    if (y1 >= y0) {  // some tap of the group lies in the image
+      const int pitch_px = (x1 - x0 + 1 + 3) & ~3, gpr = pitch_px >> 2;
+      const bool staged = 2 * pitch_px <= kCropCap;  // a chunk holds at least the two tap rows of a point
+      const int chunk_rows = staged ? kCropCap / pitch_px : (1 << 30);
+      const unsigned gmagic = (1u << 20) / (unsigned)gpr + 1u;
+      // chunks [r0, r0 + chunk_rows) advance by chunk_rows - 1: a point whose first in-image row is lo belongs to the chunk
+      // with r0 <= lo < r0 + chunk_rows - 1 (the last chunk takes the rest), which also holds its second row
+      for (int r0 = y0; r0 <= y1; r0 += staged ? chunk_rows - 1 : (1 << 30)) {
+        const int r1 = min(y1 + 1, r0 + chunk_rows);  // rows [r0, r1)
+        const bool last = r1 == y1 + 1;
+        if (staged) {
+          __syncthreads();  // the previous chunk's taps have been read
+          const unsigned groups = (unsigned)(r1 - r0) * (unsigned)gpr;
+          for (int kk = 0; kk * 64 < (int)groups; kk++) {
+            const unsigned g = (unsigned)(kk * 64 + lane);
+            const unsigned q = __umul24(g, gmagic) >> 20;  // g / gpr
+            const unsigned gc = g - __umul24(q, (unsigned)gpr);
+            const unsigned voff = (((unsigned)r0 + q) * (unsigned)width + (unsigned)x0 + gc * 4u) * 4u;
+            if (g < groups) {
+#pragma unroll
+              for (int c = 0; c < kChPerWave; c++)
+                dma_dwordx4(srd, plane0 + (unsigned)(c * kCropPlane + kk * 256) * 4u, voff, (unsigned)(c * plane_px * 4));
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();  // the chunk has landed
+        }
+        if (cl < cvalid)
+          for (int p = slot; p < np; p += kCropSlots) {
+            const int in = tab.in[p];
+            if (in == 0) continue;
+            const int xTL = tab.x[p], yTL = tab.y[p];
+            const int lo = max(yTL, 0);
+            if (lo < r0 || (!last && lo >= r0 + chunk_rows - 1)) continue;  // another chunk's point
+            float inTopLeft = 0, inTopRight = 0, inBottomLeft = 0, inBottomRight = 0;
+            if (staged) {
+              const float* a = img + cl * kCropPlane + (yTL - r0) * pitch_px + (xTL - x0);
+              if (in & 1) inTopLeft = a[0];
+              if (in & 2) inTopRight = a[1];
+              if (in & 4) inBottomLeft = a[pitch_px];
+              if (in & 8) inBottomRight = a[pitch_px + 1];
+            } else {
+              const float* a = src + (long long)cl * plane_px + (long long)yTL * width + xTL;
+              if (in & 1) inTopLeft = a[0];
+              if (in & 2) inTopRight = a[1];
+              if (in & 4) inBottomLeft = a[width];
+              if (in & 8) inBottomRight = a[width + 1];
+            }
+            // :100-103
+            tile[cl * ts + p] = tab.w_tl[p] * inTopLeft + tab.w_tr[p] * inTopRight + tab.w_bl[p] * inBottomLeft +
+                                tab.w_br[p] * inBottomRight;
+          }
+        if (last) break;
+      }
+    }
+    __syncthreads();  // the tile is complete
+    // [channel][points of the group] leave as contiguous runs; a point without a tap in the image is not written (:92-93)
+    float* __restrict__ dst = output + ((long long)r * channels + c0) * points + p0;
+    for (int i = tid; i < cvalid * np; i += kCropThreads) {
+      const int c = i / np, p = i - c * np;
+      if (tab.in[p] != 0) dst[(long long)c * points + p] = tile[c * ts + p];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kCropThreads)
+roi_crop_bwd(const float* __restrict__ grids, const float* __restrict__ grad_output, float* __restrict__ grad_input,
+             int batch, int channels, int height, int width, int gh, int gw, int roiPerImage) {
+  __shared__ PointTab tab;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int tiles = (channels + kCropCT - 1) / kCropCT;
+  const int r = blockIdx.x / tiles, c0 = (blockIdx.x - r * tiles) * kCropCT;
+  const int points = gh * gw;
+  const int b_input = r / roiPerImage;  // :128
+  const bool image_ok = b_input < batch;
+  const int cvalid = min(kCropCT, channels - c0);
+  const long long plane_px = (long long)height * width;
+  float* __restrict__ dst = grad_input + ((long long)(image_ok ? b_input : 0) * channels + c0) * plane_px;
+  const float* __restrict__ gsrc = grad_output + ((long long)r * channels + c0) * points;
+  for (int p0 = 0; p0 < points; p0 += kCropPts) {
+    const int np = min(kCropPts, points - p0);
+    __syncthreads();
+    if (wave == 0) crop_build_table(&tab, grids, (long long)r * points + p0, np, lane, height, width, image_ok);
+    __syncthreads();
+    if (uniform(tab.box[1]) < uniform(tab.box[0])) continue;  // no tap of the group lies in the image
+    for (int i = tid; i < cvalid * np; i += kCropThreads) {
+      const int c = i / np, p = i - c * np;
+      const int in = tab.in[p];
+      if (in == 0) continue;
+      const float gradOutValue = gsrc[(long long)c * points + p0 + p];
+      float* a = dst + (long long)c * plane_px + (long long)tab.y[p] * width + tab.x[p];
+      if (in & 1) atomicAdd(a, tab.w_tl[p] * gradOutValue);  // :169-172
+      if (in & 2) atomicAdd(a + 1, tab.w_tr[p] * gradOutValue);
+      if (in & 4) atomicAdd(a + width, tab.w_bl[p] * gradOutValue);
+      if (in & 8) atomicAdd(a + width + 1, tab.w_br[p] * gradOutValue);
+    }
   }
 }
 
@@ -98,6 +226,7 @@ int check_crop(const void* a, const void* grid, const void* b, int batch, int ch
   MI_REQUIRE(num_rois == 0 || num_rois / batch > 0,
              "roi_crop: fewer RoIs (%d) than images (%d): RoIs-per-image would be 0 (reference divides by it)",
              num_rois, batch);
+  MI_REQUIRE((long long)height * width * 4 * kCropCT < (1LL << 31), "roi_crop: a 32-channel slab of the map exceeds 2 GB");
   if ((long long)num_rois * channels > 0)
     MI_REQUIRE(a != nullptr && grid != nullptr && b != nullptr, "roi_crop: null pointer");
   return MI_OK;
@@ -114,10 +243,9 @@ extern "C" int mi_roi_crop_forward(const float* input, const float* grid_yx, flo
   if (rc != MI_OK) return rc;
   const long long total = (long long)num_rois * channels * grid_height * grid_width;
   if (total == 0) return MI_OK;
-  const int block = 256;
-  roi_crop_fwd<<<mi::grid_for(total, block), block, 0, mi::as_stream(stream)>>>(
-      total, input, grid_yx, output, channels, height, width, grid_height, grid_width,
-      num_rois / batch);
+  const int tiles = (channels + kCropCT - 1) / kCropCT;
+  roi_crop_fwd<<<num_rois * tiles, kCropThreads, (size_t)kCropCT * kCropPlane * 4, mi::as_stream(stream)>>>(
+      input, grid_yx, output, batch, channels, height, width, grid_height, grid_width, num_rois / batch);
   return mi::check_launch("roi_crop_fwd");
 }
 
@@ -132,9 +260,8 @@ extern "C" int mi_roi_crop_backward(const float* input, const float* grid_yx,
   if (rc != MI_OK) return rc;
   const long long total = (long long)num_rois * channels * grid_height * grid_width;
   if (total == 0) return MI_OK;
-  const int block = 256;
-  roi_crop_bwd<<<mi::grid_for(total, block), block, 0, mi::as_stream(stream)>>>(
-      total, grid_yx, grad_output, grad_input, channels, height, width, grid_height, grid_width,
-      num_rois / batch);
+  const int tiles = (channels + kCropCT - 1) / kCropCT;
+  roi_crop_bwd<<<num_rois * tiles, kCropThreads, 0, mi::as_stream(stream)>>>(
+      grid_yx, grad_output, grad_input, batch, channels, height, width, grid_height, grid_width, num_rois / batch);
   return mi::check_launch("roi_crop_bwd");
 }

@@ -1,20 +1,34 @@
 // roi_pool.hip -- RoIPool forward / backward for gfx950, C-ABI mi_roi_pool_*.
 //
-// Arithmetic contract: lib/model/roi_pooling/src/roi_pooling_kernel.cu:24-93 (forward, max with
-// first-max-wins row-major scan and int32 flat argmax) and :128-203 (backward).
+// Arithmetic contract: lib/model/roi_pooling/src/roi_pooling_kernel.cu:24-93 (forward: max over the bin's pixels, strict >,
+// scanned row-major so the first maximum wins, int32 flat argmax over the whole input tensor, empty bin -> 0 / -1) and
+// :128-203 (backward).
 //
-// The reference backward launches one thread per INPUT element and loops over all R RoIs and
-// their candidate bins comparing argmax == index: O(N*C*H*W*R).  The same sums are produced
-// here by scattering each output gradient through its argmax (one fp32 atomic per output
-// element, O(R*C*PH*PW)); the reference's extra conditions -- the argmax pixel must lie inside
-// the rounded RoI rectangle [start, end] (:161-165, false for malformed RoIs whose width was
-// forced to 1) -- are re-checked so the set of contributing terms is identical.  Only the
-// floating-point addition order differs (reference: ascending RoI index).
+// Forward (round 6; until then the reference's one-lane-per-output loop re-typed): one 256-lane workgroup per (RoI,
+// 32-channel tile), tile = blockIdx % tiles so that one XCD's L2 serves one channel slab.  The RoI's rectangle is decoded
+// once per workgroup (wave-uniform, SGPRs); its rows arrive in LDS by LDS-DMA (buffer_load_dwordx4 ... lds, lanes flattened
+// over (row, 16-byte group), one odd-stride plane per channel) in chunks of as many rows as the image holds; lane & 31 =
+// channel (32 banks), half-wave = output column; every lane scans the part of its bins that lies in the chunk and carries
+// (max, argmax) in the LDS tile, so a bin taller than a chunk is scanned across chunks in the reference's row-major order.
+// The [32][bins] tile of values and of indices then leaves as contiguous runs.  Bit-exact: the comparisons are the
+// reference's, on the same values in the same order.
+// A window wider than the LDS image (more than 336 columns) is scanned from memory by the same lanes.
+//
+// Backward: the reference launches one thread per INPUT element and loops over all R RoIs and their candidate bins
+// comparing argmax == index: O(N*C*H*W*R).  The same sums are produced here by scattering each output gradient through
+// its argmax (one fp32 atomic per output element, O(R*C*PH*PW)); the reference's extra conditions -- the argmax pixel
+// must lie inside the rounded RoI rectangle [start, end] (:161-165, false for malformed RoIs whose width was forced to
+// 1) -- are re-checked so the set of contributing terms is identical.  Only the floating-point addition order differs
+// (reference: ascending RoI index).
 #include "common.h"
+#include "lds_dma.h"
 
 #include <cfloat>
 
 namespace {
+
+using namespace mi;
+using const_float_ptr = const __attribute__((address_space(4))) float*;
 
 struct PoolRoi {
   int batch_ind, start_w, start_h, end_w, end_h;
@@ -30,47 +44,148 @@ __device__ __forceinline__ PoolRoi pool_roi(const float* __restrict__ roi, float
   return r;
 }
 
-__global__ void __launch_bounds__(256)
-roi_pool_fwd(long long total, const float* __restrict__ bottom_data,
-             const float* __restrict__ rois, float* __restrict__ top_data,
-             int32_t* __restrict__ argmax_data, int batch, int channels, int height, int width,
-             int pooled_height, int pooled_width, float spatial_scale) {
-  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
-       index += (long long)gridDim.x * blockDim.x) {
-    int pw = (int)(index % pooled_width);
-    int ph = (int)((index / pooled_width) % pooled_height);
-    int c = (int)((index / pooled_width / pooled_height) % channels);
-    int n = (int)(index / pooled_width / pooled_height / channels);
-    PoolRoi r = pool_roi(rois + (long long)n * 5, spatial_scale);
-    int roi_width = (int)fmaxf((float)(r.end_w - r.start_w + 1), 1.f);  // :52-53
-    int roi_height = (int)fmaxf((float)(r.end_h - r.start_h + 1), 1.f);
-    float bin_size_h = (float)(roi_height) / (float)(pooled_height);  // :54-55
-    float bin_size_w = (float)(roi_width) / (float)(pooled_width);
-    int hstart = (int)(floorf((float)(ph)*bin_size_h));  // :57-60
-    int wstart = (int)(floorf((float)(pw)*bin_size_w));
-    int hend = (int)(ceilf((float)(ph + 1) * bin_size_h));
-    int wend = (int)(ceilf((float)(pw + 1) * bin_size_w));
-    hstart = (int)fminf(fmaxf((float)(hstart + r.start_h), 0.f), (float)height);  // :63-66
-    hend = (int)fminf(fmaxf((float)(hend + r.start_h), 0.f), (float)height);
-    wstart = (int)fminf(fmaxf((float)(wstart + r.start_w), 0.f), (float)width);
-    wend = (int)fminf(fmaxf((float)(wend + r.start_w), 0.f), (float)width);
-    bool is_empty = (hend <= hstart) || (wend <= wstart) || r.batch_ind < 0 || r.batch_ind >= batch;
-    float maxval = is_empty ? 0.f : -FLT_MAX;  // :70
-    int maxidx = -1;                           // :72
-    if (!is_empty) {
-      int bottom_data_offset = (r.batch_ind * channels + c) * height * width;  // :75-76
-      for (int h = hstart; h < hend; ++h)
-        for (int w = wstart; w < wend; ++w) {
-          int bottom_index = h * width + w;
-          float v = bottom_data[bottom_data_offset + bottom_index];
-          if (v > maxval) {  // :83 strict >, first max in row-major order wins
-            maxval = v;
-            maxidx = bottom_data_offset + bottom_index;
-          }
-        }
+constexpr int kPoolCT = 32;        // channels per workgroup
+constexpr int kPoolThreads = 256;
+constexpr int kPoolSlots = kPoolThreads / kPoolCT;  // half-waves
+constexpr int kPoolCap = 336;      // window pixels per channel of the LDS image (43 KB: three workgroups per CU)
+constexpr int kPoolPlane = kPoolCap | 1;
+constexpr int kPoolTileBins = 56;  // bins per channel the LDS tile holds at least (whole 7 x 7 outputs)
+
+// bin p of an axis: [start, end) in map coordinates, clamped to the map (roi_pooling_kernel.cu:57-66)
+__device__ __forceinline__ void pool_bin(int p, float bin_size, int roi_start, int size, int& lo, int& hi) {
+  lo = (int)floorf((float)p * bin_size);
+  hi = (int)ceilf((float)(p + 1) * bin_size);
+  lo = (int)fminf(fmaxf((float)(lo + roi_start), 0.f), (float)size);
+  hi = (int)fminf(fmaxf((float)(hi + roi_start), 0.f), (float)size);
+}
+
+__global__ void __launch_bounds__(kPoolThreads)
+roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ rois, float* __restrict__ top_data,
+             int32_t* __restrict__ argmax_data, int batch, int channels, int height, int width, int pooled_height,
+             int pooled_width, float spatial_scale, int rows_per_group) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tile_bins = rows_per_group * pooled_width, ts = tile_bins | 1;
+  float* tval = smem;                                        // [kPoolCT][ts]
+  int* targ = reinterpret_cast<int*>(smem + kPoolCT * ts);   // [kPoolCT][ts]
+  float* img = smem + 2 * kPoolCT * ts;                      // [kPoolCT][kPoolPlane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int cl = tid % kPoolCT, slot = tid / kPoolCT;
+  const int tiles = (channels + kPoolCT - 1) / kPoolCT;
+  const int r = blockIdx.x / tiles, c0 = (blockIdx.x - r * tiles) * kPoolCT;
+  const int bins = pooled_height * pooled_width;
+  // ---- the RoI, once per workgroup (five scalar loads) ----
+  const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)r * 5);
+  const int batch_ind = (int)roi[0];
+  const int start_w = (int)roundf(roi[1] * spatial_scale), start_h = (int)roundf(roi[2] * spatial_scale);  // :46-49
+  const int end_w = (int)roundf(roi[3] * spatial_scale), end_h = (int)roundf(roi[4] * spatial_scale);
+  const int roi_width = (int)fmaxf((float)(end_w - start_w + 1), 1.f);  // :52-53
+  const int roi_height = (int)fmaxf((float)(end_h - start_h + 1), 1.f);
+  const float bin_size_h = (float)roi_height / (float)pooled_height;  // :54-55
+  const float bin_size_w = (float)roi_width / (float)pooled_width;
+  const bool no_image = batch_ind < 0 || batch_ind >= batch;
+  // window columns: bin starts and ends grow with pw, so the first start and the last end bound them all
+  int wlo, whi, t0, t1;
+  pool_bin(0, bin_size_w, start_w, width, wlo, t0);
+  pool_bin(pooled_width - 1, bin_size_w, start_w, width, t1, whi);
+  const int ww = whi - wlo;
+  const int pitch_px = (max(ww, 1) + 3) & ~3, gpr = pitch_px >> 2;
+  const bool staged = pitch_px <= kPoolCap;
+  const int chunk_rows = staged ? kPoolCap / pitch_px : (1 << 30);
+  const unsigned gmagic = (1u << 20) / (unsigned)gpr + 1u;
+  const long long plane_px = (long long)height * width;
+  const int cvalid = min(kPoolCT, channels - c0);  // channels of this tile that exist
+  const float* __restrict__ src = bottom_data + ((long long)(no_image ? 0 : batch_ind) * channels + c0) * plane_px;
+  constexpr int kChPerWave = kPoolCT / (kPoolThreads / 64);
+  // this wave's DMA covers the planes of its kChPerWave channels (those that exist); a lane past them reads zeros
+  const int wave_ch = max(0, min(kChPerWave, cvalid - wave * kChPerWave));
+  const srd_t srd = make_srd(src + (long long)wave * kChPerWave * plane_px, (unsigned)(wave_ch * plane_px * 4));
+  const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kPoolPlane);
+
+  for (int pa = 0; pa < pooled_height; pa += rows_per_group) {
+    const int pb = min(pooled_height, pa + rows_per_group);
+    const int nb = (pb - pa) * pooled_width;
+    // rows of this group of bin rows
+    int ra, rb;
+    pool_bin(pa, bin_size_h, start_h, height, ra, t0);
+    pool_bin(pb - 1, bin_size_h, start_h, height, t1, rb);
+    // ---- tile: every bin starts empty-or-open (:68-72) ----
+    for (int b = slot; b < nb; b += kPoolSlots) {
+      const int ph = pa + b / pooled_width, pw = b % pooled_width;
+      int hs, he, ws, we;
+      pool_bin(ph, bin_size_h, start_h, height, hs, he);
+      pool_bin(pw, bin_size_w, start_w, width, ws, we);
+      const bool is_empty = he <= hs || we <= ws || no_image;
+      tval[cl * ts + b] = is_empty ? 0.f : -FLT_MAX;
+      targ[cl * ts + b] = -1;
     }
-    top_data[index] = maxval;
-    if (argmax_data != nullptr) argmax_data[index] = maxidx;
+    if (!no_image && ww > 0)
+      for (int r0 = ra; r0 < rb; r0 += chunk_rows) {
+        const int r1 = min(rb, r0 + chunk_rows);
+        if (staged) {
+          __syncthreads();  // the previous chunk's scans are done with the image
+          const unsigned groups = (unsigned)(r1 - r0) * (unsigned)gpr;
+          for (int kk = 0; kk * 64 < (int)groups; kk++) {
+            const unsigned g = (unsigned)(kk * 64 + lane);
+            const unsigned q = __umul24(g, gmagic) >> 20;  // g / gpr
+            const unsigned gc = g - __umul24(q, (unsigned)gpr);
+            const unsigned voff = (((unsigned)r0 + q) * (unsigned)width + (unsigned)wlo + gc * 4u) * 4u;
+            if (g < groups) {
+#pragma unroll
+              for (int c = 0; c < kChPerWave; c++)
+                dma_dwordx4(srd, plane0 + (unsigned)(c * kPoolPlane + kk * 256) * 4u, voff, (unsigned)(c * plane_px * 4));
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();  // the chunk has landed
+        }
+        if (cl < cvalid)
+          for (int b = slot; b < nb; b += kPoolSlots) {
+            const int ph = pa + b / pooled_width, pw = b % pooled_width;
+            int hs, he, ws, we;
+            pool_bin(ph, bin_size_h, start_h, height, hs, he);
+            pool_bin(pw, bin_size_w, start_w, width, ws, we);
+            hs = max(hs, r0);
+            he = min(he, r1);
+            if (he <= hs || we <= ws) continue;
+            float maxval = tval[cl * ts + b];
+            int maxidx = targ[cl * ts + b];
+            const int bottom_data_offset = (batch_ind * channels + c0 + cl) * height * width;  // :75-76
+            if (staged) {
+              const float* plane = img + cl * kPoolPlane;
+              for (int h = hs; h < he; ++h)
+                for (int w = ws; w < we; ++w) {
+                  const float v = plane[(h - r0) * pitch_px + (w - wlo)];
+                  if (v > maxval) {  // :83 strict >: the first maximum in row-major order wins
+                    maxval = v;
+                    maxidx = bottom_data_offset + h * width + w;
+                  }
+                }
+            } else {
+              const float* plane = src + (long long)cl * plane_px;
+              for (int h = hs; h < he; ++h)
+                for (int w = ws; w < we; ++w) {
+                  const float v = plane[h * width + w];
+                  if (v > maxval) {
+                    maxval = v;
+                    maxidx = bottom_data_offset + h * width + w;
+                  }
+                }
+            }
+            tval[cl * ts + b] = maxval;
+            targ[cl * ts + b] = maxidx;
+          }
+      }
+    __syncthreads();  // the tile is complete
+    // ---- [channel][bins of the group] leave as contiguous runs (the whole [32][bins] block when the group is the RoI) ----
+    float* __restrict__ dst = top_data + ((long long)r * channels + c0) * bins + pa * pooled_width;
+    int32_t* __restrict__ adst = argmax_data != nullptr ? argmax_data + ((long long)r * channels + c0) * bins + pa * pooled_width : nullptr;
+    const unsigned nb_magic = (1u << 20) / (unsigned)nb + 1u;
+    for (int i = tid; i < cvalid * nb; i += kPoolThreads) {
+      const int c = nb <= 128 ? (int)(((unsigned)i * nb_magic) >> 20) : i / nb, b = i - c * nb;
+      dst[(long long)c * bins + b] = tval[c * ts + b];
+      if (adst != nullptr) adst[(long long)c * bins + b] = targ[c * ts + b];
+    }
+    __syncthreads();  // before the next group rewrites the tile
   }
 }
 
@@ -120,10 +235,19 @@ extern "C" int mi_roi_pool_forward(const float* features, const float* rois, flo
   if (rc != MI_OK) return rc;
   const long long total = (long long)num_rois * channels * pooled_height * pooled_width;
   if (total == 0) return MI_OK;
-  const int block = 256;
-  roi_pool_fwd<<<mi::grid_for(total, block), block, 0, mi::as_stream(stream)>>>(
-      total, features, rois, output, argmax, batch, channels, height, width, pooled_height,
-      pooled_width, spatial_scale);
+  // bin rows per LDS tile: the whole output when it has at most kPoolTileBins bins per channel (7 x 7), else as many rows
+  // as fit (at least one: a row of pooled_width bins)
+  const int rows_per_group = pooled_height * pooled_width <= kPoolTileBins ? pooled_height
+                                                                           : (kPoolTileBins / pooled_width > 0 ? kPoolTileBins / pooled_width : 1);
+  const size_t lds = (size_t)(2 * kPoolCT * ((rows_per_group * pooled_width) | 1) + kPoolCT * kPoolPlane) * 4;
+  MI_REQUIRE(lds <= 160 * 1024 - 2048, "roi_pool: pooled_width %d needs an output tile of %zu bytes of LDS", pooled_width, lds);
+  MI_REQUIRE((long long)height * width * 4 * kPoolCT < (1LL << 31), "roi_pool: a 32-channel slab of the map exceeds 2 GB");
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_pool_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int tiles = (channels + kPoolCT - 1) / kPoolCT;
+  roi_pool_fwd<<<num_rois * tiles, kPoolThreads, lds, mi::as_stream(stream)>>>(
+      features, rois, output, argmax, batch, channels, height, width, pooled_height, pooled_width, spatial_scale,
+      rows_per_group);
   return mi::check_launch("roi_pool_fwd");
 }
 

@@ -558,6 +558,73 @@ def test_roi_pool_golden_and_oracle(oracle_mod):
     assert_close(f.grad, oracle_mod.roi_pool_backward(gtop, rois, ref_arg, feat.shape, 1.0 / 16, threads=8), "bwd")
 
 
+@pytest.mark.parametrize("shape,res,scale,nrois", [
+    ((1, 32, 50, 84), (7, 7), 1.0 / 16, 64),      # stride-16 map: whole-image RoIs, bins taller than an LDS chunk
+    ((2, 70, 25, 42), (7, 7), 1.0 / 32, 48),      # 70 channels: a ragged last tile of 6
+    ((1, 32, 40, 400), (7, 7), 1.0 / 4, 40),      # windows wider than the LDS image (> 336 columns): scanned from memory
+    ((1, 64, 60, 90), (14, 14), 1.0 / 8, 40),     # 196 bins: the output tile is cut into groups of bin rows
+    ((1, 32, 30, 30), (3, 60), 1.0 / 16, 24),     # pooled_width beyond the default tile
+    ((2, 8, 9, 11), (2, 3), 1.0 / 16, 20)])       # fewer channels than a tile, tiny map
+def test_roi_pool_lds_kernel_shapes_vs_oracle(oracle_mod, shape, res, scale, nrois):
+    """roi_pool_fwd stages a RoI's rows through LDS in chunks and carries (max, argmax) across them: values AND flat int32
+    argmax bit-equal to the oracle (roi_pooling_kernel.cu:24-93) on every way the rows can be cut, including RoIs outside the
+    map, malformed ones and RoIs of no image."""
+    from detectron_pytorch_amd.roi_pool import roi_pool_forward
+
+    n, c, h, w = shape
+    feat = syn.feature_map(n, c, h, w, seed=31)
+    feat[0, 0, :3, :3] = 7.5          # ties: the FIRST maximum in row-major order must win
+    feat[-1, -1] = -np.inf            # a plane nothing beats -FLT_MAX in: value -FLT_MAX, argmax -1
+    rois = syn.rois_adversarial(nrois, n, h, w, scale, seed=32)
+    ref_out, ref_arg = oracle_mod.roi_pool_forward(feat, rois, res[0], res[1], scale, threads=8)
+    rois[-1, 0] = n + 3               # RoIs of no image: the reference (and its oracle) would read past the input; here: empty bins
+    rois[-2, 0] = -1
+    out, argmax = roi_pool_forward(to_dev(feat), to_dev(rois), res[0], res[1], scale)
+    ok = (rois[:, 0] >= 0) & (rois[:, 0] < n)
+    assert np.array_equal(out.cpu().numpy()[ok], ref_out[ok])
+    assert np.array_equal(argmax.cpu().numpy()[ok], ref_arg[ok])
+    assert not out.cpu().numpy()[~ok].any() and (argmax.cpu().numpy()[~ok] == -1).all()
+
+
+@pytest.mark.parametrize("shape,grid_hw,nrois,span", [
+    ((2, 32, 50, 84), (14, 14), 16, 1.25),   # 196 points: four groups of 64
+    ((1, 70, 33, 47), (7, 7), 9, 1.6),       # ragged channel tile, grids largely outside the image
+    ((1, 32, 40, 400), (7, 7), 8, 1.0),      # boxes wider than the LDS image: sampled from memory
+    ((3, 8, 6, 5), (3, 2), 12, 1.3)])        # tiny
+def test_roi_crop_lds_kernel_shapes_vs_oracle(oracle_mod, shape, grid_hw, nrois, span):
+    """roi_crop_fwd samples from an LDS copy of the grid's bounding box, cut into row chunks that share a row: bit-equal to
+    the oracle (roi_crop_cuda_kernel.cu:47-109), unwritten elements stay as the caller left them; the backward's sums to 1e-4."""
+    from detectron_pytorch_amd import _lib
+
+    n, c, h, w = shape
+    feat = syn.feature_map(n, c, h, w, seed=41)
+    grid = syn.crop_grid(nrois, grid_hw[0], grid_hw[1], seed=42, span=span)
+    grid[0] = np.random.RandomState(43).uniform(-1.1, 1.1, grid[0].shape)   # a grid that is no box: arbitrary points
+    if shape[3] == 400:
+        grid[1, ..., 1] = np.linspace(-1, 1, grid_hw[1])[None, :]           # spans the whole width
+    gtop = np.random.RandomState(44).randn(nrois, c, *grid_hw).astype(np.float32)
+    lib = _lib.lib()
+    out = torch.full((nrois, c) + tuple(grid_hw), 123.0, device=dev())
+    f, gr = to_dev(feat), to_dev(grid)
+    rc = lib.mi_roi_crop_forward(f.data_ptr(), gr.data_ptr(), out.data_ptr(), n, c, h, w, nrois, grid_hw[0], grid_hw[1],
+                                 _lib.current_stream_handle(dev()))
+    assert rc == 0, lib.mi_last_error()
+    ref = oracle_mod.roi_crop_forward(feat, grid)           # zero where nothing is written
+    ref_sentinel = oracle_mod.roi_crop_forward(feat + 1e3, grid)  # which elements ARE written: those that moved
+    written = ref_sentinel != ref
+    got = out.cpu().numpy()
+    assert np.array_equal(got[written], ref[written])
+    nw = ~written   # not written by the reference (all four taps outside), or written with in-image weights that sum to 0
+    assert ((got[nw] == 123.0) | (got[nw] == ref[nw])).all()
+    if span > 1.2:
+        assert (got == 123.0).any(), "some points of these grids have no tap in the image: they must stay unwritten"
+    gin = torch.zeros_like(f)
+    rc = lib.mi_roi_crop_backward(f.data_ptr(), gr.data_ptr(), to_dev(gtop).data_ptr(), gin.data_ptr(), n, c, h, w, nrois,
+                                  grid_hw[0], grid_hw[1], _lib.current_stream_handle(dev()))
+    assert rc == 0, lib.mi_last_error()
+    assert_close(gin, oracle_mod.roi_crop_backward(feat, grid, gtop), "roi_crop bwd")
+
+
 # ---- RoICrop ---------------------------------------------------------------------------------------
 def test_roi_crop_golden_and_oracle(oracle_mod):
     from detectron_pytorch_amd.roi_crop import RoICropFunction
