@@ -35,6 +35,8 @@ def hipcc():
 def flags():
     out = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
            "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    if os.environ.get("MI_EXTRA_DEFINES"):  # tools/ only: compile-time variants of one kernel for an A/B arm
+        out += ["-D" + d for d in os.environ["MI_EXTRA_DEFINES"].split()]
     if os.environ.get("MI_TUNING_BUILD"):  # tools/ only: keeps the MI_ROI_ALIGN_ABLATE switches alive in the kernels
         out.append("-DMI_TUNING=1")
     return out
