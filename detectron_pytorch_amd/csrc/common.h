@@ -53,7 +53,6 @@ inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
 //   MI_ROI_ALIGN_NO_WS=1       ignore the caller's workspace (no records path)
 //   MI_ROI_ALIGN_CAP=192|256|336|448|640   window pixels per channel of the NCHW forward LDS image
 //   MI_ROI_ALIGN_FWD_SPLIT=1|2|4           workgroups an NCHW forward item's stages are dealt to (0: by the launch's size)
-//   MI_ROI_ALIGN_FWD_PAIR=0|1              NCHW forward: a workgroup takes two sweep-adjacent RoIs, windows after the first land in VGPRs
 //   MI_ROI_ALIGN_BWD_TH=8|16|32            rows per backward tile
 //   MI_ROI_ALIGN_BWD_SLICE=n   RoIs per list slice of the planned backward (32; 0: no plan, no atomics)
 //   MI_ROI_ALIGN_NHWC_V / _PB / _ORDER_MUL / _ZIGZAG   channels-last forward variants
@@ -61,7 +60,7 @@ inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
 struct Tuning {
   bool force_direct, no_ws;
   int cap_px, bwd_tile_rows, bwd_slice;
-  int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag, fwd_split, fwd_pair;
+  int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag, fwd_split;
   int ablate;
   int copy_variant;  // MI_COPY_VARIANT of mi_dbg_copy_float4 (tools/copy_sweep.py)
 };

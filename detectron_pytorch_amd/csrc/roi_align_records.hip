@@ -14,7 +14,9 @@
 //       slab of the feature map a tile reads is served by one XCD's L2.  Record by scalar load -> window by LDS-DMA ->
 //       vmcnt + barrier -> bins (packed FMAs) -> LDS tile -> contiguous 16-byte stores; the stages of an item are pipelined
 //       (next window issued before the tile is stored).  (Removed after measurement: a variant that prefetched the next
-//       window under the current arithmetic, 16-channel workgroups, roles on waves, a resident ticketed grid -- see
+//       window under the current arithmetic, 16-channel workgroups, roles on waves, a resident ticketed grid, and -- round 6 --
+//       static pairs of ranks with the next window landing in VGPRs: a wave spends its time ISSUING the window pieces, not
+//       waiting for them, and register loads stall it at the same place: +28 %, profiles/r06_forward_pair_ab.txt -- see
 //       DESIGN.md section 5 and docs/history.md.)
 //   roi_align_bwd_plan / roi_align_bwd_tiles   the backward over the same records (see below).
 //
@@ -517,7 +519,7 @@ __device__ __forceinline__ bool fwd_patch_edge(const FwdRec& h, float* img, int 
 
 // Bins [pa, pb) x aligned_width of this lane's channel -> the LDS tile.  Half-wave = output column; taps of 4 bin rows in
 // flight before the first use; 0.25 * sum_iy (hy * R(y) + ly * R(y + 1)), R(row) = sum_ix (hx * F[x] + lx * F[x + 1]).
-template <int kSR, int kNSlots, int kBatch = 4>
+template <int kSR, int kNSlots>
 __device__ __forceinline__ void fwd_bins(const TabEntry* ty, const TabEntry* tx, const float* img_c, float* tile_c,
                                          int slot, int pa, int pb, int ph0, int base_off, int pitch, int aligned_width,
                                          int gh, int gw) {
@@ -572,14 +574,12 @@ __device__ __forceinline__ void fwd_bins(const TabEntry* ty, const TabEntry* tx,
           tile_c[(ph + b - ph0) * aligned_width + pw] = acc.x + acc.y;
         }
       };
-      // kBatch bin rows of taps in flight before their first use (4: the per-item kernel; the pair kernel, whose lanes
-      // also hold the next window, takes fewer)
       int ph = pa;
-      for (; ph + kBatch <= pb; ph += kBatch) rows(ph, std::integral_constant<int, kBatch>());
+      for (; ph + 4 <= pb; ph += 4) rows(ph, std::integral_constant<int, 4>());
       switch (pb - ph) {
-        case 3: if (kBatch > 3) rows(ph, std::integral_constant<int, (kBatch > 3 ? 3 : 1)>()); break;
-        case 2: if (kBatch > 2) rows(ph, std::integral_constant<int, (kBatch > 2 ? 2 : 1)>()); break;
-        case 1: if (kBatch > 1) rows(ph, std::integral_constant<int, 1>()); break;
+        case 3: rows(ph, std::integral_constant<int, 3>()); break;
+        case 2: rows(ph, std::integral_constant<int, 2>()); break;
+        case 1: rows(ph, std::integral_constant<int, 1>()); break;
         default: break;
       }
     }
@@ -788,189 +788,6 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     pp = n_pp;
     row0 = n_row0;
     nrows = n_nrows;
-  }
-}
-
-// -------------------------------------------------------------------------------------------------------------------
-// roi_align_fwd_records_pair (round 6): the register file as a second landing zone.  The per-item kernel above is a latency
-// chain -- counters: HBM, L2 and the TA all below half of their rates, three workgroups per CU is all the LDS holds, and a
-// workgroup's 43 KB image receives bytes only ~40 % of its life (idle through bins and stores).  Here a workgroup takes a
-// STATIC PAIR of sweep-adjacent ranks (2 p, 2 p + 1) of one channel tile and walks their stages as one sequence of units:
-// only the first unit's window arrives by LDS-DMA; the window of every later unit is fetched into VGPRs (buffer_load_dwordx4,
-// 11 pieces per lane = the whole 336-pixel image of the wave's 8 channels, lanes flattened over (channel, row, 16-byte group))
-// BEFORE the current unit's landing wait, stays in flight under its bins, and is written into the image (ds_write) once the
-// bins are done.  Same addresses, clamps and over-reads as fwd_issue_window, so the image -- and the output -- is bit-equal.
-// Hardware dispatch balances at 2-item granularity (no tickets, no resident grid).  168 VGPRs = still three waves per SIMD.
-// -------------------------------------------------------------------------------------------------------------------
-typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-constexpr int kPairPieces = 11;  // ceil(8 channels x 84 groups / 64 lanes)
-#ifndef MI_PAIR_BATCH
-#define MI_PAIR_BATCH 2
-#endif
-constexpr int kPairBatch = MI_PAIR_BATCH;  // bin rows of taps in flight in the pair kernel's bins
-
-struct PairUnit {
-  int it;                 // 0 / 1: item of the pair; -1: none
-  int k;                  // stage of the item
-  int pp, row0, nrows;    // ph0 | ph1 << 16, first window row, rows
-};
-
-template <int kSR, int kCap, int kA>
-__global__ void __launch_bounds__(kCT * 8) __attribute__((amdgpu_waves_per_eu(3, 3)))
-roi_align_fwd_records_pair(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
-                           const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height_arg,
-                           int aligned_width_arg, int sampling_ratio, int single) {
-  const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
-  constexpr int kChPerWave = kCT / (kThreads / 64);
-  static_assert(kChPerWave * (kCap / 4) <= kPairPieces * 64, "a unit's window must fit the lane's pieces");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kPlane = kCap | 1;
-  constexpr int kTileWords = kCT * (kTileBins + 1);
-  TabEntry* tab = reinterpret_cast<TabEntry*>(smem);            // [2 items][y: kMaxS | x: kMaxS]
-  float* tile = reinterpret_cast<float*>(tab + 4 * kMaxS);
-  float* img = tile + kTileWords;
-  const int tid = threadIdx.x;
-  const int bins = aligned_height * aligned_width;
-  const int tiles = channels / kCT;
-  const int pair = blockIdx.x / tiles;
-  const int c0 = (blockIdx.x - pair * tiles) * kCT;
-  const int wave = uniform(tid >> 6), lane = tid & 63;
-  const int cl = tid % kCT, slot = (tid / kCT) & 7;
-  const int* __restrict__ records = ws + kCounterDwords;
-  // single (MI_ROI_ALIGN_FWD_PAIR=2, measurement only): one item per workgroup, only its later stages land in registers
-  const int pos0 = single ? pair : 2 * pair, pos1 = single ? pair : min(2 * pair + 1, num_rois - 1);
-  const bool two = !single && 2 * pair + 1 < num_rois;
-  const FwdRec h0 = fwd_load_rec(records, pos0), h1 = fwd_load_rec(records, pos1);
-  const int gh = kSR > 0 ? kSR : 0, gw = kSR > 0 ? kSR : 0;  // (kSR > 0 only: the launcher sends adaptive grids to the per-item kernel)
-  // items the LDS image cannot serve: reference order, straight from memory
-  if (!(h0.flags & kFlagFast))
-    fwd_direct_item<kCT, kThreads>(h0, lv, rois, out + ((long long)h0.r * channels + c0) * bins, tid, c0, channels,
-                                   aligned_height, aligned_width, sampling_ratio);
-  if (two && !(h1.flags & kFlagFast))
-    fwd_direct_item<kCT, kThreads>(h1, lv, rois, out + ((long long)h1.r * channels + c0) * bins, tid, c0, channels,
-                                   aligned_height, aligned_width, sampling_ratio);
-  const int n0 = (h0.flags & kFlagFast) ? h0.nstages : 0, n1 = (two && (h1.flags & kFlagFast)) ? h1.nstages : 0;
-  if (n0 + n1 == 0) return;
-  {  // warm this XCD's L2 with the records a later workgroup of this XCD starts from (see roi_align_fwd_records)
-    constexpr int kAhead = 64;
-    const int ahead = pos0 + kAhead;
-    if (wave == kThreads / 64 - 1 && ahead < num_rois && lane < 26)
-      dma_dword(make_srd(records + (long long)ahead * kRecDwords, 2 * kRecDwords * 4), lds_addr_uniform(tile),
-                (unsigned)((lane % 13) * 128 + (lane / 13) * kRecDwords * 4), 0u);
-  }
-  const const_int_ptr rec0 = (const_int_ptr)(uintptr_t)(records + (long long)pos0 * kRecDwords);
-  const const_int_ptr rec1 = (const_int_ptr)(uintptr_t)(records + (long long)pos1 * kRecDwords);
-  auto unit_at = [&](int it, int k) {  // stage k of item it; stage 0 rides in the header
-    PairUnit u;
-    u.it = it;
-    u.k = k;
-    const FwdRec& h = it ? h1 : h0;
-    u.pp = h.st_pp;
-    u.row0 = h.st_row0;
-    u.nrows = h.st_nrows;
-    if (k > 0) {
-      const const_int_ptr st = (it ? rec1 : rec0) + kRecStages + 4 * k;
-      u.pp = st[0];
-      u.row0 = st[1];
-      u.nrows = st[2];
-    }
-    return u;
-  };
-  auto next_of = [&](const PairUnit& u) {
-    if (u.k + 1 < (u.it ? n1 : n0)) return unit_at(u.it, u.k + 1);
-    if (u.it == 0 && n1 > 0) return unit_at(1, 0);
-    PairUnit none;
-    none.it = -1;
-    none.k = none.pp = none.row0 = none.nrows = 0;
-    return none;
-  };
-  PairUnit cur = n0 > 0 ? unit_at(0, 0) : unit_at(1, 0);
-  // ---- the first unit by LDS-DMA, the axis tables of both items ----
-  const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kPlane);
-  fwd_issue_window<kChPerWave, kPlane>(cur.it ? h1 : h0, c0 + wave * kChPerWave, plane0, lane, cur.row0, cur.nrows);
-  if (n0 > 0) fwd_issue_tables(records, pos0, wave, lane, tab, aligned_height * gh, aligned_width * gw);
-  if (n1 > 0) fwd_issue_tables(records, pos1, wave, lane, tab + 2 * kMaxS, aligned_height * gh, aligned_width * gw);
-  // One round of the loop below: this unit's bins and store, with (kNext) the next unit's window in flight in registers.
-  // Two straight-line instances (with / without a next unit) rather than conditions inside one: hipcc's s_waitcnt
-  // insertion merges paths without looking at their conditions, and "loads issued on one path, consumed on another"
-  // leaves it believing the registers still have loads pending -- it then drains the stores at the top of the next round
-  // before it lets the address arithmetic reuse them.
-  auto round = [&](const PairUnit& cur, const PairUnit& nxt, bool first, auto has_next) {
-    constexpr bool kNext = decltype(has_next)::value;
-    const FwdRec& h = cur.it ? h1 : h0;
-    v4u_t reg[kPairPieces];
-    unsigned n_groups = 1, n_groups_magic = 0;
-    if (kNext) {
-      const FwdRec& hn = nxt.it ? h1 : h0;
-      const unsigned plane_bytes = (unsigned)hn.height * (unsigned)hn.width * 4u;
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(reinterpret_cast<const char*>(hn.img)) + (size_t)(c0 + wave * kChPerWave) * plane_bytes, (short)0,
-          (int)((unsigned)kChPerWave * plane_bytes), 0x00020000);
-      const unsigned gpr = (((unsigned)hn.ww + 3u) & ~3u) >> 2, groups = (unsigned)nxt.nrows * gpr;
-      const unsigned groups_magic = (1u << 20) / groups + 1u;
-      n_groups = groups;
-      n_groups_magic = groups_magic;
-#pragma unroll
-      for (int kk = 0; kk < kPairPieces; kk++) {
-        const unsigned j = (unsigned)(kk * 64 + lane);
-        const unsigned c = __umul24(j, groups_magic) >> 20;  // j / groups
-        const unsigned g = j - __umul24(c, groups);
-        const unsigned q = __umul24(g, hn.gmagic) >> 20;      // g / gpr
-        const unsigned gc = g - __umul24(q, gpr);
-        const bool live = c < (unsigned)kChPerWave;
-        const unsigned voff = c * plane_bytes + (__umul24(min((unsigned)nxt.row0 + q, (unsigned)hn.height - 1u), (unsigned)hn.width) +
-                                                 (unsigned)hn.wx0 + gc * 4u) * 4u;
-        // a piece past the wave's channels reads past the descriptor: zeros, no request
-        reg[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, live ? voff : 0xfffffff0u, 0, 0);
-      }
-    }
-    // this unit's window is in the image: by DMA (first unit: everything older than the register loads), or written
-    // from registers at the end of the previous round
-    if (first) {
-      if (kNext) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    const int pitch = ((h.ww + 3) & ~3) * 4;
-    if (fwd_patch_edge<kCT, kThreads, kPlane>(h, img, tid, cur.nrows)) __syncthreads();
-    const int ph0 = cur.pp & 0xffff, ph1 = cur.pp >> 16;
-    const int nb = (ph1 - ph0) * aligned_width;
-    const int ts = nb | 1;
-    const TabEntry* t = tab + cur.it * 2 * kMaxS;
-    fwd_bins<kSR, kSlots, kPairBatch>(t, t + kMaxS, img + cl * kPlane, tile + cl * ts, slot, ph0, ph1, ph0, cur.row0 * pitch,
-                                      pitch, aligned_width, gh, gw);
-    __syncthreads();  // the tile is complete, the image is free
-    if (kNext) {
-      // every register is consumed on every path (see above), then the live pieces go to their place in the image -- computed
-      // again rather than kept in a register through the bins
-#pragma unroll
-      for (int kk = 0; kk < kPairPieces; kk++) asm volatile("" ::"v"(reg[kk]));
-      const unsigned img0 = (unsigned)(uintptr_t)(lds_cfloat_t)(img + wave * kChPerWave * kPlane);
-#pragma unroll
-      for (int kk = 0; kk < kPairPieces; kk++) {
-        const unsigned j = (unsigned)(kk * 64 + lane);
-        const unsigned c = __umul24(j, n_groups_magic) >> 20;  // j / groups
-        const unsigned g = j - __umul24(c, n_groups);
-        if (c < (unsigned)kChPerWave) {
-          __attribute__((address_space(3))) unsigned* d =
-              (__attribute__((address_space(3))) unsigned*)(uintptr_t)(img0 + c * (unsigned)(kPlane * 4) + g * 16u);
-          d[0] = reg[kk].x;
-          d[1] = reg[kk].y;
-          d[2] = reg[kk].z;
-          d[3] = reg[kk].w;
-        }
-      }
-    }
-    float* __restrict__ dst = out + ((long long)h.r * channels + c0) * bins;
-    fwd_store<kCT, kThreads>(tile, dst, tid, ph0, nb, ts, bins, aligned_width);
-  };
-  bool first = true;
-  while (cur.it >= 0) {
-    const PairUnit nxt = next_of(cur);
-    if (nxt.it >= 0) round(cur, nxt, first, std::true_type());
-    else round(cur, nxt, first, std::false_type());
-    first = false;
-    cur = nxt;
   }
 }
 
@@ -1276,7 +1093,8 @@ roi_align_bwd_untabled(const float* __restrict__ top_grad, const float* __restri
 // kA > 0: aligned_height == aligned_width == kA at compile time (7 and 14, the sizes of the box / mask heads): the
 // per-lane index arithmetic of the g block (divisions by the channel stride and the padded height, once per workgroup
 // for eight DMA pieces per lane) and the loop bounds of pass 1 fold to constants.
-template <int kSR, int KC, int kTH, int kA = 0>
+// kNHWC: the gradient maps are stored channels-last (its store path costs the planar instance registers it does not have)
+template <int kNHWC, int KC, int kTH, int kA = 0>
 __global__ void __launch_bounds__(kTH * 32)
     __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
 roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, int* __restrict__ ws,
@@ -1520,17 +1338,50 @@ roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, int
 #pragma unroll
   for (int c = 0; c < KC; c++) acc[c] = acc2[c >> 1][c & 1];
   const int row = y0 + prow, col = x0 + pcol;
-  if (row < height && col < width && nslices > 1) {
+  // Channels-last, whole list (no atomics): a lane holds ITS pixel's KC channels, and storing them from there is KC / 4
+  // 16-byte stores per lane, each instruction touching 64 cache lines (the pixels lie channels * 4 bytes apart).  The sums go
+  // through LDS instead -- [pixel][KC + 4] over the g / T buffers nobody reads any more, as many tile rows per pass as fit --
+  // and leave with KC / 4 neighbouring lanes on one pixel's 4 * KC-byte run: whole lines per store instruction.
+  const int xpose_rows = min((int)kTH, (2 * g_words + aligned_height * kTW * kCS) / (kTW * kCS));
+  if (kNHWC && nslices == 1 && xpose_rows > 0 && !(ablate & 4)) {
+    float* X = g0;
+    constexpr int kQ = KC / 4;
+    for (int r0 = 0; r0 < kTH; r0 += xpose_rows) {
+      __syncthreads();  // the visit loop (first pass) / the previous pass is done with the buffer
+      if (prow >= r0 && prow < r0 + xpose_rows) {
+        float4* xp = reinterpret_cast<float4*>(X + ((prow - r0) * kTW + pcol) * kCS);
+#pragma unroll
+        for (int c4 = 0; c4 < kQ; c4++) xp[c4] = make_float4(acc[4 * c4 + 0], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
+      }
+      __syncthreads();
+      const int rows_here = min(xpose_rows, (int)kTH - r0);
+      for (int i = tid; i < rows_here * kTW * kQ; i += kThreads) {
+        const int px = i / kQ, q = i - px * kQ;
+        const int rr = y0 + r0 + px / kTW, cc = x0 + (px & (kTW - 1));
+        if (rr >= height || cc >= width) continue;
+        float4 v = reinterpret_cast<const float4*>(X + px * kCS)[q];
+        float4* dst = reinterpret_cast<float4*>(bottom_grad + (((long long)n * height + rr) * width + cc) * channels + c0) + q;
+        if (!(overwrite & 1)) {
+          const float4 o = *dst;
+          v.x += o.x;
+          v.y += o.y;
+          v.z += o.z;
+          v.w += o.w;
+        }
+        *dst = v;
+      }
+    }
+  } else if (row < height && col < width && nslices > 1) {
     // the slices of a long list add into the tile the plan kernel zero-filled (or the caller's values): hardware fp32
     // atomics, the order of the slices' sums is not fixed (the reference's backward is atomic throughout)
-    const long long cs = (overwrite & 2) ? 1 : (long long)height * width;
-    float* dst = (overwrite & 2) ? bottom_grad + (((long long)n * height + row) * width + col) * channels + c0
+    const long long cs = kNHWC ? 1 : (long long)height * width;
+    float* dst = kNHWC ? bottom_grad + (((long long)n * height + row) * width + col) * channels + c0
                                  : bottom_grad + (((long long)n * channels + c0) * height + row) * width + col;
 #pragma unroll
     for (int c = 0; c < KC; c++)
       if (acc[c] != 0.f) atomicAdd(dst + c * cs, acc[c]);
   } else if (row < height && col < width) {
-    if (overwrite & 2) {
+    if (kNHWC) {
       float4* dst = reinterpret_cast<float4*>(bottom_grad + (((long long)n * height + row) * width + col) * channels + c0);
 #pragma unroll
       for (int c4 = 0; c4 < KC / 4; c4++) {
@@ -1614,20 +1465,6 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
         tuning().ablate MI_TL_ARG);                                                                                   \
   } while (0)
   const int a = aligned_height == aligned_width ? aligned_height : 0;
-  if constexpr (kCap == 336) {
-    if (tuning().fwd_pair > 0 && sampling_ratio == 2 && (a == 7 || a == 14) && split == 1) {
-      const size_t lds_pair = lds + 2 * kMaxS * sizeof(TabEntry);
-      const int single = tuning().fwd_pair == 2 ? 1 : 0;
-      const int pairs = (single ? num_rois : (num_rois + 1) / 2) * (channels / kCT);
-      if (a == 7)
-        roi_align_fwd_records_pair<2, 336, 7><<<pairs, kThreads, lds_pair, stream>>>(
-            lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, single);
-      else
-        roi_align_fwd_records_pair<2, 336, 14><<<pairs, kThreads, lds_pair, stream>>>(
-            lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, single);
-      return check_launch("roi_align_fwd_records_pair");
-    }
-  }
   if (sampling_ratio == 2 && kCap == 336 && a == 7)
     MI_LAUNCH_REC(2, (kCap == 336 ? 7 : 0));
   else if (sampling_ratio == 2 && kCap == 336 && a == 14)
@@ -1708,7 +1545,7 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
     if (rc != MI_OK) return rc;
     grid = (tiles + bwd_plan_extra(num_rois)) * (channels / kc);  // upper bound of the entries: every tile once + the budget of extra slices
   }
-#define MI_LAUNCH_TILES_A(SR, KC, TH, A)                                                                              \
+#define MI_LAUNCH_TILES_A(SR, KC, TH, A) /* SR: 1 = channels-last gradient maps */                                      \
   do {                                                                                                                \
     if (lds > 64 * 1024)                                                                                              \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC, TH, A>),                  \
@@ -1736,14 +1573,14 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
       MI_LAUNCH_TILES_TH(SR, KC, 8);                                                                                  \
   } while (0)
   if (g_ablate_p & 8) {
-  } else if (kc == 32 && sampling_ratio == 2) {
-    MI_LAUNCH_TILES(2, 32);
-  } else if (kc == 32) {
+  } else if (kc == 32 && !nhwc) {
     MI_LAUNCH_TILES(0, 32);
-  } else if (sampling_ratio == 2) {
-    MI_LAUNCH_TILES(2, 16);
-  } else {
+  } else if (kc == 32) {
+    MI_LAUNCH_TILES(1, 32);
+  } else if (!nhwc) {
     MI_LAUNCH_TILES(0, 16);
+  } else {
+    MI_LAUNCH_TILES(1, 16);
   }
 #undef MI_LAUNCH_TILES
 #undef MI_LAUNCH_TILES_TH

@@ -19,7 +19,7 @@ import torch  # noqa: E402
 from detectron_pytorch_amd import _lib, synthetic as syn  # noqa: E402
 
 TUNING_VARS = ("MI_ROI_ALIGN_BWD_SLICE", "MI_ROI_ALIGN_BWD_TH", "MI_ROI_ALIGN_CAP", "MI_ROI_ALIGN_ABLATE", "MI_ROI_ALIGN_IMPL",
-               "MI_ROI_ALIGN_NO_WS", "MI_ROI_ALIGN_FWD_PAIR", "MI_ROI_ALIGN_NHWC_V", "MI_ROI_ALIGN_NHWC_PB", "MI_ROI_ALIGN_NHWC_ZIGZAG", "MI_ROI_ALIGN_FWD_SPLIT")
+               "MI_ROI_ALIGN_NO_WS", "MI_ROI_ALIGN_NHWC_V", "MI_ROI_ALIGN_NHWC_PB", "MI_ROI_ALIGN_NHWC_ZIGZAG", "MI_ROI_ALIGN_FWD_SPLIT")
 _LIBS = {}
 
 
@@ -112,25 +112,29 @@ def shapes(dev, which):
         out["fpn_step_%s" % ("box" if res == 7 else "mask")] = (call, o, (maps, rois, idx, ws, ftab))
     # ---- backward cases: (call, output, keep, setup) -- setup(lib) runs that library's forward so that ITS records are in
     # the workspace (the record layout differs between builds); the timed call has RECORDS_READY | OVERWRITE set
-    if "bwd_config2" in which:
+    for key, layout in (("bwd_config2", 0), ("bwd_nhwc", 1)):
+        if key not in which:
+            continue
         from detectron_pytorch_amd.roi_align import _backward_workspace_bytes
         n, r, res = 1, 512, 7
         feat = torch.from_numpy(syn.feature_map(n, c, h, w, seed=0)).to(dev)
+        if layout:
+            feat = feat.permute(0, 2, 3, 1).contiguous()
         rois = torch.from_numpy(syn.rois_canonical(r, n, seed=0)).to(dev)
         o = torch.empty((r, c, res, res), device=dev)
         gtop = torch.randn(r, c, res, res, device=dev)
-        gin = torch.empty(n, c, h, w, device=dev)
+        gin = torch.empty_like(feat)
         ws = torch.empty(_backward_workspace_bytes([(h, w)], n, r) + 65536, dtype=torch.uint8, device=dev)
         stream = _lib.current_stream_handle(dev)
 
-        def setup(lib, n=n, r=r, res=res, feat=feat, rois=rois, o=o, ws=ws):
+        def setup(lib, n=n, r=r, res=res, feat=feat, rois=rois, o=o, ws=ws, layout=layout):
             assert lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), o.data_ptr(), n, c, h, w, r, res, res,
-                                               scale, 2, 0, 0, ws.data_ptr(), ws.numel(), stream) == 0
+                                               scale, 2, 0, layout, ws.data_ptr(), ws.numel(), stream) == 0
 
-        def call(lib, n=n, r=r, res=res, gtop=gtop, rois=rois, gin=gin, ws=ws):
+        def call(lib, n=n, r=r, res=res, gtop=gtop, rois=rois, gin=gin, ws=ws, layout=layout):
             return lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), n, c, h, w, r, res, res,
-                                                scale, 2, 0, 0, ws.data_ptr(), ws.numel(), 3, stream)
-        out["bwd_config2"] = (call, gin, (feat, rois, ws, gtop, o), setup)
+                                                scale, 2, 0, layout, ws.data_ptr(), ws.numel(), 3, stream)
+        out[key] = (call, gin, (feat, rois, ws, gtop, o), setup)
     for key, res in (("bwd_fpn", 7), ("bwd_fpnmask", 14)):
         if key not in which:
             continue
