@@ -288,9 +288,10 @@ def sync_parameters(model, src=0, group=None, bucket_bytes=BUCKET_BYTES):
 
 
 def replica_checksum(model):
-    """A 64-bit checksum of every parameter and buffer: the wrapping int64 sum of the tensors' bit patterns, each weighted
-    by its position (so that swapped tensors do not cancel).  Cheap enough to run every K steps: one pass over the
-    state, no host copy until `.item()`."""
+    """A 64-bit checksum of every parameter and buffer: the wrapping int64 sum of the tensors' bit patterns, every ELEMENT
+    weighted by an odd multiplier of its position and of its tensor's index (differences inside a tensor -- swapped
+    elements, +d here and -d there -- do not cancel, nor do swapped tensors).  Cheap enough to run every K steps: one pass
+    over the state, no host copy until `.item()`."""
     total = None
     for k, t in enumerate(_state_tensors(model)):
         if t.numel() == 0:
@@ -304,7 +305,9 @@ def replica_checksum(model):
             bits = flat.view(torch.int16).to(torch.int64)
         else:
             bits = flat.view(torch.uint8).to(torch.int64)
-        s = (bits * (2 * k + 1)).sum()
+        # odd per-element weight (Knuth's multiplicative constant over the position, wrapping int64 arithmetic)
+        pos = torch.arange(bits.numel(), dtype=torch.int64, device=bits.device)
+        s = (bits * ((pos * 2654435761 + (2 * k + 1)) | 1)).sum()
         total = s if total is None else total + s
     return total if total is not None else torch.zeros((), dtype=torch.int64)
 

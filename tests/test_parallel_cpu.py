@@ -10,6 +10,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -93,7 +94,7 @@ def _reducer_job(rank, world_size, overlap, detect_unused):
     ref = _Net()
     ref.load_state_dict(net.state_dict())
     red = parallel.GradientAllReducer(net.parameters(), bucket_bytes=32 << 10, overlap=overlap, detect_unused=detect_unused)
-    assert red.active and red.world == 2 and len(red.buckets) >= 2
+    assert red.active and red.world == world_size and len(red.buckets) >= 2
     opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
     opt_ref = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
     xs = [torch.randn(8, 32, generator=torch.Generator().manual_seed(10 * r + 1)) for r in range(world_size)]
@@ -137,6 +138,16 @@ def _no_overlap_job(rank, world_size):
 def test_reducer_hook_mode_matches_the_reference_mean_and_replicas_stay_identical():
     out = _run(_hooks_job)
     assert out[0] == out[1]  # bit-identical parameter checksums after every one of the three SGD steps
+
+
+@pytest.mark.parametrize("world_size", [4, 8])
+def test_reducer_at_four_and_eight_ranks(world_size):
+    """The rank counts BASELINE's configs 4 / 5 run at.  Hook mode with in-order bucket launches (a head without work on
+    every rank but one in step 1), then the no-overlap mode with unused-parameter detection: gradients equal the
+    single-process mean over the ranks' losses, the replicas' parameter checksums stay bit-identical over three SGD steps."""
+    for job in (_hooks_job, _no_overlap_job):
+        out = _run(job, world_size)
+        assert all(o == out[0] for o in out)
 
 
 def test_reducer_without_overlap_and_with_unused_parameter_detection():
@@ -190,13 +201,16 @@ def _sync_and_losses_job(rank, world_size):
     return diverged, same_as_rank0, sent, logged, int(parallel.replica_checksum(net).item())
 
 
-def test_sync_parameters_makes_a_perturbed_replica_bit_identical_and_losses_are_averaged():
-    out = _run(_sync_and_losses_job)
-    assert out[0][0] and out[1][0]                       # the divergence was seen on both ranks
-    assert out[0][1] and out[1][1]                       # afterwards both hold rank 0's state, bit for bit
-    assert out[0][2] == out[1][2] > 0 and out[0][4] == out[1][4]
-    want = {"losses": {"loss_cls": 1.5, "loss_bbox": 0.75}, "metrics": {"accuracy_cls": 0.5}, "total_loss": 4.5}
-    assert out[0][3] == out[1][3] == want                # = the mean of the shard values (training_stats.py:84)
+@pytest.mark.parametrize("world_size", [2, 4, 8])
+def test_sync_parameters_makes_a_perturbed_replica_bit_identical_and_losses_are_averaged(world_size):
+    out = _run(_sync_and_losses_job, world_size)
+    assert all(o[0] for o in out)                        # the divergence (of rank 1 alone) was seen on every rank
+    assert all(o[1] for o in out)                        # afterwards all hold rank 0's state, bit for bit
+    assert all(o[2] == out[0][2] > 0 and o[4] == out[0][4] for o in out)
+    mean_rank = (world_size - 1) / 2.0
+    want = {"losses": {"loss_cls": 1.0 + mean_rank, "loss_bbox": 0.5 * (mean_rank + 1)},
+            "metrics": {"accuracy_cls": 0.25 + 0.5 * mean_rank}, "total_loss": 3.0 * (mean_rank + 1)}
+    assert all(o[3] == want for o in out)                # = the mean of the shard values (training_stats.py:84)
 
 
 def _no_hook_job(rank, world_size):
@@ -215,8 +229,9 @@ def _no_hook_job(rank, world_size):
     return False
 
 
-def test_detect_unused_without_hooks_on_one_rank_raises_on_every_rank():
-    assert _run(_no_hook_job) == [True, True]
+@pytest.mark.parametrize("world_size", [2, 4, 8])
+def test_detect_unused_without_hooks_on_one_rank_raises_on_every_rank(world_size):
+    assert _run(_no_hook_job, world_size) == [True] * world_size
 
 
 def test_replica_helpers_without_a_process_group():
@@ -227,6 +242,14 @@ def test_replica_helpers_without_a_process_group():
     with torch.no_grad():
         net.weight[0, 0] += 1e-3
     assert int(parallel.replica_checksum(net).item()) != c0
+    # differences INSIDE one tensor must not cancel: two elements swapped, and +d / -d on two integer elements
+    buf = torch.nn.Module()
+    buf.register_buffer("a", torch.tensor([5, 9, 2, 7], dtype=torch.int64))
+    c1 = int(parallel.replica_checksum(buf).item())
+    buf.a[0], buf.a[1] = 9, 5
+    assert int(parallel.replica_checksum(buf).item()) != c1
+    buf.a[0], buf.a[1] = 5 + 3, 9 - 3
+    assert int(parallel.replica_checksum(buf).item()) != c1
 
 
 def test_single_process_is_a_no_op():
