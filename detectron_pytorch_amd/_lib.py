@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_detectron_ops.so")
 
 MI_OK = 0
-ABI_VERSION = 5  # MI_ABI_VERSION of include/mi_detectron_ops.h this binding was written against
+ABI_VERSION = 6  # MI_ABI_VERSION of include/mi_detectron_ops.h this binding was written against
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 ROI_ALIGN_CAFFE2, ROI_ALIGN_LEGACY = 0, 1
 NMS_GE_ORIG_ASC, NMS_GT_SORTED_POS = 0, 1
@@ -49,6 +49,7 @@ SIGNATURES = {
     "mi_topk_batched_workspace_bytes": (_c_size_t, [_c_int, _c_void_p, _c_void_p]),
     "mi_topk_batched": (_c_int, [_c_int] + [_c_void_p] * 6 + [_c_size_t, _c_void_p]),
     "mi_rpn_collect_candidates": (_c_int, [_c_int] + [_c_void_p] * 6 + [_c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "mi_fpn_level_index_from_restore": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "mi_rpn_collect_finish": (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [_c_float, _c_float] + [_c_void_p] * 4),
     "mi_roi_align_fpn_supported": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "mi_keypoint_nms_oks": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, ctypes.c_double, _c_void_p, _c_void_p, _c_void_p]),

@@ -37,8 +37,11 @@ inline void begin_call() { (void)hipGetLastError(); }
 
 inline int ceil_div(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
 
-// Grid size of a grid-stride element-wise kernel: enough workgroups to fill 256 CUs x 8.
-inline int grid_for(long long total, int block, int max_blocks = 256 * 16) {
+int compute_units();  // of the current device; asked once (abi.hip)
+
+// Grid size of a grid-stride element-wise kernel: at most 16 workgroups per compute unit of the device.
+inline int grid_for(long long total, int block) {
+  const long long max_blocks = (long long)compute_units() * 16;
   long long g = (total + block - 1) / block;
   if (g < 1) g = 1;
   if (g > max_blocks) g = max_blocks;
@@ -65,7 +68,6 @@ struct Tuning {
   int copy_variant;  // MI_COPY_VARIANT of mi_dbg_copy_float4 (tools/copy_sweep.py)
 };
 const Tuning& tuning();
-int compute_units();  // of the current device; asked once
 void reload_tuning();  // mi_dbg_reload_tuning() only
 
 #ifdef MI_TUNING

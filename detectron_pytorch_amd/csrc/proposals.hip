@@ -221,6 +221,51 @@ extern "C" int mi_rpn_collect_finish(const float* top_scores, const int64_t* top
   return mi::check_launch("rpn_collect_finish");
 }
 
+// Row i of a pyramid's RoI blob in dataloader order sits at position restore[i] of the level-major concatenation
+// (utils/fpn.py:31-58 builds rois_idx_restore_int32 that way): its level is the one whose rows span that position.
+struct LevelSpans {
+  int count;
+  int end[8];    // exclusive prefix ends of the levels' row counts, level-major
+  int value[8];  // what to write for a row of that span
+};
+template <typename Index>
+__global__ void __launch_bounds__(256)
+fpn_level_of_restore(const Index* __restrict__ restore, int rows, const LevelSpans spans, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  const long long pos = (long long)restore[i];
+  int v = spans.value[spans.count - 1];
+  for (int k = spans.count - 1; k >= 0; k--)
+    if (pos < spans.end[k]) v = spans.value[k];
+  out[i] = v;
+}
+
+extern "C" int mi_fpn_level_index_from_restore(const void* restore, int restore_is_int64, int rows, int num_spans,
+                                               const int* span_rows_host, const int* span_value_host, int32_t* out,
+                                               mi_stream_t stream) {
+  mi::begin_call();
+  MI_REQUIRE(rows >= 0 && num_spans >= 1 && num_spans <= 8, "fpn_level_index_from_restore: 1..8 spans");
+  if (rows == 0) return MI_OK;
+  MI_REQUIRE(restore != nullptr && span_rows_host != nullptr && span_value_host != nullptr && out != nullptr,
+             "fpn_level_index_from_restore: null pointer");
+  LevelSpans sp;
+  sp.count = num_spans;
+  int run = 0;
+  for (int k = 0; k < num_spans; k++) {
+    MI_REQUIRE(span_rows_host[k] >= 0, "fpn_level_index_from_restore: negative span");
+    run += span_rows_host[k];
+    sp.end[k] = run;
+    sp.value[k] = span_value_host[k];
+  }
+  if (restore_is_int64)
+    fpn_level_of_restore<long long><<<mi::ceil_div(rows, 256), 256, 0, mi::as_stream(stream)>>>(
+        static_cast<const long long*>(restore), rows, sp, out);
+  else
+    fpn_level_of_restore<int><<<mi::ceil_div(rows, 256), 256, 0, mi::as_stream(stream)>>>(static_cast<const int*>(restore),
+                                                                                          rows, sp, out);
+  return mi::check_launch("fpn_level_of_restore");
+}
+
 extern "C" int mi_rpn_decode_proposals(const float* bbox_pred, const float* topk_scores, const int64_t* topk_idx,
                                        const float* im_info, const double* base_anchors_host, int num_images,
                                        int num_anchors, int height, int width, int k, double feat_stride,

@@ -6,15 +6,11 @@
 //   LEGACY variant: lib/model/roi_align/src/roi_align_kernel.cu:15-70 (fwd), :94-143 (bwd)
 //
 // Kernels in this file:
-//   roi_align_fwd_direct / roi_align_bwd_direct   one lane per output element, any layout
-//       (generic path: NHWC storage, legacy variant, windows that do not fit the LDS tile).
-//   roi_align_fwd_tile   NCHW fast path: one workgroup per (RoI, 64-channel tile); the RoI's
-//       feature window is staged in LDS with coalesced row loads, lanes own channels so every
-//       LDS read is bank-conflict-free and all sampling geometry is wave-uniform (SALU);
-//       results are transposed through LDS and stored as contiguous rows.
-//   roi_align_bwd_tile   mirror image: per-(RoI, channel tile) gradient window accumulated in
-//       LDS without atomics (a lane owns its channel plane), flushed with one coalesced
-//       atomic add per window pixel instead of 4*samples per output element.
+//   roi_align_fwd_direct / roi_align_bwd_direct   one lane per output element, any layout, reference operation order
+//       (bit-exact): the generic path -- legacy variant, shapes / alignments the fast paths decline, MI_ROI_ALIGN_IMPL=direct.
+//   the dispatch of mi_roi_align_* to the fast paths, which live in files of their own: roi_align_records.hip (records,
+//       NCHW forward, tile backward), roi_align_nhwc.hip (channels-last forward), roi_align_fwd_tile.hip (NCHW forward
+//       without a workspace).
 #include "common.h"
 #include "roi_align_device.h"
 

@@ -15,18 +15,18 @@ and sampling, H2D of the RoI blobs per level and per head: SURVEY.md section 3.1
 
 The training forward has no device-to-host synchronisation.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import fpn_proposals, nms, roi_xform, segms
 from .. import roi_align as roi_align_mod
-
-import os
+from . import fpn as fpn_mod
+from . import heads, targets
 
 # A/B switch of the measurement tools: 0 = the box head's pooling call writes its records itself
 PRODUCER_RECORDS = os.environ.get("MI_RCNN_PRODUCER_RECORDS", "1") != "0"
-from . import fpn as fpn_mod
-from . import heads, targets
 
 
 def _conv_body(cfg):

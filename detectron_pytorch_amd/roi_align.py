@@ -53,8 +53,8 @@ def _check_inputs(features, rois):
 def roi_align_forward(features, rois, aligned_height, aligned_width, spatial_scale, sampling_ratio,
                       variant=_lib.ROI_ALIGN_CAFFE2, return_workspace=False, want_backward=None):
     """Raw forward (no autograd): returns a new [R, C, ah, aw] tensor and, on request, the device scratch holding the
-    per-RoI records a backward over the same rois can reuse -- None when the forward wrote none (NCHW features: the
-    tile-centric kernel needs no scratch at all).  want_backward (default: return_workspace): size the scratch for the
+    per-RoI records a backward over the same rois can reuse -- None when the forward wrote none (shapes only the generic
+    kernel serves).  want_backward (default: return_workspace): size the scratch for the
     planned backward, which also makes the forward write the records' backward block (2 us; an inference call skips it)."""
     if want_backward is None:
         want_backward = return_workspace

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from .roi_align import RoIAlignFunction, roi_align_fpn, roi_align_fpn_supported
 from .roi_pool import RoIPoolFunction
 from .roi_crop import RoICropFunction
@@ -123,31 +124,38 @@ def roi_feature_transform(blobs_in, rpn_ret, blob_rois="rois", method="RoIPoolF"
         return out
     level_rois = [rpn_ret["%s_fpn%d" % (blob_rois, lvl)] for lvl in range(k_min, k_max + 1)]
     restore = rpn_ret[blob_rois + "_idx_restore_int32"]
-    if isinstance(restore, np.ndarray):
-        restore = torch.from_numpy(restore.astype(np.int64, copy=False))
     device = blobs_in[0].device
-    restore = restore.to(device=device, dtype=torch.int64)
+    if isinstance(restore, np.ndarray):
+        restore = torch.from_numpy(np.ascontiguousarray(restore))
+    restore = restore.to(device=device, non_blocking=True)
+    if restore.dtype not in (torch.int32, torch.int64):
+        restore = restore.to(torch.int64)
     num_rois = sum(len(x) for x in level_rois)
     if fused and method == "RoIAlign" and roi_align_fpn_supported(list(blobs_in), num_rois, resolution, resolution):
         # one call for the whole pyramid: the RoIs go back to dataloader order BEFORE pooling (a [R,5] gather instead
         # of the [R,C,res,res] one at :306), each with the index of its map in blobs_in (coarsest level first).
         # rpn_ret[blob_rois] -- the un-split blob the reference's data layer also provides -- already is that order.
+        # The map index of every row comes from the restore index and the levels' row counts (host-side sizes) in ONE
+        # launch (mi_fpn_level_index_from_restore; until round 6: four slice fills, a dtype conversion and a gather).
+        import ctypes
+
         counts = [len(x) for x in level_rois]
         map_index = [k_max - lvl for lvl in range(k_min, k_max + 1)]
-        # level-major map indices from host-side counts only (slice fills: no host-to-device copy, no sync)
-        lvl_cat = torch.empty((num_rois,), dtype=torch.int32, device=device)
-        first = 0
-        for k, cnt in zip(map_index, counts):
-            if cnt:
-                lvl_cat[first:first + cnt] = k
-            first += cnt
-        lvl_of_roi = lvl_cat[restore]
+        lvl_of_roi = torch.empty((num_rois,), dtype=torch.int32, device=device)
+        restore = restore.contiguous()
+        with torch.cuda.device(device):
+            rc = _lib.lib().mi_fpn_level_index_from_restore(
+                restore.data_ptr(), 1 if restore.dtype == torch.int64 else 0, num_rois, len(counts),
+                (ctypes.c_int * len(counts))(*counts), (ctypes.c_int * len(counts))(*map_index), lvl_of_roi.data_ptr(),
+                _lib.current_stream_handle(device))
+        _lib.check(rc, "mi_fpn_level_index_from_restore")
         if blob_rois in rpn_ret and len(rpn_ret[blob_rois]) == num_rois:
             rois = _as_device_rois(rpn_ret[blob_rois], device)
         else:
-            rois = torch.cat([_as_device_rois(x, device) for x in level_rois if len(x)], dim=0)[restore]
+            rois = torch.cat([_as_device_rois(x, device) for x in level_rois if len(x)], dim=0)[restore.long()]
         return roi_align_fpn(list(blobs_in), list(spatial_scale), rois, lvl_of_roi, resolution, resolution,
                              sampling_ratio)
+    restore = restore.long()
     pooled = []
     for lvl, rois_l in zip(range(k_min, k_max + 1), level_rois):
         features = blobs_in[k_max - lvl]

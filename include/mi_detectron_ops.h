@@ -41,8 +41,11 @@ extern "C" {
  * (mi_roi_align_forward_tiles_workspace_bytes, mi_roi_align_forward_fpn_writes_records) are gone -- measured slower on
  * every shape but one; every fast forward now leaves its records (mi_roi_align_forward_writes_records).  4 (round 5):
  * mi_rpn_collect_finish_records + mi_roi_align_forward_fpn_records (the producer of the RoIs writes their records); a
- * dword-aligned top_grad is served by the generic backward instead of refused. */
-#define MI_ABI_VERSION 5
+ * dword-aligned top_grad is served by the generic backward instead of refused.  5 (round 5): mi_polys_to_masks_wrt_boxes;
+ * the generic backward zero-fills under MI_ROI_ALIGN_OVERWRITE.  6 (round 6): mi_fpn_level_index_from_restore; the RoIAlign
+ * backward over a workspace is two launches (no trailing launch: its plan counters alternate between two sets), the
+ * RoIPool / RoICrop kernels are LDS-staged (same entry points, same results). */
+#define MI_ABI_VERSION 6
 
 typedef void* mi_stream_t; /* hipStream_t */
 
@@ -178,6 +181,8 @@ int mi_roi_align_forward_fpn_records(const mi_fpn_levels* levels, const float* r
                                      float* output, int batch, int channels, int num_rois, int aligned_height,
                                      int aligned_width, int sampling_ratio, int layout, void* workspace,
                                      size_t workspace_bytes, mi_stream_t stream);
+/* (mi_roi_align_backward_fpn has no generic fallback: `top_grad` must be 16-byte aligned -- MI_ERR_BAD_ARGUMENT otherwise;
+ * a caller with a dword-aligned gradient copies it once, as the autograd mirror does, or calls the per-level entry point.) */
 int mi_roi_align_backward_fpn(const mi_fpn_levels* levels, const float* top_grad, const float* rois,
                               const int32_t* roi_levels, int batch, int channels, int num_rois, int aligned_height,
                               int aligned_width, int sampling_ratio, int layout, void* workspace,
@@ -327,6 +332,15 @@ int mi_rpn_collect_candidates(int num_problems, const float* const* dets, const 
 int mi_rpn_collect_finish(const float* top_scores, const int64_t* top_indices, const float* cand_rois, int rows,
                           int mark_invalid, int k_min, int k_max, float canonical_scale, float canonical_level,
                           float* rois, uint8_t* valid, int32_t* levels, mi_stream_t stream);
+/* The map index of every row of a pyramid RoI blob that arrives as the reference's data layer ships it -- per-level blobs
+ * `rois_fpn<l>` plus `rois_idx_restore_int32` (utils/fpn.py:31-58; consumed by modeling/model_builder.py:296-303, which
+ * concatenates the pooled levels and gathers them back): row i of the blob in dataloader order lies at position
+ * restore[i] of the level-major concatenation, whose spans have span_rows_host[k] rows (HOST array, num_spans <= 8,
+ * level-major); out[i] = span_value_host[k] of the span that holds it.  restore: int32 or int64 device array.  One launch
+ * in place of the slice fills + gather the mirror of roi_feature_transform used to issue (17 us of 84). */
+int mi_fpn_level_index_from_restore(const void* restore, int restore_is_int64, int rows, int num_spans,
+                                    const int* span_rows_host, const int* span_value_host, int32_t* out,
+                                    mi_stream_t stream);
 /* mi_rpn_collect_finish that ALSO leaves the RoIAlign records of the blob it writes (same outputs, bit for bit) -- the
  * producer of the RoIs holds every one of them in a launch of its own, so the per-RoI records of the box head's pyramid
  * call (sweep rank, window, tap tables: what mi_roi_align_forward_fpn's first launch computes) are written here and
@@ -436,7 +450,7 @@ int mi_keypoint_nms_oks(const float* xy_preds, const float* rois, int num_rois, 
                         int64_t* keep, int32_t* num_keep, mi_stream_t stream);
 
 /* ---- diagnostics (no reference counterpart) ---------------------------------------------------
- * Tuning aid used by tools/timeline.py: while a non-NULL device buffer of 8 int64 per forward workgroup is set,
+ * Tuning aid used by tools/timeline_records.py / timeline_nhwc.py / timeline_bwd.py: while a non-NULL device buffer of 8 int64 per forward workgroup is set,
  * the RoIAlign forward kernels stamp the shader clock at their phase boundaries into it (layout per kernel: see the tools). */
 void mi_dbg_roi_align_timeline(long long* device_buffer);
 /* The MI_ROI_ALIGN_* tuning variables (csrc/common.h) are read from the environment ONCE, at the first RoIAlign call, and

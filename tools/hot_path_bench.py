@@ -149,6 +149,13 @@ def roofline_roi_align_forward(device, iters):
     traffic, traffic_src = pmc_traffic("forward")
     info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            # "bound" names the roofline the fraction is quoted against (the contract's enum).  What LIMITS the kernel is
+            # not HBM: counters (profiles/r05_pmc_roi_align.json) have HBM at 1.2 x the algorithmic bytes, the L2 at ~42 %
+            # of its rate, the TA at ~50 %; the timeline (profiles/r04_records_timeline.txt) has a wave 2.2 us in the ISSUE
+            # of its window pieces -- 5.2 x the algorithmic bytes cross L2 -> L1 as cache lines, a 72-byte NCHW row segment
+            # dragging in 1.5 of them -- and 0.3 us waiting for their landing
+            "limited_by": "vector-memory issue of the per-RoI window gather (L2->L1 cache lines = 5.2 x algorithmic bytes); "
+                          "not HBM, L2 bandwidth or LDS landing capacity (profiles/r06_forward_pair_ab.txt)",
             "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
             "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
             "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
@@ -218,12 +225,14 @@ def roofline_roi_align_forward(device, iters):
                         "achieved": round(bwd_bytes / sec_bwd / 1e9, 1), "unit": "GB/s",
                         "algorithmic_bytes": int(bwd_bytes), "planned": bws_bytes > ws_bytes,
                         "unplanned_us": round(sec_unplanned * 1e6, 2),
-                        "what": "planned = roi_align_bwd_plan + _tiles + _slow with the workspace the autograd Function "
+                        "what": "planned = roi_align_bwd_plan + _tiles (two launches) with the workspace the autograd Function "
                                 "allocates (the plan files every tile's list in a cost class -- longest first -- and cuts the "
                                 "long lists of a training step's clustered RoIs into slices: roi_align_step_rois); unplanned = "
                                 "the same call under MI_ROI_ALIGN_BWD_SLICE=0 (one workgroup per tile scans the RoIs itself and "
-                                "walks the whole list: no atomics, bit-reproducible)"}
+                                "walks the whole list: no atomics, bit-reproducible; + roi_align_bwd_untabled behind it)"}
+    info["l2_line_frac"] = pmc_l2_line_frac(info.get("records_ready", {}).get("avg_launch_us"))
     info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
+    info["roi_pool_roi_crop"] = pool_and_crop(device, max(iters // 2, 20))
     if layout == _lib.LAYOUT_NCHW:
         info["channels_last"] = channels_last_variant(device, lib, stream, feat, rois, out, ws, alg_bytes, gtop, iters)
     if layout == _lib.LAYOUT_NCHW:
@@ -410,6 +419,108 @@ def fpn_variant(device, iters):
             "rois_per_level": {int(l): int((lvls == l).sum()) for l in (2, 3, 4, 5)}}
 
 
+def pool_and_crop(device, iters):
+    """RoIPool and RoICrop at the config-2 shape -- 512 RoIs x 256 channels x 7x7 on the
+    200 x 336 P2 map of one image -- per C-ABI call, HIP events.  Algorithmic bytes, by the rule of section 8d (compulsory
+    traffic): RoIPool forward 8 R C PH PW (values + int32 argmax written) + 4 C U (U = distinct pixels inside the RoIs' bins)
+    + 20 R; RoICrop forward 4 R C GH GW written + 8 R GH GW (grid) + 4 C U (U = distinct in-image taps); the backwards
+    read the output-sized gradient (+ the argmax) and write the zero-filled map once: + 4 N C H W (the caller's fill, timed
+    with the call as the reference's functions do it)."""
+    from detectron_pytorch_amd import _lib
+
+    lib, stream = _lib.lib(), _lib.current_stream_handle(device)
+    h, w, scale = syn.FPN_LEVELS[2]
+    c, r, res = syn.FPN_DIM, 512, 7
+    feat_np = syn.feature_map(1, c, h, w, seed=0)
+    rois_np = syn.rois_canonical(r, 1, seed=0)
+    feat, rois = torch.from_numpy(feat_np).to(device), torch.from_numpy(rois_np).to(device)
+    out = torch.empty((r, c, res, res), device=device)
+    argmax = torch.empty((r, c, res, res), dtype=torch.int32, device=device)
+    gtop = torch.randn(r, c, res, res, device=device)
+    gin = torch.empty(1, c, h, w, device=device)
+    result = {"shape": "R=512 C=256 7x7 on 200x336 (config 2's inputs)", "unit": "GB/s"}
+
+    def entry(sec, nbytes):
+        return {"us": round(sec * 1e6, 2), "algorithmic_bytes": int(nbytes), "achieved": round(nbytes / sec / 1e9, 1),
+                "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- RoIPool ----
+    def pool_fwd():
+        assert lib.mi_roi_pool_forward(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), argmax.data_ptr(), 1, c, h, w, r, res,
+                                       res, scale, stream) == 0
+
+    def pool_bwd():
+        gin.zero_()
+        assert lib.mi_roi_pool_backward(gtop.data_ptr(), rois.data_ptr(), argmax.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res,
+                                        res, scale, stream) == 0
+
+    x1 = np.clip(np.floor(rois_np[:, 1] * scale + 0.5), 0, w).astype(int)   # round half up == roundf for these positive values
+    y1 = np.clip(np.floor(rois_np[:, 2] * scale + 0.5), 0, h).astype(int)
+    x2 = np.clip(np.floor(rois_np[:, 3] * scale + 0.5) + 1, 0, w).astype(int)
+    y2 = np.clip(np.floor(rois_np[:, 4] * scale + 0.5) + 1, 0, h).astype(int)
+    seen = np.zeros((h, w), bool)
+    for a, b, cc, d in zip(y1, y2, x1, x2):
+        seen[a:b, cc:d] = True
+    u_pool = int(seen.sum())
+    out_bytes = 4 * r * c * res * res
+    result["roi_pool_fwd"] = dict(entry(time_kernel(pool_fwd, iters), 2 * out_bytes + 4 * c * u_pool + 20 * r),
+                                  kernel="roi_pool_fwd", distinct_pixels=u_pool)
+    result["roi_pool_bwd"] = dict(entry(time_kernel(pool_bwd, max(iters // 4, 10)), 2 * out_bytes + 4 * c * h * w + 20 * r),
+                                  kernel="zero fill + roi_pool_bwd (one atomic per output element through its argmax)")
+    # ---- RoICrop: the affine grids of the same 512 boxes (what model_builder.py:279-287 builds from the RoIs) ----
+    cx = (rois_np[:, 1] + rois_np[:, 3]) * 0.5 * scale / (w - 1) * 2 - 1
+    cy = (rois_np[:, 2] + rois_np[:, 4]) * 0.5 * scale / (h - 1) * 2 - 1
+    sx = (rois_np[:, 3] - rois_np[:, 1]) * 0.5 * scale / (w - 1) * 2
+    sy = (rois_np[:, 4] - rois_np[:, 2]) * 0.5 * scale / (h - 1) * 2
+    lin = np.linspace(-1, 1, res, dtype=np.float64)
+    gy = cy[:, None, None] + sy[:, None, None] * lin[None, :, None] + 0 * lin[None, None, :]
+    gx = cx[:, None, None] + sx[:, None, None] * lin[None, None, :] + 0 * lin[None, :, None]
+    grid_np = np.stack([gy, gx], axis=3).astype(np.float32)
+    grid = torch.from_numpy(grid_np).to(device)
+    ty = np.floor((grid_np[..., 0].astype(np.float64) + 1) * (h - 1) / 2).astype(int)
+    tx = np.floor((grid_np[..., 1].astype(np.float64) + 1) * (w - 1) / 2).astype(int)
+    seen = np.zeros((h + 2, w + 2), bool)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            yy, xx = np.clip(ty + dy, -1, h) + 1, np.clip(tx + dx, -1, w) + 1
+            seen[yy, xx] = True
+    u_crop = int(seen[1:h + 1, 1:w + 1].sum())
+
+    def crop_fwd():
+        out.zero_()   # functions/roi_crop.py:11: the zero fill is part of the reference's forward
+        assert lib.mi_roi_crop_forward(feat.data_ptr(), grid.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, stream) == 0
+
+    def crop_bwd():
+        gin.zero_()
+        assert lib.mi_roi_crop_backward(feat.data_ptr(), grid.data_ptr(), gtop.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
+                                        stream) == 0
+
+    result["roi_crop_fwd"] = dict(entry(time_kernel(crop_fwd, iters), out_bytes + 8 * r * res * res + 4 * c * u_crop),
+                                  kernel="zero fill + roi_crop_fwd", distinct_pixels=u_crop)
+    result["roi_crop_bwd"] = dict(entry(time_kernel(crop_bwd, max(iters // 4, 10)), out_bytes + 8 * r * res * res + 4 * c * h * w),
+                                  kernel="zero fill + roi_crop_bwd (four atomics per output element, as the reference)")
+    return result
+
+
+def pmc_l2_line_frac(kernel_us):
+    """L2 -> L1 cache-line traffic of the forward kernel as a fraction of the L2's rate: TCP_TCC_READ_REQ x 128 B of the newest
+    committed PMC summary / the kernel's duration / 34.5 TB/s (MI355X_MICROARCH.md: aggregate L2 read bandwidth)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_roi_align.json")))
+    if not files or not kernel_us:
+        return None
+    try:
+        with open(files[-1]) as f:
+            kernels = json.load(f)["forward"]["kernels"]
+        req = max(v.get("TCP_TCC_READ_REQ_sum", 0.0) for v in kernels.values())
+        line_bytes = req * 128.0
+        return {"l2_to_l1_line_bytes": int(line_bytes), "frac_of_l2_rate": round(line_bytes / (kernel_us * 1e-6) / 34.5e12, 3),
+                "l2_peak": "34.5 TB/s", "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def pmc_traffic(direction):
     """HBM bytes per call from the newest committed PMC summary (profiles/rNN_pmc_roi_align.json), or None."""
     import glob
@@ -464,6 +575,13 @@ def nms_latency(device, iters):
 
     sec = time_kernel(launch_soft, 5, warmup=2)
     out["soft_nms_linear_uniform_n1000"] = {"us_per_call": round(sec * 1e6, 1), "kept": int(num.item())}
+    # IoU matrix (utils/cython_bbox.pyx:32-73): the labelling shape of a step (2000 proposals x 8 gt boxes) and a square one
+    for name, nb, nq in (("bbox_overlaps_2000x8", 2000, 8), ("bbox_overlaps_1000x1000", 1000, 1000)):
+        b = torch.from_numpy(syn.boxes_uniform(nb, seed=1)[:, :4].copy()).to(device)
+        q = torch.from_numpy(syn.boxes_uniform(nq, seed=2)[:, :4].copy()).to(device)
+        o = torch.empty((nb, nq), device=device)
+        sec = time_kernel(lambda: lib.mi_bbox_overlaps(b.data_ptr(), nb, q.data_ptr(), nq, o.data_ptr(), stream), 50)
+        out[name] = {"us_per_call": round(sec * 1e6, 2), "pairs_per_s": round(nb * nq / sec, 0)}
     # the test-time caller of NMS (core/test.py:732-790): 1000 RoIs x 81 classes, classes batched, two host syncs
     from detectron_pytorch_amd import detection
 
