@@ -11,19 +11,19 @@
 // 32-channel tile), tile = blockIdx % tiles (one XCD's L2 serves one channel slab).  A grid point's top-left tap, its four
 // weights and which of its taps lie in the image do not depend on the channel: they are computed ONCE per workgroup --
 // 64 points at a time, one per lane of wave 0 -- into an LDS table (the reference recomputes them in every thread: 32 x
-// per point here), with the bounding box of the group's taps reduced across the wave.
-//   forward   the box's rows arrive in LDS by LDS-DMA (buffer_load_dwordx4 ... lds; one odd-stride plane per channel,
-//             lane & 31 = channel: 32 banks), in chunks of as many rows as the image holds (consecutive chunks share a row,
-//             so the two tap rows of a point always lie in one chunk); half-wave = point, four ds_reads and the reference's
-//             expression per (point, channel); the [32][points] tile leaves as contiguous runs, points without a tap in
-//             the image left unwritten.  A box wider than the image's capacity is sampled from memory by the same lanes.
+// per point here), with the bounding box of the group's in-image taps reduced across the wave (an empty box: skip).
+//   forward   lanes flattened over (channel, point) with the point fastest: the four taps straight from memory (a sampler's
+//             taps are sparse in its box -- 4 x 49 of ~1000 pixels at 7 x 7: staging the box through LDS, built first this
+//             round, moved five times the bytes the taps need and measured 62 us against 53 at the config-2 shape), the
+//             reference's expression with the table's products, neighbouring lanes on neighbouring outputs; points
+//             without a tap in the image are left unwritten.
 //   backward  lanes flattened over (channel, point) with the point fastest -- the gradient block is read as it lies in
 //             memory -- and the reference's four atomics per element with the table's weights.  (A sampler's taps are
 //             sparse in its box -- 4 x 49 of ~1000 pixels at 7 x 7 -- so accumulating the box in LDS and flushing it would
 //             issue MORE atomics than the taps themselves; the scatter stays a scatter.)
 // Bit-exact forward: the same fp32 products and sums in the reference's order (-ffp-contract=off).
 #include "common.h"
-#include "lds_dma.h"
+#include "lds_dma.h"  // uniform()
 
 namespace {
 
@@ -31,9 +31,6 @@ using namespace mi;
 
 constexpr int kCropCT = 32;        // channels per workgroup
 constexpr int kCropThreads = 256;
-constexpr int kCropSlots = kCropThreads / kCropCT;
-constexpr int kCropCap = 336;      // box pixels per channel of the LDS image
-constexpr int kCropPlane = kCropCap | 1;
 constexpr int kCropPts = 64;       // grid points per group: one per lane of the wave that builds the table
 
 // roi_crop_cuda_kernel.cu:17-23
@@ -95,10 +92,7 @@ __global__ void __launch_bounds__(kCropThreads)
 roi_crop_fwd(const float* __restrict__ input, const float* __restrict__ grids, float* __restrict__ output, int batch,
              int channels, int height, int width, int gh, int gw, int roiPerImage) {
   __shared__ PointTab tab;
-  __shared__ float tile[kCropCT * (kCropPts + 1)];
-  extern __shared__ __attribute__((aligned(16))) float img[];  // [kCropCT][kCropPlane]
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-  const int cl = tid % kCropCT, slot = tid / kCropCT;
   const int tiles = (channels + kCropCT - 1) / kCropCT;
   const int r = blockIdx.x / tiles, c0 = (blockIdx.x - r * tiles) * kCropCT;
   const int points = gh * gw;
@@ -107,79 +101,29 @@ roi_crop_fwd(const float* __restrict__ input, const float* __restrict__ grids, f
   const int cvalid = min(kCropCT, channels - c0);
   const long long plane_px = (long long)height * width;
   const float* __restrict__ src = input + ((long long)(image_ok ? b_input : 0) * channels + c0) * plane_px;
-  constexpr int kChPerWave = kCropCT / (kCropThreads / 64);
-  const int wave_ch = max(0, min(kChPerWave, cvalid - wave * kChPerWave));
-  const srd_t srd = make_srd(src + (long long)wave * kChPerWave * plane_px, (unsigned)(wave_ch * plane_px * 4));
-  const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kCropPlane);
-  constexpr int ts = kCropPts + 1;
-
+  float* __restrict__ dst = output + ((long long)r * channels + c0) * points;
   for (int p0 = 0; p0 < points; p0 += kCropPts) {
     const int np = min(kCropPts, points - p0);
-    __syncthreads();  // the previous group's table and tile are no longer read
+    __syncthreads();  // the previous group's table is no longer read
     if (wave == 0) crop_build_table(&tab, grids, (long long)r * points + p0, np, lane, height, width, image_ok);
     __syncthreads();
-    const int y0 = uniform(tab.box[0]), y1 = uniform(tab.box[1]), x0 = uniform(tab.box[2]), x1 = uniform(tab.box[3]);
-    if (y1 >= y0) {  // some tap of the group lies in the image
-      const int pitch_px = (x1 - x0 + 1 + 3) & ~3, gpr = pitch_px >> 2;
-      const bool staged = 2 * pitch_px <= kCropCap;  // a chunk holds at least the two tap rows of a point
-      const int chunk_rows = staged ? kCropCap / pitch_px : (1 << 30);
-      const unsigned gmagic = (1u << 20) / (unsigned)gpr + 1u;
-      // chunks [r0, r0 + chunk_rows) advance by chunk_rows - 1: a point whose first in-image row is lo belongs to the chunk
-      // with r0 <= lo < r0 + chunk_rows - 1 (the last chunk takes the rest), which also holds its second row
-      for (int r0 = y0; r0 <= y1; r0 += staged ? chunk_rows - 1 : (1 << 30)) {
-        const int r1 = min(y1 + 1, r0 + chunk_rows);  // rows [r0, r1)
-        const bool last = r1 == y1 + 1;
-        if (staged) {
-          __syncthreads();  // the previous chunk's taps have been read
-          const unsigned groups = (unsigned)(r1 - r0) * (unsigned)gpr;
-          for (int kk = 0; kk * 64 < (int)groups; kk++) {
-            const unsigned g = (unsigned)(kk * 64 + lane);
-            const unsigned q = __umul24(g, gmagic) >> 20;  // g / gpr
-            const unsigned gc = g - __umul24(q, (unsigned)gpr);
-            const unsigned voff = (((unsigned)r0 + q) * (unsigned)width + (unsigned)x0 + gc * 4u) * 4u;
-            if (g < groups) {
-#pragma unroll
-              for (int c = 0; c < kChPerWave; c++)
-                dma_dwordx4(srd, plane0 + (unsigned)(c * kCropPlane + kk * 256) * 4u, voff, (unsigned)(c * plane_px * 4));
-            }
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();  // the chunk has landed
-        }
-        if (cl < cvalid)
-          for (int p = slot; p < np; p += kCropSlots) {
-            const int in = tab.in[p];
-            if (in == 0) continue;
-            const int xTL = tab.x[p], yTL = tab.y[p];
-            const int lo = max(yTL, 0);
-            if (lo < r0 || (!last && lo >= r0 + chunk_rows - 1)) continue;  // another chunk's point
-            float inTopLeft = 0, inTopRight = 0, inBottomLeft = 0, inBottomRight = 0;
-            if (staged) {
-              const float* a = img + cl * kCropPlane + (yTL - r0) * pitch_px + (xTL - x0);
-              if (in & 1) inTopLeft = a[0];
-              if (in & 2) inTopRight = a[1];
-              if (in & 4) inBottomLeft = a[pitch_px];
-              if (in & 8) inBottomRight = a[pitch_px + 1];
-            } else {
-              const float* a = src + (long long)cl * plane_px + (long long)yTL * width + xTL;
-              if (in & 1) inTopLeft = a[0];
-              if (in & 2) inTopRight = a[1];
-              if (in & 4) inBottomLeft = a[width];
-              if (in & 8) inBottomRight = a[width + 1];
-            }
-            // :100-103
-            tile[cl * ts + p] = tab.w_tl[p] * inTopLeft + tab.w_tr[p] * inTopRight + tab.w_bl[p] * inBottomLeft +
-                                tab.w_br[p] * inBottomRight;
-          }
-        if (last) break;
-      }
-    }
-    __syncthreads();  // the tile is complete
-    // [channel][points of the group] leave as contiguous runs; a point without a tap in the image is not written (:92-93)
-    float* __restrict__ dst = output + ((long long)r * channels + c0) * points + p0;
+    if (uniform(tab.box[1]) < uniform(tab.box[0])) continue;  // no tap of the group lies in the image: nothing is written
+    // lanes over (channel, point), the point fastest: neighbouring lanes tap neighbouring pixels of one plane and write
+    // neighbouring outputs
+    const unsigned np_magic = (1u << 20) / (unsigned)np + 1u;
     for (int i = tid; i < cvalid * np; i += kCropThreads) {
-      const int c = i / np, p = i - c * np;
-      if (tab.in[p] != 0) dst[(long long)c * points + p] = tile[c * ts + p];
+      const int c = (int)(((unsigned)i * np_magic) >> 20), p = i - c * np;  // i / np, exact for i < 32 * 64
+      const int in = tab.in[p];
+      if (in == 0) continue;  // :92-93: not written
+      const float* a = src + (long long)c * plane_px + (long long)tab.y[p] * width + tab.x[p];
+      float inTopLeft = 0, inTopRight = 0, inBottomLeft = 0, inBottomRight = 0;
+      if (in & 1) inTopLeft = a[0];
+      if (in & 2) inTopRight = a[1];
+      if (in & 4) inBottomLeft = a[width];
+      if (in & 8) inBottomRight = a[width + 1];
+      // :100-103
+      dst[(long long)c * points + p0 + p] = tab.w_tl[p] * inTopLeft + tab.w_tr[p] * inTopRight + tab.w_bl[p] * inBottomLeft +
+                                           tab.w_br[p] * inBottomRight;
     }
   }
 }
@@ -244,7 +188,7 @@ extern "C" int mi_roi_crop_forward(const float* input, const float* grid_yx, flo
   const long long total = (long long)num_rois * channels * grid_height * grid_width;
   if (total == 0) return MI_OK;
   const int tiles = (channels + kCropCT - 1) / kCropCT;
-  roi_crop_fwd<<<num_rois * tiles, kCropThreads, (size_t)kCropCT * kCropPlane * 4, mi::as_stream(stream)>>>(
+  roi_crop_fwd<<<num_rois * tiles, kCropThreads, 0, mi::as_stream(stream)>>>(
       input, grid_yx, output, batch, channels, height, width, grid_height, grid_width, num_rois / batch);
   return mi::check_launch("roi_crop_fwd");
 }

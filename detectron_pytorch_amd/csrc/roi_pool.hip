@@ -8,11 +8,16 @@
 // 32-channel tile), tile = blockIdx % tiles so that one XCD's L2 serves one channel slab.  The RoI's rectangle is decoded
 // once per workgroup (wave-uniform, SGPRs); its rows arrive in LDS by LDS-DMA (buffer_load_dwordx4 ... lds, lanes flattened
 // over (row, 16-byte group), one odd-stride plane per channel) in chunks of as many rows as the image holds; lane & 31 =
-// channel (32 banks), half-wave = output column; every lane scans the part of its bins that lies in the chunk and carries
+// channel (32 banks), half-wave = bin row, the wave walks the bin columns together (scalar loop bounds); every lane scans the part of its bins that lies in the chunk and carries
 // (max, argmax) in the LDS tile, so a bin taller than a chunk is scanned across chunks in the reference's row-major order.
 // The [32][bins] tile of values and of indices then leaves as contiguous runs.  Bit-exact: the comparisons are the
 // reference's, on the same values in the same order.
-// A window wider than the LDS image (more than 336 columns) is scanned from memory by the same lanes.
+// A window wider than the LDS image (more than 296 columns) is scanned from memory by the same lanes.
+// Measured at the config-2 shape (profiles/r06_pool_crop.txt): 86 us against 100 us for the one-lane-per-output kernel it
+// replaces; by ablation 26 us of window DMA, 44 us of scan -- a chain of LDS round trips per bin (tile entry, bin columns,
+// one per row pair), not VALU issue (per pixel: one compare, two selects) -- 8 us of stores, 14 us of skeleton.  Tried and
+// not kept: 512 / 1024-lane workgroups (108-127 us), all seven bins of a bin row in registers per image row (103 us: the
+// per-bin column bounds in SGPRs spill).
 //
 // Backward: the reference launches one thread per INPUT element and loops over all R RoIs and their candidate bins
 // comparing argmax == index: O(N*C*H*W*R).  The same sums are produced here by scattering each output gradient through
@@ -24,6 +29,11 @@
 #include "lds_dma.h"
 
 #include <cfloat>
+
+#ifndef MI_POOL_THREADS
+#define MI_POOL_THREADS 256
+#define MI_POOL_CAP 296
+#endif
 
 namespace {
 
@@ -45,9 +55,9 @@ __device__ __forceinline__ PoolRoi pool_roi(const float* __restrict__ roi, float
 }
 
 constexpr int kPoolCT = 32;        // channels per workgroup
-constexpr int kPoolThreads = 256;
+constexpr int kPoolThreads = MI_POOL_THREADS;
 constexpr int kPoolSlots = kPoolThreads / kPoolCT;  // half-waves
-constexpr int kPoolCap = 336;      // window pixels per channel of the LDS image (43 KB: three workgroups per CU)
+constexpr int kPoolCap = MI_POOL_CAP;  // window pixels per channel of the LDS image
 constexpr int kPoolPlane = kPoolCap | 1;
 constexpr int kPoolTileBins = 56;  // bins per channel the LDS tile holds at least (whole 7 x 7 outputs)
 
@@ -59,10 +69,46 @@ __device__ __forceinline__ void pool_bin(int p, float bin_size, int roi_start, i
   hi = (int)fminf(fmaxf((float)(hi + roi_start), 0.f), (float)size);
 }
 
-__global__ void __launch_bounds__(kPoolThreads)
+// Rows [hs, he) x kN columns of one bin from the LDS image, two rows per step: all 2 * kN pixels are read before the first
+// compare.  Order of the compares = the reference's scan (:77-87): row-major, strict >.
+template <int kN>
+__device__ __forceinline__ void pool_scan_rows(const float* rowp, int pitch_px, int hs, int he, int rowidx, int width,
+                                               float& maxval, int& maxidx) {
+  for (int h = hs; h < he; h += 2) {
+    float a[kN], b[kN];
+    const bool two = h + 1 < he;
+#pragma unroll
+    for (int j = 0; j < kN; j++) a[j] = rowp[j];
+#pragma unroll
+    for (int j = 0; j < kN; j++) b[j] = rowp[pitch_px + j];  // (past the bin on its last odd row: read, never compared)
+    // the scan is bound by VALU issue: per pixel one compare and two selects -- the winner's POSITION in the row pair is an
+    // instruction constant, its flat index is formed once per row pair
+    int best = -1;
+#pragma unroll
+    for (int j = 0; j < kN; j++) {
+      const bool up = a[j] > maxval;
+      maxval = up ? a[j] : maxval;
+      best = up ? j : best;
+    }
+    if (two) {
+#pragma unroll
+      for (int j = 0; j < kN; j++) {
+        const bool up = b[j] > maxval;
+        maxval = up ? b[j] : maxval;
+        best = up ? kN + j : best;
+      }
+    }
+    if (best >= 0) maxidx = rowidx + (best >= kN ? width + best - kN : best);
+    rowp += 2 * pitch_px;
+    rowidx += 2 * width;
+  }
+}
+
+__global__ void __launch_bounds__(kPoolThreads) __attribute__((amdgpu_waves_per_eu(kPoolThreads >= 1024 ? 8 : 1, 8)))
 roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ rois, float* __restrict__ top_data,
              int32_t* __restrict__ argmax_data, int batch, int channels, int height, int width, int pooled_height,
-             int pooled_width, float spatial_scale, int rows_per_group) {
+             int pooled_width, float spatial_scale, int rows_per_group, int ablate_arg) {
+  const int ablate = MI_ABLATE(ablate_arg);  // tuning builds: 1 = no window DMA, 2 = no scan, 4 = no store
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tile_bins = rows_per_group * pooled_width, ts = tile_bins | 1;
   float* tval = smem;                                        // [kPoolCT][ts]
@@ -101,27 +147,41 @@ roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ ro
   const srd_t srd = make_srd(src + (long long)wave * kChPerWave * plane_px, (unsigned)(wave_ch * plane_px * 4));
   const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kPoolPlane);
 
+  // bin rows / columns of this RoI, once per workgroup: hb[2 ph] .. = [start, end) of bin row ph, wb likewise per bin column
+  int* hb = reinterpret_cast<int*>(img + kPoolCT * kPoolPlane);
+  int* wb = hb + 2 * pooled_height;
+  for (int p = tid; p < pooled_height + pooled_width; p += kPoolThreads) {
+    int lo, hi;
+    if (p < pooled_height) {
+      pool_bin(p, bin_size_h, start_h, height, lo, hi);
+      hb[2 * p] = lo;
+      hb[2 * p + 1] = hi;
+    } else {
+      pool_bin(p - pooled_height, bin_size_w, start_w, width, lo, hi);
+      wb[2 * (p - pooled_height)] = lo;
+      wb[2 * (p - pooled_height) + 1] = hi;
+    }
+  }
+  __syncthreads();
+  const int bottom_data_offset = (batch_ind * channels + c0 + cl) * height * width;  // :75-76
   for (int pa = 0; pa < pooled_height; pa += rows_per_group) {
     const int pb = min(pooled_height, pa + rows_per_group);
     const int nb = (pb - pa) * pooled_width;
-    // rows of this group of bin rows
-    int ra, rb;
-    pool_bin(pa, bin_size_h, start_h, height, ra, t0);
-    pool_bin(pb - 1, bin_size_h, start_h, height, t1, rb);
-    // ---- tile: every bin starts empty-or-open (:68-72) ----
-    for (int b = slot; b < nb; b += kPoolSlots) {
-      const int ph = pa + b / pooled_width, pw = b % pooled_width;
-      int hs, he, ws, we;
-      pool_bin(ph, bin_size_h, start_h, height, hs, he);
-      pool_bin(pw, bin_size_w, start_w, width, ws, we);
-      const bool is_empty = he <= hs || we <= ws || no_image;
-      tval[cl * ts + b] = is_empty ? 0.f : -FLT_MAX;
-      targ[cl * ts + b] = -1;
+    const int ra = uniform(hb[2 * pa]), rb = uniform(hb[2 * (pb - 1) + 1]);  // rows of this group of bin rows
+    // ---- tile: every bin starts empty-or-open (:68-72).  A half-wave owns bin rows slot, slot + 8, ...: the bins a lane
+    // initialises are the bins it scans and updates, chunk after chunk ----
+    for (int ph = pa + slot; ph < pb; ph += kPoolSlots) {
+      const bool row_empty = hb[2 * ph + 1] <= hb[2 * ph] || no_image;
+      for (int pw = 0; pw < pooled_width; pw++) {
+        const bool is_empty = row_empty || wb[2 * pw + 1] <= wb[2 * pw];
+        tval[cl * ts + (ph - pa) * pooled_width + pw] = is_empty ? 0.f : -FLT_MAX;
+        targ[cl * ts + (ph - pa) * pooled_width + pw] = -1;
+      }
     }
     if (!no_image && ww > 0)
       for (int r0 = ra; r0 < rb; r0 += chunk_rows) {
         const int r1 = min(rb, r0 + chunk_rows);
-        if (staged) {
+        if (staged && !(ablate & 1)) {
           __syncthreads();  // the previous chunk's scans are done with the image
           const unsigned groups = (unsigned)(r1 - r0) * (unsigned)gpr;
           for (int kk = 0; kk * 64 < (int)groups; kk++) {
@@ -138,41 +198,67 @@ roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ ro
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();  // the chunk has landed
         }
-        if (cl < cvalid)
-          for (int b = slot; b < nb; b += kPoolSlots) {
-            const int ph = pa + b / pooled_width, pw = b % pooled_width;
-            int hs, he, ws, we;
-            pool_bin(ph, bin_size_h, start_h, height, hs, he);
-            pool_bin(pw, bin_size_w, start_w, width, ws, we);
-            hs = max(hs, r0);
-            he = min(he, r1);
-            if (he <= hs || we <= ws) continue;
-            float maxval = tval[cl * ts + b];
-            int maxidx = targ[cl * ts + b];
-            const int bottom_data_offset = (batch_ind * channels + c0 + cl) * height * width;  // :75-76
-            if (staged) {
-              const float* plane = img + cl * kPoolPlane;
-              for (int h = hs; h < he; ++h)
-                for (int w = ws; w < we; ++w) {
-                  const float v = plane[(h - r0) * pitch_px + (w - wlo)];
-                  if (v > maxval) {  // :83 strict >: the first maximum in row-major order wins
-                    maxval = v;
-                    maxidx = bottom_data_offset + h * width + w;
-                  }
+        // Scan.  Bin COLUMNS are walked by the whole wave together (scalar loop bounds, the column offset of a tap is an
+        // instruction immediate or an SGPR), bin ROWS belong to half-waves: per pixel one LDS read, one compare, two selects
+        // and the index add.
+        if (cl < cvalid && !(ablate & 2))
+          for (int ph = pa + slot; ph < pb; ph += kPoolSlots) {
+            const int hs = max(hb[2 * ph], r0), he = min(hb[2 * ph + 1], r1);
+            if (he <= hs) continue;
+            for (int pw = 0; pw < pooled_width; pw++) {
+              const int ws = uniform(wb[2 * pw]), we = uniform(wb[2 * pw + 1]);
+              if (we <= ws) continue;
+              const int b = (ph - pa) * pooled_width + pw;
+              float maxval = tval[cl * ts + b];
+              int maxidx = targ[cl * ts + b];
+              const int ncol = we - ws;
+              if (staged && ncol <= 8) {
+                // two rows of the bin in registers per step (one LDS wait for 2 * ncol pixels instead of one per pixel),
+                // compared in the reference's order: row h left to right, then row h + 1
+                const float* rowp = img + cl * kPoolPlane + (hs - r0) * pitch_px + (ws - wlo);
+                const int rowidx = bottom_data_offset + hs * width + ws;
+                switch (ncol) {
+                  case 1: pool_scan_rows<1>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
+                  case 2: pool_scan_rows<2>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
+                  case 3: pool_scan_rows<3>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
+                  case 4: pool_scan_rows<4>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
+                  case 5: pool_scan_rows<5>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
+                  case 6: pool_scan_rows<6>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
+                  case 7: pool_scan_rows<7>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
+                  default: pool_scan_rows<8>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
                 }
-            } else {
-              const float* plane = src + (long long)cl * plane_px;
-              for (int h = hs; h < he; ++h)
-                for (int w = ws; w < we; ++w) {
-                  const float v = plane[h * width + w];
-                  if (v > maxval) {
-                    maxval = v;
-                    maxidx = bottom_data_offset + h * width + w;
+              } else if (staged) {
+                const float* rowp = img + cl * kPoolPlane + (hs - r0) * pitch_px + (ws - wlo);
+                int rowidx = bottom_data_offset + hs * width + ws;
+                for (int h = hs; h < he; ++h) {
+                  for (int w = 0; w < ncol; ++w) {
+                    const float v = rowp[w];
+                    if (v > maxval) {  // :83 strict >: the first maximum in row-major order wins
+                      maxval = v;
+                      maxidx = rowidx + w;
+                    }
                   }
+                  rowp += pitch_px;
+                  rowidx += width;
                 }
+              } else {
+                const float* rowp = src + (long long)cl * plane_px + (long long)hs * width + ws;
+                int rowidx = bottom_data_offset + hs * width + ws;
+                for (int h = hs; h < he; ++h) {
+                  for (int w = 0; w < ncol; ++w) {
+                    const float v = rowp[w];
+                    if (v > maxval) {
+                      maxval = v;
+                      maxidx = rowidx + w;
+                    }
+                  }
+                  rowp += width;
+                  rowidx += width;
+                }
+              }
+              tval[cl * ts + b] = maxval;
+              targ[cl * ts + b] = maxidx;
             }
-            tval[cl * ts + b] = maxval;
-            targ[cl * ts + b] = maxidx;
           }
       }
     __syncthreads();  // the tile is complete
@@ -180,7 +266,7 @@ roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ ro
     float* __restrict__ dst = top_data + ((long long)r * channels + c0) * bins + pa * pooled_width;
     int32_t* __restrict__ adst = argmax_data != nullptr ? argmax_data + ((long long)r * channels + c0) * bins + pa * pooled_width : nullptr;
     const unsigned nb_magic = (1u << 20) / (unsigned)nb + 1u;
-    for (int i = tid; i < cvalid * nb; i += kPoolThreads) {
+    for (int i = tid; i < cvalid * nb && !(ablate & 4); i += kPoolThreads) {
       const int c = nb <= 128 ? (int)(((unsigned)i * nb_magic) >> 20) : i / nb, b = i - c * nb;
       dst[(long long)c * bins + b] = tval[c * ts + b];
       if (adst != nullptr) adst[(long long)c * bins + b] = targ[c * ts + b];
@@ -239,7 +325,8 @@ extern "C" int mi_roi_pool_forward(const float* features, const float* rois, flo
   // as fit (at least one: a row of pooled_width bins)
   const int rows_per_group = pooled_height * pooled_width <= kPoolTileBins ? pooled_height
                                                                            : (kPoolTileBins / pooled_width > 0 ? kPoolTileBins / pooled_width : 1);
-  const size_t lds = (size_t)(2 * kPoolCT * ((rows_per_group * pooled_width) | 1) + kPoolCT * kPoolPlane) * 4;
+  const size_t lds = (size_t)(2 * kPoolCT * ((rows_per_group * pooled_width) | 1) + kPoolCT * kPoolPlane +
+                              2 * (pooled_height + pooled_width)) * 4;
   MI_REQUIRE(lds <= 160 * 1024 - 2048, "roi_pool: pooled_width %d needs an output tile of %zu bytes of LDS", pooled_width, lds);
   MI_REQUIRE((long long)height * width * 4 * kPoolCT < (1LL << 31), "roi_pool: a 32-channel slab of the map exceeds 2 GB");
   if (lds > 64 * 1024)
@@ -247,7 +334,7 @@ extern "C" int mi_roi_pool_forward(const float* features, const float* rois, flo
   const int tiles = (channels + kPoolCT - 1) / kPoolCT;
   roi_pool_fwd<<<num_rois * tiles, kPoolThreads, lds, mi::as_stream(stream)>>>(
       features, rois, output, argmax, batch, channels, height, width, pooled_height, pooled_width, spatial_scale,
-      rows_per_group);
+      rows_per_group, mi::tuning().ablate);
   return mi::check_launch("roi_pool_fwd");
 }
 

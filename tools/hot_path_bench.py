@@ -433,6 +433,9 @@ def pool_and_crop(device, iters):
     c, r, res = syn.FPN_DIM, 512, 7
     feat_np = syn.feature_map(1, c, h, w, seed=0)
     rois_np = syn.rois_canonical(r, 1, seed=0)
+    if os.environ.get("MI_BENCH_SORT_ROIS"):  # tuning experiment only: RoIs in a spatial sweep order
+        key = (rois_np[:, 2] + rois_np[:, 4]) // (2 * 64) * 4096 + (rois_np[:, 1] + rois_np[:, 3]) / 2
+        rois_np = np.ascontiguousarray(rois_np[np.argsort(key, kind="stable")])
     feat, rois = torch.from_numpy(feat_np).to(device), torch.from_numpy(rois_np).to(device)
     out = torch.empty((r, c, res, res), device=device)
     argmax = torch.empty((r, c, res, res), dtype=torch.int32, device=device)
