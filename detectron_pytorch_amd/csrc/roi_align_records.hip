@@ -639,6 +639,15 @@ __device__ __forceinline__ int fwd_store_count(const float* dst, int wave, int n
 
 __device__ __forceinline__ void wait_vmcnt_at_most(int n) {
   // s_waitcnt takes an immediate; n is wave-uniform.  Waiting for MORE than asked (a smaller immediate) is always safe.
+  // What the partial wait assumes: (1) on the gfx9 family (gfx90a / gfx942 / gfx950) loads -- LDS-DMA included -- and stores
+  // share ONE counter, vmcnt, which retires in issue order, so "at most n outstanding" with n = the stores issued after the
+  // window pieces means the pieces have landed; (2) fwd_store_count() is an upper bound of the store instructions a wave
+  // issues per fwd_store() -- if the compiler merged stores the wait would only be stricter, if it split one it would be too
+  // weak.  (2) is pinned by test_roi_align_forward_partial_wait_equals_the_full_wait (MI_ROI_ALIGN_FWD_FULL_WAIT=1 against
+  // the default, bit for bit, on multi-stage shapes in the release build); any other target takes vmcnt(0).
+#if !(defined(__gfx950__) || defined(__gfx942__) || defined(__gfx940__) || defined(__gfx90a__))
+  n = 0;
+#endif
   if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -689,7 +698,7 @@ template <int kSR, int kCap, int kA = 0>
 __global__ void __launch_bounds__(kCT * 8)
 roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
                       const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height_arg,
-                      int aligned_width_arg, int sampling_ratio, int split, int ablate_arg MI_TL_PARAM) {
+                      int aligned_width_arg, int sampling_ratio, int split, int ablate_arg, int full_wait MI_TL_PARAM) {
   MI_STAMP(0);
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   const int ablate = MI_ABLATE(ablate_arg);
@@ -765,7 +774,7 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
       n_nrows = st[2];
     }
     const int ph0 = pp & 0xffff, ph1 = pp >> 16;
-    wait_vmcnt_at_most((ablate & 16) ? 0 : stores_out);
+    wait_vmcnt_at_most(((ablate & 16) || full_wait) ? 0 : stores_out);
     __syncthreads();  // this stage's window has landed; the previous tile is out of LDS
     if (k == part) MI_STAMP(3);  // landed, published
     if (fwd_patch_edge<kCT, kThreads, kPlane>(h, img, tid, nrows)) __syncthreads();
@@ -1462,7 +1471,7 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
     roi_align_fwd_records<SR, kCap, A><<<items, kThreads, lds, stream>>>(                                             \
         lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, split,        \
-        tuning().ablate MI_TL_ARG);                                                                                   \
+        tuning().ablate, tuning().fwd_full_wait MI_TL_ARG);                                                           \
   } while (0)
   const int a = aligned_height == aligned_width ? aligned_height : 0;
   if (sampling_ratio == 2 && kCap == 336 && a == 7)

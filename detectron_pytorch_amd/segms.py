@@ -34,8 +34,10 @@ class PackedPolygons(object):
         for polys in segms:
             for poly in polys:
                 p = torch.as_tensor(poly, dtype=torch.float32).reshape(-1, 2)
-                if p.size(0) == 0:
-                    raise ValueError("PackedPolygons: empty polygon")
+                if p.size(0) < 3:
+                    # json_dataset.py keeps polygons of >= 6 numbers only; pycocotools' frPyObjects would read a first
+                    # element of 4 numbers as a BOX (frBbox), which this rasteriser does not
+                    raise ValueError("PackedPolygons: a polygon needs at least 3 vertices (got %d)" % p.size(0))
                 pts.append(p)
                 poly_start.append(poly_start[-1] + p.size(0))
             inst_start.append(len(poly_start) - 1)

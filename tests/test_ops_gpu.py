@@ -519,6 +519,29 @@ def test_roi_align_forward_stages_dealt_to_several_workgroups(oracle_mod, tuning
 
 
 # ---- RoIAlign (legacy) ----------------------------------------------------------------------------
+def test_roi_align_forward_partial_wait_equals_the_full_wait(tuning_env):
+    """The stage pipeline of roi_align_fwd_records waits with s_waitcnt vmcnt(#stores of the previous stage) for the next
+    window (roi_align_records.hip, wait_vmcnt_at_most): correct as long as vmcnt retires in order and the store count is
+    an upper bound of what the compiler emitted.  MI_ROI_ALIGN_FWD_FULL_WAIT=1 makes the same (release) kernel wait with
+    vmcnt(0); on shapes whose items have several stages -- 14 x 14 heads, large windows, one or two workgroups per item --
+    both must give the same bits."""
+    from detectron_pytorch_amd.roi_align import roi_align_forward
+
+    h, w, scale = syn.FPN_LEVELS[2]
+    feat = to_dev(syn.feature_map(1, 64, h, w, seed=5))
+    for res, rois_np in ((14, syn.rois_canonical(96, 1, seed=6)), (7, syn.rois_canonical(96, 1, seed=7, side=(120.0, 420.0))),
+                         (14, syn.rois_canonical(40, 1, seed=8, side=(200.0, 700.0)))):
+        rois = to_dev(rois_np)
+        outs = {}
+        for split in (1, 2):
+            for full in (None, 1):
+                tuning_env(MI_ROI_ALIGN_FWD_FULL_WAIT=full, MI_ROI_ALIGN_FWD_SPLIT=split)
+                outs[(split, full)] = roi_align_forward(feat, rois, res, res, scale, 2).clone()
+        ref = outs[(1, 1)]
+        for key, o in outs.items():
+            assert torch.equal(o, ref), "res %d, (split, full wait) %r differs from the full-wait single-workgroup result" % (res, key)
+
+
 def test_roi_align_legacy_golden_and_oracle(oracle_mod):
     from detectron_pytorch_amd.roi_align import LegacyRoIAlignFunction
 
