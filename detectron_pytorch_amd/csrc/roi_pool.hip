@@ -4,20 +4,19 @@
 // scanned row-major so the first maximum wins, int32 flat argmax over the whole input tensor, empty bin -> 0 / -1) and
 // :128-203 (backward).
 //
-// Forward (round 6; until then the reference's one-lane-per-output loop re-typed): one 256-lane workgroup per (RoI,
-// 32-channel tile), tile = blockIdx % tiles so that one XCD's L2 serves one channel slab.  The RoI's rectangle is decoded
-// once per workgroup (wave-uniform, SGPRs); its rows arrive in LDS by LDS-DMA (buffer_load_dwordx4 ... lds, lanes flattened
-// over (row, 16-byte group), one odd-stride plane per channel) in chunks of as many rows as the image holds; lane & 31 =
-// channel (32 banks), half-wave = bin row, the wave walks the bin columns together (scalar loop bounds); every lane scans the part of its bins that lies in the chunk and carries
-// (max, argmax) in the LDS tile, so a bin taller than a chunk is scanned across chunks in the reference's row-major order.
-// The [32][bins] tile of values and of indices then leaves as contiguous runs.  Bit-exact: the comparisons are the
-// reference's, on the same values in the same order.
-// A window wider than the LDS image (more than 296 columns) is scanned from memory by the same lanes.
-// Measured at the config-2 shape (profiles/r06_pool_crop.txt): 86 us against 100 us for the one-lane-per-output kernel it
-// replaces; by ablation 26 us of window DMA, 44 us of scan -- a chain of LDS round trips per bin (tile entry, bin columns,
-// one per row pair), not VALU issue (per pixel: one compare, two selects) -- 8 us of stores, 14 us of skeleton.  Tried and
-// not kept: 512 / 1024-lane workgroups (108-127 us), all seven bins of a bin row in registers per image row (103 us: the
-// per-bin column bounds in SGPRs spill).
+// Forward (round 6): one 256-lane workgroup per (RoI, 32-channel tile), tile = blockIdx % tiles so that one XCD's L2 serves
+// one channel slab.  The RoI's rectangle is decoded once per workgroup (wave-uniform, SGPRs) and its bin rows / columns
+// tabulated in LDS (the reference's threads each redo the rounding, floor and ceil: 49 x 32 times per workgroup here).  Lanes
+// run over (channel, bin) with the bin fastest -- neighbouring lanes scan neighbouring bins of one plane and write neighbouring
+// outputs -- and a bin's pixels come straight from memory, FOUR ROWS x EIGHT COLUMNS IN FLIGHT PER WAIT (masked past the bin:
+// the sentinel -FLT_MAX never wins a strict >), compared in the reference's row-major order with one compare and two selects
+// per pixel (the winner's position in the batch is an instruction constant; its flat index is formed once per batch).
+// Bit-exact: the comparisons are the reference's, on the same values in the same order.
+// Built first this round and measured against it (profiles/r06_pool_crop.txt; code: commit e830f0d): the RoI's rows staged
+// through LDS by LDS-DMA in chunks, lane = channel, (max, argmax) carried across chunks in an LDS tile -- 86 us at the
+// config-2 shape and 103 us on a stride-16 map with image-sized RoIs, against 79 and 96 us for this form and 100 and 112 us
+// for the one-pixel-per-wait loop of rounds 1-5: a bin's taps are few and its neighbours' overlap is served by L1 / L2, so
+// the image, its barriers and the chain of LDS round trips (tile entry, bin bounds, rows) cost more than they save.
 //
 // Backward: the reference launches one thread per INPUT element and loops over all R RoIs and their candidate bins
 // comparing argmax == index: O(N*C*H*W*R).  The same sums are produced here by scattering each output gradient through
@@ -26,14 +25,9 @@
 // 1) -- are re-checked so the set of contributing terms is identical.  Only the floating-point addition order differs
 // (reference: ascending RoI index).
 #include "common.h"
-#include "lds_dma.h"
+#include "lds_dma.h"  // uniform()
 
 #include <cfloat>
-
-#ifndef MI_POOL_THREADS
-#define MI_POOL_THREADS 256
-#define MI_POOL_CAP 296
-#endif
 
 namespace {
 
@@ -55,11 +49,11 @@ __device__ __forceinline__ PoolRoi pool_roi(const float* __restrict__ roi, float
 }
 
 constexpr int kPoolCT = 32;        // channels per workgroup
-constexpr int kPoolThreads = MI_POOL_THREADS;
-constexpr int kPoolSlots = kPoolThreads / kPoolCT;  // half-waves
-constexpr int kPoolCap = MI_POOL_CAP;  // window pixels per channel of the LDS image
-constexpr int kPoolPlane = kPoolCap | 1;
-constexpr int kPoolTileBins = 56;  // bins per channel the LDS tile holds at least (whole 7 x 7 outputs)
+constexpr int kPoolThreads = 256;
+#ifndef MI_POOL_GATHER_ROWS
+#define MI_POOL_GATHER_ROWS 4
+#endif
+constexpr int kGatherRows = MI_POOL_GATHER_ROWS;  // rows of a bin in flight per wait
 
 // bin p of an axis: [start, end) in map coordinates, clamped to the map (roi_pooling_kernel.cu:57-66)
 __device__ __forceinline__ void pool_bin(int p, float bin_size, int roi_start, int size, int& lo, int& hi) {
@@ -69,57 +63,17 @@ __device__ __forceinline__ void pool_bin(int p, float bin_size, int roi_start, i
   hi = (int)fminf(fmaxf((float)(hi + roi_start), 0.f), (float)size);
 }
 
-// Rows [hs, he) x kN columns of one bin from the LDS image, two rows per step: all 2 * kN pixels are read before the first
-// compare.  Order of the compares = the reference's scan (:77-87): row-major, strict >.
-template <int kN>
-__device__ __forceinline__ void pool_scan_rows(const float* rowp, int pitch_px, int hs, int he, int rowidx, int width,
-                                               float& maxval, int& maxidx) {
-  for (int h = hs; h < he; h += 2) {
-    float a[kN], b[kN];
-    const bool two = h + 1 < he;
-#pragma unroll
-    for (int j = 0; j < kN; j++) a[j] = rowp[j];
-#pragma unroll
-    for (int j = 0; j < kN; j++) b[j] = rowp[pitch_px + j];  // (past the bin on its last odd row: read, never compared)
-    // the scan is bound by VALU issue: per pixel one compare and two selects -- the winner's POSITION in the row pair is an
-    // instruction constant, its flat index is formed once per row pair
-    int best = -1;
-#pragma unroll
-    for (int j = 0; j < kN; j++) {
-      const bool up = a[j] > maxval;
-      maxval = up ? a[j] : maxval;
-      best = up ? j : best;
-    }
-    if (two) {
-#pragma unroll
-      for (int j = 0; j < kN; j++) {
-        const bool up = b[j] > maxval;
-        maxval = up ? b[j] : maxval;
-        best = up ? kN + j : best;
-      }
-    }
-    if (best >= 0) maxidx = rowidx + (best >= kN ? width + best - kN : best);
-    rowp += 2 * pitch_px;
-    rowidx += 2 * width;
-  }
-}
-
-__global__ void __launch_bounds__(kPoolThreads) __attribute__((amdgpu_waves_per_eu(kPoolThreads >= 1024 ? 8 : 1, 8)))
+__global__ void __launch_bounds__(kPoolThreads)
 roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ rois, float* __restrict__ top_data,
-             int32_t* __restrict__ argmax_data, int batch, int channels, int height, int width, int pooled_height,
-             int pooled_width, float spatial_scale, int rows_per_group, int ablate_arg) {
-  const int ablate = MI_ABLATE(ablate_arg);  // tuning builds: 1 = no window DMA, 2 = no scan, 4 = no store
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tile_bins = rows_per_group * pooled_width, ts = tile_bins | 1;
-  float* tval = smem;                                        // [kPoolCT][ts]
-  int* targ = reinterpret_cast<int*>(smem + kPoolCT * ts);   // [kPoolCT][ts]
-  float* img = smem + 2 * kPoolCT * ts;                      // [kPoolCT][kPoolPlane]
-  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-  const int cl = tid % kPoolCT, slot = tid / kPoolCT;
+                    int32_t* __restrict__ argmax_data, int batch, int channels, int height, int width, int pooled_height,
+                    int pooled_width, float spatial_scale) {
+  extern __shared__ __attribute__((aligned(16))) int tabs[];  // hb[2 PH] | wb[2 PW]
+  int* hb = tabs;
+  int* wb = tabs + 2 * pooled_height;
+  const int tid = threadIdx.x;
   const int tiles = (channels + kPoolCT - 1) / kPoolCT;
   const int r = blockIdx.x / tiles, c0 = (blockIdx.x - r * tiles) * kPoolCT;
   const int bins = pooled_height * pooled_width;
-  // ---- the RoI, once per workgroup (five scalar loads) ----
   const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)r * 5);
   const int batch_ind = (int)roi[0];
   const int start_w = (int)roundf(roi[1] * spatial_scale), start_h = (int)roundf(roi[2] * spatial_scale);  // :46-49
@@ -129,27 +83,6 @@ roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ ro
   const float bin_size_h = (float)roi_height / (float)pooled_height;  // :54-55
   const float bin_size_w = (float)roi_width / (float)pooled_width;
   const bool no_image = batch_ind < 0 || batch_ind >= batch;
-  // window columns: bin starts and ends grow with pw, so the first start and the last end bound them all
-  int wlo, whi, t0, t1;
-  pool_bin(0, bin_size_w, start_w, width, wlo, t0);
-  pool_bin(pooled_width - 1, bin_size_w, start_w, width, t1, whi);
-  const int ww = whi - wlo;
-  const int pitch_px = (max(ww, 1) + 3) & ~3, gpr = pitch_px >> 2;
-  const bool staged = pitch_px <= kPoolCap;
-  const int chunk_rows = staged ? kPoolCap / pitch_px : (1 << 30);
-  const unsigned gmagic = (1u << 20) / (unsigned)gpr + 1u;
-  const long long plane_px = (long long)height * width;
-  const int cvalid = min(kPoolCT, channels - c0);  // channels of this tile that exist
-  const float* __restrict__ src = bottom_data + ((long long)(no_image ? 0 : batch_ind) * channels + c0) * plane_px;
-  constexpr int kChPerWave = kPoolCT / (kPoolThreads / 64);
-  // this wave's DMA covers the planes of its kChPerWave channels (those that exist); a lane past them reads zeros
-  const int wave_ch = max(0, min(kChPerWave, cvalid - wave * kChPerWave));
-  const srd_t srd = make_srd(src + (long long)wave * kChPerWave * plane_px, (unsigned)(wave_ch * plane_px * 4));
-  const unsigned plane0 = lds_addr_uniform(img + wave * kChPerWave * kPoolPlane);
-
-  // bin rows / columns of this RoI, once per workgroup: hb[2 ph] .. = [start, end) of bin row ph, wb likewise per bin column
-  int* hb = reinterpret_cast<int*>(img + kPoolCT * kPoolPlane);
-  int* wb = hb + 2 * pooled_height;
   for (int p = tid; p < pooled_height + pooled_width; p += kPoolThreads) {
     int lo, hi;
     if (p < pooled_height) {
@@ -163,115 +96,61 @@ roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ ro
     }
   }
   __syncthreads();
-  const int bottom_data_offset = (batch_ind * channels + c0 + cl) * height * width;  // :75-76
-  for (int pa = 0; pa < pooled_height; pa += rows_per_group) {
-    const int pb = min(pooled_height, pa + rows_per_group);
-    const int nb = (pb - pa) * pooled_width;
-    const int ra = uniform(hb[2 * pa]), rb = uniform(hb[2 * (pb - 1) + 1]);  // rows of this group of bin rows
-    // ---- tile: every bin starts empty-or-open (:68-72).  A half-wave owns bin rows slot, slot + 8, ...: the bins a lane
-    // initialises are the bins it scans and updates, chunk after chunk ----
-    for (int ph = pa + slot; ph < pb; ph += kPoolSlots) {
-      const bool row_empty = hb[2 * ph + 1] <= hb[2 * ph] || no_image;
-      for (int pw = 0; pw < pooled_width; pw++) {
-        const bool is_empty = row_empty || wb[2 * pw + 1] <= wb[2 * pw];
-        tval[cl * ts + (ph - pa) * pooled_width + pw] = is_empty ? 0.f : -FLT_MAX;
-        targ[cl * ts + (ph - pa) * pooled_width + pw] = -1;
-      }
-    }
-    if (!no_image && ww > 0)
-      for (int r0 = ra; r0 < rb; r0 += chunk_rows) {
-        const int r1 = min(rb, r0 + chunk_rows);
-        if (staged && !(ablate & 1)) {
-          __syncthreads();  // the previous chunk's scans are done with the image
-          const unsigned groups = (unsigned)(r1 - r0) * (unsigned)gpr;
-          for (int kk = 0; kk * 64 < (int)groups; kk++) {
-            const unsigned g = (unsigned)(kk * 64 + lane);
-            const unsigned q = __umul24(g, gmagic) >> 20;  // g / gpr
-            const unsigned gc = g - __umul24(q, (unsigned)gpr);
-            const unsigned voff = (((unsigned)r0 + q) * (unsigned)width + (unsigned)wlo + gc * 4u) * 4u;
-            if (g < groups) {
+  const int cvalid = min(kPoolCT, channels - c0);
+  float* __restrict__ dst = top_data + ((long long)r * channels + c0) * bins;
+  int32_t* __restrict__ adst = argmax_data != nullptr ? argmax_data + ((long long)r * channels + c0) * bins : nullptr;
+  const unsigned bins_magic = (1u << 20) / (unsigned)bins + 1u;
+  for (int i = tid; i < cvalid * bins; i += kPoolThreads) {
+    const int c = bins <= 128 ? (int)(((unsigned)i * bins_magic) >> 20) : i / bins, b = i - c * bins;
+    const int ph = b / pooled_width, pw = b - ph * pooled_width;
+    const int hs = hb[2 * ph], he = hb[2 * ph + 1], ws = wb[2 * pw], we = wb[2 * pw + 1];
+    const bool is_empty = he <= hs || we <= ws || no_image;
+    float maxval = is_empty ? 0.f : -FLT_MAX;  // :70
+    int maxidx = -1;                           // :72
+    if (!is_empty) {
+      const int off = (batch_ind * channels + c0 + c) * height * width;  // :75-76
+      const float* plane = bottom_data + off;
+      const int ncol = we - ws;
+      if (ncol <= 8) {
+        for (int h = hs; h < he; h += kGatherRows) {
+          const float* rowp = plane + h * width + ws;
+          float v[kGatherRows][8];
 #pragma unroll
-              for (int c = 0; c < kChPerWave; c++)
-                dma_dwordx4(srd, plane0 + (unsigned)(c * kPoolPlane + kk * 256) * 4u, voff, (unsigned)(c * plane_px * 4));
+          for (int k = 0; k < kGatherRows; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[k][j] = (h + k < he && j < ncol) ? rowp[k * width + j] : -FLT_MAX;
+          int best = -1;
+#pragma unroll
+          for (int k = 0; k < kGatherRows; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const bool up = v[k][j] > maxval;  // :83 strict >, row-major
+              maxval = up ? v[k][j] : maxval;
+              best = up ? k * 8 + j : best;
             }
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();  // the chunk has landed
+          if (best >= 0) maxidx = off + (h + (best >> 3)) * width + ws + (best & 7);
         }
-        // Scan.  Bin COLUMNS are walked by the whole wave together (scalar loop bounds, the column offset of a tap is an
-        // instruction immediate or an SGPR), bin ROWS belong to half-waves: per pixel one LDS read, one compare, two selects
-        // and the index add.
-        if (cl < cvalid && !(ablate & 2))
-          for (int ph = pa + slot; ph < pb; ph += kPoolSlots) {
-            const int hs = max(hb[2 * ph], r0), he = min(hb[2 * ph + 1], r1);
-            if (he <= hs) continue;
-            for (int pw = 0; pw < pooled_width; pw++) {
-              const int ws = uniform(wb[2 * pw]), we = uniform(wb[2 * pw + 1]);
-              if (we <= ws) continue;
-              const int b = (ph - pa) * pooled_width + pw;
-              float maxval = tval[cl * ts + b];
-              int maxidx = targ[cl * ts + b];
-              const int ncol = we - ws;
-              if (staged && ncol <= 8) {
-                // two rows of the bin in registers per step (one LDS wait for 2 * ncol pixels instead of one per pixel),
-                // compared in the reference's order: row h left to right, then row h + 1
-                const float* rowp = img + cl * kPoolPlane + (hs - r0) * pitch_px + (ws - wlo);
-                const int rowidx = bottom_data_offset + hs * width + ws;
-                switch (ncol) {
-                  case 1: pool_scan_rows<1>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
-                  case 2: pool_scan_rows<2>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
-                  case 3: pool_scan_rows<3>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
-                  case 4: pool_scan_rows<4>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
-                  case 5: pool_scan_rows<5>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
-                  case 6: pool_scan_rows<6>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
-                  case 7: pool_scan_rows<7>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
-                  default: pool_scan_rows<8>(rowp, pitch_px, hs, he, rowidx, width, maxval, maxidx); break;
-                }
-              } else if (staged) {
-                const float* rowp = img + cl * kPoolPlane + (hs - r0) * pitch_px + (ws - wlo);
-                int rowidx = bottom_data_offset + hs * width + ws;
-                for (int h = hs; h < he; ++h) {
-                  for (int w = 0; w < ncol; ++w) {
-                    const float v = rowp[w];
-                    if (v > maxval) {  // :83 strict >: the first maximum in row-major order wins
-                      maxval = v;
-                      maxidx = rowidx + w;
-                    }
-                  }
-                  rowp += pitch_px;
-                  rowidx += width;
-                }
-              } else {
-                const float* rowp = src + (long long)cl * plane_px + (long long)hs * width + ws;
-                int rowidx = bottom_data_offset + hs * width + ws;
-                for (int h = hs; h < he; ++h) {
-                  for (int w = 0; w < ncol; ++w) {
-                    const float v = rowp[w];
-                    if (v > maxval) {
-                      maxval = v;
-                      maxidx = rowidx + w;
-                    }
-                  }
-                  rowp += width;
-                  rowidx += width;
-                }
-              }
-              tval[cl * ts + b] = maxval;
-              targ[cl * ts + b] = maxidx;
+      } else {
+        // a wide bin (the stride-16 maps of the C4 configs): row by row, eight columns per wait
+        for (int h = hs; h < he; ++h)
+          for (int cb = 0; cb < ncol; cb += 8) {
+            const float* rowp = plane + h * width + ws + cb;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = cb + j < ncol ? rowp[j] : -FLT_MAX;
+            int best = -1;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const bool up = v[j] > maxval;
+              maxval = up ? v[j] : maxval;
+              best = up ? j : best;
             }
+            if (best >= 0) maxidx = off + h * width + ws + cb + best;
           }
       }
-    __syncthreads();  // the tile is complete
-    // ---- [channel][bins of the group] leave as contiguous runs (the whole [32][bins] block when the group is the RoI) ----
-    float* __restrict__ dst = top_data + ((long long)r * channels + c0) * bins + pa * pooled_width;
-    int32_t* __restrict__ adst = argmax_data != nullptr ? argmax_data + ((long long)r * channels + c0) * bins + pa * pooled_width : nullptr;
-    const unsigned nb_magic = (1u << 20) / (unsigned)nb + 1u;
-    for (int i = tid; i < cvalid * nb && !(ablate & 4); i += kPoolThreads) {
-      const int c = nb <= 128 ? (int)(((unsigned)i * nb_magic) >> 20) : i / nb, b = i - c * nb;
-      dst[(long long)c * bins + b] = tval[c * ts + b];
-      if (adst != nullptr) adst[(long long)c * bins + b] = targ[c * ts + b];
     }
-    __syncthreads();  // before the next group rewrites the tile
+    dst[i] = maxval;
+    if (adst != nullptr) adst[i] = maxidx;
   }
 }
 
@@ -321,20 +200,10 @@ extern "C" int mi_roi_pool_forward(const float* features, const float* rois, flo
   if (rc != MI_OK) return rc;
   const long long total = (long long)num_rois * channels * pooled_height * pooled_width;
   if (total == 0) return MI_OK;
-  // bin rows per LDS tile: the whole output when it has at most kPoolTileBins bins per channel (7 x 7), else as many rows
-  // as fit (at least one: a row of pooled_width bins)
-  const int rows_per_group = pooled_height * pooled_width <= kPoolTileBins ? pooled_height
-                                                                           : (kPoolTileBins / pooled_width > 0 ? kPoolTileBins / pooled_width : 1);
-  const size_t lds = (size_t)(2 * kPoolCT * ((rows_per_group * pooled_width) | 1) + kPoolCT * kPoolPlane +
-                              2 * (pooled_height + pooled_width)) * 4;
-  MI_REQUIRE(lds <= 160 * 1024 - 2048, "roi_pool: pooled_width %d needs an output tile of %zu bytes of LDS", pooled_width, lds);
-  MI_REQUIRE((long long)height * width * 4 * kPoolCT < (1LL << 31), "roi_pool: a 32-channel slab of the map exceeds 2 GB");
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_pool_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  MI_REQUIRE(pooled_height + pooled_width <= 4096, "roi_pool: pooled size %d x %d beyond the bin table", pooled_height, pooled_width);
   const int tiles = (channels + kPoolCT - 1) / kPoolCT;
-  roi_pool_fwd<<<num_rois * tiles, kPoolThreads, lds, mi::as_stream(stream)>>>(
-      features, rois, output, argmax, batch, channels, height, width, pooled_height, pooled_width, spatial_scale,
-      rows_per_group, mi::tuning().ablate);
+  roi_pool_fwd<<<num_rois * tiles, kPoolThreads, (size_t)2 * (pooled_height + pooled_width) * 4, mi::as_stream(stream)>>>(
+      features, rois, output, argmax, batch, channels, height, width, pooled_height, pooled_width, spatial_scale);
   return mi::check_launch("roi_pool_fwd");
 }
 

@@ -582,16 +582,16 @@ def test_roi_pool_golden_and_oracle(oracle_mod):
 
 
 @pytest.mark.parametrize("shape,res,scale,nrois", [
-    ((1, 32, 50, 84), (7, 7), 1.0 / 16, 64),      # stride-16 map: whole-image RoIs, bins taller than an LDS chunk
+    ((1, 32, 50, 84), (7, 7), 1.0 / 16, 64),      # stride-16 map: whole-image RoIs, bins wider than eight columns
     ((2, 70, 25, 42), (7, 7), 1.0 / 32, 48),      # 70 channels: a ragged last tile of 6
-    ((1, 32, 40, 400), (7, 7), 1.0 / 4, 40),      # windows wider than the LDS image (> 336 columns): scanned from memory
-    ((1, 64, 60, 90), (14, 14), 1.0 / 8, 40),     # 196 bins: the output tile is cut into groups of bin rows
-    ((1, 32, 30, 30), (3, 60), 1.0 / 16, 24),     # pooled_width beyond the default tile
+    ((1, 32, 40, 400), (7, 7), 1.0 / 4, 40),      # bins of up to 58 columns: several column blocks per row
+    ((1, 64, 60, 90), (14, 14), 1.0 / 8, 40),     # 196 bins per channel
+    ((1, 32, 30, 30), (3, 60), 1.0 / 16, 24),     # more bin columns than pixels
     ((2, 8, 9, 11), (2, 3), 1.0 / 16, 20)])       # fewer channels than a tile, tiny map
-def test_roi_pool_lds_kernel_shapes_vs_oracle(oracle_mod, shape, res, scale, nrois):
-    """roi_pool_fwd stages a RoI's rows through LDS in chunks and carries (max, argmax) across them: values AND flat int32
-    argmax bit-equal to the oracle (roi_pooling_kernel.cu:24-93) on every way the rows can be cut, including RoIs outside the
-    map, malformed ones and RoIs of no image."""
+def test_roi_pool_kernel_shapes_vs_oracle(oracle_mod, shape, res, scale, nrois):
+    """roi_pool_fwd reads a bin four rows x eight columns at a time (masked past the bin) and takes wide bins row by row in
+    column blocks: values AND flat int32 argmax bit-equal to the oracle (roi_pooling_kernel.cu:24-93) on narrow, wide and
+    tall bins, ragged channel tiles, RoIs outside the map, malformed ones and RoIs of no image."""
     from detectron_pytorch_amd.roi_pool import roi_pool_forward
 
     n, c, h, w = shape
@@ -612,11 +612,11 @@ def test_roi_pool_lds_kernel_shapes_vs_oracle(oracle_mod, shape, res, scale, nro
 @pytest.mark.parametrize("shape,grid_hw,nrois,span", [
     ((2, 32, 50, 84), (14, 14), 16, 1.25),   # 196 points: four groups of 64
     ((1, 70, 33, 47), (7, 7), 9, 1.6),       # ragged channel tile, grids largely outside the image
-    ((1, 32, 40, 400), (7, 7), 8, 1.0),      # boxes wider than the LDS image: sampled from memory
+    ((1, 32, 40, 400), (7, 7), 8, 1.0),      # grids spanning a 400-pixel-wide map
     ((3, 8, 6, 5), (3, 2), 12, 1.3)])        # tiny
-def test_roi_crop_lds_kernel_shapes_vs_oracle(oracle_mod, shape, grid_hw, nrois, span):
-    """roi_crop_fwd samples from an LDS copy of the grid's bounding box, cut into row chunks that share a row: bit-equal to
-    the oracle (roi_crop_cuda_kernel.cu:47-109), unwritten elements stay as the caller left them; the backward's sums to 1e-4."""
+def test_roi_crop_kernel_shapes_vs_oracle(oracle_mod, shape, grid_hw, nrois, span):
+    """roi_crop_fwd / _bwd work from a per-workgroup table of the grid points (64 per group): forward bit-equal to the oracle
+    (roi_crop_cuda_kernel.cu:47-109), unwritten elements stay as the caller left them; the backward's sums to 1e-4."""
     from detectron_pytorch_amd import _lib
 
     n, c, h, w = shape

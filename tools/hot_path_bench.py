@@ -420,7 +420,7 @@ def fpn_variant(device, iters):
 
 
 def pool_and_crop(device, iters):
-    """RoIPool and RoICrop at the config-2 shape -- 512 RoIs x 256 channels x 7x7 on the
+    """RoIPool and RoICrop (roi_pool.hip, roi_crop.hip) at the config-2 shape -- 512 RoIs x 256 channels x 7x7 on the
     200 x 336 P2 map of one image -- per C-ABI call, HIP events.  Algorithmic bytes, by the rule of section 8d (compulsory
     traffic): RoIPool forward 8 R C PH PW (values + int32 argmax written) + 4 C U (U = distinct pixels inside the RoIs' bins)
     + 20 R; RoICrop forward 4 R C GH GW written + 8 R GH GW (grid) + 4 C U (U = distinct in-image taps); the backwards
