@@ -846,6 +846,31 @@ def test_roi_feature_transform_level_vector_without_the_fused_call(oracle_mod, t
         assert dev_feats[5 - lvl].grad is not None and float(dev_feats[5 - lvl].grad.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_fpn_level_index_from_restore_equals_the_host_expression(dtype):
+    """mi_fpn_level_index_from_restore: the map index of every RoI of a pyramid blob in dataloader order, from the reference's
+    restore index (utils/fpn.py:31-58) and the levels' row counts -- against np.repeat(values, counts)[restore], with empty
+    levels, int32 and int64 indices."""
+    import ctypes
+
+    from detectron_pytorch_amd import _lib
+
+    lib = _lib.lib()
+    rng = np.random.RandomState(3)
+    for counts in ([561, 181, 186, 72], [0, 40, 0, 9], [5, 0, 0, 0], [1, 1, 1, 1]):
+        values = [3, 2, 1, 0]
+        n = sum(counts)
+        restore = rng.permutation(n).astype(dtype)
+        want = np.repeat(np.array(values, np.int32), counts)[restore]
+        out = torch.full((n,), -7, dtype=torch.int32, device=dev())
+        rc = lib.mi_fpn_level_index_from_restore(to_dev(restore).data_ptr(), 1 if dtype == np.int64 else 0, n, 4,
+                                                 (ctypes.c_int * 4)(*counts), (ctypes.c_int * 4)(*values), out.data_ptr(),
+                                                 _lib.current_stream_handle(dev()))
+        assert rc == 0, lib.mi_last_error()
+        assert np.array_equal(out.cpu().numpy(), want)
+    assert lib.mi_fpn_level_index_from_restore(None, 0, 4, 9, None, None, None, None) != 0   # more than 8 spans: refused
+
+
 @pytest.mark.parametrize("method", ["RoIPoolF", "RoICrop", "RoIAlign"])
 def test_roi_feature_transform_single_level_methods(oracle_mod, method):
     from detectron_pytorch_amd import roi_xform
