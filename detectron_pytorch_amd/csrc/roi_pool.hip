@@ -154,26 +154,387 @@ roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ ro
   }
 }
 
-__global__ void __launch_bounds__(256)
-roi_pool_bwd(long long total, const float* __restrict__ top_diff, const float* __restrict__ rois,
-             const int32_t* __restrict__ argmax_data, float* __restrict__ bottom_diff, int batch,
-             int channels, int height, int width, int pooled_height, int pooled_width,
-             float spatial_scale) {
-  const long long limit = (long long)batch * channels * height * width;
-  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
-       index += (long long)gridDim.x * blockDim.x) {
-    int n = (int)(index / pooled_width / pooled_height / channels);
-    int am = argmax_data[index];
-    if (am < 0 || am >= limit) continue;
-    PoolRoi r = pool_roi(rois + (long long)n * 5, spatial_scale);
-    int w = am % width;
-    int h = (am / width) % height;
-    int img = am / width / height / channels;
-    if (img != r.batch_ind) continue;  // :151-153
-    const bool in_roi = (w >= r.start_w && w <= r.end_w && h >= r.start_h && h <= r.end_h);  // :161-165
-    if (!in_roi) continue;
-    atomicAdd(bottom_diff + am, top_diff[index]);
+// ---- backward -----------------------------------------------------------------------------------------------------------
+// The reference's gather (one thread per INPUT element over all R RoIs, :128-203) turned inside out without giving up its
+// result: a workgroup owns a 16 x 32-pixel tile of one image for 32 channels, its sums live in LDS, and it OVERWRITES the
+// tile (:202 -- no zero fill by the caller, no global atomics).  The RoIs whose rounded rectangle meets the tile are listed
+// in ascending index (the reference's outer loop order, :146); every wave walks the whole list for 8 of the channels, so
+// no two waves ever touch one accumulator and nothing but program order inside a wave orders the sums.  Per (RoI, tile) the
+// workgroup tabulates once, for every tile row / column, the set of bin rows / columns the reference would try for that
+// pixel (:181-189, as a bit mask); a wave fetches only the bins those sets span -- argmax and gradient, lane = (channel,
+// bin row), the next RoI's block in flight under the current one -- decodes each argmax to a tile pixel, applies the
+// reference's tests (same image, same channel, pixel inside the rectangle :161-165, bin among the pixel's candidates
+// :191-193) and adds the gradient into LDS with ds_add_f32 (lanes with nothing to add aim at a dword of their own).
+// ORDER: a pixel's terms must be added by ascending (RoI, ph, pw) (:146,:191-192).  When no pixel has more than two
+// candidate bin rows or columns (every RoI at least a pixel per bin, i.e. all but tiny ones) bins two rows apart share
+// no pixel, so the bin rows are taken in three passes, each walking the columns in ascending order: even rows for the
+// pixels whose FIRST candidate row they are, odd rows, even rows for the pixels whose first candidate row is the odd row
+// above.  Otherwise the span's bins are taken one at a time in row-major order.  Either way every pixel sees the
+// reference's sequence of fp32 additions: the result is bit-equal, run to run and to the reference.
+// (Rounds 1-6a: one global atomic per output element into a zero-filled map, 221 us at the config-2 shape.)
+#ifndef MI_POOL_TILE_H
+#define MI_POOL_TILE_H 8
+#endif
+constexpr int kTileH = MI_POOL_TILE_H, kTileW = 32;  // pixels per tile
+constexpr int kTileKC = 32;                  // channels per workgroup
+constexpr int kTileCW = 8;                   // channels per wave
+constexpr int kTileSlots = 64 / kTileCW;     // bin rows a wave holds at once
+constexpr int kTileAcc = kTileH * kTileW + 4;  // accumulator stride of a channel: 16-byte rows, channels 4 banks apart
+constexpr int kTileScan = kTileH == 8 ? 512 : 1024;  // RoIs scanned per round
+constexpr int kTileSub = kTileH == 8 ? 16 : 32;      // (RoI, tile) entries tabulated at once
+constexpr int kTileEnt = 12;                 // dwords of an entry
+constexpr int kTileRowSets = 34;             // [0]: empty, [1 + b]: the tile rows whose pixels try bin row ph0 + b (b < 32), [33]: empty
+constexpr int kTileSets = kTileRowSets + 16; // ... then [kTileRowSets + j]: the tile columns whose pixels try bin column pw0 + j
+constexpr int kTileThreads = 256;
+// LDS, in dwords
+constexpr int kLdsHits = kTileKC * kTileAcc;                 // [kTileScan] RoI indices of the round, ascending
+constexpr int kLdsTab = kLdsHits + kTileScan;                // [kTileSub][kTileSets] bit sets of tile rows / columns
+constexpr int kLdsEnt = kLdsTab + kTileSub * kTileSets;      // [kTileSub][kTileEnt]
+constexpr int kLdsWaveHits = kLdsEnt + kTileSub * kTileEnt;  // [4 passes][4 waves]
+constexpr int kLdsDwords = kLdsWaveHits + 16;
+enum { E_R = 0, E_PH0, E_NPH, E_PW0, E_NPW, E_FAST, E_SW, E_SH, E_EW, E_EH };
+
+struct PoolTileRoi {  // what :155-179 derive from a RoI
+  int start_w, start_h, end_w, end_h;
+  float bin_size_h, bin_size_w;
+};
+__device__ __forceinline__ PoolTileRoi pool_tile_roi(int start_w, int start_h, int end_w, int end_h, int pooled_height,
+                                                     int pooled_width) {
+  PoolTileRoi g;
+  g.start_w = start_w, g.start_h = start_h, g.end_w = end_w, g.end_h = end_h;
+  const int roi_width = (int)fmaxf((float)(end_w - start_w + 1), 1.f);  // :175-176
+  const int roi_height = (int)fmaxf((float)(end_h - start_h + 1), 1.f);
+  g.bin_size_h = (float)roi_height / (float)pooled_height;  // :178-179
+  g.bin_size_w = (float)roi_width / (float)pooled_width;
+  return g;
+}
+// the bins [lo, hi) the reference tries for a pixel at distance d from the rectangle's start (:181-189)
+__device__ __forceinline__ void pool_candidates(int d, float bin, int pooled, int& lo, int& hi) {
+  lo = (int)floorf((float)d / bin);
+  hi = (int)ceilf((float)(d + 1) / bin);
+  lo = (int)fminf(fmaxf((float)lo, 0.f), (float)pooled);
+  hi = (int)fminf(fmaxf((float)hi, 0.f), (float)pooled);
+}
+
+#ifdef MI_POOL_PHASES
+__device__ unsigned long long pool_dbg[16];
+#define POOL_T0()                                                        \
+  const unsigned long long t_mark0 = __builtin_readcyclecounter();       \
+  unsigned long long t_mark = t_mark0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define POOL_T(i)                                                        \
+  do {                                                                   \
+    const unsigned long long t_now = __builtin_readcyclecounter();       \
+    t_acc[i] += t_now - t_mark;                                          \
+    t_mark = t_now;                                                      \
+  } while (0)
+#define POOL_COUNT(i, v) t_acc[i] += (unsigned long long)(v)
+#else
+#define POOL_T0()
+#define POOL_T(i)
+#define POOL_COUNT(i, v)
+#endif
+using lds_float_ptr = __attribute__((address_space(3))) float*;
+using lds_int_ptr = __attribute__((address_space(3))) int*;
+__device__ __forceinline__ void lds_add(unsigned byte_addr, float v) {
+  __hip_atomic_fetch_add((lds_float_ptr)(uintptr_t)byte_addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int PWT>
+__global__ void __launch_bounds__(kTileThreads)
+roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__ rois, const int32_t* __restrict__ argmax_data,
+                   float* __restrict__ bottom_diff, int batch, int channels, int height, int width, int num_rois,
+                   int pooled_height, int pooled_width, float spatial_scale, int tiles_x, int tiles_y, int cgroups,
+                   unsigned magic, int vec_ok, int ablate) {
+  extern __shared__ __attribute__((aligned(16))) float pool_lds[];
+  float* acc = pool_lds;
+  int* ilds = (int*)pool_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int cg = blockIdx.x % cgroups;  // one XCD's L2 serves the gradients of its channel groups
+  int tile = blockIdx.x / cgroups;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y, n = tile / tiles_y;
+  const int th0 = ty * kTileH, tw0 = tx * kTileW, vh = min(kTileH, height - th0), vw = min(kTileW, width - tw0);
+  const int c0 = cg * kTileKC;
+  const int bins = pooled_height * pooled_width;
+  const bool masks_fit = pooled_height <= 32 && pooled_width <= PWT && magic != 0;
+
+  POOL_T0();
+  for (int i = tid; i < kTileKC * kTileAcc / 4; i += kTileThreads) ((float4*)acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  POOL_T(1);
+
+  // this lane in the walk: channel cl of the wave's eight, bin row slot k
+  const int cl = lane & (kTileCW - 1), k = lane >> 3;
+  const int c = c0 + wave * kTileCW + cl;
+  const bool cvalid = c < channels;
+  const bool even = (k & 1) == 0;
+  const int tile_base = (((n * channels + (cvalid ? c : 0)) * height) + th0) * width + tw0;  // this lane's plane, the tile's corner
+  const unsigned acc_bytes = (unsigned)((wave * kTileCW + cl) * kTileAcc) * 4u;
+  // kernel arguments are wave-uniform: descriptors over the two output-sized arrays (a lane without an element reads 0 past the end)
+  const int out_bytes = (int)((unsigned)num_rois * (unsigned)channels * (unsigned)bins * 4u);
+  const __amdgpu_buffer_rsrc_t arg_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(argmax_data), 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t top_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(top_diff), 0, out_bytes, 0x00020000);
+
+  for (int base = 0; base < num_rois; base += kTileScan) {
+    // ---- the RoIs of this round whose rectangle meets the tile, in ascending index
+    unsigned long long votes[kTileScan / kTileThreads];
+#pragma unroll
+    for (int m = 0; m < kTileScan / kTileThreads; m++) {
+      const int r = base + m * kTileThreads + tid;
+      bool hit = false;
+      if (r < num_rois) {
+        const float* roi = rois + (long long)r * 5;
+        const int start_w = (int)roundf(roi[1] * spatial_scale), start_h = (int)roundf(roi[2] * spatial_scale);
+        const int end_w = (int)roundf(roi[3] * spatial_scale), end_h = (int)roundf(roi[4] * spatial_scale);
+        hit = (int)roi[0] == n && start_w <= end_w && start_h <= end_h && start_w < tw0 + vw && end_w >= tw0 &&
+              start_h < th0 + vh && end_h >= th0;
+      }
+      votes[m] = __ballot(hit);
+      if (lane == 0) ilds[kLdsWaveHits + m * 4 + wave] = __popcll(votes[m]);
+    }
+    __syncthreads();  // (the first round: also the zeroed accumulators)
+    int total = 0;
+#pragma unroll
+    for (int m = 0; m < kTileScan / kTileThreads; m++) {
+      int before = total;
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int h = ilds[kLdsWaveHits + m * 4 + v];
+        before += v < wave ? h : 0;
+        total += h;
+      }
+      if ((votes[m] >> lane) & 1ull) ilds[kLdsHits + before + __popcll(votes[m] & ((1ull << lane) - 1ull))] = base + m * kTileThreads + tid;
+    }
+    total = uniform(total);
+    if (MI_ABLATE(ablate & 1)) total = 0;
+    POOL_T(2);
+
+    for (int sub = 0; sub < total; sub += kTileSub) {
+      const int nsub = min(kTileSub, total - sub);
+      __syncthreads();  // the hit list is written / the previous entries are no longer read
+      // ---- tabulate the entries, a wave per entry: lane < 16 = tile row, lane 16..47 = tile column -> the bins the reference
+      // tries for that pixel (:181-189); then, turned around by ballots, for every bin row / column of the span the SET of
+      // tile rows / columns that try it (what a lane of the walk needs: its bin row is fixed, the pixel varies)
+      for (int e = wave; e < nsub; e += kTileThreads / 64) {
+        const int r = uniform(ilds[kLdsHits + sub + e]);
+        const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)r * 5);
+        const PoolTileRoi g = pool_tile_roi((int)roundf(roi[1] * spatial_scale), (int)roundf(roi[2] * spatial_scale),
+                                            (int)roundf(roi[3] * spatial_scale), (int)roundf(roi[4] * spatial_scale), pooled_height,
+                                            pooled_width);
+        const bool row = lane < kTileH;
+        const int pos = row ? lane : lane - kTileH;
+        const int p = row ? th0 + pos : tw0 + pos;
+        const int s0 = row ? g.start_h : g.start_w, s1 = row ? g.end_h : g.end_w;
+        const bool inside = lane < kTileH + kTileW && pos < (row ? vh : vw) && p >= s0 && p <= s1;  // :161-165, and the pixel exists
+        int lo = 0, hi = 0;
+        if (inside) pool_candidates(p - s0, row ? g.bin_size_h : g.bin_size_w, row ? pooled_height : pooled_width, lo, hi);
+        const bool wide = __ballot(hi - lo > 2) != 0;
+        // the candidate sets grow with the pixel: the bins over the tile's part of the rectangle are
+        // [first of the first pixel, last of the last)
+        const int hA = max(g.start_h, th0) - th0, hB = min(g.end_h, th0 + vh - 1) - th0;
+        const int wA = max(g.start_w, tw0) - tw0, wB = min(g.end_w, tw0 + vw - 1) - tw0;
+        int ph0 = 0, nph = 0, pw0 = 0, npw = 0;
+        if (hA <= hB && wA <= wB) {  // (the list holds only RoIs that meet the tile)
+          ph0 = __builtin_amdgcn_readlane(lo, hA);
+          nph = __builtin_amdgcn_readlane(hi, hB) - ph0;
+          pw0 = __builtin_amdgcn_readlane(lo, kTileH + wA);
+          npw = __builtin_amdgcn_readlane(hi, kTileH + wB) - pw0;
+        }
+        if (nph <= 0 || npw <= 0) nph = npw = 0;
+        const bool fast = masks_fit && !wide;
+        int* sets = ilds + kLdsTab + e * kTileSets;
+        if (fast) {
+          const unsigned upto_hi = hi >= 32 ? 0xffffffffu : (1u << hi) - 1u, upto_lo = lo >= 32 ? 0xffffffffu : (1u << lo) - 1u;
+          const unsigned tries = upto_hi & ~upto_lo;  // bit b: this pixel row / column tries bin b
+          if (lane == 0) sets[0] = 0;
+          for (int b = 0; b <= nph && b < 33; b++) {  // (one past the span: empty, the sentinel the last row reads)
+            const unsigned long long set = __ballot(row && ((tries >> ((ph0 + b) & 31)) & 1u) && ph0 + b < 32);
+            if (lane == 0) sets[1 + b] = (int)(unsigned)set;
+          }
+          for (int j = 0; j < PWT; j++) {
+            const unsigned long long set = __ballot(!row && ((tries >> ((pw0 + j) & 31)) & 1u) && j < npw);
+            if (lane == 0) sets[kTileRowSets + j] = (int)(unsigned)(set >> kTileH);
+          }
+        }
+        if (lane == 0) {
+          int* ent = ilds + kLdsEnt + e * kTileEnt;
+          ent[E_R] = r;
+          ent[E_PH0] = ph0;
+          ent[E_NPH] = nph;
+          ent[E_PW0] = pw0;
+          ent[E_NPW] = npw;
+          ent[E_FAST] = fast ? 1 : 0;
+          ent[E_SW] = g.start_w;
+          ent[E_SH] = g.start_h;
+          ent[E_EW] = g.end_w;
+          ent[E_EH] = g.end_h;
+        }
+      }
+      __syncthreads();
+      POOL_T(3);
+      POOL_COUNT(8, nsub);
+
+      // ---- the walk: every wave, every entry, its own eight channels
+      // rows [first_row, first_row + 8) of an entry's bins: lane (cl, k) takes row k, columns pw0 .. pw0 + PWT - 1 (those
+      // beyond the span are never looked at; past the arrays a lane reads 0)
+      auto fetch = [&](const int* ent, int first_row, int (&a)[PWT], float (&g)[PWT]) {
+        const int r = uniform(ent[E_R]), ph0 = uniform(ent[E_PH0]), nph = uniform(ent[E_NPH]), pw0 = uniform(ent[E_PW0]);
+        const bool live = cvalid && first_row + k < nph && !MI_ABLATE(ablate & 8);
+        const unsigned block = (unsigned)r * (unsigned)(channels * bins) * 4u;  // wave-uniform (the arrays stay below 4 GB)
+        const int off = live ? ((c * pooled_height + ph0 + first_row + k) * pooled_width + pw0) * 4 : -64;  // beyond the descriptor: 0
+#pragma unroll
+        for (int j = 0; j < PWT; j++) {
+          a[j] = __builtin_amdgcn_raw_buffer_load_b32(arg_srd, off + j * 4, block, 0);
+          g[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(top_srd, off + j * 4, block, 0));
+        }
+      };
+      // one block of eight bin rows of a fast entry: decode, then the three ordered passes
+      auto add_rows = [&](const int* ent, int i, int row0, const int (&a)[PWT], const float (&g)[PWT]) {
+        const int nph = uniform(ent[E_NPH]), npw = uniform(ent[E_NPW]);
+        const int* sets = ilds + kLdsTab + i * kTileSets;
+        const bool live = cvalid && row0 + k < nph;
+        const int slot = min(row0 + k, 32);
+        const unsigned own_rows = live ? (unsigned)sets[1 + slot] : 0u;       // tile rows whose pixels try this lane's bin row
+        const unsigned rows_above = live && even ? (unsigned)sets[slot] : 0u;  // ... the bin row above (an even row waits for it)
+        unsigned col_sets[PWT];
+#pragma unroll
+        for (int j = 0; j < PWT; j++) col_sets[j] = (unsigned)sets[kTileRowSets + j];
+        constexpr unsigned kNone = 0xffffffffu;
+        unsigned own_pass[PWT], late_pass[PWT];  // where the element is added (kNone: nowhere): its row's own pass / the third pass
+        bool any_late = false;
+#pragma unroll
+        for (int j = 0; j < PWT; j++) {
+          own_pass[j] = late_pass[j] = kNone;
+          if (j < npw) {
+            const unsigned rel = (unsigned)(a[j] - tile_base);  // same image and channel, from the tile's first row on: small
+            const unsigned hl = __umulhi(rel, magic);             // rel / width, exact below 16 * width (width < 16384)
+            const unsigned wl = rel - hl * (unsigned)width;
+            const bool ok = hl < (unsigned)kTileH && wl < (unsigned)kTileW && (((own_rows >> hl) & (col_sets[j] >> wl)) & 1u);
+            const bool late = ok && ((rows_above >> hl) & 1u);  // an even row that is the pixel's SECOND candidate row
+            const unsigned addr = acc_bytes + (hl << 7) + (wl << 2);
+            own_pass[j] = ok && !late ? addr : kNone;
+            late_pass[j] = late ? addr : kNone;
+            any_late = any_late || late;
+          }
+        }
+        POOL_T(5);
+        if (MI_ABLATE(ablate & 2)) return;
+        if (even) {
+#pragma unroll
+          for (int j = 0; j < PWT; j++)
+            if (j < npw && own_pass[j] != kNone) lds_add(own_pass[j], g[j]);
+        }
+        __builtin_amdgcn_wave_barrier();  // a pixel's additions in program order
+        if (!even) {
+#pragma unroll
+          for (int j = 0; j < PWT; j++)
+            if (j < npw && own_pass[j] != kNone) lds_add(own_pass[j], g[j]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (__ballot(any_late) != 0) {
+#pragma unroll
+          for (int j = 0; j < PWT; j++)
+            if (j < npw && late_pass[j] != kNone) lds_add(late_pass[j], g[j]);
+          POOL_COUNT(10, 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        POOL_T(6);
+      };
+      // tiny RoIs (a pixel in three or more bins of an axis), pooled sizes beyond the masks / the register block, maps too
+      // wide for the reciprocal: one bin at a time, the reference's tests as written
+      auto one_bin_at_a_time = [&](const int* ent) {
+        const int r = uniform(ent[E_R]), ph0 = uniform(ent[E_PH0]), nph = uniform(ent[E_NPH]), pw0 = uniform(ent[E_PW0]),
+                  npw = uniform(ent[E_NPW]);
+        const PoolTileRoi g = pool_tile_roi(uniform(ent[E_SW]), uniform(ent[E_SH]), uniform(ent[E_EW]), uniform(ent[E_EH]),
+                                            pooled_height, pooled_width);
+        const long long block = (long long)r * channels * bins;
+        for (int b = 0; b < nph * npw; b++) {
+          const int ph = ph0 + b / npw, pw = pw0 + b % npw;
+          if (cvalid && k == 0) {
+            const int off = (c * pooled_height + ph) * pooled_width + pw;
+            const unsigned rel = (unsigned)(argmax_data[block + off] - tile_base);
+            if (rel < (unsigned)(vh * width)) {
+              const int hl = (int)(rel / (unsigned)width), wl = (int)(rel - (unsigned)hl * (unsigned)width);
+              const int h = th0 + hl, w = tw0 + wl;
+              if (wl < vw && w >= g.start_w && w <= g.end_w && h >= g.start_h && h <= g.end_h) {  // :161-165
+                int phstart, phend, pwstart, pwend;
+                pool_candidates(h - g.start_h, g.bin_size_h, pooled_height, phstart, phend);
+                pool_candidates(w - g.start_w, g.bin_size_w, pooled_width, pwstart, pwend);
+                if (ph >= phstart && ph < phend && pw >= pwstart && pw < pwend)
+                  lds_add(acc_bytes + (unsigned)((hl * kTileW + wl) << 2), top_diff[block + off]);
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      };
+      const int* ents = ilds + kLdsEnt;
+      auto entry = [&](int ii) { return ents + min(ii, nsub - 1) * kTileEnt; };
+      auto take = [&](int ii, const int (&a)[PWT], const float (&g)[PWT]) {
+        if (ii >= nsub || MI_ABLATE(ablate & 4)) return;
+        const int* ent = ents + ii * kTileEnt;
+        if (uniform(ent[E_FAST])) {
+          add_rows(ent, ii, 0, a, g);
+          const int nph = uniform(ent[E_NPH]);
+          for (int row0 = kTileSlots; row0 < nph; row0 += kTileSlots) {  // pooled heights above 8: further blocks, fetched in place
+            int a_x[PWT];
+            float g_x[PWT];
+            fetch(ent, row0, a_x, g_x);
+            add_rows(ent, ii, row0, a_x, g_x);
+          }
+        } else {
+          one_bin_at_a_time(ent);
+        }
+      };
+      // four register sets: the blocks of the next three entries are in flight under the current one (a fetch past the
+      // last entry repeats it: every fetch issues the same loads, so the waits the compiler places stay partial)
+      int a_0[PWT], a_1[PWT], a_2[PWT], a_3[PWT];
+      float g_0[PWT], g_1[PWT], g_2[PWT], g_3[PWT];
+      fetch(entry(0), 0, a_0, g_0);
+      fetch(entry(1), 0, a_1, g_1);
+      fetch(entry(2), 0, a_2, g_2);
+      for (int i = 0; i < nsub; i += 4) {
+        fetch(entry(i + 3), 0, a_3, g_3);
+        take(i, a_0, g_0);
+        fetch(entry(i + 4), 0, a_0, g_0);
+        take(i + 1, a_1, g_1);
+        fetch(entry(i + 5), 0, a_1, g_1);
+        take(i + 2, a_2, g_2);
+        fetch(entry(i + 6), 0, a_2, g_2);
+        take(i + 3, a_3, g_3);
+      }
+      POOL_T(4);
+    }
+    __syncthreads();  // the hit list is rewritten by the next round / the sums are complete
+    POOL_T(9);
   }
+  if (num_rois <= 0) __syncthreads();
+
+  // ---- the tile leaves as rows of 128 bytes
+  const int q = tid & 7, hrow = tid >> 3;  // a lane: four pixels of one row; 128 lanes per channel -> two channels per trip
+  for (int cc = hrow / kTileH; cc < kTileKC; cc += kTileThreads / 8 / kTileH) {
+    const int ch = c0 + cc, hl = hrow & (kTileH - 1);
+    if (ch >= channels || hl >= vh || q * 4 >= vw) continue;
+    const float4 v = *(const float4*)(acc + cc * kTileAcc + hl * kTileW + q * 4);
+    float* dst = bottom_diff + (((long long)n * channels + ch) * height + th0 + hl) * width + tw0 + q * 4;
+    if (q * 4 + 3 < vw && vec_ok) {
+      *(float4*)dst = v;
+    } else {
+      dst[0] = v.x;
+      if (q * 4 + 1 < vw) dst[1] = v.y;
+      if (q * 4 + 2 < vw) dst[2] = v.z;
+      if (q * 4 + 3 < vw) dst[3] = v.w;
+    }
+  }
+  POOL_T(7);
+#ifdef MI_POOL_PHASES
+  t_acc[0] = __builtin_readcyclecounter() - t_mark0;
+  t_acc[11] = wall_clock64();
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 11; i++) atomicAdd(&pool_dbg[i], t_acc[i]);
+  if (threadIdx.x == 0) atomicMax(&pool_dbg[11], t_acc[11]);
+  if (threadIdx.x == 0) atomicMin(&pool_dbg[12], t_acc[11]);
+#endif
 }
 
 int check_pool(const void* a, const void* rois, const void* b, int batch, int channels, int height,
@@ -189,6 +550,17 @@ int check_pool(const void* a, const void* rois, const void* b, int batch, int ch
 }
 
 }  // namespace
+
+#ifdef MI_POOL_PHASES
+// -DMI_POOL_PHASES builds only: the per-phase clock sums of roi_pool_bwd_tiles (one count per wave), then cleared
+extern "C" int mi_dbg_pool_counters(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pool_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return MI_ERR_LAUNCH;
+  unsigned long long zero[16] = {};
+  zero[12] = ~0ull;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(pool_dbg), zero, sizeof(zero)) != hipSuccess) return MI_ERR_LAUNCH;
+  return MI_OK;
+}
+#endif
 
 extern "C" int mi_roi_pool_forward(const float* features, const float* rois, float* output,
                                    int32_t* argmax, int batch, int channels, int height, int width,
@@ -217,11 +589,31 @@ extern "C" int mi_roi_pool_backward(const float* top_grad, const float* rois,
                       pooled_height, pooled_width);
   if (rc != MI_OK) return rc;
   MI_REQUIRE(argmax != nullptr || (long long)num_rois * channels == 0, "roi_pool: null argmax");
-  const long long total = (long long)num_rois * channels * pooled_height * pooled_width;
-  if (total == 0) return MI_OK;
-  const int block = 256;
-  roi_pool_bwd<<<mi::grid_for(total, block), block, 0, mi::as_stream(stream)>>>(
-      total, top_grad, rois, argmax, bottom_grad, batch, channels, height, width, pooled_height,
-      pooled_width, spatial_scale);
+  MI_REQUIRE(pooled_height < 32768 && pooled_width < 32768, "roi_pool: pooled size %d x %d beyond the tile tables", pooled_height, pooled_width);
+  if ((long long)batch * channels * height * width == 0) return MI_OK;
+  MI_REQUIRE(bottom_grad != nullptr, "roi_pool: null pointer");
+  // every element of bottom_grad is written (roi_pooling_kernel.cu:202), also without a single RoI
+  const int tiles_x = mi::ceil_div(width, kTileW), tiles_y = mi::ceil_div(height, kTileH);
+  const int cgroups = mi::ceil_div(channels, kTileKC);
+  const long long grid = (long long)batch * tiles_y * tiles_x * cgroups;
+  MI_REQUIRE(grid < (1LL << 31), "roi_pool: too many tiles");
+  MI_REQUIRE((long long)num_rois * channels * pooled_height * pooled_width * 4 < (1LL << 32), "roi_pool: output gradient beyond 4 GB");
+  const unsigned magic = (width >= 2 && width < 16384) ? 0xffffffffu / (unsigned)width + 1u : 0u;
+  const size_t lds = (size_t)kLdsDwords * 4;
+  // (the attribute is per device: set per call, as the RoIAlign launchers do -- it is a table write, not a synchronisation)
+#define MI_POOL_BWD(PWT)                                                                                                     \
+  do {                                                                                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_pool_bwd_tiles<PWT>),                                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
+    roi_pool_bwd_tiles<PWT><<<(int)grid, kTileThreads, lds, mi::as_stream(stream)>>>(                                       \
+        top_grad, rois, argmax, bottom_grad, batch, channels, height, width, num_rois, pooled_height, pooled_width,          \
+        spatial_scale, tiles_x, tiles_y, cgroups, magic, vec_ok, mi::tuning().ablate);                                                           \
+  } while (0)
+  const int vec_ok = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(bottom_grad) & 15) == 0;
+  if (pooled_width <= 8)
+    MI_POOL_BWD(8);
+  else
+    MI_POOL_BWD(16);
+#undef MI_POOL_BWD
   return mi::check_launch("roi_pool_bwd");
 }

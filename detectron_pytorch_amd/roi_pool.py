@@ -41,7 +41,8 @@ def roi_pool_backward(grad_output, rois, argmax, feature_size, pooled_height, po
     _lib.require_cuda(grad_output, "grad_output")
     grad_output = grad_output.contiguous()
     n, c, h, w = feature_size
-    grad_input = torch.zeros((n, c, h, w), dtype=grad_output.dtype, device=grad_output.device)
+    # every element is written by the call (roi_pooling_kernel.cu:202): no zero fill (the reference's .zero_() is redundant there too)
+    grad_input = torch.empty((n, c, h, w), dtype=grad_output.dtype, device=grad_output.device)
     with torch.cuda.device(grad_output.device):
         rc = _lib.lib().mi_roi_pool_backward(grad_output.data_ptr(), rois.data_ptr(), argmax.data_ptr(),
                                              grad_input.data_ptr(), n, c, h, w, rois.size(0),

@@ -569,7 +569,7 @@ def test_roi_pool_golden_and_oracle(oracle_mod):
     _, argmax = roi_pool_forward(to_dev(g["feat"]), to_dev(g["rois"]), 7, 7, scale)
     assert np.array_equal(argmax.cpu().numpy(), g["argmax"])
     out.backward(to_dev(g["gtop"]))
-    assert_close(f.grad, g["bwd"], "roi_pool bwd")
+    assert np.array_equal(f.grad.cpu().numpy(), g["bwd"])   # the tile backward adds in the reference's order: bit-equal
     feat = syn.feature_map(2, 40, 38, 50, seed=12)
     rois = syn.rois_adversarial(100, 2, 38, 50, 1.0 / 16, seed=13)
     gtop = np.random.RandomState(14).randn(100, 40, 7, 7).astype(np.float32)
@@ -578,7 +578,7 @@ def test_roi_pool_golden_and_oracle(oracle_mod):
     ref_out, ref_arg = oracle_mod.roi_pool_forward(feat, rois, 7, 7, 1.0 / 16, threads=8)
     assert np.array_equal(out.detach().cpu().numpy(), ref_out)
     out.backward(to_dev(gtop))
-    assert_close(f.grad, oracle_mod.roi_pool_backward(gtop, rois, ref_arg, feat.shape, 1.0 / 16, threads=8), "bwd")
+    assert np.array_equal(f.grad.cpu().numpy(), oracle_mod.roi_pool_backward(gtop, rois, ref_arg, feat.shape, 1.0 / 16, threads=8))
 
 
 @pytest.mark.parametrize("shape,res,scale,nrois", [
@@ -607,6 +607,64 @@ def test_roi_pool_kernel_shapes_vs_oracle(oracle_mod, shape, res, scale, nrois):
     assert np.array_equal(out.cpu().numpy()[ok], ref_out[ok])
     assert np.array_equal(argmax.cpu().numpy()[ok], ref_arg[ok])
     assert not out.cpu().numpy()[~ok].any() and (argmax.cpu().numpy()[~ok] == -1).all()
+
+
+@pytest.mark.parametrize("shape,res,scale,nrois,kind", [
+    ((1, 32, 50, 84), (7, 7), 1.0 / 16, 64, "adversarial"),    # whole-image RoIs: every tile, long lists
+    ((2, 70, 25, 42), (7, 7), 1.0 / 32, 48, "adversarial"),    # 70 channels: ragged channel group and ragged wave; W % 4 != 0
+    ((1, 40, 60, 90), (14, 14), 1.0 / 8, 40, "adversarial"),   # 14 bin rows: two row blocks per RoI, the 16-column register block
+    ((1, 32, 30, 30), (3, 60), 1.0 / 16, 24, "adversarial"),   # pooled width beyond the register block: one bin at a time
+    ((2, 8, 9, 11), (2, 3), 1.0 / 16, 20, "adversarial"),      # a map smaller than a tile
+    ((1, 16, 40, 70), (7, 7), 1.0 / 4, 300, "tiny"),           # RoIs of 1-6 pixels: a pixel in up to seven bins of an axis
+    ((2, 32, 48, 64), (7, 7), 1.0 / 8, 600, "clustered"),      # three rounds of the RoI scan, hundreds of RoIs on the same tiles
+    ((1, 8, 35, 1), (4, 1), 1.0 / 16, 12, "adversarial")])     # width 1
+def test_roi_pool_backward_tiles_bit_equal_to_the_reference_order(oracle_mod, shape, res, scale, nrois, kind):
+    """roi_pool_bwd_tiles (LDS accumulators per 16 x 32 tile, RoIs in ascending index, bin rows in three ordered passes or
+    one bin at a time) against the oracle of ROIPoolBackward (roi_pooling_kernel.cu:128-203), which adds a pixel's terms by
+    ascending (RoI, ph, pw): BIT-equal, every element of a NaN-filled gradient map overwritten (:202), through the raw C-ABI."""
+    from detectron_pytorch_amd import _lib
+
+    n, c, h, w = shape
+    rng = np.random.RandomState(77)
+    feat = syn.feature_map(n, c, h, w, seed=51)
+    feat = np.round(feat * 4) / 4          # many ties: overlapping bins of one RoI pick the SAME pixel (the order matters)
+    if kind == "adversarial":
+        rois = syn.rois_adversarial(nrois, n, h, w, scale, seed=52)
+    elif kind == "tiny":
+        x1 = rng.uniform(0, w / scale, nrois)
+        y1 = rng.uniform(0, h / scale, nrois)
+        rois = np.stack([np.zeros(nrois), x1, y1, x1 + rng.uniform(0, 6 / scale, nrois), y1 + rng.uniform(0, 6 / scale, nrois)], 1).astype(np.float32)
+    else:
+        cx, cy = rng.uniform(0.3, 0.7, 2)
+        x1 = (cx + rng.normal(0, 0.05, nrois)) * w / scale
+        y1 = (cy + rng.normal(0, 0.05, nrois)) * h / scale
+        rois = np.stack([rng.randint(0, n, nrois), x1, y1, x1 + rng.uniform(8, 200, nrois), y1 + rng.uniform(8, 200, nrois)], 1).astype(np.float32)
+    ref_out, ref_arg = oracle_mod.roi_pool_forward(feat, rois, res[0], res[1], scale, threads=8)
+    gtop = rng.randn(nrois, c, *res).astype(np.float32)
+    want = oracle_mod.roi_pool_backward(gtop, rois, ref_arg, feat.shape, scale, threads=8)
+    lib = _lib.lib()
+    got = torch.full((n, c, h, w), float("nan"), device=dev())
+    d_gtop, d_rois, d_arg = to_dev(gtop), to_dev(rois), to_dev(ref_arg)
+    rc = lib.mi_roi_pool_backward(d_gtop.data_ptr(), d_rois.data_ptr(), d_arg.data_ptr(), got.data_ptr(), n, c, h, w,
+                                  nrois, res[0], res[1], scale, _lib.current_stream_handle(dev()))
+    assert rc == 0, lib.mi_last_error()
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.abs(want).sum() > 0
+    # a fabricated argmax (other channels, other images, pixels outside the rectangle, out of range): the reference adds a
+    # term only where the index is the pixel's own (:193); no RoI at all: zeros
+    fake = (ref_arg.astype(np.int64) + rng.choice([0, 0, 0, 1, -1, w, -w, h * w, -h * w, c * h * w, -c * h * w, 10 ** 9], ref_arg.shape))
+    fake = np.clip(fake, -3, 2 ** 31 - 1).astype(np.int32)
+    want = oracle_mod.roi_pool_backward(gtop, rois, fake, feat.shape, scale, threads=8)
+    got.fill_(float("nan"))
+    d_fake = to_dev(fake)
+    rc = lib.mi_roi_pool_backward(d_gtop.data_ptr(), d_rois.data_ptr(), d_fake.data_ptr(), got.data_ptr(), n, c, h, w,
+                                  nrois, res[0], res[1], scale, _lib.current_stream_handle(dev()))
+    assert rc == 0, lib.mi_last_error()
+    assert np.array_equal(got.cpu().numpy(), want)
+    got.fill_(float("nan"))
+    rc = lib.mi_roi_pool_backward(None, None, None, got.data_ptr(), n, c, h, w, 0, res[0], res[1], scale, _lib.current_stream_handle(dev()))
+    assert rc == 0, lib.mi_last_error()
+    assert not got.cpu().numpy().any()
 
 
 @pytest.mark.parametrize("shape,grid_hw,nrois,span", [

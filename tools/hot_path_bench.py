@@ -452,8 +452,7 @@ def pool_and_crop(device, iters):
         assert lib.mi_roi_pool_forward(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), argmax.data_ptr(), 1, c, h, w, r, res,
                                        res, scale, stream) == 0
 
-    def pool_bwd():
-        gin.zero_()
+    def pool_bwd():   # overwrites every element (roi_pooling_kernel.cu:202): no fill
         assert lib.mi_roi_pool_backward(gtop.data_ptr(), rois.data_ptr(), argmax.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res,
                                         res, scale, stream) == 0
 
@@ -469,7 +468,7 @@ def pool_and_crop(device, iters):
     result["roi_pool_fwd"] = dict(entry(time_kernel(pool_fwd, iters), 2 * out_bytes + 4 * c * u_pool + 20 * r),
                                   kernel="roi_pool_fwd", distinct_pixels=u_pool)
     result["roi_pool_bwd"] = dict(entry(time_kernel(pool_bwd, max(iters // 4, 10)), 2 * out_bytes + 4 * c * h * w + 20 * r),
-                                  kernel="zero fill + roi_pool_bwd (one atomic per output element through its argmax)")
+                                  kernel="roi_pool_bwd_tiles (LDS accumulators per 16x32 tile, the reference's addition order, no fill, no global atomics)")
     # ---- RoICrop: the affine grids of the same 512 boxes (what model_builder.py:279-287 builds from the RoIs) ----
     cx = (rois_np[:, 1] + rois_np[:, 3]) * 0.5 * scale / (w - 1) * 2 - 1
     cy = (rois_np[:, 2] + rois_np[:, 4]) * 0.5 * scale / (h - 1) * 2 - 1

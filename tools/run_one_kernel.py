@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling aid: launch ONE hot-path kernel a few times (config-2 shape) so that a rocprofv3 --pmc pass
-sees only it.  usage: python tools/run_one_kernel.py {roi_align_fwd|roi_align_bwd|nms} [iters]"""
+sees only it.  usage: python tools/run_one_kernel.py {roi_align_fwd|roi_align_bwd|roi_pool_bwd|roi_crop_bwd|nms} [iters]"""
 import os
 import sys
 
@@ -44,6 +44,18 @@ if which == "roi_align_bwd" and not os.environ.get("MI_BENCH_BWD_UNPLANNED"):  #
 
     fws_bytes = max(fws_bytes, _backward_workspace_bytes([(h, w)], 1, r))
 fws = torch.empty(fws_bytes, dtype=torch.uint8, device=dev)
+if which in ("roi_pool_bwd", "roi_crop_bwd"):
+    import numpy as np
+    argmax = torch.empty((r, c, res, res), dtype=torch.int32, device=dev)
+    assert lib.mi_roi_pool_forward(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), argmax.data_ptr(), 1, c, h, w, r, res, res, scale, stream) == 0
+    lin = np.linspace(-1, 1, res)
+    cx = (rois_np[:, 1] + rois_np[:, 3]) * 0.5 * scale / (w - 1) * 2 - 1
+    cy = (rois_np[:, 2] + rois_np[:, 4]) * 0.5 * scale / (h - 1) * 2 - 1
+    sx = (rois_np[:, 3] - rois_np[:, 1]) * 0.5 * scale / (w - 1) * 2
+    sy = (rois_np[:, 4] - rois_np[:, 2]) * 0.5 * scale / (h - 1) * 2
+    gy = cy[:, None, None] + sy[:, None, None] * lin[None, :, None] + 0 * lin[None, None, :]
+    gx = cx[:, None, None] + sx[:, None, None] * lin[None, None, :] + 0 * lin[None, :, None]
+    grid = torch.from_numpy(np.stack([gy, gx], axis=3).astype(np.float32)).to(dev)
 torch.cuda.synchronize()
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 warm = 20 if os.environ.get("MI_BENCH_TIME") else 0       # MI_BENCH_TIME: 20 untimed calls, then `iters` timed ones
@@ -56,6 +68,10 @@ for it in range(warm + iters):
     elif which == "roi_align_bwd":
         rc = lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
                                           scale, sr, 0, 0, fws.data_ptr(), fws.numel(), 2, stream)
+    elif which == "roi_pool_bwd":
+        rc = lib.mi_roi_pool_backward(gtop.data_ptr(), rois.data_ptr(), argmax.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res, scale, stream)
+    elif which == "roi_crop_bwd":
+        rc = lib.mi_roi_crop_backward(feat.data_ptr(), grid.data_ptr(), gtop.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res, stream)
     else:
         rc = lib.mi_nms(dets.data_ptr(), 2000, 0.7, 0, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), wsb, stream)
     assert rc == 0
