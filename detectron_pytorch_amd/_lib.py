@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_detectron_ops.so")
 
 MI_OK = 0
-ABI_VERSION = 6  # MI_ABI_VERSION of include/mi_detectron_ops.h this binding was written against
+ABI_VERSION = 7  # MI_ABI_VERSION of include/mi_detectron_ops.h this binding was written against
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 ROI_ALIGN_CAFFE2, ROI_ALIGN_LEGACY = 0, 1
 NMS_GE_ORIG_ASC, NMS_GT_SORTED_POS = 0, 1
@@ -36,6 +36,8 @@ SIGNATURES = {
     "mi_roi_pool_backward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_float, _c_void_p]),
     "mi_roi_crop_forward": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p]),
     "mi_roi_crop_backward": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_void_p]),
+    "mi_roi_crop_backward_workspace_bytes": (_c_size_t, [_c_int]),
+    "mi_roi_crop_backward_ws": (_c_int, [_c_void_p] * 4 + [_c_int] * 7 + [_c_void_p, _c_size_t, _c_void_p]),
     "mi_nms_workspace_bytes": (_c_size_t, [_c_int]),
     "mi_nms": (_c_int, [_c_void_p, _c_int, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "mi_nms_batched_workspace_bytes": (_c_size_t, [_c_int, _c_void_p]),

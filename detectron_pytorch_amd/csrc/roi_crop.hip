@@ -162,6 +162,236 @@ roi_crop_bwd(const float* __restrict__ grids, const float* __restrict__ grad_out
   }
 }
 
+// ---- backward, tile form (mi_roi_crop_backward_ws) ----------------------------------------------------------------------
+// The reference adds every output element's four products into the image gradient with global atomics (:169-190).  Here
+// a workgroup owns an 8 x 32-pixel tile of one image for 32 channels, its sums live in LDS and it OVERWRITES the tile (no
+// zero fill, no global atomics).  A first launch leaves every RoI's bounding box of in-image taps in the caller's
+// workspace (16 bytes per RoI); a tile lists the RoIs whose box meets it.  Per (RoI, 64 grid points, tile) one wave
+// tabulates the points that have a tap in the tile (tile-local top-left, which taps, the four weight products of :169-172);
+// every wave then walks the entries for its eight channels, lane = (channel, point), eight points per instruction.
+// The additions are plain LDS read / add / write (ds_add_f32 retires one lane per ~3 clocks on gfx950,
+// tools/micro/lds_atomic_bench.hip): one tap index at a time, so two lanes of one instruction meet in a pixel only if two
+// points of the entry share their top-left pixel -- the tabulating wave finds that (each point writes its lane into a map
+// of the tile and reads it back) and such entries (grids denser than the pixels) take ds_add_f32 instead.  The sums are
+// the reference's terms, (x weight * y weight) * gradient, in another order (the reference's is undefined).
+constexpr int kBtH = 8, kBtW = 32, kBtKC = 32, kBtCW = 8, kBtThreads = 256;
+constexpr int kBtAcc = kBtH * kBtW + 4;   // accumulator stride of a channel (dwords)
+constexpr int kBtScan = 512;              // RoIs scanned per round
+constexpr int kBtSub = 8;                 // entries tabulated at once
+constexpr int kBtMap = (kBtH + 1) * (kBtW + 2);  // top-left cells a point with a tap in the tile can have (+ padding)
+// LDS, dwords
+constexpr int kBtHits = kBtKC * kBtAcc;
+constexpr int kBtMeta = kBtHits + kBtScan;             // [kBtSub][64] (ty + 1) | (tx + 1) << 8 | taps << 16 | point << 20
+constexpr int kBtWts = kBtMeta + kBtSub * 64;          // [kBtSub][64][4]  (16-byte aligned)
+constexpr int kBtEnt = kBtWts + kBtSub * 64 * 4;       // [kBtSub][4]  RoI, points kept, some two points share a top-left
+constexpr int kBtOwner = kBtEnt + kBtSub * 4;          // [4 waves][kBtMap]
+constexpr int kBtWaveHits = kBtOwner + 4 * kBtMap;     // [2][4]
+constexpr int kBtScratch = kBtWaveHits + 8;            // [256] a dword per lane
+constexpr int kBtDwords = kBtScratch + kBtThreads;
+static_assert(kBtWts % 4 == 0, "weights must be 16-byte aligned");
+
+using lds_f32_ptr = __attribute__((address_space(3))) float*;
+
+// one wave per RoI: rows [y0, y1] and columns [x0, x1] of its taps that lie in the image (y1 < y0: none)
+__global__ void __launch_bounds__(256)
+roi_crop_boxes(const float* __restrict__ grids, int4* __restrict__ boxes, int batch, int height, int width, int num_rois,
+               int points, int roiPerImage) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= num_rois) return;
+  const bool image_ok = r / roiPerImage < batch;
+  int ylo = 0x3fffffff, yhi = -1, xlo = 0x3fffffff, xhi = -1;
+  for (int p = lane; p < points && image_ok; p += 64) {
+    int xTL, yTL;
+    float xw, yw;
+    get_top_left(grids[((long long)r * points + p) * 2 + 1], width, xTL, xw);
+    get_top_left(grids[((long long)r * points + p) * 2], height, yTL, yw);
+    const bool anyx = between(xTL, 0, width - 1) || between(xTL + 1, 0, width - 1);
+    const bool anyy = between(yTL, 0, height - 1) || between(yTL + 1, 0, height - 1);
+    if (anyx && anyy) {
+      ylo = min(ylo, max(yTL, 0));
+      yhi = max(yhi, min(yTL + 1, height - 1));
+      xlo = min(xlo, max(xTL, 0));
+      xhi = max(xhi, min(xTL + 1, width - 1));
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    ylo = min(ylo, __shfl_xor(ylo, d));
+    yhi = max(yhi, __shfl_xor(yhi, d));
+    xlo = min(xlo, __shfl_xor(xlo, d));
+    xhi = max(xhi, __shfl_xor(xhi, d));
+  }
+  if (lane == 0) boxes[r] = make_int4(ylo, yhi, xlo, xhi);
+}
+
+__global__ void __launch_bounds__(kBtThreads)
+roi_crop_bwd_tiles(const float* __restrict__ grids, const float* __restrict__ grad_output, float* __restrict__ grad_input,
+                   const int4* __restrict__ boxes, int batch, int channels, int height, int width, int num_rois, int points,
+                   int roiPerImage, int tiles_x, int tiles_y, int cgroups, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) float crop_lds[];
+  float* acc = crop_lds;
+  int* ilds = (int*)crop_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int cg = blockIdx.x % cgroups;  // one XCD's L2 serves the gradients of its channel groups
+  int tile = blockIdx.x / cgroups;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y, n = tile / tiles_y;
+  const int th0 = ty * kBtH, tw0 = tx * kBtW, vh = min(kBtH, height - th0), vw = min(kBtW, width - tw0);
+  const int c0 = cg * kBtKC;
+  const int groups = (points + 63) / 64;
+
+  for (int i = tid; i < kBtKC * kBtAcc / 4; i += kBtThreads) ((float4*)acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // this lane in the walk: channel cl of the wave's eight, point slot k of eight
+  const int cl = lane & (kBtCW - 1), k = lane >> 3;
+  const int c = c0 + wave * kBtCW + cl;
+  const bool cvalid = c < channels;
+  const unsigned acc_bytes = (unsigned)((wave * kBtCW + cl) * kBtAcc) * 4u;
+  const unsigned scratch_dword = (unsigned)(kBtScratch + tid) * 4u;
+  const int out_bytes = (int)((unsigned)num_rois * (unsigned)channels * (unsigned)points * 4u);
+  const __amdgpu_buffer_rsrc_t top_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_output), 0, out_bytes, 0x00020000);
+
+  // the RoIs of image n (:128): r / roiPerImage == n
+  const int r_first = n * roiPerImage, r_end = min(num_rois, r_first + roiPerImage);
+  for (int base = r_first; base < r_end || base == r_first; base += kBtScan) {
+    unsigned long long votes[kBtScan / kBtThreads];
+#pragma unroll
+    for (int m = 0; m < kBtScan / kBtThreads; m++) {
+      const int r = base + m * kBtThreads + tid;
+      bool hit = false;
+      if (r < r_end) {
+        const int4 b = boxes[r];
+        hit = b.x < th0 + vh && b.y >= th0 && b.z < tw0 + vw && b.w >= tw0 && b.y >= b.x;
+      }
+      votes[m] = __ballot(hit);
+      if (lane == 0) ilds[kBtWaveHits + m * 4 + wave] = __popcll(votes[m]);
+    }
+    __syncthreads();  // (the first round: also the zeroed accumulators)
+    int total = 0;
+#pragma unroll
+    for (int m = 0; m < kBtScan / kBtThreads; m++) {
+      int before = total;
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int h = ilds[kBtWaveHits + m * 4 + v];
+        before += v < wave ? h : 0;
+        total += h;
+      }
+      if ((votes[m] >> lane) & 1ull) ilds[kBtHits + before + __popcll(votes[m] & ((1ull << lane) - 1ull))] = base + m * kBtThreads + tid;
+    }
+    const int entries = uniform(total) * groups;  // an entry: (RoI, 64 of its grid points)
+
+    for (int sub = 0; sub < entries; sub += kBtSub) {
+      const int nsub = min(kBtSub, entries - sub);
+      __syncthreads();  // the hit list is written / the previous tables are no longer read
+      // ---- tabulate, a wave per entry, a lane per grid point
+      for (int e = wave; e < nsub; e += kBtThreads / 64) {
+        const int r = uniform(ilds[kBtHits + (sub + e) / groups]), p = ((sub + e) % groups) * 64 + lane;
+        int xTL = 0, yTL = 0, taps = 0;
+        float xw = 0.f, yw = 0.f;
+        if (p < points) {
+          get_top_left(grids[((long long)r * points + p) * 2 + 1], width, xTL, xw);  // :140-141
+          get_top_left(grids[((long long)r * points + p) * 2], height, yTL, yw);
+          const int lx = xTL - tw0, ly = yTL - th0;  // in the image AND in the tile
+          const bool xl = lx >= 0 && lx < vw, xr = lx + 1 >= 0 && lx + 1 < vw, yt = ly >= 0 && ly < vh, yb = ly + 1 >= 0 && ly + 1 < vh;
+          taps = ((xl && yt) ? 1 : 0) | ((xr && yt) ? 2 : 0) | ((xl && yb) ? 4 : 0) | ((xr && yb) ? 8 : 0);
+        }
+        const int lx1 = xTL - tw0 + 1, ly1 = yTL - th0 + 1;  // 0 .. kBtW, 0 .. kBtH where taps != 0
+        int* owner = ilds + kBtOwner + wave * kBtMap;
+        const int cell = taps ? ly1 * (kBtW + 2) + lx1 : 0;
+        if (taps) owner[cell] = lane;
+        __builtin_amdgcn_wave_barrier();
+        const bool shared = taps && owner[cell] != lane;   // another point of the entry has this top-left pixel
+        const unsigned long long keep = __ballot(taps != 0);
+        const int slot = __popcll(keep & ((1ull << lane) - 1ull));
+        if (taps) {
+          ilds[kBtMeta + e * 64 + slot] = ly1 | (lx1 << 8) | (taps << 16) | (p << 20);
+          // the products of :169-172, formed as the reference forms them
+          *(float4*)(crop_lds + kBtWts + (e * 64 + slot) * 4) = make_float4(xw * yw, (1 - xw) * yw, xw * (1 - yw), (1 - xw) * (1 - yw));
+        }
+        const bool any_shared = __ballot(shared) != 0;
+        if (lane == 0) {
+          ilds[kBtEnt + e * 4] = r;
+          ilds[kBtEnt + e * 4 + 1] = __popcll(keep);
+          ilds[kBtEnt + e * 4 + 2] = any_shared ? 1 : 0;
+        }
+      }
+      __syncthreads();
+
+      // ---- the walk: every wave, every entry, its own eight channels
+      for (int e = 0; e < nsub; e++) {
+        const int r = uniform(ilds[kBtEnt + e * 4]), npts = uniform(ilds[kBtEnt + e * 4 + 1]);
+        const bool shared = uniform(ilds[kBtEnt + e * 4 + 2]) != 0;
+        if (npts == 0) continue;
+        const unsigned roi_bytes = (unsigned)r * (unsigned)channels * (unsigned)points * 4u;  // wave-uniform
+        const int chan_bytes = c * points * 4;
+        for (int q0 = 0; q0 < npts; q0 += 32) {  // 32 points at a time: four per lane
+          unsigned at[4][4];
+          float term[4][4];
+#pragma unroll
+          for (int s = 0; s < 4; s++) {
+            const int q = q0 + s * 8 + k;
+            const bool live = cvalid && q < npts;
+            const int meta = ilds[kBtMeta + e * 64 + min(q, 63)];
+            const float4 w = *(const float4*)(crop_lds + kBtWts + (e * 64 + min(q, 63)) * 4);
+            const float g = __builtin_bit_cast(  // (a lane without a point reads 0 from beyond the descriptor)
+                float, __builtin_amdgcn_raw_buffer_load_b32(top_srd, live ? chan_bytes + (int)((unsigned)meta >> 20) * 4 : -64, roi_bytes, 0));
+            const int taps = live ? (meta >> 16) & 15 : 0;
+            // the top-left pixel, tile-local, may lie one row above / one column left of the tile: only taps in it are used
+            const unsigned tl = acc_bytes + (unsigned)((((meta & 0xff) - 1) * kBtW + ((meta >> 8) & 0xff) - 1) * 4);
+            at[s][0] = (taps & 1) ? tl : scratch_dword;
+            at[s][1] = (taps & 2) ? tl + 4u : scratch_dword;
+            at[s][2] = (taps & 4) ? tl + kBtW * 4u : scratch_dword;
+            at[s][3] = (taps & 8) ? tl + kBtW * 4u + 4u : scratch_dword;
+            term[s][0] = w.x * g;
+            term[s][1] = w.y * g;
+            term[s][2] = w.z * g;
+            term[s][3] = w.w * g;
+          }
+          if (!shared) {
+            // one tap index at a time: the pixels of one instruction's lanes are distinct, so read all, add, write all
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              float v[4];
+#pragma unroll
+              for (int s = 0; s < 4; s++) v[s] = *(lds_f32_ptr)(uintptr_t)at[s][t];
+#pragma unroll
+              for (int s = 0; s < 4; s++) *(lds_f32_ptr)(uintptr_t)at[s][t] = v[s] + term[s][t];
+              __builtin_amdgcn_wave_barrier();
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+              for (int s = 0; s < 4; s++)
+                if (at[s][t] != scratch_dword)
+                  __hip_atomic_fetch_add((lds_f32_ptr)(uintptr_t)at[s][t], term[s][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+    __syncthreads();  // the hit list is rewritten by the next round / the sums are complete
+  }
+
+  // ---- the tile leaves as rows of 128 bytes
+  const int q = tid & 7, hrow = tid >> 3;  // a lane: four pixels of one row
+  for (int cc = hrow / kBtH; cc < kBtKC; cc += kBtThreads / 8 / kBtH) {
+    const int ch = c0 + cc, hl = hrow & (kBtH - 1);
+    if (ch >= channels || hl >= vh || q * 4 >= vw) continue;
+    const float4 v = *(const float4*)(acc + cc * kBtAcc + hl * kBtW + q * 4);
+    float* dst = grad_input + (((long long)n * channels + ch) * height + th0 + hl) * width + tw0 + q * 4;
+    if (q * 4 + 3 < vw && vec_ok) {
+      *(float4*)dst = v;
+    } else {
+      dst[0] = v.x;
+      if (q * 4 + 1 < vw) dst[1] = v.y;
+      if (q * 4 + 2 < vw) dst[2] = v.z;
+      if (q * 4 + 3 < vw) dst[3] = v.w;
+    }
+  }
+}
+
 int check_crop(const void* a, const void* grid, const void* b, int batch, int channels, int height,
                int width, int num_rois, int gh, int gw) {
   MI_REQUIRE(batch > 0 && channels >= 0 && height > 0 && width > 0 && num_rois >= 0 && gh > 0 &&
@@ -208,4 +438,41 @@ extern "C" int mi_roi_crop_backward(const float* input, const float* grid_yx,
   roi_crop_bwd<<<num_rois * tiles, kCropThreads, 0, mi::as_stream(stream)>>>(
       grid_yx, grad_output, grad_input, batch, channels, height, width, grid_height, grid_width, num_rois / batch);
   return mi::check_launch("roi_crop_bwd");
+}
+
+extern "C" size_t mi_roi_crop_backward_workspace_bytes(int num_rois) { return (size_t)(num_rois > 0 ? num_rois : 0) * sizeof(int4) + 16; }
+
+extern "C" int mi_roi_crop_backward_ws(const float* input, const float* grid_yx, const float* grad_output, float* grad_input,
+                                       int batch, int channels, int height, int width, int num_rois, int grid_height,
+                                       int grid_width, void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+  mi::begin_call();
+  (void)input;  // the reference reads it only for the grid gradient it then discards (:166-190)
+  int rc = check_crop(grad_output, grid_yx, grad_input, batch, channels, height, width, num_rois, grid_height, grid_width);
+  if (rc != MI_OK) return rc;
+  if ((long long)batch * channels * height * width == 0) return MI_OK;
+  MI_REQUIRE(grad_input != nullptr, "roi_crop: null pointer");
+  MI_REQUIRE(workspace != nullptr && workspace_bytes >= mi_roi_crop_backward_workspace_bytes(num_rois) &&
+                 (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+             "roi_crop: the backward needs a 16-byte aligned workspace of mi_roi_crop_backward_workspace_bytes(num_rois) bytes");
+  const int points = grid_height * grid_width;
+  MI_REQUIRE(points < 4096, "roi_crop: more than 4095 grid points per RoI");
+  MI_REQUIRE((long long)num_rois * channels * points * 4 < (1LL << 32), "roi_crop: output gradient beyond 4 GB");
+  const int roiPerImage = num_rois > 0 ? num_rois / batch : 1;
+  int4* boxes = static_cast<int4*>(workspace);
+  if (num_rois > 0) {
+    roi_crop_boxes<<<mi::ceil_div(num_rois, 4), 256, 0, mi::as_stream(stream)>>>(grid_yx, boxes, batch, height, width, num_rois,
+                                                                                points, roiPerImage);
+    rc = mi::check_launch("roi_crop_boxes");
+    if (rc != MI_OK) return rc;
+  }
+  const int tiles_x = mi::ceil_div(width, kBtW), tiles_y = mi::ceil_div(height, kBtH), cgroups = mi::ceil_div(channels, kBtKC);
+  const long long grid = (long long)batch * tiles_y * tiles_x * cgroups;
+  MI_REQUIRE(grid < (1LL << 31), "roi_crop: too many tiles");
+  const size_t lds = (size_t)kBtDwords * 4;
+  const int vec_ok = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(grad_input) & 15) == 0;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_crop_bwd_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  roi_crop_bwd_tiles<<<(int)grid, kBtThreads, lds, mi::as_stream(stream)>>>(grid_yx, grad_output, grad_input, boxes, batch, channels,
+                                                                            height, width, num_rois, points, roiPerImage, tiles_x,
+                                                                            tiles_y, cgroups, vec_ok);
+  return mi::check_launch("roi_crop_bwd_tiles");
 }

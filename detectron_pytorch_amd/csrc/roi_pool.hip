@@ -191,7 +191,8 @@ constexpr int kLdsHits = kTileKC * kTileAcc;                 // [kTileScan] RoI 
 constexpr int kLdsTab = kLdsHits + kTileScan;                // [kTileSub][kTileSets] bit sets of tile rows / columns
 constexpr int kLdsEnt = kLdsTab + kTileSub * kTileSets;      // [kTileSub][kTileEnt]
 constexpr int kLdsWaveHits = kLdsEnt + kTileSub * kTileEnt;  // [4 passes][4 waves]
-constexpr int kLdsDwords = kLdsWaveHits + 16;
+constexpr int kLdsScratch = kLdsWaveHits + 16;                // [256] a dword per lane: where a lane with nothing to add reads and writes
+constexpr int kLdsDwords = kLdsScratch + kTileThreads;
 enum { E_R = 0, E_PH0, E_NPH, E_PW0, E_NPW, E_FAST, E_SW, E_SH, E_EW, E_EH };
 
 struct PoolTileRoi {  // what :155-179 derive from a RoI
@@ -270,6 +271,7 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
   const bool even = (k & 1) == 0;
   const int tile_base = (((n * channels + (cvalid ? c : 0)) * height) + th0) * width + tw0;  // this lane's plane, the tile's corner
   const unsigned acc_bytes = (unsigned)((wave * kTileCW + cl) * kTileAcc) * 4u;
+  const unsigned scratch_dword = (unsigned)(kLdsScratch + tid) * 4u;
   // kernel arguments are wave-uniform: descriptors over the two output-sized arrays (a lane without an element reads 0 past the end)
   const int out_bytes = (int)((unsigned)num_rois * (unsigned)channels * (unsigned)bins * 4u);
   const __amdgpu_buffer_rsrc_t arg_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(argmax_data), 0, out_bytes, 0x00020000);
@@ -419,25 +421,34 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
         }
         POOL_T(5);
         if (MI_ABLATE(ablate & 2)) return;
-        if (even) {
+        // One pass: the lanes of `who` add their row's elements, columns ascending.  No two of them touch one accumulator
+        // (that is what the passes are for), so the additions need not be atomic (ds_add_f32 retires ONE LANE per ~3 clocks
+        // on gfx950 -- tools/micro/lds_atomic_bench.hip -- a plain read / add / write sixteen times that): all sums are read
+        // first, a lane chains in registers the elements that hit the pixel of their left neighbour (bins two columns apart
+        // share none), and the sums go back in column order.  Lanes with nothing to add work on a dword of their own.
+        auto pass = [&](bool who, const unsigned (&where)[PWT]) {
+          unsigned at[PWT];
+          float sum[PWT];
 #pragma unroll
           for (int j = 0; j < PWT; j++)
-            if (j < npw && own_pass[j] != kNone) lds_add(own_pass[j], g[j]);
-        }
-        __builtin_amdgcn_wave_barrier();  // a pixel's additions in program order
-        if (!even) {
+            if (j < npw) {
+              at[j] = who && where[j] != kNone ? where[j] : scratch_dword;
+              sum[j] = *(lds_float_ptr)(uintptr_t)at[j];
+            }
 #pragma unroll
           for (int j = 0; j < PWT; j++)
-            if (j < npw && own_pass[j] != kNone) lds_add(own_pass[j], g[j]);
-        }
-        __builtin_amdgcn_wave_barrier();
+            if (j < npw) sum[j] = (j > 0 && at[j] == at[j - 1] ? sum[j - 1] : sum[j]) + g[j];
+#pragma unroll
+          for (int j = 0; j < PWT; j++)
+            if (j < npw) *(lds_float_ptr)(uintptr_t)at[j] = sum[j];
+          __builtin_amdgcn_wave_barrier();  // a pixel's additions in program order
+        };
+        pass(even, own_pass);
+        pass(!even, own_pass);
         if (__ballot(any_late) != 0) {
-#pragma unroll
-          for (int j = 0; j < PWT; j++)
-            if (j < npw && late_pass[j] != kNone) lds_add(late_pass[j], g[j]);
+          pass(true, late_pass);
           POOL_COUNT(10, 1);
         }
-        __builtin_amdgcn_wave_barrier();
         POOL_T(6);
       };
       // tiny RoIs (a pixel in three or more bins of an axis), pooled sizes beyond the masks / the register block, maps too

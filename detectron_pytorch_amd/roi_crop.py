@@ -39,12 +39,15 @@ def roi_crop_backward(input1, grid_yx, grad_output):
     grad_output = grad_output.contiguous()
     n, c, h, w = input1.shape
     r, gh, gw, _ = grid_yx.shape
-    grad_input1 = torch.zeros_like(input1, memory_format=torch.contiguous_format)
+    # the tile kernel writes every element: no zero fill (functions/roi_crop.py:18), no atomics
+    grad_input1 = torch.empty_like(input1, memory_format=torch.contiguous_format)
+    lib = _lib.lib()
+    workspace = torch.empty(lib.mi_roi_crop_backward_workspace_bytes(r), dtype=torch.uint8, device=input1.device)
     with torch.cuda.device(input1.device):
-        rc = _lib.lib().mi_roi_crop_backward(input1.data_ptr(), grid_yx.data_ptr(), grad_output.data_ptr(),
-                                             grad_input1.data_ptr(), n, c, h, w, r, gh, gw,
-                                             _lib.current_stream_handle(input1.device))
-    _lib.check(rc, "mi_roi_crop_backward")
+        rc = lib.mi_roi_crop_backward_ws(input1.data_ptr(), grid_yx.data_ptr(), grad_output.data_ptr(),
+                                         grad_input1.data_ptr(), n, c, h, w, r, gh, gw, workspace.data_ptr(), workspace.numel(),
+                                         _lib.current_stream_handle(input1.device))
+    _lib.check(rc, "mi_roi_crop_backward_ws")
     return grad_input1
 
 

@@ -44,8 +44,10 @@ extern "C" {
  * dword-aligned top_grad is served by the generic backward instead of refused.  5 (round 5): mi_polys_to_masks_wrt_boxes;
  * the generic backward zero-fills under MI_ROI_ALIGN_OVERWRITE.  6 (round 6): mi_fpn_level_index_from_restore; the RoIAlign
  * backward over a workspace is two launches (no trailing launch: its plan counters alternate between two sets), the
- * RoIPool / RoICrop kernels are LDS-staged (same entry points, same results). */
-#define MI_ABI_VERSION 6
+ * RoIPool / RoICrop kernels are LDS-staged (same entry points, same results).  7 (round 6): mi_roi_pool_backward OVERWRITES
+ * (tile kernel, the reference's addition order, no atomics); mi_roi_crop_backward_ws + _workspace_bytes (tile kernel,
+ * overwrites, no atomics). */
+#define MI_ABI_VERSION 7
 
 typedef void* mi_stream_t; /* hipStream_t */
 
@@ -198,6 +200,9 @@ int mi_roi_pool_forward(const float* features, const float* rois, float* output,
                         int pooled_height, int pooled_width, float spatial_scale,
                         mi_stream_t stream);
 
+/* The backward OVERWRITES bottom_grad, every element, as ROIPoolBackward does (roi_pooling_kernel.cu:202): no zero fill by
+ * the caller.  Since ABI 7 it adds a pixel's terms in the reference's order (ascending RoI, ph, pw) without atomics: the
+ * result is bit-equal to the reference's and the same from run to run. */
 int mi_roi_pool_backward(const float* top_grad, const float* rois, const int32_t* argmax,
                          float* bottom_grad,
                          int batch, int channels, int height, int width, int num_rois,
@@ -220,6 +225,19 @@ int mi_roi_crop_backward(const float* input, const float* grid_yx, const float* 
                          float* grad_input,
                          int batch, int channels, int height, int width,
                          int num_rois, int grid_height, int grid_width, mi_stream_t stream);
+
+/* The same sums WITHOUT global atomics and WITHOUT the caller's zero fill (ABI 7): grad_input is OVERWRITTEN, every
+ * element.  Each 8 x 32-pixel tile of the image gradient is accumulated in LDS from the RoIs whose taps reach it; the
+ * workspace (mi_roi_crop_backward_workspace_bytes(num_rois) bytes, 16-byte aligned, caller-owned, contents irrelevant)
+ * receives every RoI's bounding box of taps in a first launch.  What the autograd mirror calls; the terms are the
+ * reference's ((x weight * y weight) * gradient, roi_crop_cuda_kernel.cu:169-190), their order of addition differs (the
+ * reference's atomics leave it undefined). */
+size_t mi_roi_crop_backward_workspace_bytes(int num_rois);
+int mi_roi_crop_backward_ws(const float* input, const float* grid_yx, const float* grad_output,
+                            float* grad_input,
+                            int batch, int channels, int height, int width,
+                            int num_rois, int grid_height, int grid_width,
+                            void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* ---- RPN proposal decode ------------------------------------------------------------------------------------------
  * steps 1-3 of GenerateProposalsOp.proposals_for_one_image (lib/modeling/generate_proposals.py:105-153; helpers

@@ -22,7 +22,7 @@ def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
     for required in ["mi_roi_align_forward", "mi_roi_align_forward_ws", "mi_roi_align_forward_workspace_bytes",
                      "mi_roi_align_backward", "mi_roi_align_backward_ws", "mi_roi_align_backward_overwrites", "mi_roi_pool_forward", "mi_roi_pool_backward",
-                     "mi_roi_crop_forward", "mi_roi_crop_backward", "mi_nms", "mi_nms_workspace_bytes", "mi_nms_batched", "mi_nms_batched_workspace_bytes", "mi_soft_nms", "mi_rpn_decode_proposals", "mi_roi_align_fpn_supported", "mi_roi_align_forward_fpn", "mi_roi_align_backward_fpn", "mi_soft_nms_segmented", "mi_roi_align_forward_writes_records",
+                     "mi_roi_crop_forward", "mi_roi_crop_backward", "mi_roi_crop_backward_ws", "mi_roi_crop_backward_workspace_bytes", "mi_nms", "mi_nms_workspace_bytes", "mi_nms_batched", "mi_nms_batched_workspace_bytes", "mi_soft_nms", "mi_rpn_decode_proposals", "mi_roi_align_fpn_supported", "mi_roi_align_forward_fpn", "mi_roi_align_backward_fpn", "mi_soft_nms_segmented", "mi_roi_align_forward_writes_records",
                      "mi_bbox_overlaps", "mi_last_error", "mi_abi_version"]:
         assert required in syms
 

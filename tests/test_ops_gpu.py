@@ -703,7 +703,50 @@ def test_roi_crop_kernel_shapes_vs_oracle(oracle_mod, shape, grid_hw, nrois, spa
     rc = lib.mi_roi_crop_backward(f.data_ptr(), gr.data_ptr(), to_dev(gtop).data_ptr(), gin.data_ptr(), n, c, h, w, nrois,
                                   grid_hw[0], grid_hw[1], _lib.current_stream_handle(dev()))
     assert rc == 0, lib.mi_last_error()
-    assert_close(gin, oracle_mod.roi_crop_backward(feat, grid, gtop), "roi_crop bwd")
+    want = oracle_mod.roi_crop_backward(feat, grid, gtop)
+    assert_close(gin, want, "roi_crop bwd")
+    # the tile form (mi_roi_crop_backward_ws): no atomics, OVERWRITES a NaN-filled gradient, same sums in another order
+    gin2 = torch.full_like(f, float("nan"))
+    ws = torch.empty(lib.mi_roi_crop_backward_workspace_bytes(nrois), dtype=torch.uint8, device=dev())
+    d_gtop = to_dev(gtop)
+    rc = lib.mi_roi_crop_backward_ws(f.data_ptr(), gr.data_ptr(), d_gtop.data_ptr(), gin2.data_ptr(), n, c, h, w, nrois,
+                                     grid_hw[0], grid_hw[1], ws.data_ptr(), ws.numel(), _lib.current_stream_handle(dev()))
+    assert rc == 0, lib.mi_last_error()
+    assert_close(gin2, want, "roi_crop bwd tiles")
+    assert lib.mi_roi_crop_backward_ws(f.data_ptr(), gr.data_ptr(), d_gtop.data_ptr(), gin2.data_ptr(), n, c, h, w, nrois,
+                                       grid_hw[0], grid_hw[1], ws.data_ptr(), 8, _lib.current_stream_handle(dev())) != 0   # workspace too small
+
+
+def test_roi_crop_backward_tiles_dense_grids_and_no_rois(oracle_mod):
+    """Grids denser than the pixels (several points of a RoI share their top-left pixel: the entries that take LDS atomics
+    instead of plain read / add / write), grids of one pixel, RoIs of a second image, and no RoI at all (zeros)."""
+    from detectron_pytorch_amd import _lib
+
+    lib = _lib.lib()
+    n, c, h, w, nrois, gh, gw = 2, 40, 21, 45, 12, 7, 7
+    rng = np.random.RandomState(5)
+    feat = syn.feature_map(n, c, h, w, seed=61)
+    grid = np.empty((nrois, gh, gw, 2), np.float32)
+    for r in range(nrois):
+        cy, cx = rng.uniform(-0.9, 0.9, 2)
+        span = [0.0, 0.01, 0.05, 0.2][r % 4]            # 0: all 49 points in one pixel; 0.05: ~2 x 1 pixels
+        grid[r, ..., 0] = cy + span * np.linspace(-1, 1, gh)[:, None]
+        grid[r, ..., 1] = cx + span * np.linspace(-1, 1, gw)[None, :]
+    gtop = rng.randn(nrois, c, gh, gw).astype(np.float32)
+    want = oracle_mod.roi_crop_backward(feat, grid, gtop)
+    f, gr, gt = to_dev(feat), to_dev(grid), to_dev(gtop)
+    got = torch.full_like(f, float("nan"))
+    ws = torch.empty(lib.mi_roi_crop_backward_workspace_bytes(nrois), dtype=torch.uint8, device=dev())
+    rc = lib.mi_roi_crop_backward_ws(f.data_ptr(), gr.data_ptr(), gt.data_ptr(), got.data_ptr(), n, c, h, w, nrois, gh, gw,
+                                     ws.data_ptr(), ws.numel(), _lib.current_stream_handle(dev()))
+    assert rc == 0, lib.mi_last_error()
+    assert_close(got, want, "dense grids")
+    assert np.abs(want[1]).sum() > 0
+    got.fill_(float("nan"))
+    rc = lib.mi_roi_crop_backward_ws(f.data_ptr(), None, None, got.data_ptr(), n, c, h, w, 0, gh, gw, ws.data_ptr(), ws.numel(),
+                                     _lib.current_stream_handle(dev()))
+    assert rc == 0, lib.mi_last_error()
+    assert not got.cpu().numpy().any()
 
 
 # ---- RoICrop ---------------------------------------------------------------------------------------

@@ -492,15 +492,24 @@ def pool_and_crop(device, iters):
         out.zero_()   # functions/roi_crop.py:11: the zero fill is part of the reference's forward
         assert lib.mi_roi_crop_forward(feat.data_ptr(), grid.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res, stream) == 0
 
-    def crop_bwd():
+    def crop_bwd_atomics():
         gin.zero_()
         assert lib.mi_roi_crop_backward(feat.data_ptr(), grid.data_ptr(), gtop.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
                                         stream) == 0
 
+    crop_ws = torch.empty(lib.mi_roi_crop_backward_workspace_bytes(r), dtype=torch.uint8, device=device) if hasattr(lib, "mi_roi_crop_backward_ws") else None
+
+    def crop_bwd():   # the tile form: overwrites, no fill
+        assert lib.mi_roi_crop_backward_ws(feat.data_ptr(), grid.data_ptr(), gtop.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
+                                           crop_ws.data_ptr(), crop_ws.numel(), stream) == 0
+
     result["roi_crop_fwd"] = dict(entry(time_kernel(crop_fwd, iters), out_bytes + 8 * r * res * res + 4 * c * u_crop),
                                   kernel="zero fill + roi_crop_fwd", distinct_pixels=u_crop)
-    result["roi_crop_bwd"] = dict(entry(time_kernel(crop_bwd, max(iters // 4, 10)), out_bytes + 8 * r * res * res + 4 * c * h * w),
-                                  kernel="zero fill + roi_crop_bwd (four atomics per output element, as the reference)")
+    if crop_ws is not None:
+        result["roi_crop_bwd"] = dict(entry(time_kernel(crop_bwd, max(iters // 4, 10)), out_bytes + 8 * r * res * res + 4 * c * h * w),
+                                      kernel="roi_crop_boxes + roi_crop_bwd_tiles (LDS accumulators per 8x32 tile, no fill, no global atomics)")
+    result["roi_crop_bwd_atomics"] = dict(entry(time_kernel(crop_bwd_atomics, max(iters // 4, 10)), out_bytes + 8 * r * res * res + 4 * c * h * w),
+                                          kernel="zero fill + roi_crop_bwd (four global atomics per output element, as the reference; the entry point without a workspace)")
     return result
 
 
