@@ -174,21 +174,34 @@ roi_crop_bwd(const float* __restrict__ grids, const float* __restrict__ grad_out
 // points of the entry share their top-left pixel -- the tabulating wave finds that (each point writes its lane into a map
 // of the tile and reads it back) and such entries (grids denser than the pixels) take ds_add_f32 instead.  The sums are
 // the reference's terms, (x weight * y weight) * gradient, in another order (the reference's is undefined).
-constexpr int kBtH = 8, kBtW = 32, kBtKC = 32, kBtCW = 8, kBtThreads = 256;
-constexpr int kBtAcc = kBtH * kBtW + 4;   // accumulator stride of a channel (dwords)
-constexpr int kBtScan = 512;              // RoIs scanned per round
-constexpr int kBtSub = 8;                 // entries tabulated at once
+#ifndef MI_CROP_ACC_STRIDE
+#define MI_CROP_ACC_STRIDE 260
+#endif
+#ifndef MI_CROP_SCAN
+#define MI_CROP_SCAN 256
+#endif
+#ifndef MI_CROP_KC
+#define MI_CROP_KC 32
+#endif
+#ifndef MI_CROP_SUB
+#define MI_CROP_SUB 4
+#endif
+constexpr int kBtH = 8, kBtW = 32, kBtKC = MI_CROP_KC, kBtCW = 8, kBtThreads = kBtKC / kBtCW * 64, kBtWaves = kBtThreads / 64;
+constexpr int kBtAcc = MI_CROP_ACC_STRIDE;  // accumulator stride of a channel (dwords): rows of 32, 16-byte aligned, banks spread
+constexpr int kBtScan = MI_CROP_SCAN;     // RoIs scanned per round
+constexpr int kBtSub = MI_CROP_SUB;       // entries tabulated at once
+constexpr int kBtTab = 64 * 5;            // dwords of an entry's table: 64 x meta, 64 x 4 weights
 constexpr int kBtMap = (kBtH + 1) * (kBtW + 2);  // top-left cells a point with a tap in the tile can have (+ padding)
+static_assert(kBtMap <= kBtTab, "the map of top-left cells is laid over the table it precedes");
 // LDS, dwords
 constexpr int kBtHits = kBtKC * kBtAcc;
-constexpr int kBtMeta = kBtHits + kBtScan;             // [kBtSub][64] (ty + 1) | (tx + 1) << 8 | taps << 16 | point << 20
-constexpr int kBtWts = kBtMeta + kBtSub * 64;          // [kBtSub][64][4]  (16-byte aligned)
-constexpr int kBtEnt = kBtWts + kBtSub * 64 * 4;       // [kBtSub][4]  RoI, points kept, some two points share a top-left
-constexpr int kBtOwner = kBtEnt + kBtSub * 4;          // [4 waves][kBtMap]
-constexpr int kBtWaveHits = kBtOwner + 4 * kBtMap;     // [2][4]
-constexpr int kBtScratch = kBtWaveHits + 8;            // [256] a dword per lane
+constexpr int kBtTabs = kBtHits + kBtScan;             // [kBtSub][kBtTab]: 64 x meta = (ty + 1) | (tx + 1) << 8 | taps << 16 | point << 20,
+constexpr int kBtTabWts = 64;                          //                   then 64 x 4 weights (16-byte aligned)
+constexpr int kBtEnt = kBtTabs + kBtSub * kBtTab;      // [kBtSub][4]  RoI, points kept, some two points share a top-left
+constexpr int kBtWaveHits = kBtEnt + kBtSub * 4;       // [scan passes][waves]
+constexpr int kBtScratch = kBtWaveHits + (kBtScan + kBtThreads - 1) / kBtThreads * kBtWaves;  // [threads] a dword per lane
 constexpr int kBtDwords = kBtScratch + kBtThreads;
-static_assert(kBtWts % 4 == 0, "weights must be 16-byte aligned");
+static_assert((kBtTabs + kBtTabWts) % 4 == 0 && kBtTab % 4 == 0 && kBtAcc % 4 == 0 && kBtAcc >= kBtH * kBtW, "16-byte alignment of weights and accumulator rows");
 
 using lds_f32_ptr = __attribute__((address_space(3))) float*;
 
@@ -255,26 +268,27 @@ roi_crop_bwd_tiles(const float* __restrict__ grids, const float* __restrict__ gr
   // the RoIs of image n (:128): r / roiPerImage == n
   const int r_first = n * roiPerImage, r_end = min(num_rois, r_first + roiPerImage);
   for (int base = r_first; base < r_end || base == r_first; base += kBtScan) {
-    unsigned long long votes[kBtScan / kBtThreads];
+    constexpr int kPasses = (kBtScan + kBtThreads - 1) / kBtThreads;
+    unsigned long long votes[kPasses];
 #pragma unroll
-    for (int m = 0; m < kBtScan / kBtThreads; m++) {
+    for (int m = 0; m < kPasses; m++) {
       const int r = base + m * kBtThreads + tid;
       bool hit = false;
-      if (r < r_end) {
+      if (r < r_end && m * kBtThreads + tid < kBtScan) {
         const int4 b = boxes[r];
         hit = b.x < th0 + vh && b.y >= th0 && b.z < tw0 + vw && b.w >= tw0 && b.y >= b.x;
       }
       votes[m] = __ballot(hit);
-      if (lane == 0) ilds[kBtWaveHits + m * 4 + wave] = __popcll(votes[m]);
+      if (lane == 0) ilds[kBtWaveHits + m * kBtWaves + wave] = __popcll(votes[m]);
     }
     __syncthreads();  // (the first round: also the zeroed accumulators)
     int total = 0;
 #pragma unroll
-    for (int m = 0; m < kBtScan / kBtThreads; m++) {
+    for (int m = 0; m < kPasses; m++) {
       int before = total;
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const int h = ilds[kBtWaveHits + m * 4 + v];
+      for (int v = 0; v < kBtWaves; v++) {
+        const int h = ilds[kBtWaveHits + m * kBtWaves + v];
         before += v < wave ? h : 0;
         total += h;
       }
@@ -286,7 +300,7 @@ roi_crop_bwd_tiles(const float* __restrict__ grids, const float* __restrict__ gr
       const int nsub = min(kBtSub, entries - sub);
       __syncthreads();  // the hit list is written / the previous tables are no longer read
       // ---- tabulate, a wave per entry, a lane per grid point
-      for (int e = wave; e < nsub; e += kBtThreads / 64) {
+      for (int e = wave; e < nsub; e += kBtWaves) {
         const int r = uniform(ilds[kBtHits + (sub + e) / groups]), p = ((sub + e) % groups) * 64 + lane;
         int xTL = 0, yTL = 0, taps = 0;
         float xw = 0.f, yw = 0.f;
@@ -298,17 +312,18 @@ roi_crop_bwd_tiles(const float* __restrict__ grids, const float* __restrict__ gr
           taps = ((xl && yt) ? 1 : 0) | ((xr && yt) ? 2 : 0) | ((xl && yb) ? 4 : 0) | ((xr && yb) ? 8 : 0);
         }
         const int lx1 = xTL - tw0 + 1, ly1 = yTL - th0 + 1;  // 0 .. kBtW, 0 .. kBtH where taps != 0
-        int* owner = ilds + kBtOwner + wave * kBtMap;
+        int* owner = ilds + kBtTabs + e * kBtTab;  // the map of top-left cells, laid over the table this entry is about to get
         const int cell = taps ? ly1 * (kBtW + 2) + lx1 : 0;
         if (taps) owner[cell] = lane;
         __builtin_amdgcn_wave_barrier();
         const bool shared = taps && owner[cell] != lane;   // another point of the entry has this top-left pixel
+        __builtin_amdgcn_wave_barrier();                   // (the map is read before the table goes over it)
         const unsigned long long keep = __ballot(taps != 0);
         const int slot = __popcll(keep & ((1ull << lane) - 1ull));
         if (taps) {
-          ilds[kBtMeta + e * 64 + slot] = ly1 | (lx1 << 8) | (taps << 16) | (p << 20);
+          ilds[kBtTabs + e * kBtTab + slot] = ly1 | (lx1 << 8) | (taps << 16) | (p << 20);
           // the products of :169-172, formed as the reference forms them
-          *(float4*)(crop_lds + kBtWts + (e * 64 + slot) * 4) = make_float4(xw * yw, (1 - xw) * yw, xw * (1 - yw), (1 - xw) * (1 - yw));
+          *(float4*)(crop_lds + kBtTabs + e * kBtTab + kBtTabWts + slot * 4) = make_float4(xw * yw, (1 - xw) * yw, xw * (1 - yw), (1 - xw) * (1 - yw));
         }
         const bool any_shared = __ballot(shared) != 0;
         if (lane == 0) {
@@ -333,8 +348,8 @@ roi_crop_bwd_tiles(const float* __restrict__ grids, const float* __restrict__ gr
           for (int s = 0; s < 4; s++) {
             const int q = q0 + s * 8 + k;
             const bool live = cvalid && q < npts;
-            const int meta = ilds[kBtMeta + e * 64 + min(q, 63)];
-            const float4 w = *(const float4*)(crop_lds + kBtWts + (e * 64 + min(q, 63)) * 4);
+            const int meta = ilds[kBtTabs + e * kBtTab + min(q, 63)];
+            const float4 w = *(const float4*)(crop_lds + kBtTabs + e * kBtTab + kBtTabWts + min(q, 63) * 4);
             const float g = __builtin_bit_cast(  // (a lane without a point reads 0 from beyond the descriptor)
                 float, __builtin_amdgcn_raw_buffer_load_b32(top_srd, live ? chan_bytes + (int)((unsigned)meta >> 20) * 4 : -64, roi_bytes, 0));
             const int taps = live ? (meta >> 16) & 15 : 0;

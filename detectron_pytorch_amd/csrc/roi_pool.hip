@@ -179,7 +179,10 @@ constexpr int kTileH = MI_POOL_TILE_H, kTileW = 32;  // pixels per tile
 constexpr int kTileKC = 32;                  // channels per workgroup
 constexpr int kTileCW = 8;                   // channels per wave
 constexpr int kTileSlots = 64 / kTileCW;     // bin rows a wave holds at once
-constexpr int kTileAcc = kTileH * kTileW + 4;  // accumulator stride of a channel: 16-byte rows, channels 4 banks apart
+#ifndef MI_POOL_ACC_PAD
+#define MI_POOL_ACC_PAD 4
+#endif
+constexpr int kTileAcc = kTileH * kTileW + MI_POOL_ACC_PAD;  // accumulator stride of a channel: 16-byte rows, channels PAD banks apart
 constexpr int kTileScan = kTileH == 8 ? 512 : 1024;  // RoIs scanned per round
 constexpr int kTileSub = kTileH == 8 ? 16 : 32;      // (RoI, tile) entries tabulated at once
 constexpr int kTileEnt = 12;                 // dwords of an entry
@@ -497,6 +500,10 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
           one_bin_at_a_time(ent);
         }
       };
+#ifndef MI_POOL_RING
+#define MI_POOL_RING 2
+#endif
+#if MI_POOL_RING == 4
       // four register sets: the blocks of the next three entries are in flight under the current one (a fetch past the
       // last entry repeats it: every fetch issues the same loads, so the waits the compiler places stay partial)
       int a_0[PWT], a_1[PWT], a_2[PWT], a_3[PWT];
@@ -514,6 +521,20 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
         fetch(entry(i + 6), 0, a_2, g_2);
         take(i + 3, a_3, g_3);
       }
+#else
+      // two register sets: the block of the next entry is in flight under the current one (a fetch past the last entry
+      // repeats it: every fetch issues the same loads, so the waits the compiler places stay partial).  Four sets measured
+      // the same time with twice the code.
+      int a_0[PWT], a_1[PWT];
+      float g_0[PWT], g_1[PWT];
+      fetch(entry(0), 0, a_0, g_0);
+      for (int i = 0; i < nsub; i += 2) {
+        fetch(entry(i + 1), 0, a_1, g_1);
+        take(i, a_0, g_0);
+        fetch(entry(i + 2), 0, a_0, g_0);
+        take(i + 1, a_1, g_1);
+      }
+#endif
       POOL_T(4);
     }
     __syncthreads();  // the hit list is rewritten by the next round / the sums are complete

@@ -56,6 +56,7 @@ if which in ("roi_pool_bwd", "roi_crop_bwd"):
     gy = cy[:, None, None] + sy[:, None, None] * lin[None, :, None] + 0 * lin[None, None, :]
     gx = cx[:, None, None] + sx[:, None, None] * lin[None, None, :] + 0 * lin[None, :, None]
     grid = torch.from_numpy(np.stack([gy, gx], axis=3).astype(np.float32)).to(dev)
+    crop_ws = torch.empty(lib.mi_roi_crop_backward_workspace_bytes(r), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 warm = 20 if os.environ.get("MI_BENCH_TIME") else 0       # MI_BENCH_TIME: 20 untimed calls, then `iters` timed ones
@@ -71,7 +72,8 @@ for it in range(warm + iters):
     elif which == "roi_pool_bwd":
         rc = lib.mi_roi_pool_backward(gtop.data_ptr(), rois.data_ptr(), argmax.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res, scale, stream)
     elif which == "roi_crop_bwd":
-        rc = lib.mi_roi_crop_backward(feat.data_ptr(), grid.data_ptr(), gtop.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res, stream)
+        rc = lib.mi_roi_crop_backward_ws(feat.data_ptr(), grid.data_ptr(), gtop.data_ptr(), gin.data_ptr(), 1, c, h, w, r, res, res,
+                                         crop_ws.data_ptr(), crop_ws.numel(), stream)
     else:
         rc = lib.mi_nms(dets.data_ptr(), 2000, 0.7, 0, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), wsb, stream)
     assert rc == 0
