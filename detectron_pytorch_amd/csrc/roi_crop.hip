@@ -237,6 +237,10 @@ roi_crop_boxes(const float* __restrict__ grids, int4* __restrict__ boxes, int ba
   if (lane == 0) boxes[r] = make_int4(ylo, yhi, xlo, xhi);
 }
 
+#ifdef MI_TILE_TIMELINE
+__device__ unsigned long long crop_tl[4 * 8192];  // per workgroup: start, end (100 MHz), entries walked, hardware id
+#endif
+
 __global__ void __launch_bounds__(kBtThreads)
 roi_crop_bwd_tiles(const float* __restrict__ grids, const float* __restrict__ grad_output, float* __restrict__ grad_input,
                    const int4* __restrict__ boxes, int batch, int channels, int height, int width, int num_rois, int points,
@@ -253,6 +257,10 @@ roi_crop_bwd_tiles(const float* __restrict__ grids, const float* __restrict__ gr
   const int th0 = ty * kBtH, tw0 = tx * kBtW, vh = min(kBtH, height - th0), vw = min(kBtW, width - tw0);
   const int c0 = cg * kBtKC;
   const int groups = (points + 63) / 64;
+#ifdef MI_TILE_TIMELINE
+  const unsigned long long tl_start = wall_clock64();
+  int tl_entries = 0;
+#endif
 
   for (int i = tid; i < kBtKC * kBtAcc / 4; i += kBtThreads) ((float4*)acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -295,6 +303,9 @@ roi_crop_bwd_tiles(const float* __restrict__ grids, const float* __restrict__ gr
       if ((votes[m] >> lane) & 1ull) ilds[kBtHits + before + __popcll(votes[m] & ((1ull << lane) - 1ull))] = base + m * kBtThreads + tid;
     }
     const int entries = uniform(total) * groups;  // an entry: (RoI, 64 of its grid points)
+#ifdef MI_TILE_TIMELINE
+    tl_entries += entries;
+#endif
 
     for (int sub = 0; sub < entries; sub += kBtSub) {
       const int nsub = min(kBtSub, entries - sub);
@@ -405,6 +416,19 @@ roi_crop_bwd_tiles(const float* __restrict__ grids, const float* __restrict__ gr
       if (q * 4 + 3 < vw) dst[3] = v.w;
     }
   }
+#ifdef MI_TILE_TIMELINE
+  __syncthreads();
+  if (tid == 0 && blockIdx.x < 8192) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    crop_tl[4 * blockIdx.x] = tl_start;
+    crop_tl[4 * blockIdx.x + 1] = wall_clock64();
+    crop_tl[4 * blockIdx.x + 2] = tl_entries;
+    crop_tl[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 
 int check_crop(const void* a, const void* grid, const void* b, int batch, int channels, int height,
@@ -491,3 +515,10 @@ extern "C" int mi_roi_crop_backward_ws(const float* input, const float* grid_yx,
                                                                             tiles_y, cgroups, vec_ok);
   return mi::check_launch("roi_crop_bwd_tiles");
 }
+
+#ifdef MI_TILE_TIMELINE
+// -DMI_TILE_TIMELINE builds only (tools/tile_timeline.py): start / end / entries / hardware id of the last launch's workgroups
+extern "C" int mi_dbg_crop_timeline(unsigned long long* out, int workgroups) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(crop_tl), (size_t)workgroups * 4 * sizeof(unsigned long long)) == hipSuccess ? MI_OK : MI_ERR_LAUNCH;
+}
+#endif

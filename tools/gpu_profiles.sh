@@ -2,7 +2,7 @@
 # The round's profiles (ROUND=r05 bash tools/gpu_profiles.sh ...): the judged bench line; rocprofv3 kernel statistics of the training step (steady-state window); the
 # MFMA utilisation (PMC pass) of the training step AND of BASELINE config 5 (X-101-64x4d: grouped convolutions); the
 # config-2 kernel durations of every RoIAlign forward / backward variant.  Run on the GPU box through gpurun; output
-# gpurun_out/prof_$ROUND/, copy what is judged into profiles/.   usage: [ROUND=r05] bash tools/gpu_profiles.sh [all|bench|trace|mfma|config2|pmc]
+# gpurun_out/prof_$ROUND/, copy what is judged into profiles/.   usage: [ROUND=r05] bash tools/gpu_profiles.sh [all|bench|trace|mfma|config2|pmc|poolcrop]
 ROUND=${ROUND:-r05}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$ROUND; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 STAGE=${1:-all}
 if [ $STAGE = all ] || [ $STAGE = bench ]; then
@@ -65,4 +65,31 @@ for variant in records bwd; do
 done
 unset MI_ROI_ALIGN_IMPL
 fi
-cut -c1-600 $O/bench_line.json 2>/dev/null; echo; head -24 $O/train_step_steady_state.txt 2>/dev/null | cut -c1-150; head -14 $O/train_step_mfma_util.txt $O/config5_mfma_util.txt 2>/dev/null | cut -c1-130; cat $O/config2_kernel_durations.csv 2>/dev/null; cat $O/pmc_records.txt $O/pmc_bwd.txt 2>/dev/null
+if [ $STAGE = all ] || [ $STAGE = poolcrop ]; then
+# RoIPool / RoICrop backward tile kernels (round 6): durations alone, then the counter groups
+echo "pass,kernel,calls,avg_ns,min_ns,max_ns" > $O/pool_crop_bwd_kernel_durations.csv
+for k in roi_pool_bwd roi_crop_bwd; do
+  timeout 120 rocprofv3 --kernel-trace --stats -d $O/pc_$k -o c -f csv -- python $R/tools/run_one_kernel.py $k 50 > $O/pc_$k.log 2>&1
+  python - $O/pc_$k $k >> $O/pool_crop_bwd_kernel_durations.csv <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "roi_pool" in row["Name"] or "roi_crop" in row["Name"]:
+            name = row["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+            print("%s,\"%s\",%s,%.1f,%s,%s" % (sys.argv[2], name, row["Calls"], float(row["AverageNs"]), row["MinNs"], row["MaxNs"]))
+PY
+  rm -rf $O/pc_$k
+  j=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
+             "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
+             "SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"; do
+    j=$((j+1))
+    timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $O/pmc_${k}_$j -o p -- python $R/tools/run_one_kernel.py $k 5 > $O/pmc_${k}_$j.log 2>&1
+  done
+  python $R/tools/rocpd_pmc.py --json $O/pmc_$k.json $O/pmc_${k}_*/*.db | grep "roi_pool\|roi_crop" | cut -c1-120 > $O/pmc_$k.txt
+  rm -rf $O/pmc_${k}_*/ $O/pmc_${k}_*.log
+done
+(cd $R && python tools/pool_crop_time.py 100 > $O/pool_crop_time.json 2>/dev/null)
+fi
+cut -c1-600 $O/bench_line.json 2>/dev/null; echo; head -24 $O/train_step_steady_state.txt 2>/dev/null | cut -c1-150; head -14 $O/train_step_mfma_util.txt $O/config5_mfma_util.txt 2>/dev/null | cut -c1-130; cat $O/config2_kernel_durations.csv 2>/dev/null; cat $O/pmc_records.txt $O/pmc_bwd.txt $O/pool_crop_bwd_kernel_durations.csv $O/pmc_roi_pool_bwd.txt $O/pmc_roi_crop_bwd.txt 2>/dev/null

@@ -468,7 +468,7 @@ def pool_and_crop(device, iters):
     result["roi_pool_fwd"] = dict(entry(time_kernel(pool_fwd, iters), 2 * out_bytes + 4 * c * u_pool + 20 * r),
                                   kernel="roi_pool_fwd", distinct_pixels=u_pool)
     result["roi_pool_bwd"] = dict(entry(time_kernel(pool_bwd, max(iters // 4, 10)), 2 * out_bytes + 4 * c * h * w + 20 * r),
-                                  kernel="roi_pool_bwd_tiles (LDS accumulators per 16x32 tile, the reference's addition order, no fill, no global atomics)")
+                                  kernel="roi_pool_bwd_tiles (LDS accumulators per 8x32 tile, the reference's addition order, no fill, no global atomics)")
     # ---- RoICrop: the affine grids of the same 512 boxes (what model_builder.py:279-287 builds from the RoIs) ----
     cx = (rois_np[:, 1] + rois_np[:, 3]) * 0.5 * scale / (w - 1) * 2 - 1
     cy = (rois_np[:, 2] + rois_np[:, 4]) * 0.5 * scale / (h - 1) * 2 - 1
