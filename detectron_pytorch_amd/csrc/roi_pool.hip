@@ -156,46 +156,50 @@ roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ ro
 
 // ---- backward -----------------------------------------------------------------------------------------------------------
 // The reference's gather (one thread per INPUT element over all R RoIs, :128-203) turned inside out without giving up its
-// result: a workgroup owns a 16 x 32-pixel tile of one image for 32 channels, its sums live in LDS, and it OVERWRITES the
-// tile (:202 -- no zero fill by the caller, no global atomics).  The RoIs whose rounded rectangle meets the tile are listed
-// in ascending index (the reference's outer loop order, :146); every wave walks the whole list for 8 of the channels, so
-// no two waves ever touch one accumulator and nothing but program order inside a wave orders the sums.  Per (RoI, tile) the
-// workgroup tabulates once, for every tile row / column, the set of bin rows / columns the reference would try for that
-// pixel (:181-189, as a bit mask); a wave fetches only the bins those sets span -- argmax and gradient, lane = (channel,
-// bin row), the next RoI's block in flight under the current one -- decodes each argmax to a tile pixel, applies the
-// reference's tests (same image, same channel, pixel inside the rectangle :161-165, bin among the pixel's candidates
-// :191-193) and adds the gradient into LDS with ds_add_f32 (lanes with nothing to add aim at a dword of their own).
+// result: a workgroup owns an 8 x 32-pixel tile of one image for 32 channels, its sums live in LDS (33 KB: four
+// workgroups = 16 waves per CU), and it OVERWRITES the tile (:202 -- no zero fill by the caller, no global atomics).  The
+// RoIs whose rounded rectangle meets the tile are listed in ascending index (the reference's outer loop order, :146);
+// every wave walks the whole list for 8 of the channels, so no two waves ever touch one accumulator and nothing but
+// program order inside a wave orders the sums.
+// Per (RoI, tile) ONE wave tabulates: for every tile row / column the bins the reference would try for that pixel
+// (:181-189), turned around by ballots into, per bin row / column of the span, the SET of tile rows / columns that try it,
+// and then one dword per bin of the span (its offset in a channel's block, its row set, the row set of the bin row above,
+// its column).  A walking wave takes the span's bins in row-major chunks of 32, lane = (channel, bin): argmax and gradient
+// straight from memory, the argmax decoded to a tile pixel (a reciprocal multiplication in fp32, exact for these sizes),
+// the reference's tests (same image, same channel, pixel inside the rectangle :161-165, bin among the pixel's candidates
+// :191-193) as two shifts into the sets.
 // ORDER: a pixel's terms must be added by ascending (RoI, ph, pw) (:146,:191-192).  When no pixel has more than two
-// candidate bin rows or columns (every RoI at least a pixel per bin, i.e. all but tiny ones) bins two rows apart share
-// no pixel, so the bin rows are taken in three passes, each walking the columns in ascending order: even rows for the
-// pixels whose FIRST candidate row they are, odd rows, even rows for the pixels whose first candidate row is the odd row
-// above.  Otherwise the span's bins are taken one at a time in row-major order.  Either way every pixel sees the
-// reference's sequence of fp32 additions: the result is bit-equal, run to run and to the reference.
-// (Rounds 1-6a: one global atomic per output element into a zero-filled map, 221 us at the config-2 shape.)
-#ifndef MI_POOL_TILE_H
-#define MI_POOL_TILE_H 8
-#endif
-constexpr int kTileH = MI_POOL_TILE_H, kTileW = 32;  // pixels per tile
+// candidate bin rows or columns (every RoI at least a pixel per bin, i.e. all but tiny ones) a pixel gets at most four
+// terms from a RoI, one per combination (first / second candidate row) x (first / second candidate column) -- and that
+// pair, read as a number 0..3, IS their row-major order.  So a chunk is added in four passes by that number; inside a pass
+// no two lanes meet in an accumulator, so the additions are plain LDS read / add / write (ds_add_f32 retires one lane
+// per ~3 clocks on gfx950, tools/micro/lds_atomic_bench.hip), lanes with nothing to add working on a dword of their own.
+// Otherwise the span's bins are taken one at a time.  Either way every pixel sees the reference's sequence of fp32
+// additions: the result is bit-equal, run to run and to the reference.
+// (Rounds 1-6a: one global atomic per output element into a zero-filled map, 221 us at the config-2 shape; the first tile
+// form -- lane = (channel, bin row), columns in registers, three passes by row parity -- 104.6 us: 385 VALU instructions per
+// (RoI, tile, 8 channels) with 12 of 64 lanes active on average.)
+constexpr int kTileH = 8, kTileW = 32;       // pixels per tile
 constexpr int kTileKC = 32;                  // channels per workgroup
 constexpr int kTileCW = 8;                   // channels per wave
-constexpr int kTileSlots = 64 / kTileCW;     // bin rows a wave holds at once
-#ifndef MI_POOL_ACC_PAD
-#define MI_POOL_ACC_PAD 4
-#endif
-constexpr int kTileAcc = kTileH * kTileW + MI_POOL_ACC_PAD;  // accumulator stride of a channel: 16-byte rows, channels PAD banks apart
-constexpr int kTileScan = kTileH == 8 ? 512 : 1024;  // RoIs scanned per round
-constexpr int kTileSub = kTileH == 8 ? 16 : 32;      // (RoI, tile) entries tabulated at once
+constexpr int kTileAcc = kTileH * kTileW + 4;  // accumulator stride of a channel: 16-byte rows, channels 4 banks apart
+constexpr int kTileScan = 512;               // RoIs scanned per round
+constexpr int kTileSub = 6;                  // (RoI, tile) entries tabulated at once
+constexpr int kTileBins = 128;               // elements of a span's range an entry's table holds (more: one bin at a time)
 constexpr int kTileEnt = 12;                 // dwords of an entry
-constexpr int kTileRowSets = 34;             // [0]: empty, [1 + b]: the tile rows whose pixels try bin row ph0 + b (b < 32), [33]: empty
-constexpr int kTileSets = kTileRowSets + 16; // ... then [kTileRowSets + j]: the tile columns whose pixels try bin column pw0 + j
+constexpr int kTabRows = 0;                  // [1 + b]: the tile rows whose pixels try bin row ph0 + b; [0]: none
+constexpr int kTabCols = 12;                 // [1 + j]: the tile columns whose pixels try bin column pw0 + j; [0]: none
+constexpr int kTabBins = kTabCols + 36;      // [q]: element q of the span's range: row set | row set of the bin row above << 8 | j << 16
+constexpr int kTabDwords = kTabBins + kTileBins;
 constexpr int kTileThreads = 256;
 // LDS, in dwords
 constexpr int kLdsHits = kTileKC * kTileAcc;                 // [kTileScan] RoI indices of the round, ascending
-constexpr int kLdsTab = kLdsHits + kTileScan;                // [kTileSub][kTileSets] bit sets of tile rows / columns
-constexpr int kLdsEnt = kLdsTab + kTileSub * kTileSets;      // [kTileSub][kTileEnt]
-constexpr int kLdsWaveHits = kLdsEnt + kTileSub * kTileEnt;  // [4 passes][4 waves]
-constexpr int kLdsScratch = kLdsWaveHits + 16;                // [256] a dword per lane: where a lane with nothing to add reads and writes
+constexpr int kLdsTab = kLdsHits + kTileScan;                // [kTileSub][kTabDwords]
+constexpr int kLdsEnt = kLdsTab + kTileSub * kTabDwords;     // [kTileSub][kTileEnt]
+constexpr int kLdsWaveHits = kLdsEnt + kTileSub * kTileEnt;  // [scan passes][4 waves]
+constexpr int kLdsScratch = kLdsWaveHits + 8;                 // [256] a dword per lane: where a lane with nothing to add reads and writes
 constexpr int kLdsDwords = kLdsScratch + kTileThreads;
+static_assert(kLdsDwords * 4 * 4 <= 160 * 1024, "four workgroups per CU");
 enum { E_R = 0, E_PH0, E_NPH, E_PW0, E_NPW, E_FAST, E_SW, E_SH, E_EW, E_EH };
 
 struct PoolTileRoi {  // what :155-179 derive from a RoI
@@ -220,35 +224,18 @@ __device__ __forceinline__ void pool_candidates(int d, float bin, int pooled, in
   hi = (int)fminf(fmaxf((float)hi, 0.f), (float)pooled);
 }
 
-#ifdef MI_POOL_PHASES
-__device__ unsigned long long pool_dbg[16];
-#define POOL_T0()                                                        \
-  const unsigned long long t_mark0 = __builtin_readcyclecounter();       \
-  unsigned long long t_mark = t_mark0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define POOL_T(i)                                                        \
-  do {                                                                   \
-    const unsigned long long t_now = __builtin_readcyclecounter();       \
-    t_acc[i] += t_now - t_mark;                                          \
-    t_mark = t_now;                                                      \
-  } while (0)
-#define POOL_COUNT(i, v) t_acc[i] += (unsigned long long)(v)
-#else
-#define POOL_T0()
-#define POOL_T(i)
-#define POOL_COUNT(i, v)
-#endif
 using lds_float_ptr = __attribute__((address_space(3))) float*;
-using lds_int_ptr = __attribute__((address_space(3))) int*;
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_add(unsigned byte_addr, float v) {
   __hip_atomic_fetch_add((lds_float_ptr)(uintptr_t)byte_addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int PWT>
 __global__ void __launch_bounds__(kTileThreads)
 roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__ rois, const int32_t* __restrict__ argmax_data,
                    float* __restrict__ bottom_diff, int batch, int channels, int height, int width, int num_rois,
                    int pooled_height, int pooled_width, float spatial_scale, int tiles_x, int tiles_y, int cgroups,
-                   unsigned magic, int vec_ok, int ablate) {
+                   float inv_width, int vec_ok, int ablate) {
   extern __shared__ __attribute__((aligned(16))) float pool_lds[];
   float* acc = pool_lds;
   int* ilds = (int*)pool_lds;
@@ -261,20 +248,19 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
   const int th0 = ty * kTileH, tw0 = tx * kTileW, vh = min(kTileH, height - th0), vw = min(kTileW, width - tw0);
   const int c0 = cg * kTileKC;
   const int bins = pooled_height * pooled_width;
-  const bool masks_fit = pooled_height <= 32 && pooled_width <= PWT && magic != 0;
+  // the bit sets hold bins < 32; the decode's reciprocal is exact for maps narrower than 16384 (inv_width 0: wider)
+  const bool sets_fit = pooled_height <= 32 && pooled_width <= 32 && inv_width != 0.f;
 
-  POOL_T0();
   for (int i = tid; i < kTileKC * kTileAcc / 4; i += kTileThreads) ((float4*)acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  POOL_T(1);
 
-  // this lane in the walk: channel cl of the wave's eight, bin row slot k
+  // this lane in the walk: channel cl of the wave's eight, bin slot k of eight
   const int cl = lane & (kTileCW - 1), k = lane >> 3;
   const int c = c0 + wave * kTileCW + cl;
   const bool cvalid = c < channels;
-  const bool even = (k & 1) == 0;
   const int tile_base = (((n * channels + (cvalid ? c : 0)) * height) + th0) * width + tw0;  // this lane's plane, the tile's corner
   const unsigned acc_bytes = (unsigned)((wave * kTileCW + cl) * kTileAcc) * 4u;
   const unsigned scratch_dword = (unsigned)(kLdsScratch + tid) * 4u;
+  const int chan_bytes = c * bins * 4;
   // kernel arguments are wave-uniform: descriptors over the two output-sized arrays (a lane without an element reads 0 past the end)
   const int out_bytes = (int)((unsigned)num_rois * (unsigned)channels * (unsigned)bins * 4u);
   const __amdgpu_buffer_rsrc_t arg_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(argmax_data), 0, out_bytes, 0x00020000);
@@ -312,20 +298,18 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
     }
     total = uniform(total);
     if (MI_ABLATE(ablate & 1)) total = 0;
-    POOL_T(2);
 
     for (int sub = 0; sub < total; sub += kTileSub) {
       const int nsub = min(kTileSub, total - sub);
       __syncthreads();  // the hit list is written / the previous entries are no longer read
-      // ---- tabulate the entries, a wave per entry: lane < 16 = tile row, lane 16..47 = tile column -> the bins the reference
-      // tries for that pixel (:181-189); then, turned around by ballots, for every bin row / column of the span the SET of
-      // tile rows / columns that try it (what a lane of the walk needs: its bin row is fixed, the pixel varies)
+      // ---- tabulate the entries, a wave per entry
       for (int e = wave; e < nsub; e += kTileThreads / 64) {
         const int r = uniform(ilds[kLdsHits + sub + e]);
         const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)r * 5);
         const PoolTileRoi g = pool_tile_roi((int)roundf(roi[1] * spatial_scale), (int)roundf(roi[2] * spatial_scale),
                                             (int)roundf(roi[3] * spatial_scale), (int)roundf(roi[4] * spatial_scale), pooled_height,
                                             pooled_width);
+        // lane < 8: tile row, lane 8..39: tile column -> the bins the reference tries for that pixel
         const bool row = lane < kTileH;
         const int pos = row ? lane : lane - kTileH;
         const int p = row ? th0 + pos : tw0 + pos;
@@ -346,19 +330,33 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
           npw = __builtin_amdgcn_readlane(hi, kTileH + wB) - pw0;
         }
         if (nph <= 0 || npw <= 0) nph = npw = 0;
-        const bool fast = masks_fit && !wide;
-        int* sets = ilds + kLdsTab + e * kTileSets;
-        if (fast) {
+        // (no pixel in more than two bins of an axis: at most kTileH + 1 bin rows and kTileW + 1 bin columns over the tile)
+        // 1: every pixel in at most two bins of an axis (four ordered passes); 2: tiny RoIs, a pixel in three or more bins of an
+        // axis (the same tables, the elements one at a time); 0: no tables (pooled sizes beyond the sets, maps too wide for
+        // the reciprocal, spans beyond the table)
+        const bool tabled = sets_fit && nph >= 1 && nph <= kTabCols - 2 && npw <= kTileW + 1 && (nph - 1) * pooled_width + npw <= kTileBins;
+        const int mode = tabled ? (wide ? 2 : 1) : 0;
+        int* tab = ilds + kLdsTab + e * kTabDwords;
+        if (tabled) {
           const unsigned upto_hi = hi >= 32 ? 0xffffffffu : (1u << hi) - 1u, upto_lo = lo >= 32 ? 0xffffffffu : (1u << lo) - 1u;
           const unsigned tries = upto_hi & ~upto_lo;  // bit b: this pixel row / column tries bin b
-          if (lane == 0) sets[0] = 0;
-          for (int b = 0; b <= nph && b < 33; b++) {  // (one past the span: empty, the sentinel the last row reads)
-            const unsigned long long set = __ballot(row && ((tries >> ((ph0 + b) & 31)) & 1u) && ph0 + b < 32);
-            if (lane == 0) sets[1 + b] = (int)(unsigned)set;
+          if (lane == 0) tab[kTabRows] = tab[kTabCols] = 0;
+          for (int b = 0; b < nph; b++) {
+            const unsigned long long set = __ballot(row && ((tries >> ((ph0 + b) & 31)) & 1u));
+            if (lane == 0) tab[kTabRows + 1 + b] = (int)(unsigned)set;
           }
-          for (int j = 0; j < PWT; j++) {
-            const unsigned long long set = __ballot(!row && ((tries >> ((pw0 + j) & 31)) & 1u) && j < npw);
-            if (lane == 0) sets[kTileRowSets + j] = (int)(unsigned)(set >> kTileH);
+          for (int j = 0; j < npw; j++) {
+            const unsigned long long set = __ballot(!row && ((tries >> ((pw0 + j) & 31)) & 1u));
+            if (lane == 0) tab[kTabCols + 1 + j] = (int)(unsigned)(set >> kTileH);
+          }
+          __builtin_amdgcn_wave_barrier();
+          // the span as it lies in a channel's block of the output: elements first .. last, row-major; those of the rows'
+          // ends that are not in the span get an empty row set
+          const int first = ph0 * pooled_width + pw0, count = (nph - 1) * pooled_width + npw;
+          for (int q = lane; q < count; q += 64) {
+            const int ph = (first + q) / pooled_width, j = first + q - ph * pooled_width - pw0, b = ph - ph0;
+            const bool in_span = j >= 0 && j < npw;
+            tab[kTabBins + q] = in_span ? tab[kTabRows + 1 + b] | (tab[kTabRows + b] << 8) | (j << 16) : 0;
           }
         }
         if (lane == 0) {
@@ -368,7 +366,7 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
           ent[E_NPH] = nph;
           ent[E_PW0] = pw0;
           ent[E_NPW] = npw;
-          ent[E_FAST] = fast ? 1 : 0;
+          ent[E_FAST] = mode;
           ent[E_SW] = g.start_w;
           ent[E_SH] = g.start_h;
           ent[E_EW] = g.end_w;
@@ -376,174 +374,132 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
         }
       }
       __syncthreads();
-      POOL_T(3);
-      POOL_COUNT(8, nsub);
 
       // ---- the walk: every wave, every entry, its own eight channels
-      // rows [first_row, first_row + 8) of an entry's bins: lane (cl, k) takes row k, columns pw0 .. pw0 + PWT - 1 (those
-      // beyond the span are never looked at; past the arrays a lane reads 0)
-      auto fetch = [&](const int* ent, int first_row, int (&a)[PWT], float (&g)[PWT]) {
-        const int r = uniform(ent[E_R]), ph0 = uniform(ent[E_PH0]), nph = uniform(ent[E_NPH]), pw0 = uniform(ent[E_PW0]);
-        const bool live = cvalid && first_row + k < nph && !MI_ABLATE(ablate & 8);
-        const unsigned block = (unsigned)r * (unsigned)(channels * bins) * 4u;  // wave-uniform (the arrays stay below 4 GB)
-        const int off = live ? ((c * pooled_height + ph0 + first_row + k) * pooled_width + pw0) * 4 : -64;  // beyond the descriptor: 0
-#pragma unroll
-        for (int j = 0; j < PWT; j++) {
-          a[j] = __builtin_amdgcn_raw_buffer_load_b32(arg_srd, off + j * 4, block, 0);
-          g[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(top_srd, off + j * 4, block, 0));
-        }
+      // 32 elements of an entry's range from q0: lane = (channel, four consecutive elements) -- one 16-byte load per array
+      // (per-element dword loads, 8 per chunk instead of 2, measured 99.9 us: the address coalescer, not the memory)
+      auto fetch = [&](int e, int q0, bool wanted, int (&am)[4], float (&grad)[4]) {
+        const int* ent = ilds + kLdsEnt + e * kTileEnt;
+        const int r = uniform(ent[E_R]), first = uniform(ent[E_PH0]) * pooled_width + uniform(ent[E_PW0]);
+        const unsigned roi_bytes = (unsigned)r * (unsigned)(channels * bins) * 4u;  // wave-uniform (the arrays stay below 4 GB)
+        const int off = wanted && cvalid && uniform(ent[E_FAST]) ? chan_bytes + (first + q0 + 4 * k) * 4 : -64;  // (beyond the descriptor: 0)
+        const v4i a = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(arg_srd, off, roi_bytes, 0));
+        const v4f g = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(top_srd, off, roi_bytes, 0));
+        am[0] = a.x, am[1] = a.y, am[2] = a.z, am[3] = a.w;
+        grad[0] = g.x, grad[1] = g.y, grad[2] = g.z, grad[3] = g.w;
       };
-      // one block of eight bin rows of a fast entry: decode, then the three ordered passes
-      auto add_rows = [&](const int* ent, int i, int row0, const int (&a)[PWT], const float (&g)[PWT]) {
-        const int nph = uniform(ent[E_NPH]), npw = uniform(ent[E_NPW]);
-        const int* sets = ilds + kLdsTab + i * kTileSets;
-        const bool live = cvalid && row0 + k < nph;
-        const int slot = min(row0 + k, 32);
-        const unsigned own_rows = live ? (unsigned)sets[1 + slot] : 0u;       // tile rows whose pixels try this lane's bin row
-        const unsigned rows_above = live && even ? (unsigned)sets[slot] : 0u;  // ... the bin row above (an even row waits for it)
-        unsigned col_sets[PWT];
+      // a fetched chunk: decode, then the four ordered passes
+      auto add_chunk = [&](int e, int q0, int count, int mode, const int (&am)[4], const float (&grad)[4]) {
+        const int* tab = ilds + kLdsTab + e * kTabDwords;
+        unsigned at[4];
+        int pass[4];  // 2 x (the bin row is the pixel's second) + (the bin column is the pixel's second); -1: nothing to add
 #pragma unroll
-        for (int j = 0; j < PWT; j++) col_sets[j] = (unsigned)sets[kTileRowSets + j];
-        constexpr unsigned kNone = 0xffffffffu;
-        unsigned own_pass[PWT], late_pass[PWT];  // where the element is added (kNone: nowhere): its row's own pass / the third pass
-        bool any_late = false;
-#pragma unroll
-        for (int j = 0; j < PWT; j++) {
-          own_pass[j] = late_pass[j] = kNone;
-          if (j < npw) {
-            const unsigned rel = (unsigned)(a[j] - tile_base);  // same image and channel, from the tile's first row on: small
-            const unsigned hl = __umulhi(rel, magic);             // rel / width, exact below 16 * width (width < 16384)
-            const unsigned wl = rel - hl * (unsigned)width;
-            const bool ok = hl < (unsigned)kTileH && wl < (unsigned)kTileW && (((own_rows >> hl) & (col_sets[j] >> wl)) & 1u);
-            const bool late = ok && ((rows_above >> hl) & 1u);  // an even row that is the pixel's SECOND candidate row
-            const unsigned addr = acc_bytes + (hl << 7) + (wl << 2);
-            own_pass[j] = ok && !late ? addr : kNone;
-            late_pass[j] = late ? addr : kNone;
-            any_late = any_late || late;
-          }
+        for (int s = 0; s < 4; s++) {
+          const int q = q0 + 4 * k + s;
+          const unsigned meta = cvalid && q < count ? (unsigned)tab[kTabBins + min(q, kTileBins - 1)] : 0u;
+          const int j = (int)(meta >> 16);
+          const unsigned cols = (unsigned)tab[kTabCols + 1 + j], cols_left = (unsigned)tab[kTabCols + j];
+          // same image and channel, from the tile's first row on: a small number; its row = floor(rel / width), by the
+          // reciprocal: (rel + 0.5) / width is at least 0.5 / width > 2^-15 away from an integer, the two roundings
+          // move it by less than 2^-19 (rel < 8 * width < 2^17 where it matters; anything larger lands on rows >= 8)
+          const unsigned rel = (unsigned)(am[s] - tile_base);
+          const unsigned hl = (unsigned)(((float)rel + 0.5f) * inv_width);
+          const unsigned wl = rel - hl * (unsigned)width;
+          const unsigned rows = meta & 0xffu, rows_above = (meta >> 8) & 0xffu;
+          const bool ok = hl < (unsigned)kTileH && wl < (unsigned)kTileW && (((rows >> hl) & (cols >> wl)) & 1u);
+          at[s] = acc_bytes + (hl << 7) + (wl << 2);
+          pass[s] = ok ? (int)(((rows_above >> hl) & 1u) * 2u + ((cols_left >> wl) & 1u)) : -1;
         }
-        POOL_T(5);
         if (MI_ABLATE(ablate & 2)) return;
-        // One pass: the lanes of `who` add their row's elements, columns ascending.  No two of them touch one accumulator
-        // (that is what the passes are for), so the additions need not be atomic (ds_add_f32 retires ONE LANE per ~3 clocks
-        // on gfx950 -- tools/micro/lds_atomic_bench.hip -- a plain read / add / write sixteen times that): all sums are read
-        // first, a lane chains in registers the elements that hit the pixel of their left neighbour (bins two columns apart
-        // share none), and the sums go back in column order.  Lanes with nothing to add work on a dword of their own.
-        auto pass = [&](bool who, const unsigned (&where)[PWT]) {
-          unsigned at[PWT];
-          float sum[PWT];
+        if (mode == 2) {
+          // a pixel in three or more bins of an axis: no pairing orders them -- the elements in their order, eight lanes
+          // (the channels) at a time
+          for (int kk = 0; kk < 8 && q0 + 4 * kk < count; kk++) {
 #pragma unroll
-          for (int j = 0; j < PWT; j++)
-            if (j < npw) {
-              at[j] = who && where[j] != kNone ? where[j] : scratch_dword;
-              sum[j] = *(lds_float_ptr)(uintptr_t)at[j];
-            }
-#pragma unroll
-          for (int j = 0; j < PWT; j++)
-            if (j < npw) sum[j] = (j > 0 && at[j] == at[j - 1] ? sum[j - 1] : sum[j]) + g[j];
-#pragma unroll
-          for (int j = 0; j < PWT; j++)
-            if (j < npw) *(lds_float_ptr)(uintptr_t)at[j] = sum[j];
-          __builtin_amdgcn_wave_barrier();  // a pixel's additions in program order
-        };
-        pass(even, own_pass);
-        pass(!even, own_pass);
-        if (__ballot(any_late) != 0) {
-          pass(true, late_pass);
-          POOL_COUNT(10, 1);
-        }
-        POOL_T(6);
-      };
-      // tiny RoIs (a pixel in three or more bins of an axis), pooled sizes beyond the masks / the register block, maps too
-      // wide for the reciprocal: one bin at a time, the reference's tests as written
-      auto one_bin_at_a_time = [&](const int* ent) {
-        const int r = uniform(ent[E_R]), ph0 = uniform(ent[E_PH0]), nph = uniform(ent[E_NPH]), pw0 = uniform(ent[E_PW0]),
-                  npw = uniform(ent[E_NPW]);
-        const PoolTileRoi g = pool_tile_roi(uniform(ent[E_SW]), uniform(ent[E_SH]), uniform(ent[E_EW]), uniform(ent[E_EH]),
-                                            pooled_height, pooled_width);
-        const long long block = (long long)r * channels * bins;
-        for (int b = 0; b < nph * npw; b++) {
-          const int ph = ph0 + b / npw, pw = pw0 + b % npw;
-          if (cvalid && k == 0) {
-            const int off = (c * pooled_height + ph) * pooled_width + pw;
-            const unsigned rel = (unsigned)(argmax_data[block + off] - tile_base);
-            if (rel < (unsigned)(vh * width)) {
-              const int hl = (int)(rel / (unsigned)width), wl = (int)(rel - (unsigned)hl * (unsigned)width);
-              const int h = th0 + hl, w = tw0 + wl;
-              if (wl < vw && w >= g.start_w && w <= g.end_w && h >= g.start_h && h <= g.end_h) {  // :161-165
-                int phstart, phend, pwstart, pwend;
-                pool_candidates(h - g.start_h, g.bin_size_h, pooled_height, phstart, phend);
-                pool_candidates(w - g.start_w, g.bin_size_w, pooled_width, pwstart, pwend);
-                if (ph >= phstart && ph < phend && pw >= pwstart && pw < pwend)
-                  lds_add(acc_bytes + (unsigned)((hl * kTileW + wl) << 2), top_diff[block + off]);
-              }
+            for (int s = 0; s < 4; s++) {
+              if (k == kk && pass[s] >= 0) lds_add(at[s], grad[s]);
+              __builtin_amdgcn_wave_barrier();
             }
           }
-          __builtin_amdgcn_wave_barrier();
+          return;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          // the terms whose pair is t: no two in one accumulator -- read all, add, write all
+          unsigned where[4];
+          float sum[4];
+#pragma unroll
+          for (int s = 0; s < 4; s++) {
+            where[s] = pass[s] == t ? at[s] : scratch_dword;
+            sum[s] = *(lds_float_ptr)(uintptr_t)where[s];
+          }
+#pragma unroll
+          for (int s = 0; s < 4; s++) *(lds_float_ptr)(uintptr_t)where[s] = sum[s] + grad[s];
+          __builtin_amdgcn_wave_barrier();  // a pixel's additions in program order
         }
       };
-      const int* ents = ilds + kLdsEnt;
-      auto entry = [&](int ii) { return ents + min(ii, nsub - 1) * kTileEnt; };
-      auto take = [&](int ii, const int (&a)[PWT], const float (&g)[PWT]) {
-        if (ii >= nsub || MI_ABLATE(ablate & 4)) return;
-        const int* ent = ents + ii * kTileEnt;
-        if (uniform(ent[E_FAST])) {
-          add_rows(ent, ii, 0, a, g);
-          const int nph = uniform(ent[E_NPH]);
-          for (int row0 = kTileSlots; row0 < nph; row0 += kTileSlots) {  // pooled heights above 8: further blocks, fetched in place
-            int a_x[PWT];
-            float g_x[PWT];
-            fetch(ent, row0, a_x, g_x);
-            add_rows(ent, ii, row0, a_x, g_x);
+      auto take = [&](int e, const int (&am)[4], const float (&grad)[4]) {
+        if (e >= nsub || MI_ABLATE(ablate & 4)) return;
+        const int* ent = ilds + kLdsEnt + e * kTileEnt;
+        const int r = uniform(ent[E_R]), nph = uniform(ent[E_NPH]), npw = uniform(ent[E_NPW]);
+        if (nph == 0) return;
+        const int mode = uniform(ent[E_FAST]);
+        if (mode != 0) {
+          const int count = (nph - 1) * pooled_width + npw;
+          add_chunk(e, 0, count, mode, am, grad);
+          for (int q0 = 32; q0 < count; q0 += 32) {  // ranges of more than 32 elements: further chunks, fetched in place
+            int am_x[4];
+            float grad_x[4];
+            fetch(e, q0, true, am_x, grad_x);
+            add_chunk(e, q0, count, mode, am_x, grad_x);
           }
         } else {
-          one_bin_at_a_time(ent);
+          // pooled sizes beyond the sets, spans beyond the table, maps too wide for the reciprocal: one bin at a time, the
+          // reference's tests as written
+          const int ph0 = uniform(ent[E_PH0]), pw0 = uniform(ent[E_PW0]);
+          const PoolTileRoi g = pool_tile_roi(uniform(ent[E_SW]), uniform(ent[E_SH]), uniform(ent[E_EW]), uniform(ent[E_EH]),
+                                              pooled_height, pooled_width);
+          const long long block = (long long)r * channels * bins;
+          for (int b = 0; b < nph * npw; b++) {
+            const int ph = ph0 + b / npw, pw = pw0 + b % npw;
+            if (cvalid && k == 0) {
+              const int off = (c * pooled_height + ph) * pooled_width + pw;
+              const unsigned rel = (unsigned)(argmax_data[block + off] - tile_base);
+              if (rel < (unsigned)(vh * width)) {
+                const int hl = (int)(rel / (unsigned)width), wl = (int)(rel - (unsigned)hl * (unsigned)width);
+                const int h = th0 + hl, w = tw0 + wl;
+                if (wl < vw && w >= g.start_w && w <= g.end_w && h >= g.start_h && h <= g.end_h) {  // :161-165
+                  int phstart, phend, pwstart, pwend;
+                  pool_candidates(h - g.start_h, g.bin_size_h, pooled_height, phstart, phend);
+                  pool_candidates(w - g.start_w, g.bin_size_w, pooled_width, pwstart, pwend);
+                  if (ph >= phstart && ph < phend && pw >= pwstart && pw < pwend)
+                    lds_add(acc_bytes + (unsigned)((hl * kTileW + wl) << 2), top_diff[block + off]);
+                }
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
         }
       };
-#ifndef MI_POOL_RING
-#define MI_POOL_RING 2
-#endif
-#if MI_POOL_RING == 4
-      // four register sets: the blocks of the next three entries are in flight under the current one (a fetch past the
-      // last entry repeats it: every fetch issues the same loads, so the waits the compiler places stay partial)
-      int a_0[PWT], a_1[PWT], a_2[PWT], a_3[PWT];
-      float g_0[PWT], g_1[PWT], g_2[PWT], g_3[PWT];
-      fetch(entry(0), 0, a_0, g_0);
-      fetch(entry(1), 0, a_1, g_1);
-      fetch(entry(2), 0, a_2, g_2);
-      for (int i = 0; i < nsub; i += 4) {
-        fetch(entry(i + 3), 0, a_3, g_3);
-        take(i, a_0, g_0);
-        fetch(entry(i + 4), 0, a_0, g_0);
-        take(i + 1, a_1, g_1);
-        fetch(entry(i + 5), 0, a_1, g_1);
-        take(i + 2, a_2, g_2);
-        fetch(entry(i + 6), 0, a_2, g_2);
-        take(i + 3, a_3, g_3);
+      // two register sets: the first chunk of the next entry is in flight under the current one (a fetch past the last
+      // entry repeats it: every fetch issues the same loads, so the waits the compiler places stay partial; all six
+      // entries fetched up front measured 106 us against 100)
+      int am_0[4], am_1[4];
+      float grad_0[4], grad_1[4];
+      fetch(0, 0, true, am_0, grad_0);
+      for (int e = 0; e < nsub; e += 2) {
+        fetch(min(e + 1, nsub - 1), 0, true, am_1, grad_1);
+        take(e, am_0, grad_0);
+        fetch(min(e + 2, nsub - 1), 0, true, am_0, grad_0);
+        take(e + 1, am_1, grad_1);
       }
-#else
-      // two register sets: the block of the next entry is in flight under the current one (a fetch past the last entry
-      // repeats it: every fetch issues the same loads, so the waits the compiler places stay partial).  Four sets measured
-      // the same time with twice the code.
-      int a_0[PWT], a_1[PWT];
-      float g_0[PWT], g_1[PWT];
-      fetch(entry(0), 0, a_0, g_0);
-      for (int i = 0; i < nsub; i += 2) {
-        fetch(entry(i + 1), 0, a_1, g_1);
-        take(i, a_0, g_0);
-        fetch(entry(i + 2), 0, a_0, g_0);
-        take(i + 1, a_1, g_1);
-      }
-#endif
-      POOL_T(4);
     }
     __syncthreads();  // the hit list is rewritten by the next round / the sums are complete
-    POOL_T(9);
   }
   if (num_rois <= 0) __syncthreads();
 
   // ---- the tile leaves as rows of 128 bytes
-  const int q = tid & 7, hrow = tid >> 3;  // a lane: four pixels of one row; 128 lanes per channel -> two channels per trip
+  const int q = tid & 7, hrow = tid >> 3;  // a lane: four pixels of one row; 64 lanes per channel -> four channels per trip
   for (int cc = hrow / kTileH; cc < kTileKC; cc += kTileThreads / 8 / kTileH) {
     const int ch = c0 + cc, hl = hrow & (kTileH - 1);
     if (ch >= channels || hl >= vh || q * 4 >= vw) continue;
@@ -558,15 +514,6 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
       if (q * 4 + 3 < vw) dst[3] = v.w;
     }
   }
-  POOL_T(7);
-#ifdef MI_POOL_PHASES
-  t_acc[0] = __builtin_readcyclecounter() - t_mark0;
-  t_acc[11] = wall_clock64();
-  if ((threadIdx.x & 63) == 0)
-    for (int i = 0; i < 11; i++) atomicAdd(&pool_dbg[i], t_acc[i]);
-  if (threadIdx.x == 0) atomicMax(&pool_dbg[11], t_acc[11]);
-  if (threadIdx.x == 0) atomicMin(&pool_dbg[12], t_acc[11]);
-#endif
 }
 
 int check_pool(const void* a, const void* rois, const void* b, int batch, int channels, int height,
@@ -582,17 +529,6 @@ int check_pool(const void* a, const void* rois, const void* b, int batch, int ch
 }
 
 }  // namespace
-
-#ifdef MI_POOL_PHASES
-// -DMI_POOL_PHASES builds only: the per-phase clock sums of roi_pool_bwd_tiles (one count per wave), then cleared
-extern "C" int mi_dbg_pool_counters(unsigned long long* out16) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pool_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return MI_ERR_LAUNCH;
-  unsigned long long zero[16] = {};
-  zero[12] = ~0ull;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(pool_dbg), zero, sizeof(zero)) != hipSuccess) return MI_ERR_LAUNCH;
-  return MI_OK;
-}
-#endif
 
 extern "C" int mi_roi_pool_forward(const float* features, const float* rois, float* output,
                                    int32_t* argmax, int batch, int channels, int height, int width,
@@ -630,22 +566,11 @@ extern "C" int mi_roi_pool_backward(const float* top_grad, const float* rois,
   const long long grid = (long long)batch * tiles_y * tiles_x * cgroups;
   MI_REQUIRE(grid < (1LL << 31), "roi_pool: too many tiles");
   MI_REQUIRE((long long)num_rois * channels * pooled_height * pooled_width * 4 < (1LL << 32), "roi_pool: output gradient beyond 4 GB");
-  const unsigned magic = (width >= 2 && width < 16384) ? 0xffffffffu / (unsigned)width + 1u : 0u;
+  const float inv_width = width < 16384 ? 1.0f / (float)width : 0.f;
   const size_t lds = (size_t)kLdsDwords * 4;
-  // (the attribute is per device: set per call, as the RoIAlign launchers do -- it is a table write, not a synchronisation)
-#define MI_POOL_BWD(PWT)                                                                                                     \
-  do {                                                                                                                       \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_pool_bwd_tiles<PWT>),                                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
-    roi_pool_bwd_tiles<PWT><<<(int)grid, kTileThreads, lds, mi::as_stream(stream)>>>(                                       \
-        top_grad, rois, argmax, bottom_grad, batch, channels, height, width, num_rois, pooled_height, pooled_width,          \
-        spatial_scale, tiles_x, tiles_y, cgroups, magic, vec_ok, mi::tuning().ablate);                                                           \
-  } while (0)
   const int vec_ok = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(bottom_grad) & 15) == 0;
-  if (pooled_width <= 8)
-    MI_POOL_BWD(8);
-  else
-    MI_POOL_BWD(16);
-#undef MI_POOL_BWD
+  roi_pool_bwd_tiles<<<(int)grid, kTileThreads, lds, mi::as_stream(stream)>>>(
+      top_grad, rois, argmax, bottom_grad, batch, channels, height, width, num_rois, pooled_height, pooled_width, spatial_scale,
+      tiles_x, tiles_y, cgroups, inv_width, vec_ok, mi::tuning().ablate);
   return mi::check_launch("roi_pool_bwd");
 }
