@@ -183,8 +183,14 @@ constexpr int kTileH = 8, kTileW = 32;       // pixels per tile
 constexpr int kTileKC = 32;                  // channels per workgroup
 constexpr int kTileCW = 8;                   // channels per wave
 constexpr int kTileAcc = kTileH * kTileW + 4;  // accumulator stride of a channel: 16-byte rows, channels 4 banks apart
-constexpr int kTileScan = 512;               // RoIs scanned per round
-constexpr int kTileSub = 6;                  // (RoI, tile) entries tabulated at once
+#ifndef MI_POOL_SCAN
+#define MI_POOL_SCAN 512
+#endif
+#ifndef MI_POOL_SUB
+#define MI_POOL_SUB 6
+#endif
+constexpr int kTileScan = MI_POOL_SCAN;      // RoIs scanned per round
+constexpr int kTileSub = MI_POOL_SUB;        // (RoI, tile) entries tabulated at once
 constexpr int kTileBins = 128;               // elements of a span's range an entry's table holds (more: one bin at a time)
 constexpr int kTileEnt = 12;                 // dwords of an entry
 constexpr int kTabRows = 0;                  // [1 + b]: the tile rows whose pixels try bin row ph0 + b; [0]: none

@@ -1,6 +1,6 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_ops_gpu.py -q -x -k "roi_pool" 2>&1 | tail -5
-timeout 300 python tools/pool_crop_time.py 50 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:v['us'] for k,v in d.items() if isinstance(v,dict)})"
-for a in 2 4 1; do
-  echo -n "ablate $a "; MI_LIB_OVERRIDE=.ab_r6/libmi_tuning.so MI_ROI_ALIGN_ABLATE=$a timeout 300 python tools/pool_crop_time.py 50 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roi_pool_bwd']['us'])"
-done
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3
+ROUND=r06d bash tools/gpu_profiles.sh poolcrop > gpurun_out/r06d_poolcrop.log 2>&1
+cat gpurun_out/prof_r06d/pool_crop_bwd_kernel_durations.csv
+grep -E "FETCH_SIZE|WRITE_SIZE|INSTS_VALU|INSTS_SALU|SQ_WAVES |THREAD_CYCLES" gpurun_out/prof_r06d/pmc_roi_pool_bwd.txt | grep bwd_tiles
+cut -c1-400 gpurun_out/prof_r06d/pool_crop_time.json
