@@ -2,7 +2,8 @@
 (lib/nn/parallel/parallel_apply.py:41-59: a threading.Thread per replica, each entering the extension concurrently);
 include/mi_detectron_ops.h promises the same of this library: no process-wide mutable state on the launch path, caller-owned
 workspaces, a per-thread error text.  Here two (and four) host threads, each with its own HIP stream, its own workspace and
-its own inputs, hammer mi_roi_align_forward_ws / mi_roi_align_backward_ws / mi_nms at the same time (ctypes drops the GIL
+its own inputs, hammer mi_roi_align_forward_ws / mi_roi_align_backward_ws / mi_nms (round 6: and mi_roi_pool_forward /
+_backward / mi_roi_crop_backward_ws) at the same time (ctypes drops the GIL
 around every call); every result must equal the one the same call produced alone, on every repetition.
 
 The backward is called repeatedly over ONE workspace with RECORDS_READY: its plan counters alternate between two sets
@@ -50,6 +51,19 @@ class Job:
         self.num_keep = torch.zeros(1, dtype=torch.int32, device=d)
         self.nms_ws = torch.empty(_lib.lib().mi_nms_workspace_bytes(nb), dtype=torch.uint8, device=d)
         self.nb = nb
+        # round 6: the RoIPool / RoICrop tile kernels (NCHW only): forward + ordered backward, and the sampler's backward
+        # over a workspace of its own
+        self.pool = not channels_last
+        if self.pool:
+            self.pool_out = torch.empty((rois_n, self.c, res, res), device=d)
+            self.argmax = torch.empty((rois_n, self.c, res, res), dtype=torch.int32, device=d)
+            self.pool_gin = torch.empty_like(self.feat)
+            rr = (rois_n // self.n) * self.n
+            grid = syn.crop_grid(rr, res, res, seed=seed + 3, span=1.1)
+            self.crop_r = rr
+            self.grid = torch.from_numpy(grid).to(d)
+            self.crop_gin = torch.empty_like(self.feat)
+            self.crop_ws = torch.empty(_lib.lib().mi_roi_crop_backward_workspace_bytes(rr), dtype=torch.uint8, device=d)
 
     def run(self, lib, stream_handle):
         """forward (writes the records), backward over those records (OVERWRITE), NMS -- on `stream_handle`."""
@@ -61,6 +75,17 @@ class Job:
         rc = lib.mi_nms(self.dets.data_ptr(), self.nb, 0.5, _lib.NMS_GE_ORIG_ASC, self.keep.data_ptr(), self.num_keep.data_ptr(),
                         self.nms_ws.data_ptr(), self.nms_ws.numel(), stream_handle)
         assert rc == 0, lib.mi_last_error()
+        if self.pool:
+            rc = lib.mi_roi_pool_forward(self.feat.data_ptr(), self.rois.data_ptr(), self.pool_out.data_ptr(), self.argmax.data_ptr(),
+                                         self.n, self.c, self.h, self.w, self.r, self.res, self.res, self.scale, stream_handle)
+            assert rc == 0, lib.mi_last_error()
+            rc = lib.mi_roi_pool_backward(self.gtop.data_ptr(), self.rois.data_ptr(), self.argmax.data_ptr(), self.pool_gin.data_ptr(),
+                                          self.n, self.c, self.h, self.w, self.r, self.res, self.res, self.scale, stream_handle)
+            assert rc == 0, lib.mi_last_error()
+            rc = lib.mi_roi_crop_backward_ws(self.feat.data_ptr(), self.grid.data_ptr(), self.gtop.data_ptr(), self.crop_gin.data_ptr(),
+                                             self.n, self.c, self.h, self.w, self.crop_r, self.res, self.res, self.crop_ws.data_ptr(),
+                                             self.crop_ws.numel(), stream_handle)
+            assert rc == 0, lib.mi_last_error()
 
     def backward(self, lib, stream_handle):
         rc = lib.mi_roi_align_backward_ws(self.gtop.data_ptr(), self.rois.data_ptr(), self.gin.data_ptr(), self.n, self.c, self.h,
@@ -71,7 +96,8 @@ class Job:
 
     def snapshot(self):
         k = int(self.num_keep.item())
-        return self.out.clone(), self.gin.clone(), self.keep[:k].clone()
+        extra = (self.pool_out.clone(), self.argmax.clone(), self.pool_gin.clone(), self.crop_gin.clone()) if self.pool else ()
+        return (self.out.clone(), self.gin.clone(), self.keep[:k].clone()) + extra
 
 
 def _same(a, b):
