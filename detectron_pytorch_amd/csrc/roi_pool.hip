@@ -180,8 +180,6 @@ roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ ro
 // form -- lane = (channel, bin row), columns in registers, three passes by row parity -- 104.6 us: 385 VALU instructions per
 // (RoI, tile, 8 channels) with 12 of 64 lanes active on average.)
 constexpr int kTileH = 8, kTileW = 32;       // pixels per tile
-constexpr int kTileKC = 32;                  // channels per workgroup
-constexpr int kTileCW = 8;                   // channels per wave
 constexpr int kTileAcc = kTileH * kTileW + 4;  // accumulator stride of a channel: 16-byte rows, channels 4 banks apart
 #ifndef MI_POOL_SCAN
 #define MI_POOL_SCAN 512
@@ -198,14 +196,21 @@ constexpr int kTabCols = 12;                 // [1 + j]: the tile columns whose 
 constexpr int kTabBins = kTabCols + 36;      // [q]: element q of the span's range: row set | row set of the bin row above << 8 | j << 16
 constexpr int kTabDwords = kTabBins + kTileBins;
 constexpr int kTileThreads = 256;
-// LDS, in dwords
-constexpr int kLdsHits = kTileKC * kTileAcc;                 // [kTileScan] RoI indices of the round, ascending
-constexpr int kLdsTab = kLdsHits + kTileScan;                // [kTileSub][kTabDwords]
-constexpr int kLdsEnt = kLdsTab + kTileSub * kTabDwords;     // [kTileSub][kTileEnt]
-constexpr int kLdsWaveHits = kLdsEnt + kTileSub * kTileEnt;  // [scan passes][4 waves]
-constexpr int kLdsScratch = kLdsWaveHits + 8;                 // [256] a dword per lane: where a lane with nothing to add reads and writes
-constexpr int kLdsDwords = kLdsScratch + kTileThreads;
-static_assert(kLdsDwords * 4 * 4 <= 160 * 1024, "four workgroups per CU");
+// A wave owns CW channels (8, 4 or 2), a workgroup 4 x CW: 32 channels where the tiles alone fill the chip, fewer on small
+// maps -- a tile's list is walked once per wave whatever it owns, so what a short grid lacks in workgroups it gets from
+// thinner channel slices (a lane then holds CW / 2 of a chunk's 32 elements instead of four).
+// LDS, in dwords: [4 * CW][kTileAcc] accumulators, then
+template <int CW>
+struct PoolLds {
+  static constexpr int kc = 4 * CW;                              // channels per workgroup
+  static constexpr int hits = kc * kTileAcc;                     // [kTileScan] RoI indices of the round, ascending
+  static constexpr int tab = hits + kTileScan;                   // [kTileSub][kTabDwords]
+  static constexpr int ent = tab + kTileSub * kTabDwords;        // [kTileSub][kTileEnt]
+  static constexpr int wave_hits = ent + kTileSub * kTileEnt;    // [scan passes][4 waves]
+  static constexpr int scratch = wave_hits + 8;                  // [256] a dword per lane: where a lane with nothing to add reads and writes
+  static constexpr int dwords = scratch + kTileThreads;
+};
+static_assert(PoolLds<8>::dwords * 4 * 4 <= 160 * 1024, "four workgroups of 32 channels per CU");
 enum { E_R = 0, E_PH0, E_NPH, E_PW0, E_NPW, E_FAST, E_SW, E_SH, E_EW, E_EH };
 
 struct PoolTileRoi {  // what :155-179 derive from a RoI
@@ -233,16 +238,22 @@ __device__ __forceinline__ void pool_candidates(int d, float bin, int pooled, in
 using lds_float_ptr = __attribute__((address_space(3))) float*;
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void lds_add(unsigned byte_addr, float v) {
   __hip_atomic_fetch_add((lds_float_ptr)(uintptr_t)byte_addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+template <int CW>
 __global__ void __launch_bounds__(kTileThreads)
 roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__ rois, const int32_t* __restrict__ argmax_data,
                    float* __restrict__ bottom_diff, int batch, int channels, int height, int width, int num_rois,
                    int pooled_height, int pooled_width, float spatial_scale, int tiles_x, int tiles_y, int cgroups,
                    float inv_width, int vec_ok, int ablate) {
   extern __shared__ __attribute__((aligned(16))) float pool_lds[];
+  using L = PoolLds<CW>;
+  constexpr int kTileKC = L::kc, kLdsHits = L::hits, kLdsTab = L::tab, kLdsEnt = L::ent, kLdsWaveHits = L::wave_hits, kLdsScratch = L::scratch;
+  constexpr int kEpl = CW / 2;  // elements of a 32-element chunk per lane: one 16 / 8 / 4-byte load per array
   float* acc = pool_lds;
   int* ilds = (int*)pool_lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
@@ -259,12 +270,12 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
 
   for (int i = tid; i < kTileKC * kTileAcc / 4; i += kTileThreads) ((float4*)acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // this lane in the walk: channel cl of the wave's eight, bin slot k of eight
-  const int cl = lane & (kTileCW - 1), k = lane >> 3;
-  const int c = c0 + wave * kTileCW + cl;
+  // this lane in the walk: channel cl of the wave's CW, element group k of the chunk's 64 / CW
+  const int cl = lane % CW, k = lane / CW;
+  const int c = c0 + wave * CW + cl;
   const bool cvalid = c < channels;
   const int tile_base = (((n * channels + (cvalid ? c : 0)) * height) + th0) * width + tw0;  // this lane's plane, the tile's corner
-  const unsigned acc_bytes = (unsigned)((wave * kTileCW + cl) * kTileAcc) * 4u;
+  const unsigned acc_bytes = (unsigned)((wave * CW + cl) * kTileAcc) * 4u;
   const unsigned scratch_dword = (unsigned)(kLdsScratch + tid) * 4u;
   const int chan_bytes = c * bins * 4;
   // kernel arguments are wave-uniform: descriptors over the two output-sized arrays (a lane without an element reads 0 past the end)
@@ -382,26 +393,36 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
       __syncthreads();
 
       // ---- the walk: every wave, every entry, its own eight channels
-      // 32 elements of an entry's range from q0: lane = (channel, four consecutive elements) -- one 16-byte load per array
-      // (per-element dword loads, 8 per chunk instead of 2, measured 99.9 us: the address coalescer, not the memory)
-      auto fetch = [&](int e, int q0, bool wanted, int (&am)[4], float (&grad)[4]) {
+      // 32 elements of an entry's range from q0: lane = (channel, kEpl consecutive elements) -- one load per array
+      // (per-element dword loads at CW = 8, 8 per chunk instead of 2, measured 99.9 us against 100.8 with the rest equal)
+      auto fetch = [&](int e, int q0, bool wanted, int (&am)[kEpl], float (&grad)[kEpl]) {
         const int* ent = ilds + kLdsEnt + e * kTileEnt;
         const int r = uniform(ent[E_R]), first = uniform(ent[E_PH0]) * pooled_width + uniform(ent[E_PW0]);
         const unsigned roi_bytes = (unsigned)r * (unsigned)(channels * bins) * 4u;  // wave-uniform (the arrays stay below 4 GB)
-        const int off = wanted && cvalid && uniform(ent[E_FAST]) ? chan_bytes + (first + q0 + 4 * k) * 4 : -64;  // (beyond the descriptor: 0)
-        const v4i a = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(arg_srd, off, roi_bytes, 0));
-        const v4f g = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(top_srd, off, roi_bytes, 0));
-        am[0] = a.x, am[1] = a.y, am[2] = a.z, am[3] = a.w;
-        grad[0] = g.x, grad[1] = g.y, grad[2] = g.z, grad[3] = g.w;
+        const int off = wanted && cvalid && uniform(ent[E_FAST]) ? chan_bytes + (first + q0 + kEpl * k) * 4 : -64;  // (beyond the descriptor: 0)
+        if constexpr (kEpl == 4) {
+          const v4i a = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(arg_srd, off, roi_bytes, 0));
+          const v4f g = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(top_srd, off, roi_bytes, 0));
+          am[0] = a.x, am[1] = a.y, am[2] = a.z, am[3] = a.w;
+          grad[0] = g.x, grad[1] = g.y, grad[2] = g.z, grad[3] = g.w;
+        } else if constexpr (kEpl == 2) {
+          const v2i a = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(arg_srd, off, roi_bytes, 0));
+          const v2f g = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(top_srd, off, roi_bytes, 0));
+          am[0] = a.x, am[1] = a.y;
+          grad[0] = g.x, grad[1] = g.y;
+        } else {
+          am[0] = __builtin_amdgcn_raw_buffer_load_b32(arg_srd, off, roi_bytes, 0);
+          grad[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(top_srd, off, roi_bytes, 0));
+        }
       };
       // a fetched chunk: decode, then the four ordered passes
-      auto add_chunk = [&](int e, int q0, int count, int mode, const int (&am)[4], const float (&grad)[4]) {
+      auto add_chunk = [&](int e, int q0, int count, int mode, const int (&am)[kEpl], const float (&grad)[kEpl]) {
         const int* tab = ilds + kLdsTab + e * kTabDwords;
-        unsigned at[4];
-        int pass[4];  // 2 x (the bin row is the pixel's second) + (the bin column is the pixel's second); -1: nothing to add
+        unsigned at[kEpl];
+        int pass[kEpl];  // 2 x (the bin row is the pixel's second) + (the bin column is the pixel's second); -1: nothing to add
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int q = q0 + 4 * k + s;
+        for (int s = 0; s < kEpl; s++) {
+          const int q = q0 + kEpl * k + s;
           const unsigned meta = cvalid && q < count ? (unsigned)tab[kTabBins + min(q, kTileBins - 1)] : 0u;
           const int j = (int)(meta >> 16);
           const unsigned cols = (unsigned)tab[kTabCols + 1 + j], cols_left = (unsigned)tab[kTabCols + j];
@@ -418,11 +439,11 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
         }
         if (MI_ABLATE(ablate & 2)) return;
         if (mode == 2) {
-          // a pixel in three or more bins of an axis: no pairing orders them -- the elements in their order, eight lanes
+          // a pixel in three or more bins of an axis: no pairing orders them -- the elements in their order, CW lanes
           // (the channels) at a time
-          for (int kk = 0; kk < 8 && q0 + 4 * kk < count; kk++) {
+          for (int kk = 0; kk < 64 / CW && q0 + kEpl * kk < count; kk++) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
+            for (int s = 0; s < kEpl; s++) {
               if (k == kk && pass[s] >= 0) lds_add(at[s], grad[s]);
               __builtin_amdgcn_wave_barrier();
             }
@@ -432,19 +453,19 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           // the terms whose pair is t: no two in one accumulator -- read all, add, write all
-          unsigned where[4];
-          float sum[4];
+          unsigned where[kEpl];
+          float sum[kEpl];
 #pragma unroll
-          for (int s = 0; s < 4; s++) {
+          for (int s = 0; s < kEpl; s++) {
             where[s] = pass[s] == t ? at[s] : scratch_dword;
             sum[s] = *(lds_float_ptr)(uintptr_t)where[s];
           }
 #pragma unroll
-          for (int s = 0; s < 4; s++) *(lds_float_ptr)(uintptr_t)where[s] = sum[s] + grad[s];
+          for (int s = 0; s < kEpl; s++) *(lds_float_ptr)(uintptr_t)where[s] = sum[s] + grad[s];
           __builtin_amdgcn_wave_barrier();  // a pixel's additions in program order
         }
       };
-      auto take = [&](int e, const int (&am)[4], const float (&grad)[4]) {
+      auto take = [&](int e, const int (&am)[kEpl], const float (&grad)[kEpl]) {
         if (e >= nsub || MI_ABLATE(ablate & 4)) return;
         const int* ent = ilds + kLdsEnt + e * kTileEnt;
         const int r = uniform(ent[E_R]), nph = uniform(ent[E_NPH]), npw = uniform(ent[E_NPW]);
@@ -454,8 +475,8 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
           const int count = (nph - 1) * pooled_width + npw;
           add_chunk(e, 0, count, mode, am, grad);
           for (int q0 = 32; q0 < count; q0 += 32) {  // ranges of more than 32 elements: further chunks, fetched in place
-            int am_x[4];
-            float grad_x[4];
+            int am_x[kEpl];
+            float grad_x[kEpl];
             fetch(e, q0, true, am_x, grad_x);
             add_chunk(e, q0, count, mode, am_x, grad_x);
           }
@@ -490,8 +511,8 @@ roi_pool_bwd_tiles(const float* __restrict__ top_diff, const float* __restrict__
       // two register sets: the first chunk of the next entry is in flight under the current one (a fetch past the last
       // entry repeats it: every fetch issues the same loads, so the waits the compiler places stay partial; all six
       // entries fetched up front measured 106 us against 100)
-      int am_0[4], am_1[4];
-      float grad_0[4], grad_1[4];
+      int am_0[kEpl], am_1[kEpl];
+      float grad_0[kEpl], grad_1[kEpl];
       fetch(0, 0, true, am_0, grad_0);
       for (int e = 0; e < nsub; e += 2) {
         fetch(min(e + 1, nsub - 1), 0, true, am_1, grad_1);
@@ -568,15 +589,28 @@ extern "C" int mi_roi_pool_backward(const float* top_grad, const float* rois,
   MI_REQUIRE(bottom_grad != nullptr, "roi_pool: null pointer");
   // every element of bottom_grad is written (roi_pooling_kernel.cu:202), also without a single RoI
   const int tiles_x = mi::ceil_div(width, kTileW), tiles_y = mi::ceil_div(height, kTileH);
-  const int cgroups = mi::ceil_div(channels, kTileKC);
-  const long long grid = (long long)batch * tiles_y * tiles_x * cgroups;
+  // channels per wave: the widest of 8 / 4 / 2 that still makes four workgroups per CU (measured, 512 image-sized RoIs on 50x84:
+  // 256 channels 347 / 273 / 221 us, 1024 channels 356 / 293 / 373; the config-2 shape 71.6 / 75.6 / 105.9 -- profiles/r06_pool_crop.txt)
+  const long long tiles = (long long)batch * tiles_y * tiles_x, enough = 4LL * mi::compute_units();
+  int cw = tiles * mi::ceil_div(channels, 32) >= enough ? 8 : (tiles * mi::ceil_div(channels, 16) >= enough ? 4 : 2);
+  const int forced = MI_ABLATE(mi::tuning().ablate >> 8) & 15;  // tuning builds: MI_ROI_ALIGN_ABLATE = 2048 / 1024 / 512 forces 8 / 4 / 2
+  if (forced == 8 || forced == 4 || forced == 2) cw = forced;
+  const int cgroups = mi::ceil_div(channels, 4 * cw);
+  const long long grid = tiles * cgroups;
   MI_REQUIRE(grid < (1LL << 31), "roi_pool: too many tiles");
   MI_REQUIRE((long long)num_rois * channels * pooled_height * pooled_width * 4 < (1LL << 32), "roi_pool: output gradient beyond 4 GB");
   const float inv_width = width < 16384 ? 1.0f / (float)width : 0.f;
-  const size_t lds = (size_t)kLdsDwords * 4;
   const int vec_ok = (width & 3) == 0 && (reinterpret_cast<uintptr_t>(bottom_grad) & 15) == 0;
-  roi_pool_bwd_tiles<<<(int)grid, kTileThreads, lds, mi::as_stream(stream)>>>(
-      top_grad, rois, argmax, bottom_grad, batch, channels, height, width, num_rois, pooled_height, pooled_width, spatial_scale,
-      tiles_x, tiles_y, cgroups, inv_width, vec_ok, mi::tuning().ablate);
+#define MI_POOL_BWD(CW)                                                                                                       \
+  roi_pool_bwd_tiles<CW><<<(int)grid, kTileThreads, (size_t)PoolLds<CW>::dwords * 4, mi::as_stream(stream)>>>(                \
+      top_grad, rois, argmax, bottom_grad, batch, channels, height, width, num_rois, pooled_height, pooled_width, spatial_scale, \
+      tiles_x, tiles_y, cgroups, inv_width, vec_ok, mi::tuning().ablate)
+  if (cw == 8)
+    MI_POOL_BWD(8);
+  else if (cw == 4)
+    MI_POOL_BWD(4);
+  else
+    MI_POOL_BWD(2);
+#undef MI_POOL_BWD
   return mi::check_launch("roi_pool_bwd");
 }

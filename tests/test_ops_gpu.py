@@ -617,10 +617,14 @@ def test_roi_pool_kernel_shapes_vs_oracle(oracle_mod, shape, res, scale, nrois):
     ((2, 8, 9, 11), (2, 3), 1.0 / 16, 20, "adversarial"),      # a map smaller than a tile
     ((1, 16, 40, 70), (7, 7), 1.0 / 4, 300, "tiny"),           # RoIs of 1-6 pixels: a pixel in up to seven bins of an axis
     ((2, 32, 48, 64), (7, 7), 1.0 / 8, 600, "clustered"),      # three rounds of the RoI scan, hundreds of RoIs on the same tiles
-    ((1, 8, 35, 1), (4, 1), 1.0 / 16, 12, "adversarial")])     # width 1
+    ((1, 8, 35, 1), (4, 1), 1.0 / 16, 12, "adversarial"),      # width 1
+    ((1, 128, 200, 336), (7, 7), 1.0 / 4, 96, "adversarial"),  # 275 tiles x 4 channel groups: the 8-channels-per-wave instance
+    ((1, 64, 200, 336), (7, 7), 1.0 / 4, 96, "adversarial"),   # 275 tiles x 4 groups of 16: the 4-channels-per-wave instance
+    ((1, 128, 200, 336), (7, 7), 1.0 / 4, 200, "tiny"),        # the one-element-at-a-time path of both
+    ((1, 64, 200, 336), (7, 7), 1.0 / 4, 200, "tiny")])
 def test_roi_pool_backward_tiles_bit_equal_to_the_reference_order(oracle_mod, shape, res, scale, nrois, kind):
-    """roi_pool_bwd_tiles (LDS accumulators per 16 x 32 tile, RoIs in ascending index, bin rows in three ordered passes or
-    one bin at a time) against the oracle of ROIPoolBackward (roi_pooling_kernel.cu:128-203), which adds a pixel's terms by
+    """roi_pool_bwd_tiles (LDS accumulators per 8 x 32 tile, RoIs in ascending index, a pixel's terms in four ordered passes or
+    one element at a time; 2 channels per wave on these small maps, 8 / 4 on the last two shapes) against the oracle of ROIPoolBackward (roi_pooling_kernel.cu:128-203), which adds a pixel's terms by
     ascending (RoI, ph, pw): BIT-equal, every element of a NaN-filled gradient map overwritten (:202), through the raw C-ABI."""
     from detectron_pytorch_amd import _lib
 
