@@ -753,6 +753,100 @@ def test_roi_crop_backward_tiles_dense_grids_and_no_rois(oracle_mod):
     assert not got.cpu().numpy().any()
 
 
+def _guarded(shape, fill, dtype=torch.float32, guard=4096):
+    """A tensor of `shape` in the middle of a larger allocation whose ends hold a sentinel: (view, check)."""
+    size = int(np.prod(shape))
+    buf = torch.full((guard + size + guard,), fill, dtype=dtype, device=dev())
+    sentinel = 1234567 if dtype == torch.int32 else 12345.5
+    buf[:guard] = sentinel
+    buf[guard + size:] = sentinel
+
+    def check():
+        assert bool((buf[:guard] == sentinel).all()) and bool((buf[guard + size:] == sentinel).all()), "written outside the buffer"
+    return buf[guard:guard + size].view(shape), check
+
+
+@pytest.mark.parametrize("channels,height,width", [(40, 37, 53), (8, 200, 336)])
+def test_roi_pool_and_roi_crop_stay_inside_their_buffers_on_non_finite_geometry(oracle_mod, channels, height, width):
+    """NaN / Inf / 1e30 RoI corners, image indices and sampling-grid points (a diverged network; the reference converts them
+    to int, which is undefined there): every round-6 RoIPool / RoICrop kernel returns, writes nothing outside its output
+    (sentinel-guarded allocations), leaves the device healthy, and the rows of the WELL-FORMED RoIs / grids still equal the
+    oracle bit for bit."""
+    from detectron_pytorch_amd import _lib
+
+    lib, stream = _lib.lib(), _lib.current_stream_handle(dev())
+    n, c, h, w, scale, ph, pw = 2, channels, height, width, 1.0 / 8, 7, 7
+    rng = np.random.RandomState(9)
+    feat = syn.feature_map(n, c, h, w, seed=71)
+    rois = syn.rois_adversarial(96, n, h, w, scale, seed=72)
+    bad_values = [np.nan, np.inf, -np.inf, 1e30, -1e30, 3e9, -3e9]
+    bad_rows = np.arange(0, 96, 2)
+    for k, r in enumerate(bad_rows):
+        cols = [1 + k % 4] if k < 28 else ([0] if k < 36 else [1, 2, 3, 4])
+        for col in cols:
+            rois[r, col] = bad_values[(k + col) % len(bad_values)]
+    good = np.ones(96, bool)
+    good[bad_rows] = False
+    ref_out, ref_arg = oracle_mod.roi_pool_forward(feat, rois[good], ph, pw, scale, threads=8)
+    f, d_rois = to_dev(feat), to_dev(rois)
+    out, chk_out = _guarded((96, c, ph, pw), float("nan"))
+    arg, chk_arg = _guarded((96, c, ph, pw), -7, dtype=torch.int32)
+    rc = lib.mi_roi_pool_forward(f.data_ptr(), d_rois.data_ptr(), out.data_ptr(), arg.data_ptr(), n, c, h, w, 96, ph, pw, scale, stream)
+    assert rc == 0, lib.mi_last_error()
+    torch.cuda.synchronize()
+    chk_out(), chk_arg()
+    assert np.array_equal(out.cpu().numpy()[good], ref_out)
+    assert np.array_equal(arg.cpu().numpy()[good], ref_arg)
+    a = arg.cpu().numpy()
+    assert ((a >= -1) & (a < n * c * h * w)).all(), "an argmax outside the input"
+    gtop = to_dev(rng.randn(96, c, ph, pw).astype(np.float32))
+    gin, chk_gin = _guarded((n, c, h, w), float("nan"))
+    rc = lib.mi_roi_pool_backward(gtop.data_ptr(), d_rois.data_ptr(), arg.data_ptr(), gin.data_ptr(), n, c, h, w, 96, ph, pw, scale, stream)
+    assert rc == 0, lib.mi_last_error()
+    torch.cuda.synchronize()
+    chk_gin()
+    assert bool(torch.isfinite(gin).all()), "every element is overwritten with a finite sum"
+
+    # RoICrop: grids with non-finite / huge points in every other RoI
+    nrois = 24
+    grid = syn.crop_grid(nrois, ph, pw, seed=73, span=1.2)
+    bad = np.arange(0, nrois, 2)
+    for k, r in enumerate(bad):
+        m = rng.rand(ph, pw) < (1.0 if k % 3 == 0 else 0.3)
+        grid[r, ..., k % 2][m] = bad_values[k % len(bad_values)]
+    good = np.ones(nrois, bool)
+    good[bad] = False
+    d_grid = to_dev(grid)
+    out, chk_out = _guarded((nrois, c, ph, pw), 123.0)
+    rc = lib.mi_roi_crop_forward(f.data_ptr(), d_grid.data_ptr(), out.data_ptr(), n, c, h, w, nrois, ph, pw, stream)
+    assert rc == 0, lib.mi_last_error()
+    torch.cuda.synchronize()
+    chk_out()
+    # RoI r samples image r // (nrois / n): the oracle over ALL grids with the bad ones made harmless gives the good rows
+    safe = grid.copy()
+    safe[bad] = 5.0   # far outside: nothing written
+    ref = oracle_mod.roi_crop_forward(feat, safe)
+    ref_moved = oracle_mod.roi_crop_forward(feat + 1e3, safe)
+    written = (ref_moved != ref)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[good][written[good]], ref[good][written[good]])
+    gt = to_dev(rng.randn(nrois, c, ph, pw).astype(np.float32))
+    gin, chk_gin = _guarded((n, c, h, w), 0.0)
+    rc = lib.mi_roi_crop_backward(f.data_ptr(), d_grid.data_ptr(), gt.data_ptr(), gin.data_ptr(), n, c, h, w, nrois, ph, pw, stream)
+    assert rc == 0, lib.mi_last_error()
+    torch.cuda.synchronize()
+    chk_gin()
+    gin2, chk_gin2 = _guarded((n, c, h, w), float("nan"))
+    ws, chk_ws = _guarded((lib.mi_roi_crop_backward_workspace_bytes(nrois) // 4,), 0, dtype=torch.int32)
+    rc = lib.mi_roi_crop_backward_ws(f.data_ptr(), d_grid.data_ptr(), gt.data_ptr(), gin2.data_ptr(), n, c, h, w, nrois, ph, pw,
+                                     ws.data_ptr(), ws.numel() * 4, stream)
+    assert rc == 0, lib.mi_last_error()
+    torch.cuda.synchronize()
+    chk_gin2(), chk_ws()
+    assert not bool(torch.isnan(gin2).all()), "the tile form overwrites"
+    assert float(torch.ones(4, device=dev()).sum()) == 4.0
+
+
 # ---- RoICrop ---------------------------------------------------------------------------------------
 def test_roi_crop_golden_and_oracle(oracle_mod):
     from detectron_pytorch_amd.roi_crop import RoICropFunction

@@ -1,4 +1,5 @@
-cd /root/repo
-timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_reentrancy_gpu.py -q -x -k "roi_pool or pool" 2>&1 | tail -3
-python tools/pool_bwd_c4.py 256; python tools/pool_bwd_c4.py 1024
-python tools/pool_crop_time.py 100 | cut -c1-400
+cd /tmp && export TMPDIR=/tmp
+rm -rf /root/repo/gpurun_out/prof_inf
+rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_inf -o inf --output-format csv -- python /root/repo/bench.py --child-inference-graph box > /root/repo/gpurun_out/r6m_inf.log 2>&1
+tail -2 /root/repo/gpurun_out/r6m_inf.log | cut -c1-600
+find /root/repo/gpurun_out/prof_inf -name "*kernel_stats.csv" | head
