@@ -6,8 +6,10 @@
 //   LEGACY variant: lib/model/roi_align/src/roi_align_kernel.cu:15-70 (fwd), :94-143 (bwd)
 //
 // Kernels in this file:
-//   roi_align_fwd_direct / roi_align_bwd_direct   one lane per output element, any layout, reference operation order
-//       (bit-exact): the generic path -- legacy variant, shapes / alignments the fast paths decline, MI_ROI_ALIGN_IMPL=direct.
+//   roi_align_fwd_direct / roi_align_bwd_direct   workgroup = (RoI, 32 channels), the RoI's geometry once per workgroup,
+//       lanes over (channel, bin); any layout, reference operation order (bit-exact): the generic path -- shapes /
+//       alignments the fast paths decline, MI_ROI_ALIGN_IMPL=direct.
+//   roi_align_legacy<fwd / bwd>   the legacy variant from a per-workgroup point table (see there).
 //   the dispatch of mi_roi_align_* to the fast paths, which live in files of their own: roi_align_records.hip (records,
 //       NCHW forward, tile backward), roi_align_nhwc.hip (channels-last forward), roi_align_fwd_tile.hip (NCHW forward
 //       without a workspace).
@@ -31,26 +33,47 @@ __host__ FeatStrides make_strides(int layout, int C, int H, int W) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Generic direct kernels (one lane per output element; reference thread mapping)
+// Generic direct kernels: workgroup = (RoI, tile of 32 channels).  What the reference recomputes for every output element
+// (roi_align_kernel.cu:74-99: the RoI's box, bin sizes and sampling grid) is identical for the whole workgroup and comes
+// out of scalar loads once; lanes run over (channel, bin) with the bin fastest, so a wave's taps lie in few rows of few
+// planes and its results leave as one contiguous run (the tile's outputs are contiguous in [R][C][PH][PW]); over
+// channels-last storage the channel is the fastest lane index instead (a tap = one line of 32 channels).  The
+// arithmetic per element is the reference's, operation for operation.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-roi_align_fwd_direct(long long total, const float* __restrict__ feat, const float* __restrict__ rois,
-                     float* __restrict__ out, int batch, int channels, int height, int width,
-                     int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
-                     FeatStrides st) {
-  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
-       index += (long long)gridDim.x * blockDim.x) {
-    int pw = (int)(index % aligned_width);
-    int ph = (int)((index / aligned_width) % aligned_height);
-    int c = (int)((index / aligned_width / aligned_height) % channels);
-    int n = (int)(index / aligned_width / aligned_height / channels);
-    RoiGeom g = roi_geometry(rois + (long long)n * 5, spatial_scale, aligned_height, aligned_width,
-                             sampling_ratio);
-    if (g.batch_ind < 0 || g.batch_ind >= batch) {  // the reference would read out of bounds
-      out[index] = 0.f;
+constexpr int kDirCT = 32;
+constexpr int kDirThreads = 256;
+
+struct DirItem {
+  int n, c0, cvalid, bins;
+};
+__device__ __forceinline__ DirItem dir_item(int channels, int aligned_height, int aligned_width) {
+  const int tiles = (channels + kDirCT - 1) / kDirCT;
+  DirItem it;
+  it.n = (int)blockIdx.x / tiles;
+  it.c0 = ((int)blockIdx.x - it.n * tiles) * kDirCT;
+  it.cvalid = min(kDirCT, channels - it.c0);
+  it.bins = aligned_height * aligned_width;
+  return it;
+}
+
+__global__ void __launch_bounds__(kDirThreads)
+roi_align_fwd_direct(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out, int batch,
+                     int channels, int height, int width, int aligned_height, int aligned_width, float spatial_scale,
+                     int sampling_ratio, FeatStrides st) {
+  const DirItem it = dir_item(channels, aligned_height, aligned_width);
+  const RoiGeom g = roi_geometry(rois + (long long)it.n * 5, spatial_scale, aligned_height, aligned_width, sampling_ratio);
+  float* __restrict__ dst = out + ((long long)it.n * channels + it.c0) * it.bins;
+  const bool image_ok = g.batch_ind >= 0 && g.batch_ind < batch;  // the reference would read out of bounds
+  const float* __restrict__ tile = feat + (image_ok ? g.batch_ind : 0) * st.n + it.c0 * st.c;
+  const bool channel_fastest = st.c == 1;  // channels-last storage: a tap of 32 neighbouring lanes is one 128-byte line
+  for (int i = threadIdx.x; i < it.cvalid * it.bins; i += kDirThreads) {
+    const int c = channel_fastest ? i % it.cvalid : i / it.bins, b = channel_fastest ? i / it.cvalid : i - c * it.bins;
+    const int ph = b / aligned_width, pw = b - ph * aligned_width, o = c * it.bins + b;
+    if (!image_ok) {
+      dst[o] = 0.f;
       continue;
     }
-    const float* plane = feat + g.batch_ind * st.n + c * st.c;
+    const float* plane = tile + c * st.c;
     float output_val = 0.f;
     for (int iy = 0; iy < g.grid_h; iy++) {
       const float y = sample_y(g, ph, iy);
@@ -69,26 +92,25 @@ roi_align_fwd_direct(long long total, const float* __restrict__ feat, const floa
       }
     }
     output_val /= g.count;  // :117
-    out[index] = output_val;
+    dst[o] = output_val;
   }
 }
 
-__global__ void __launch_bounds__(256)
-roi_align_bwd_direct(long long total, const float* __restrict__ top_diff,
-                     const float* __restrict__ rois, float* __restrict__ bottom_diff, int batch,
-                     int channels, int height, int width, int aligned_height, int aligned_width,
+__global__ void __launch_bounds__(kDirThreads)
+roi_align_bwd_direct(const float* __restrict__ top_diff, const float* __restrict__ rois, float* __restrict__ bottom_diff,
+                     int batch, int channels, int height, int width, int aligned_height, int aligned_width,
                      float spatial_scale, int sampling_ratio, FeatStrides st) {
-  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
-       index += (long long)gridDim.x * blockDim.x) {
-    int pw = (int)(index % aligned_width);
-    int ph = (int)((index / aligned_width) % aligned_height);
-    int c = (int)((index / aligned_width / aligned_height) % channels);
-    int n = (int)(index / aligned_width / aligned_height / channels);
-    RoiGeom g = roi_geometry(rois + (long long)n * 5, spatial_scale, aligned_height, aligned_width,
-                             sampling_ratio);
-    if (g.batch_ind < 0 || g.batch_ind >= batch) continue;
-    float* plane = bottom_diff + g.batch_ind * st.n + c * st.c;
-    const float top_diff_this_bin = top_diff[index];
+  const DirItem it = dir_item(channels, aligned_height, aligned_width);
+  const RoiGeom g = roi_geometry(rois + (long long)it.n * 5, spatial_scale, aligned_height, aligned_width, sampling_ratio);
+  if (g.batch_ind < 0 || g.batch_ind >= batch) return;
+  const float* __restrict__ src = top_diff + ((long long)it.n * channels + it.c0) * it.bins;
+  float* __restrict__ tile = bottom_diff + g.batch_ind * st.n + it.c0 * st.c;
+  const bool channel_fastest = st.c == 1;  // (over planar storage this order costs the atomics 2x: 3.4 against 1.6 ms at config 2)
+  for (int i = threadIdx.x; i < it.cvalid * it.bins; i += kDirThreads) {
+    const int c = channel_fastest ? i % it.cvalid : i / it.bins, b = channel_fastest ? i / it.cvalid : i - c * it.bins;
+    const int ph = b / aligned_width, pw = b - ph * aligned_width;
+    float* plane = tile + c * st.c;
+    const float top_diff_this_bin = src[c * it.bins + b];
     for (int iy = 0; iy < g.grid_h; iy++) {
       const float y = sample_y(g, ph, iy);
       for (int ix = 0; ix < g.grid_w; ix++) {
@@ -110,22 +132,25 @@ roi_align_bwd_direct(long long total, const float* __restrict__ top_diff,
 }
 
 // ------------------------------------------------------------------------------------------
-// Legacy variant (lib/model/roi_align/src/roi_align_kernel.cu).  The reference mixes double
-// literals into the expressions, so parts of the arithmetic are fp64; reproduced as written.
+// Legacy variant (lib/model/roi_align/src/roi_align_kernel.cu:15-70, :94-143): ONE bilinear point per bin, at the corners
+// of an (aligned - 1) grid over the box.  The reference mixes double literals into the expressions, so parts of the
+// arithmetic are fp64; reproduced as written.  Same shape as roi_crop_fwd: workgroup = (RoI, 32 channels); one wave
+// tabulates the points of the RoI 64 at a time (top-left pixel, the two ratios, inside or not -- :32-53, identical for
+// every channel), then lanes run over (channel, point), the point fastest: neighbouring lanes tap neighbouring pixels of
+// one plane and write neighbouring outputs.  The backward walks the same table and adds with global atomics as the
+// reference does (its order is undefined there too).
 // ------------------------------------------------------------------------------------------
-struct LegacyPoint {
-  bool inside;
-  int hstart, wstart;
-  float h_ratio, w_ratio;
-  int img;
+constexpr int kLegPts = 64;
+struct LegacyTab {
+  int off[kLegPts];                        // hstart * width + wstart, or -1: the point lies outside the map (:53)
+  float h_ratio[kLegPts], w_ratio[kLegPts];
 };
 
-__device__ __forceinline__ LegacyPoint legacy_point(const float* __restrict__ roi, int ph, int pw,
-                                                    float spatial_scale, int channels, int height,
-                                                    int width, int aligned_height,
-                                                    int aligned_width) {
-  LegacyPoint p;
-  float roi_batch_ind = roi[0];
+// wave 0: points [p0, p0 + np) of the RoI
+__device__ __forceinline__ void legacy_build_table(LegacyTab* tab, const float* __restrict__ roi, int p0, int np, int lane,
+                                                   float spatial_scale, int height, int width, int aligned_height,
+                                                   int aligned_width) {
+  const int p = p0 + min(lane, np - 1), ph = p / aligned_width, pw = p - ph * aligned_width;
   float roi_start_w = roi[1] * spatial_scale;
   float roi_start_h = roi[2] * spatial_scale;
   float roi_end_w = roi[3] * spatial_scale;
@@ -136,72 +161,60 @@ __device__ __forceinline__ LegacyPoint legacy_point(const float* __restrict__ ro
   float bin_size_w = (float)((double)roi_width / ((double)aligned_width - 1.));
   float h = (float)(ph)*bin_size_h + roi_start_h;  // :44-45
   float w = (float)(pw)*bin_size_w + roi_start_w;
-  p.hstart = (int)fminf(floorf(h), (float)(height - 2));  // :47-48
-  p.wstart = (int)fminf(floorf(w), (float)(width - 2));
-  // :50 `int img_start = roi_batch_ind * channels * height * width` is a float product
-  p.img = (int)(roi_batch_ind * (float)channels * (float)height * (float)width);
-  p.inside = !(h < 0 || h >= (float)height || w < 0 || w >= (float)width);  // :53
-  p.h_ratio = h - (float)p.hstart;
-  p.w_ratio = w - (float)p.wstart;
-  return p;
+  const int hstart = (int)fminf(floorf(h), (float)(height - 2));  // :47-48
+  const int wstart = (int)fminf(floorf(w), (float)(width - 2));
+  const bool inside = !(h < 0 || h >= (float)height || w < 0 || w >= (float)width);  // :53
+  tab->off[lane] = inside ? hstart * width + wstart : -1;
+  tab->h_ratio[lane] = h - (float)hstart;
+  tab->w_ratio[lane] = w - (float)wstart;
 }
 
-__global__ void __launch_bounds__(256)
-roi_align_legacy_fwd(long long total, const float* __restrict__ bottom_data,
-                     const float* __restrict__ rois, float* __restrict__ top_data, int batch,
-                     int channels, int height, int width, int aligned_height, int aligned_width,
-                     float spatial_scale) {
+template <bool kBackward>
+__global__ void __launch_bounds__(kDirThreads)
+roi_align_legacy(const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ outp, int batch,
+                 int channels, int height, int width, int aligned_height, int aligned_width, float spatial_scale) {
+  __shared__ LegacyTab tab;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DirItem it = dir_item(channels, aligned_height, aligned_width);
+  const float* __restrict__ roi = rois + (long long)it.n * 5;
   const long long limit = (long long)batch * channels * height * width;
-  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
-       index += (long long)gridDim.x * blockDim.x) {
-    int pw = (int)(index % aligned_width);
-    int ph = (int)((index / aligned_width) % aligned_height);
-    int c = (int)((index / aligned_width / aligned_height) % channels);
-    int n = (int)(index / aligned_width / aligned_height / channels);
-    LegacyPoint p = legacy_point(rois + (long long)n * 5, ph, pw, spatial_scale, channels, height,
-                                 width, aligned_height, aligned_width);
-    float result = 0.f;
-    if (p.inside) {
-      long long upleft = (long long)p.img + ((long long)c * height + p.hstart) * width + p.wstart;
-      long long upright = upleft + 1, downleft = upleft + width, downright = downleft + 1;
-      if (upleft >= 0 && downright < limit) {  // guard; the reference reads unchecked
-        // C++ promotion rules identical to the reference expression (:63-66): float*double terms are
-        // evaluated in fp64, the float*float*float term in fp32, the sum in fp64.
-        const float h_ratio = p.h_ratio, w_ratio = p.w_ratio;
-        result = bottom_data[upleft] * (1. - h_ratio) * (1. - w_ratio) +
-                 bottom_data[upright] * (1. - h_ratio) * w_ratio +
-                 bottom_data[downleft] * h_ratio * (1. - w_ratio) +
-                 bottom_data[downright] * h_ratio * w_ratio;
+  // :50 `int img_start = roi_batch_ind * channels * height * width` is a float product
+  const long long img = (long long)(int)(roi[0] * (float)channels * (float)height * (float)width);
+  const long long plane_px = (long long)height * width;
+  const long long tile_px = img + (long long)it.c0 * plane_px;                      // map side: the tile's first plane
+  const long long tile_bins = ((long long)it.n * channels + it.c0) * it.bins;       // pooled side: the tile's first bin
+  for (int p0 = 0; p0 < it.bins; p0 += kLegPts) {
+    const int np = min(kLegPts, it.bins - p0);
+    __syncthreads();  // the previous group's table is no longer read
+    if (wave == 0) legacy_build_table(&tab, roi, p0, np, lane, spatial_scale, height, width, aligned_height, aligned_width);
+    __syncthreads();
+    const unsigned np_magic = (1u << 20) / (unsigned)np + 1u;
+    for (int i = tid; i < it.cvalid * np; i += kDirThreads) {
+      const int c = (int)(((unsigned)i * np_magic) >> 20), p = i - c * np;  // i / np, exact for i < 32 * 64
+      const long long bin = tile_bins + (long long)c * it.bins + p0 + p;
+      const int off = tab.off[p];
+      const long long upleft = tile_px + (long long)c * plane_px + off;
+      const long long upright = upleft + 1, downleft = upleft + width, downright = downleft + 1;
+      const bool ok = off >= 0 && upleft >= 0 && downright < limit;  // the second pair: a guard; the reference reads unchecked
+      const float h_ratio = tab.h_ratio[p], w_ratio = tab.w_ratio[p];
+      if (!kBackward) {
+        float result = 0.f;
+        if (ok) {
+          // C++ promotion rules identical to the reference expression (:63-66): float*double terms are
+          // evaluated in fp64, the float*float*float term in fp32, the sum in fp64.
+          result = in[upleft] * (1. - h_ratio) * (1. - w_ratio) + in[upright] * (1. - h_ratio) * w_ratio +
+                   in[downleft] * h_ratio * (1. - w_ratio) + in[downright] * h_ratio * w_ratio;
+        }
+        outp[bin] = result;
+      } else if (ok) {
+        // same literal types as the reference (:135-138): `1.` is double, `1` is int
+        const float g = in[bin];
+        atomicAdd(outp + upleft, (float)(g * (1. - h_ratio) * (1 - w_ratio)));
+        atomicAdd(outp + upright, (float)(g * (1. - h_ratio) * w_ratio));
+        atomicAdd(outp + downleft, (float)(g * h_ratio * (1 - w_ratio)));
+        atomicAdd(outp + downright, (float)(g * h_ratio * w_ratio));
       }
     }
-    top_data[index] = result;
-  }
-}
-
-__global__ void __launch_bounds__(256)
-roi_align_legacy_bwd(long long total, const float* __restrict__ top_diff,
-                     const float* __restrict__ rois, float* __restrict__ bottom_diff, int batch,
-                     int channels, int height, int width, int aligned_height, int aligned_width,
-                     float spatial_scale) {
-  const long long limit = (long long)batch * channels * height * width;
-  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
-       index += (long long)gridDim.x * blockDim.x) {
-    int pw = (int)(index % aligned_width);
-    int ph = (int)((index / aligned_width) % aligned_height);
-    int c = (int)((index / aligned_width / aligned_height) % channels);
-    int n = (int)(index / aligned_width / aligned_height / channels);
-    LegacyPoint p = legacy_point(rois + (long long)n * 5, ph, pw, spatial_scale, channels, height,
-                                 width, aligned_height, aligned_width);
-    if (!p.inside) continue;
-    long long upleft = (long long)p.img + ((long long)c * height + p.hstart) * width + p.wstart;
-    long long upright = upleft + 1, downleft = upleft + width, downright = downleft + 1;
-    if (upleft < 0 || downright >= limit) continue;
-    // same literal types as the reference (:135-138): `1.` is double, `1` is int
-    const float h_ratio = p.h_ratio, w_ratio = p.w_ratio, g = top_diff[index];
-    atomicAdd(bottom_diff + upleft, (float)(g * (1. - h_ratio) * (1 - w_ratio)));
-    atomicAdd(bottom_diff + upright, (float)(g * (1. - h_ratio) * w_ratio));
-    atomicAdd(bottom_diff + downleft, (float)(g * h_ratio * (1 - w_ratio)));
-    atomicAdd(bottom_diff + downright, (float)(g * h_ratio * w_ratio));
   }
 }
 
@@ -250,12 +263,13 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
   const long long total = (long long)num_rois * channels * aligned_height * aligned_width;
   if (total == 0) return MI_OK;
   hipStream_t s = mi::as_stream(stream);
-  const int block = 256;
+  // the generic kernels: one workgroup per (RoI, 32 channels), whose pooled bins are walked 256 at a time
+  const long long dir_grid = (long long)num_rois * mi::ceil_div(channels, kDirCT);
+  MI_REQUIRE(dir_grid < (1LL << 31) && (long long)kDirCT * aligned_height * aligned_width < (1LL << 31), "roi_align: too many (RoI, channel tile) items");
   if (variant == MI_ROI_ALIGN_LEGACY) {
-    roi_align_legacy_fwd<<<mi::grid_for(total, block), block, 0, s>>>(
-        total, features, rois, output, batch, channels, height, width, aligned_height,
-        aligned_width, spatial_scale);
-    return mi::check_launch("roi_align_legacy_fwd");
+    roi_align_legacy<false><<<(int)dir_grid, kDirThreads, 0, s>>>(features, rois, output, batch, channels, height, width,
+                                                                  aligned_height, aligned_width, spatial_scale);
+    return mi::check_launch("roi_align_legacy<fwd>");
   }
   const int cap = ring_words();
   if (workspace != nullptr) {
@@ -287,9 +301,8 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
     return mi::launch_roi_align_fwd_tile(features, rois, output, batch, channels, height, width, num_rois,
                                          aligned_height, aligned_width, spatial_scale, sampling_ratio, cap, s);
   FeatStrides st = make_strides(layout, channels, height, width);
-  roi_align_fwd_direct<<<mi::grid_for(total, block), block, 0, s>>>(
-      total, features, rois, output, batch, channels, height, width, aligned_height, aligned_width,
-      spatial_scale, sampling_ratio, st);
+  roi_align_fwd_direct<<<(int)dir_grid, kDirThreads, 0, s>>>(features, rois, output, batch, channels, height, width,
+                                                            aligned_height, aligned_width, spatial_scale, sampling_ratio, st);
   return mi::check_launch("roi_align_fwd_direct");
 }
 }  // namespace
@@ -336,12 +349,12 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
       return mi::check_launch("roi_align_backward: zero fill");
     return MI_OK;
   }
-  const int block = 256;
+  const long long dir_grid = (long long)num_rois * mi::ceil_div(channels, kDirCT);
+  MI_REQUIRE(dir_grid < (1LL << 31) && (long long)kDirCT * aligned_height * aligned_width < (1LL << 31), "roi_align: too many (RoI, channel tile) items");
   if (variant == MI_ROI_ALIGN_LEGACY) {
-    roi_align_legacy_bwd<<<mi::grid_for(total, block), block, 0, s>>>(
-        total, top_grad, rois, bottom_grad, batch, channels, height, width, aligned_height,
-        aligned_width, spatial_scale);
-    return mi::check_launch("roi_align_legacy_bwd");
+    roi_align_legacy<true><<<(int)dir_grid, kDirThreads, 0, s>>>(top_grad, rois, bottom_grad, batch, channels, height, width,
+                                                                 aligned_height, aligned_width, spatial_scale);
+    return mi::check_launch("roi_align_legacy<bwd>");
   }
   if (workspace != nullptr) {
     MI_REQUIRE(workspace_bytes >= mi::roi_align_records_workspace_bytes(num_rois),
@@ -364,9 +377,8 @@ int roi_align_backward_impl(const float* top_grad, const float* rois, float* bot
       hipMemsetAsync(bottom_grad, 0, (size_t)batch * channels * height * width * sizeof(float), s) != hipSuccess)
     return mi::check_launch("roi_align_backward: zero fill");
   FeatStrides st = make_strides(layout, channels, height, width);
-  roi_align_bwd_direct<<<mi::grid_for(total, block), block, 0, s>>>(
-      total, top_grad, rois, bottom_grad, batch, channels, height, width, aligned_height,
-      aligned_width, spatial_scale, sampling_ratio, st);
+  roi_align_bwd_direct<<<(int)dir_grid, kDirThreads, 0, s>>>(top_grad, rois, bottom_grad, batch, channels, height, width,
+                                                            aligned_height, aligned_width, spatial_scale, sampling_ratio, st);
   return mi::check_launch("roi_align_bwd_direct");
 }
 }  // namespace

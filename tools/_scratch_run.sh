@@ -1,5 +1,3 @@
-cd /tmp && export TMPDIR=/tmp
-rm -rf /root/repo/gpurun_out/prof_inf
-rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_inf -o inf --output-format csv -- python /root/repo/bench.py --child-inference-graph box > /root/repo/gpurun_out/r6m_inf.log 2>&1
-tail -2 /root/repo/gpurun_out/r6m_inf.log | cut -c1-600
-find /root/repo/gpurun_out/prof_inf -name "*kernel_stats.csv" | head
+cd /root/repo
+timeout 900 python -m pytest tests/test_ops_gpu.py -q -x -k "legacy or direct or roi_align_golden or seven or modules or misaligned or adversarial or channels_last" 2>&1 | tail -3
+MI_ROI_ALIGN_IMPL=direct timeout 300 python tools/direct_time.py 2>&1 | tail -1

@@ -510,6 +510,39 @@ def pool_and_crop(device, iters):
                                       kernel="roi_crop_boxes + roi_crop_bwd_tiles (LDS accumulators per 8x32 tile, no fill, no global atomics)")
     result["roi_crop_bwd_atomics"] = dict(entry(time_kernel(crop_bwd_atomics, max(iters // 4, 10)), out_bytes + 8 * r * res * res + 4 * c * h * w),
                                           kernel="zero fill + roi_crop_bwd (four global atomics per output element, as the reference; the entry point without a workspace)")
+    # ---- legacy RoIAlign (row a3: one bilinear point per bin at the corners of an (aligned - 1) grid, model/roi_align), same
+    # inputs; algorithmic bytes by the same rule: output + 4 C U (U = distinct in-image taps) + 20 R ----
+    def legacy(fn, src, dst):
+        def run():
+            assert fn(src.data_ptr(), rois.data_ptr(), dst.data_ptr(), 1, c, h, w, r, res, res, scale, 0, _lib.ROI_ALIGN_LEGACY,
+                      _lib.LAYOUT_NCHW, stream) == 0, lib.mi_last_error()
+        return run
+
+    sw, sh = rois_np[:, 1] * np.float32(scale), rois_np[:, 2] * np.float32(scale)
+    bw = np.maximum(rois_np[:, 3] * np.float32(scale) - sw + 1, 0) / (res - 1)
+    bh = np.maximum(rois_np[:, 4] * np.float32(scale) - sh + 1, 0) / (res - 1)
+    py = sh[:, None] + np.arange(res)[None, :] * bh[:, None]
+    px = sw[:, None] + np.arange(res)[None, :] * bw[:, None]
+    seen = np.zeros((h, w), bool)
+    for yy, xx in zip(py, px):
+        ys = np.minimum(np.floor(yy[(yy >= 0) & (yy < h)]), h - 2).astype(int)
+        xs = np.minimum(np.floor(xx[(xx >= 0) & (xx < w)]), w - 2).astype(int)
+        for dy in (0, 1):
+            for dx in (0, 1):
+                seen[np.ix_(ys + dy, xs + dx)] = True
+    u_legacy = int(seen.sum())
+    legacy_bwd = legacy(lib.mi_roi_align_backward, gtop, gin)
+
+    def legacy_bwd_filled():
+        gin.zero_()   # the reference's functions zero the gradient in front of the kernel (functions/roi_align.py:39)
+        legacy_bwd()
+
+    result["roi_align_legacy_fwd"] = dict(entry(time_kernel(legacy(lib.mi_roi_align_forward, feat, out), iters),
+                                                out_bytes + 4 * c * u_legacy + 20 * r),
+                                          kernel="roi_align_legacy<fwd> (per-workgroup point table, lanes over (channel, point))",
+                                          distinct_pixels=u_legacy)
+    result["roi_align_legacy_bwd"] = dict(entry(time_kernel(legacy_bwd_filled, max(iters // 4, 10)), out_bytes + 4 * c * h * w + 20 * r),
+                                          kernel="zero fill + roi_align_legacy<bwd> (four global atomics per output element, as the reference)")
     return result
 
 
