@@ -835,8 +835,25 @@ def main():
                                          "h2d_bytes_per_step": int(sum(h.numel() * h.element_size() for _, h in feeds)),
                                          "what": "the timed step with the image blob and the RPN target blobs copied from "
                                                  "pinned host memory in front of every step (same stream)"}
+                # the same through parallel.MinibatchFeeder: the copy of step k + 1 on a copy stream under step k (what the
+                # reference's background-stream scatter amounts to, _functions.py:62-83), then device-to-device into the
+                # resident blobs
+                feeder = _par.MinibatchFeeder([d for d, _ in feeds])
+                feeder.prefetch([h for _, h in feeds])     # the pinned buffer now holds the minibatch (a loader would refill it)
+
+                def fed_step_side_stream():
+                    feeder.commit()
+                    feeder.prefetch()
+                    return work.step()
+
+                sec2 = timed_loop(fed_step_side_stream, n_fed, 2, 1, device) / n_fed
+                feeder.commit()
+                line["h2d_inclusive"]["copy_stream"] = {
+                    "images_per_s": round(IMAGES_PER_RANK / sec2, 2), "ms_per_step": round(sec2 * 1e3, 3),
+                    "what": "parallel.MinibatchFeeder: the next step's blobs land in a staging set on a copy stream under the "
+                            "current step (one flat copy), device-to-device copies put them into the resident blobs"}
             except Exception as exc:  # noqa: BLE001
-                line["h2d_inclusive"] = {"error": repr(exc)[:300]}
+                line["h2d_inclusive"] = dict(line.get("h2d_inclusive", {}), error=repr(exc)[:300])
             line["roofline"] = hp.roofline_roi_align_forward(device, args.kernel_iters)
             line["breakdown"] = work.breakdown()
             del work

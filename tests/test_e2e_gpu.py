@@ -445,6 +445,47 @@ def test_fixed_batch_loss_decreases_at_a_safe_learning_rate(nets):
     assert losses[-1] < 0.9 * losses[0], losses
 
 
+def test_minibatch_feeder_delivers_every_minibatch_in_order():
+    """parallel.MinibatchFeeder (the input half of the reference's scatter, nn/parallel/_functions.py:62-83): pinned host blobs
+    of step k + 1 land in a staging set on a copy stream while step k runs, commit() moves them into the resident blobs.
+    Twelve steps with large blobs that change every step, a slow consumer on the step's stream, no host synchronisation inside
+    the loop: every step sees exactly its own minibatch (a staging set overwritten early, or read before it has landed,
+    shows up as a mixed checksum)."""
+    from detectron_pytorch_amd import parallel
+
+    d = dev()
+    live = [torch.zeros(24 << 20, device=d), torch.zeros((2, 3, 64, 64), dtype=torch.int32, device=d)]
+    addrs = [t.data_ptr() for t in live]
+    steps = 12
+    hosts = [[torch.full(live[0].shape, float(k + 1)).pin_memory(), torch.full(live[1].shape, 7 * k + 3, dtype=torch.int32).pin_memory()]
+             for k in range(steps)]
+    a = torch.randn(2048, 2048, device=d)
+    sums = torch.zeros((steps, 3), dtype=torch.float64, device=d)
+    feeder = parallel.MinibatchFeeder(live)
+    with pytest.raises(AssertionError):
+        feeder.commit()                       # nothing prefetched
+    feeder.prefetch(hosts[0])
+    with pytest.raises(AssertionError):
+        feeder.prefetch(hosts[0])             # twice without a commit
+    for k in range(steps):
+        feeder.commit()
+        if k + 1 < steps:
+            feeder.prefetch(hosts[k + 1])
+        b = a
+        for _ in range(6):                    # the step: long enough for the next copy to finish under it
+            b = (b @ a) * 1e-3
+        sums[k, 0] = live[0].double().sum()
+        sums[k, 1] = live[1].double().sum()
+        sums[k, 2] = live[0].double().max() - live[0].double().min()
+    torch.cuda.synchronize()
+    got = sums.cpu().numpy()
+    for k in range(steps):
+        assert got[k, 0] == float(k + 1) * live[0].numel(), k
+        assert got[k, 1] == float(7 * k + 3) * live[1].numel(), k
+        assert got[k, 2] == 0.0, k
+    assert [t.data_ptr() for t in live] == addrs      # the resident blobs keep their addresses (a captured graph reads them)
+
+
 def test_gradient_reducer_on_rccl_world_size_one(nets):
     """GradientAllReducer on the nccl (= RCCL) backend with one rank: bucket views, hooks, asynchronous all-reduce from
     the backward, and the graph-mode variant (collectives between two captured graphs) leave exactly the gradients of a
