@@ -815,7 +815,7 @@ def main():
             line["allreduce"] = comm
         line["headline_note"] = ("~95 % of this step is stock PyTorch-ROCm library time (fp32 Winograd / implicit-GEMM "
                                  "convolutions, Tensile GEMMs); the operators of this library are ~5 % of it, so `value` has been "
-                                 "flat since round 2 (49.1-49.5) and is not this tier's to move (north_star: the backbone "
+                                 "flat since round 2 (49.1-49.8) and is not this tier's to move (north_star: the backbone "
                                  "runs on PyTorch-ROCm conv) -- the library's own figures are `roofline` and its sub-objects")
         if not args.no_extras and world == 1:
             # the same step fed from pinned host memory (image blob + the data layer's RPN target blobs copied in front of
