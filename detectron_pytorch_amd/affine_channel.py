@@ -96,3 +96,67 @@ def affine_channel(x, weight, bias, residual=None, relu=False):
     if residual is not None:
         out = out + residual
     return F.relu(out) if relu else out
+
+
+# ---- convolution bias (+ residual) (+ ReLU) in the same pass --------------------------------------------------------------
+# PyTorch-ROCm adds a convolution's bias with a broadcast `add_` of its own and the model's ReLU (FPN.py:394,
+# mask_rcnn_heads.py:160-185) / the FPN's top-down sum (FPN.py:292-296) are further element-wise kernels over the whole
+# activation.  The convolution is asked for its bias-free result and the AffineChannel kernel (weight == 1: x * 1 is exact)
+# finishes it in one pass: relu?(conv(x) + b[c] (+ r)), bit-identical to the unfused expressions.  The bias IS trainable
+# here: its gradient is the sum of the (ReLU-masked) output gradient over N, H, W, as the convolution's own backward forms it.
+_ONES = {}
+_FUSE_CONV_BIAS = __import__("os").environ.get("MI_FUSED_CONV_BIAS", "1") == "1"   # A/B switch of tools/ (read at import)
+
+
+def _ones(c, device):
+    key = (c, device)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(c, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+class _BiasAct(Function):
+    """`.apply(x, bias, residual_or_None, relu)`"""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, relu):
+        layout = _layout_of(x)
+        if residual is not None:
+            residual = _dense_like(residual, layout)
+        ones = _ones(x.size(1), x.device)
+        y = affine_forward(x, ones, bias.detach().contiguous(), residual, relu, layout)
+        ctx.relu, ctx.layout, ctx.has_residual = bool(relu), layout, residual is not None
+        ctx.save_for_backward(ones, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        ones, y = ctx.saved_tensors
+        if ctx.relu:
+            grad_y = _dense_like(grad_y, ctx.layout)
+            grad_x, _ = affine_backward(grad_y, y, ones, False, True, ctx.layout)
+        else:
+            grad_x = grad_y
+        grad_b = grad_x.sum((0, 2, 3)) if ctx.needs_input_grad[1] else None
+        return grad_x, grad_b, (grad_x if ctx.has_residual and ctx.needs_input_grad[2] else None), None
+
+
+def conv_bias_act(conv, x, relu=False, residual=None):
+    """relu?(conv(x) (+ residual)) for an `nn.Conv2d` / `nn.ConvTranspose2d` with a bias: the module's parameters, the fused
+    epilogue.  Falls back to the module's own forward (+ torch add / relu) for what the kernel does not serve (CPU, bf16
+    under autocast, no bias, exotic layouts)."""
+    ok = (conv.bias is not None and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+          and conv.weight.dtype == torch.float32 and _FUSE_CONV_BIAS)
+    if ok:
+        if isinstance(conv, torch.nn.ConvTranspose2d):
+            y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding, conv.groups, conv.dilation)
+        else:
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if _layout_of(y) is not None and (residual is None or (residual.shape == y.shape and residual.dtype == y.dtype)):
+            return _BiasAct.apply(y, conv.bias, residual, bool(relu))
+        y = y + conv.bias.view(1, -1, 1, 1)
+    else:
+        y = conv(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y

@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import init
 
+from ..affine_channel import conv_bias_act
 from ..generate_proposals import GenerateProposalsOp, generate_anchors
 from . import resnet
 from .layers import smooth_l1_loss, xavier_fill
@@ -57,7 +58,7 @@ class TopdownLateral(nn.Module):
         init.constant_(self.conv_lateral.bias, 0)
 
     def forward(self, top_blob, lateral_blob):
-        return self.conv_lateral(lateral_blob) + F.interpolate(top_blob, scale_factor=2, mode="nearest")
+        return conv_bias_act(self.conv_lateral, lateral_blob, residual=F.interpolate(top_blob, scale_factor=2, mode="nearest"))
 
 
 class FPN(nn.Module):
@@ -98,10 +99,10 @@ class FPN(nn.Module):
         blobs = [body.res1(x)]
         for i in range(1, body.convX):
             blobs.append(getattr(body, "res%d" % (i + 1))(blobs[-1]))
-        inner = [self.conv_top(blobs[-1])]
+        inner = [conv_bias_act(self.conv_top, blobs[-1])]
         for i in range(self.num_backbone_stages - 1):
             inner.append(self.topdown_lateral_modules[i](inner[-1], blobs[-(i + 2)]))
-        out = [self.posthoc_modules[i](inner[i]) for i in range(self.num_backbone_stages)]
+        out = [conv_bias_act(self.posthoc_modules[i], inner[i]) for i in range(self.num_backbone_stages)]
         if hasattr(self, "maxpool_p6"):
             out.insert(0, self.maxpool_p6(out[0]))
         return out
@@ -147,9 +148,9 @@ class FpnRpnOutputs(nn.Module):
         assert len(blobs_in) == self.k_max - self.k_min + 1
         ret = {}
         for lvl in range(self.k_min, self.k_max + 1):
-            hidden = F.relu(self.FPN_RPN_conv(blobs_in[self.k_max - lvl]), inplace=True)
-            ret["rpn_cls_logits_fpn%d" % lvl] = self.FPN_RPN_cls_score(hidden)
-            ret["rpn_bbox_pred_fpn%d" % lvl] = self.FPN_RPN_bbox_pred(hidden)
+            hidden = conv_bias_act(self.FPN_RPN_conv, blobs_in[self.k_max - lvl], relu=True)
+            ret["rpn_cls_logits_fpn%d" % lvl] = conv_bias_act(self.FPN_RPN_cls_score, hidden)
+            ret["rpn_bbox_pred_fpn%d" % lvl] = conv_bias_act(self.FPN_RPN_bbox_pred, hidden)
         return ret
 
 

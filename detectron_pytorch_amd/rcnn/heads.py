@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.nn.init as init
 
+from ..affine_channel import conv_bias_act
 from .layers import BilinearInterpolation2d, msra_fill, smooth_l1_loss, xavier_fill
 
 
@@ -110,7 +111,10 @@ class MaskRcnnFcnHeadV1upXconvs(nn.Module):
         x = self.roi_xform(x, rpn_ret, blob_rois="mask_rois", method=c.ROI_XFORM_METHOD,
                            resolution=c.ROI_XFORM_RESOLUTION, spatial_scale=self.spatial_scale,
                            sampling_ratio=c.ROI_XFORM_SAMPLING_RATIO)
-        return F.relu(self.upconv(self.conv_fcn(x)), inplace=True)
+        for m in self.conv_fcn:   # [conv, ReLU] pairs: the ReLU modules are served by the convolution's fused epilogue
+            if isinstance(m, nn.Conv2d):
+                x = conv_bias_act(m, x, relu=True)
+        return conv_bias_act(self.upconv, x, relu=True)
 
 
 class MaskRcnnOutputs(nn.Module):
@@ -132,7 +136,7 @@ class MaskRcnnOutputs(nn.Module):
         init.constant_(self.classify.bias, 0)
 
     def forward(self, x):
-        x = self.classify(x)
+        x = conv_bias_act(self.classify, x)
         if self.upsample_ratio > 1:
             x = self.upsample(x)
         return x if self.training else torch.sigmoid(x)
@@ -192,7 +196,10 @@ class RoiPoseHeadV1convX(nn.Module):
         x = self.roi_xform(x, rpn_ret, blob_rois="keypoint_rois", method=c.ROI_XFORM_METHOD,
                            resolution=c.ROI_XFORM_RESOLUTION, spatial_scale=self.spatial_scale,
                            sampling_ratio=c.ROI_XFORM_SAMPLING_RATIO)
-        return self.conv_fcn(x)
+        for m in self.conv_fcn:
+            if isinstance(m, nn.Conv2d):
+                x = conv_bias_act(m, x, relu=True)
+        return x
 
 
 class KeypointOutputs(nn.Module):
@@ -227,8 +234,8 @@ class KeypointOutputs(nn.Module):
 
     def forward(self, x):
         if self.use_deconv:
-            x = F.relu(self.deconv(x), inplace=True)
-        x = self.classify(x)
+            x = conv_bias_act(self.deconv, x, relu=True)
+        x = conv_bias_act(self.classify, x)
         return self.upsample(x) if self.upsample_heatmap else x
 
 
