@@ -103,3 +103,49 @@ def test_resnet_block_uses_the_fused_pass_and_matches_the_unfused_block():
     yb.backward(dy)
     # convolution backward is the same MIOpen call on identical inputs in both runs
     assert torch.allclose(xa.grad, xb.grad, rtol=0, atol=0) or (xa.grad - xb.grad).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["conv3x3", "conv1x1", "deconv2x2"])
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_conv_bias_act_equals_the_modules_own_forward_and_gradients(kind, relu, with_residual):
+    """affine_channel.conv_bias_act (the bias, ReLU and FPN top-down sum of FPN.py:292-296,394 / mask_rcnn_heads.py:160-185
+    behind a convolution, one pass of the AffineChannel kernel with weight 1): the forward is BIT-equal to
+    `relu?(conv(x) (+ r))` of the module itself; the gradients of the input and the residual are equal (same
+    masked output gradient into the same convolution backward), those of the weight and the bias to summation order."""
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    if kind == "deconv2x2":
+        conv = torch.nn.ConvTranspose2d(16, 24, 2, 2, 0).to(dev)
+        x = torch.randn(3, 16, 14, 14, device=dev)
+    else:
+        k = 3 if kind == "conv3x3" else 1
+        conv = torch.nn.Conv2d(16, 24, k, 1, k // 2).to(dev)
+        x = torch.randn(2, 16, 25, 42, device=dev)
+    torch.nn.init.normal_(conv.bias, std=0.5)
+    ref = __import__("copy").deepcopy(conv)
+    with torch.no_grad():
+        shape = conv(x).shape
+    r = torch.randn(shape, device=dev) if with_residual else None
+    dy = torch.randn(shape, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ra = r.clone().requires_grad_(True) if r is not None else None
+    rb = r.clone().requires_grad_(True) if r is not None else None
+    ya = ac.conv_bias_act(conv, xa, relu=relu, residual=ra)
+    yb = ref(xb)
+    if rb is not None:
+        yb = yb + rb
+    if relu:
+        yb = F.relu(yb)
+    assert torch.equal(ya, yb)
+    assert ya.grad_fn is not None and "BiasAct" in type(ya.grad_fn).__name__, "the fused epilogue did not run"
+    ya.backward(dy)
+    yb.backward(dy)
+    assert torch.equal(xa.grad, xb.grad)
+    assert torch.allclose(conv.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-4)   # MIOpen's weight-gradient kernels add with atomics
+    assert torch.allclose(conv.bias.grad, ref.bias.grad, rtol=1e-5, atol=1e-5)
+    if r is not None:
+        assert torch.equal(ra.grad, rb.grad)
+    # what the kernel does not serve falls back to the module: CPU tensors, autocast
+    cpu = __import__("copy").deepcopy(ref).cpu()
+    assert torch.equal(ac.conv_bias_act(cpu, x.cpu(), relu=relu), F.relu(cpu(x.cpu())) if relu else cpu(x.cpu()))
