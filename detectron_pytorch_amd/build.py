@@ -23,6 +23,10 @@ LIB_NAME = "libmi_detectron_ops.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 SOURCES = ["abi.hip", "roi_align.hip", "roi_align_fwd_tile.hip", "roi_align_records.hip", "roi_align_nhwc.hip", "roi_pool.hip", "roi_crop.hip", "nms.hip", "soft_nms.hip", "proposals.hip", "affine_channel.hip", "topk.hip", "results.hip", "box_voting.hip", "mask_targets.hip"]
 ARCH = "gfx950"
+# Per-unit flags.  roi_align_records.hip: the leading scalar / pointer kernel arguments arrive preloaded in SGPRs (gfx950
+# kernarg preload) -- the records-free RoIAlign forward starts with a chain of dependent fetches (arguments -> the RoI's five
+# floats -> geometry -> window), and this takes the first link out of it.
+UNIT_FLAGS = {"roi_align_records.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
 
 
 def hipcc():
@@ -60,7 +64,7 @@ def build(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [hipcc()] + flags() + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc()] + flags() + UNIT_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     objs = []
     for src, obj, p in procs:

@@ -281,6 +281,13 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
     const bool bwd_tables =
         workspace_bytes >= mi::roi_align_bwd_workspace_bytes(mi::single_level(nullptr, nullptr, batch, height, width,
                                                                               spatial_scale), batch, num_rois);
+    // nobody will read records (no room for a backward): the records-free forward, one launch
+    if (layout == MI_LAYOUT_NCHW && !force_direct() && !no_ws() && !bwd_tables &&
+        mi::roi_align_fwd_slab_supported(mi::single_level(features, nullptr, batch, height, width, spatial_scale), channels,
+                                         num_rois, aligned_height, aligned_width))
+      return mi::launch_roi_align_fwd_slab(mi::single_level(features, nullptr, batch, height, width, spatial_scale), rois,
+                                           nullptr, output, batch, channels, num_rois, aligned_height, aligned_width,
+                                           sampling_ratio, s);
     if (layout == MI_LAYOUT_NCHW && !force_direct() && !no_ws() &&
         mi::roi_align_fwd_records_supported(channels, height, width, num_rois, aligned_height, aligned_width))
       return mi::launch_roi_align_fwd_records(features, rois, output, workspace, batch, channels, height, width,
@@ -296,6 +303,12 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
                                            num_rois, aligned_height, aligned_width, spatial_scale, sampling_ratio, s);
     }
   }
+  if (layout == MI_LAYOUT_NCHW && !force_direct() &&
+      mi::roi_align_fwd_slab_supported(mi::single_level(features, nullptr, batch, height, width, spatial_scale), channels,
+                                       num_rois, aligned_height, aligned_width))
+    return mi::launch_roi_align_fwd_slab(mi::single_level(features, nullptr, batch, height, width, spatial_scale), rois,
+                                         nullptr, output, batch, channels, num_rois, aligned_height, aligned_width,
+                                         sampling_ratio, s);
   if (layout == MI_LAYOUT_NCHW && !force_direct() &&
       mi::roi_align_fwd_tile_supported(channels, height, width, aligned_height, aligned_width))
     return mi::launch_roi_align_fwd_tile(features, rois, output, batch, channels, height, width, num_rois,
@@ -483,6 +496,10 @@ int roi_align_forward_fpn_impl(const mi_fpn_levels* levels, const float* rois, c
     return mi::launch_roi_align_fwd_nhwc_levels(lv, rois, output, workspace, batch, channels, num_rois, aligned_height,
                                                 aligned_width, sampling_ratio, mi::as_stream(stream));
   }
+  // nobody will read records (forward-sized workspace, none written by a producer): the records-free forward, one launch
+  if (!bwd_tables && !records_ready && mi::roi_align_fwd_slab_supported(lv, channels, num_rois, aligned_height, aligned_width))
+    return mi::launch_roi_align_fwd_slab(lv, rois, roi_levels, output, batch, channels, num_rois, aligned_height,
+                                         aligned_width, sampling_ratio, mi::as_stream(stream));
   return mi::launch_roi_align_fwd_records_levels(lv, rois, roi_levels, output, workspace, batch, channels, num_rois,
                                                  aligned_height, aligned_width, sampling_ratio, cap, bwd_tables,
                                                  mi::as_stream(stream), records_ready);

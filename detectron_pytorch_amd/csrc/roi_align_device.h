@@ -120,6 +120,11 @@ int launch_roi_align_fwd_records(const float* features, const float* rois, float
                                  int channels, int height, int width, int num_rois, int aligned_height,
                                  int aligned_width, float spatial_scale, int sampling_ratio, int cap_px, bool bwd_tables,
                                  hipStream_t stream);
+// records-free forward, one launch (roi_align_records.hip: roi_align_fwd_slab); `levels` may be nullptr (level 0)
+bool roi_align_fwd_slab_supported(const LevelTable& lv, int channels, int num_rois, int aligned_height, int aligned_width);
+int launch_roi_align_fwd_slab(const LevelTable& lv, const float* rois, const int* levels, float* output, int batch,
+                              int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
+                              hipStream_t stream);
 // records_ready: the workspace already holds the records of THESE rois at THIS geometry (written by a forward call)
 // overwrite: every element of bottom_grad is written (no zero fill needed) instead of accumulated into
 // nhwc: bottom_grad is stored channels-last ([N][H][W][C]); top_grad is always dense [R][C][PH][PW]

@@ -612,11 +612,15 @@ __device__ __forceinline__ void fwd_bins(const TabEntry* ty, const TabEntry* tx,
 // when the stage covers the RoI's whole [kCT][bins] block.
 template <int kCT, int kThreads>
 __device__ __forceinline__ void fwd_store(const float* tile, float* __restrict__ dst, int tid, int ph0, int nb, int ts,
-                                          int bins, int aligned_width) {
+                                          int bins, int aligned_width, bool plain = false) {
   if (nb == bins && ts == nb && ((kCT * nb) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
     // non-temporal: the pooled features are read next by another kernel, and a streaming store lets the workgroup's LDS go
     // ~1 % earlier (38.55 -> 38.25 us per config-2 call, three alternating runs)
     typedef float v4f_t __attribute__((ext_vector_type(4)));
+    if (plain) {
+      for (int i = tid; i < kCT * nb / 4; i += kThreads) reinterpret_cast<v4f_t*>(dst)[i] = reinterpret_cast<const v4f_t*>(tile)[i];
+      return;
+    }
     for (int i = tid; i < kCT * nb / 4; i += kThreads)
       __builtin_nontemporal_store(reinterpret_cast<const v4f_t*>(tile)[i], reinterpret_cast<v4f_t*>(dst) + i);
   } else {
@@ -795,6 +799,211 @@ roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float
     }
     MI_STAMP(6);  // stores issued
     pp = n_pp;
+    row0 = n_row0;
+    nrows = n_nrows;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// roi_align_fwd_slab: the forward WITHOUT records, one launch (round 6, late).  What the records launch buys the kernel
+// above is the sweep order -- a 32-channel slab of a 200x336 map is 8.6 MB, twice an XCD's L2, so its RoIs have to walk
+// the map coherently -- and what it costs is a launch of ~5 us plus a kernel boundary in front of a ~30 us gather.  Here
+// the slab is cut to fit instead: one WAVE per (RoI, 8 channels), grid (8 * R, phases); workgroup x of a phase works on
+// channel tile 8 * phase + (x & 7), i.e. (workgroups go round-robin over the XCDs) at any time one XCD reads ONE
+// 8-channel slab (2.15 MB of its 4 MB L2) for all RoIs in arrival order: every line comes from the fabric once whatever
+// the order of the RoIs, and nobody has to rank them.  The wave computes the RoI's geometry and axis tables itself (the
+// arithmetic of roi_align_prepare, lane = sample), cuts the stages on the fly, and runs the same window DMA, bins and
+// tile store as the record-driven kernel on its own LDS image -- no barrier anywhere, 11-14 independent waves per CU.
+// Bit-equal to roi_align_fwd_records (same tables, same bins).  Callers whose workspace announces a backward keep the
+// records path: the backward reads the records.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int kSlabCT = 8;
+#if MI_TUNING
+#define MI_SLAB_STAMP(k)                                                                                               \
+  do {                                                                                                                \
+    if (timeline != nullptr && threadIdx.x == 0)                                                                      \
+      timeline[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = (long long)clock64();                    \
+  } while (0)
+#else
+#define MI_SLAB_STAMP(k)                                                                                               \
+  do {                                                                                                                \
+  } while (0)
+#endif
+// LDS of a wave: axis tables | output tile | image.  The LDS is handed out in granules of 1280 bytes (tools/micro/
+// launch_rate.hip: residency of one-wave workgroups steps at 6400 / 7680 / 8960 / 10240 / 11520 bytes), and 8 granules is what
+// lets a CU hold 18 waves instead of 14 -- the tables and the tile are therefore sized for the instance (14 samples per axis and
+// 49 bins at 7x7, sampling ratio 2) and the image takes what is left of 10240 bytes.
+template <int kSR, int kA>
+struct SlabLds {
+  static constexpr int kNS = (kSR > 0 && kA > 0) ? kSR * kA : kMaxS;                          // table entries per axis
+  static constexpr int kTile = kSlabCT * ((kA > 0 ? (kTileBins / kA < kA ? kTileBins / kA : kA) * kA : kTileBins) | 1);  // words
+  static constexpr int kCapMax = ((10240 - 2 * kNS * 16 - kTile * 4) / (kSlabCT * 4) - 1) & ~7;
+};
+template <int kSR, int kCap, int kA>
+constexpr size_t slab_lds_bytes() {
+  return 2 * SlabLds<kSR, kA>::kNS * sizeof(TabEntry) + (size_t)(SlabLds<kSR, kA>::kTile + kSlabCT * (kCap | 1)) * 4;
+}
+// kLevels: the RoIs carry a level index (pyramid calls); otherwise level 0 and its kernel arguments, no indexed fetch
+template <int kSR, int kCap, int kA, bool kLevels>
+__global__ void __launch_bounds__(64)
+roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, const int* __restrict__ levels, int num_rois,
+                   int batch, int channels, int aligned_height_arg, int aligned_width_arg, int sampling_ratio, int full_wait,
+                   const LevelTable lv MI_TL_PARAM) {
+  MI_SLAB_STAMP(0);
+  const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kPlane = kCap | 1;
+  constexpr int kNS = SlabLds<kSR, kA>::kNS;
+  TabEntry* tab = reinterpret_cast<TabEntry*>(smem);
+  float* tile = reinterpret_cast<float*>(tab + 2 * kNS);
+  float* img = tile + SlabLds<kSR, kA>::kTile;
+  const int lane = threadIdx.x;
+  const int bins = aligned_height * aligned_width;
+  const int c0 = (blockIdx.y * 8 + (blockIdx.x & 7)) * kSlabCT;
+  // lanes of a 32-lane LDS group = 4 channels x 8 output columns (8 x 4 measured the same)
+  const int cl = lane >> 3, slot = lane & 7;
+  // The arguments in front of the level table are preloaded into SGPRs (-amdgpu-kernarg-preload-count, build.py): the RoI's
+  // five floats are fetched with the first instructions, beside -- not behind -- the rest of the kernel arguments.
+  const int r = blockIdx.x >> 3;
+  const const_int_ptr rp = (const_int_ptr)(uintptr_t)(rois + (long long)r * 5);
+  const float roi_b = __int_as_float(rp[0]), roi_x1 = __int_as_float(rp[1]), roi_y1 = __int_as_float(rp[2]);
+  const float roi_x2 = __int_as_float(rp[3]), roi_y2 = __int_as_float(rp[4]);
+  const int lvl = (kLevels && levels != nullptr) ? min(max(((const_int_ptr)(uintptr_t)levels)[r], 0), lv.count - 1) : 0;
+  if (c0 >= channels) return;
+  // ---- geometry: roi_align_prepare's arithmetic (roi_align_kernel.cu:74-110, :16-52), lane = y sample AND x sample ----
+  const int height = lv.height[lvl], width = lv.width[lvl];
+  const float spatial_scale = lv.scale[lvl];
+  const int batch_ind = (int)roi_b;
+  const float start_w = roi_x1 * spatial_scale, start_h = roi_y1 * spatial_scale;
+  const float roi_width = fmaxf(roi_x2 * spatial_scale - start_w, 1.f);
+  const float roi_height = fmaxf(roi_y2 * spatial_scale - start_h, 1.f);
+  const float bin_h = roi_height / (float)aligned_height, bin_w = roi_width / (float)aligned_width;
+  const int gh = kSR > 0 ? kSR : (sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)aligned_height));
+  const int gw = kSR > 0 ? kSR : (sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)aligned_width));
+  const float count = (float)(gh * gw);
+  const int nsy = aligned_height * gh, nsx = aligned_width * gw;
+  FwdRec h;
+  h.flags = (batch_ind < 0 || batch_ind >= batch) ? kFlagZero : 0;
+  h.r = r;
+  h.lvl = lvl;
+  h.height = height;
+  h.width = width;
+  h.gh = gh;
+  h.gw = gw;
+  float* __restrict__ dst = out + ((long long)r * channels + c0) * bins;
+  // The first and last sample of an axis ARE the window's ends (samples do not decrease along the lanes), so the window,
+  // the band test and the clamp of roi_align_prepare fall out of the per-lane taps: four v_readlane instead of four scalar
+  // axis_taps in front of everything else.
+  const int lane_y = min(lane, max(min(nsy, 64), 1) - 1), ph_of = lane_y / gh;
+  const int lane_x = min(lane, max(min(nsx, 64), 1) - 1), pw_of = lane_x / gw;
+  const float yc = coord(start_h, bin_h, ph_of, lane_y - ph_of * gh, gh);
+  const float xc = coord(start_w, bin_w, pw_of, lane_x - pw_of * gw, gw);
+  int ylo, xlo;
+  float yhw, ylw, xhw, xlw;
+  axis_taps(yc, height, ylo, yhw, ylw);
+  axis_taps(xc, width, xlo, xhw, xlw);
+  const float yf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yc), 0));
+  const float yl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yc), 63));
+  const float xf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), 0));
+  const float xl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), 63));
+  bool fast = h.flags == 0 && nsy <= kMaxS && nsx <= kMaxS && aligned_height <= kMaxStages && height >= 2 && width >= 2 &&
+              !(yf < -1.0f || yl > (float)height || xf < -1.0f || xl > (float)width) && yl >= yf && xl >= xf;
+  const int wy0 = __builtin_amdgcn_readlane(ylo, 0), wx0 = __builtin_amdgcn_readlane(xlo, 0);
+  const int wx1 = __builtin_amdgcn_readlane(xlo, 63) + 1;
+  const int ww = wx1 - wx0 + 1;
+  const int pitch_px = (ww + 3) & ~3;
+  // The stages are cut from the lower taps of the LAST sample of every bin row (lanes `is_last`): "the bin rows from ph0 on
+  // whose window still fits" is a prefix of them -- one ballot.
+  const bool is_last = lane < nsy && lane - ph_of * gh == gh - 1;
+  const int max_rows_tile = kTileBins / aligned_width;
+  auto cut = [&](int ph0, int& e, int& row0, int& nrows) {
+    row0 = __builtin_amdgcn_readlane(ylo, ph0 * gh);
+    const bool ok = is_last && ph_of >= ph0 && ph_of < ph0 + max_rows_tile && (ylo + 1 - row0 + 1) * pitch_px <= kCap;
+    e = ph0 + __popcll(__ballot(ok));
+    const int row1 = e > ph0 ? __builtin_amdgcn_readlane(ylo, e * gh - 1) + 1 : row0;
+    nrows = row1 - row0 + 1;
+  };
+  if (fast) {
+    // a bin row whose window does not fit the LDS image sends the whole RoI down the direct path (as the records do)
+    const int first = __shfl_up(ylo, gh - 1);
+    if (__ballot(is_last && (ylo + 1 - first + 1) * pitch_px > kCap) != 0ull) fast = false;
+  }
+  if (!fast) {
+    fwd_direct_item<kSlabCT, 64>(h, lv, rois, dst, lane, c0, channels, aligned_height, aligned_width, sampling_ratio);
+    return;
+  }
+  h.wx0 = wx0;
+  h.ww = ww;
+  h.gmagic = (1u << 20) / (((unsigned)ww + 3u) >> 2) + 1u;
+  h.img = reinterpret_cast<uintptr_t>(lv.feat[lvl] + (long long)batch_ind * channels * height * width);
+  const unsigned plane0 = lds_addr_uniform(img);
+  const int pitch = pitch_px * 4;
+  int ph0 = 0, ph1, row0, nrows;
+  cut(0, ph1, row0, nrows);
+  MI_SLAB_STAMP(1);  // geometry and the first stage are known
+  fwd_issue_window<kSlabCT, kPlane>(h, c0, plane0, lane, row0, nrows);
+  MI_SLAB_STAMP(2);  // window pieces issued
+  // ---- axis tables, under the window's flight (roi_align_prepare's entries: lane = sample) ----
+  if (lane < nsy) {
+    TabEntry e;
+    e.off = ylo * pitch_px * 4;
+    e.hw = yhw / count;
+    e.lw = ylw / count;
+    e.lo = ylo;
+    tab[lane] = e;
+  }
+  if (lane < nsx) {
+    TabEntry e;
+    e.off = (xlo - wx0) * 4;
+    e.hw = xhw;
+    e.lw = xlw;
+    e.lo = xlo;
+    tab[kNS + lane] = e;
+  }
+  int stores_out = 0;
+  int nst = 0;
+  while (true) {
+    int n_ph1 = 0, n_row0 = 0, n_nrows = 0;
+    if (ph1 < aligned_height) cut(ph1, n_ph1, n_row0, n_nrows);
+    wait_vmcnt_at_most((full_wait & 1) ? 0 : stores_out);  // this stage's window has landed (a single wave: no barrier)
+    if (nst == 0) MI_SLAB_STAMP(3);
+    nst++;
+    if (h.wx0 + h.ww > h.width) fwd_patch_edge<kSlabCT, 64, kPlane>(h, img, lane, nrows);
+    const int nb = (ph1 - ph0) * aligned_width;
+    const int ts = nb | 1;
+    if (!(full_wait & 4))
+      fwd_bins<kSR, 8>(tab, tab + kNS, img + cl * kPlane, tile + cl * ts, slot, ph0, ph1, ph0, row0 * pitch, pitch,
+                       aligned_width, gh, gw);
+    const bool more = ph1 < aligned_height;
+#if MI_TUNING
+    if (!more) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MI_SLAB_STAMP(4);
+      MI_SLAB_STAMP(5);
+    }
+#endif
+    if (more) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the bins' reads of the image are done
+      fwd_issue_window<kSlabCT, kPlane>(h, c0, plane0, lane, n_row0, n_nrows);
+    }
+    stores_out = 0;
+    if (!(full_wait & 2)) {
+      fwd_store<kSlabCT, 64>(tile, dst, lane, ph0, nb, ts, bins, aligned_width, (full_wait & 8) != 0);
+      stores_out = fwd_store_count<kSlabCT, 64>(dst, 0, nb, ts, bins);
+    }
+    if (!more) {
+      MI_SLAB_STAMP(6);
+#if MI_TUNING
+      if (timeline != nullptr && threadIdx.x == 0)
+        timeline[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] =
+            ((long long)nst << 48) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+            (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+      break;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has left LDS before the next bins write it
+    ph0 = ph1;
+    ph1 = n_ph1;
     row0 = n_row0;
     nrows = n_nrows;
   }
@@ -1684,6 +1893,54 @@ int launch_roi_align_fwd_records_levels(const LevelTable& lv, const float* rois,
   if (cap_px >= 256) MI_CAP(256);
   MI_CAP(192);
 #undef MI_CAP
+}
+
+bool roi_align_fwd_slab_supported(const LevelTable& lv, int channels, int num_rois, int aligned_height, int aligned_width) {
+  if (tuning().slab <= 0) return false;
+  for (int l = 0; l < lv.count; l++)
+    if ((long long)kSlabCT * lv.height[l] * lv.width[l] * 4 >= (1LL << 31)) return false;
+  return channels > 0 && channels % kSlabCT == 0 && aligned_width <= kTileBins && aligned_height > 0 && aligned_width > 0 &&
+         num_rois > 0 && num_rois <= (1 << 24) && (channels / kSlabCT + 7) / 8 <= 65535;
+}
+
+int launch_roi_align_fwd_slab(const LevelTable& lv, const float* rois, const int* levels, float* output, int batch,
+                              int channels, int num_rois, int aligned_height, int aligned_width, int sampling_ratio,
+                              hipStream_t stream) {
+  const dim3 grid((unsigned)num_rois * 8u, (unsigned)((channels / kSlabCT + 7) / 8));
+  const int cap = tuning().slab >= 64 ? tuning().slab : 0;
+  const int a = aligned_height == aligned_width ? aligned_height : 0;
+#define MI_LAUNCH_SLAB(SR, CAP, A, LV)                                                                                 \
+  roi_align_fwd_slab<SR, CAP, A, LV><<<grid, 64, slab_lds_bytes<SR, CAP, A>(), stream>>>(                              \
+      rois, output, levels, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, tuning().fwd_full_wait, lv MI_TL_ARG)
+#define MI_SLAB_PICK(CAP7, CAP14, CAPG)                                                                                \
+  do {                                                                                                                \
+    if (sampling_ratio == 2 && a == 7 && levels == nullptr)                                                           \
+      MI_LAUNCH_SLAB(2, CAP7, 7, false);                                                                              \
+    else if (sampling_ratio == 2 && a == 7)                                                                           \
+      MI_LAUNCH_SLAB(2, CAP7, 7, true);                                                                               \
+    else if (sampling_ratio == 2 && a == 14 && levels == nullptr)                                                     \
+      MI_LAUNCH_SLAB(2, CAP14, 14, false);                                                                            \
+    else if (sampling_ratio == 2 && a == 14)                                                                          \
+      MI_LAUNCH_SLAB(2, CAP14, 14, true);                                                                             \
+    else if (sampling_ratio == 2)                                                                                     \
+      MI_LAUNCH_SLAB(2, CAPG, 0, true);                                                                               \
+    else                                                                                                              \
+      MI_LAUNCH_SLAB(0, CAPG, 0, true);                                                                               \
+  } while (0)
+  // default: the largest image that keeps a wave's LDS inside 8 granules; MI_ROI_ALIGN_SLAB >= 64 picks other capacities
+  if (cap == 0)
+    MI_SLAB_PICK((SlabLds<2, 7>::kCapMax), (SlabLds<2, 14>::kCapMax), (SlabLds<0, 0>::kCapMax));
+  else if (cap >= 336)
+    MI_SLAB_PICK(336, 336, 336);
+  else if (cap >= 288)
+    MI_SLAB_PICK(288, 288, 288);
+  else if (cap >= 200)
+    MI_SLAB_PICK(208, 208, 208);
+  else
+    MI_SLAB_PICK(176, 176, 176);
+#undef MI_SLAB_PICK
+#undef MI_LAUNCH_SLAB
+  return check_launch("roi_align_fwd_slab");
 }
 
 int launch_roi_align_fwd_records(const float* features, const float* rois, float* output, void* workspace, int batch,

@@ -83,8 +83,9 @@ def roi_align_impl(request, tuning_env):
 
 def _fwd_is_exact(impl, channels):
     """The direct kernels keep the reference's operation order; the fast paths (FMA, separable) decline channel counts
-    that are no multiple of their 32-channel tile and fall back to them."""
-    return impl == "direct" or channels % 32 != 0
+    that are no multiple of their channel tile (32 for the record-driven kernels, 8 for the records-free forward that
+    takes their place) and fall back to them."""
+    return impl == "direct" or channels % 8 != 0
 
 
 def test_extension_is_loaded_not_a_fallback(hip_lib_path):

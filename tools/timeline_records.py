@@ -25,7 +25,8 @@ feat = torch.from_numpy(syn.feature_map(1, c, h, w, seed=0)).to(dev)
 rois = torch.from_numpy(syn.rois_canonical(r, 1, seed=0)).to(dev)
 out = torch.empty((r, c, res, res), device=dev)
 ws = torch.empty(lib.mi_roi_align_forward_workspace_bytes(r), dtype=torch.uint8, device=dev)
-nwg = r * (c // 32)
+SLAB = bool(int(os.environ.get("MI_ROI_ALIGN_SLAB", "0")))  # the records-free kernel: one wave per (RoI, 8 channels)
+nwg = r * (c // 8) if SLAB else r * (c // 32)
 tl = torch.zeros((nwg, 8), dtype=torch.int64, device=dev)
 
 
@@ -68,5 +69,6 @@ for label, m in (("single-stage RoIs", one), ("all", np.ones(len(raw), bool))):
     life = t[m, 6]
     print("%-30s mean %5.2f  p50 %5.2f  p90 %5.2f  max %5.2f us" % ("workgroup life (to stores issued)", life.mean(), np.median(life), np.percentile(life, 90), life.max()))
 per_cu = np.bincount(np.unique(cu_key, return_inverse=True)[1], weights=t[:, 6])
-print("sum of the lives of a compute unit's workgroups: mean %.1f  max %.1f us (3 resident at a time -> /3 = %.1f us of kernel)" % (
-    per_cu.mean(), per_cu.max(), per_cu.mean() / 3))
+RES = int(os.environ.get("RESIDENT", "15" if SLAB else "3"))
+print("sum of the lives of a compute unit's workgroups: mean %.1f  max %.1f us (%d resident at a time -> / %d = %.1f us of kernel)" % (
+    per_cu.mean(), per_cu.max(), RES, RES, per_cu.mean() / RES))
