@@ -837,22 +837,29 @@ template <int kSR, int kA>
 struct SlabLds {
   static constexpr int kNS = (kSR > 0 && kA > 0) ? kSR * kA : kMaxS;                          // table entries per axis
   static constexpr int kTile = kSlabCT * ((kA > 0 ? (kTileBins / kA < kA ? kTileBins / kA : kA) * kA : kTileBins) | 1);  // words
-  static constexpr int kCapMax = ((10240 - 2 * kNS * 16 - kTile * 4) / (kSlabCT * 4) - 1) & ~7;
+  // the largest image capacity = 4 (mod 32) pixels that keeps the wave inside 8 granules
+  static constexpr int kCapMax = (((10240 - 2 * kNS * 16 - kTile * 4) / (kSlabCT * 4) - 4) & ~31) + 4;
 };
+// Plane stride = 4 (mod 32) dwords with lanes of a 32-lane LDS group = 8 channels x 4 output columns: the eight planes start
+// on banks 0, 4, .., 28, and two lanes of a tap read meet in a bank only when two of the group's four columns are congruent
+// mod 4 -- 1.73 LDS passes per tap read on config 2's RoIs against 2.72 for an odd stride with 4 channels x 8 columns
+// (simulated over the RoI set; all-distinct banks measured 3 us faster than the odd stride, this takes about half of it).
+template <int kCap>
+constexpr int slab_plane() { return kCap % 32 == 4 ? kCap : (kCap | 1); }
 template <int kSR, int kCap, int kA>
 constexpr size_t slab_lds_bytes() {
-  return 2 * SlabLds<kSR, kA>::kNS * sizeof(TabEntry) + (size_t)(SlabLds<kSR, kA>::kTile + kSlabCT * (kCap | 1)) * 4;
+  return 2 * SlabLds<kSR, kA>::kNS * sizeof(TabEntry) + (size_t)(SlabLds<kSR, kA>::kTile + kSlabCT * slab_plane<kCap>()) * 4;
 }
 // kLevels: the RoIs carry a level index (pyramid calls); otherwise level 0 and its kernel arguments, no indexed fetch
 template <int kSR, int kCap, int kA, bool kLevels>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kA > 0 ? 5 : 4)))
 roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, const int* __restrict__ levels, int num_rois,
                    int batch, int channels, int aligned_height_arg, int aligned_width_arg, int sampling_ratio, int full_wait,
                    const LevelTable lv MI_TL_PARAM) {
   MI_SLAB_STAMP(0);
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kPlane = kCap | 1;
+  constexpr int kPlane = slab_plane<kCap>();
   constexpr int kNS = SlabLds<kSR, kA>::kNS;
   TabEntry* tab = reinterpret_cast<TabEntry*>(smem);
   float* tile = reinterpret_cast<float*>(tab + 2 * kNS);
@@ -860,8 +867,8 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
   const int lane = threadIdx.x;
   const int bins = aligned_height * aligned_width;
   const int c0 = (blockIdx.y * 8 + (blockIdx.x & 7)) * kSlabCT;
-  // lanes of a 32-lane LDS group = 4 channels x 8 output columns (8 x 4 measured the same)
-  const int cl = lane >> 3, slot = lane & 7;
+  // lanes of a 32-lane LDS group = 8 channels x 4 output columns (see slab_plane)
+  const int cl = lane & 7, slot = lane >> 3;
   // The arguments in front of the level table are preloaded into SGPRs (-amdgpu-kernarg-preload-count, build.py): the RoI's
   // five floats are fetched with the first instructions, beside -- not behind -- the rest of the kernel arguments.
   const int r = blockIdx.x >> 3;
@@ -954,7 +961,7 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
   }
   if (lane < nsx) {
     TabEntry e;
-    e.off = (xlo - wx0) * 4;
+    e.off = (full_wait & 16) ? (pw_of * 4 + (lane - pw_of * gw)) * 4 : (xlo - wx0) * 4;  // 16: conflict-free taps (wrong pixels)
     e.hw = xhw;
     e.lw = xlw;
     e.lo = xlo;
@@ -1930,14 +1937,14 @@ int launch_roi_align_fwd_slab(const LevelTable& lv, const float* rois, const int
   // default: the largest image that keeps a wave's LDS inside 8 granules; MI_ROI_ALIGN_SLAB >= 64 picks other capacities
   if (cap == 0)
     MI_SLAB_PICK((SlabLds<2, 7>::kCapMax), (SlabLds<2, 14>::kCapMax), (SlabLds<0, 0>::kCapMax));
-  else if (cap >= 336)
-    MI_SLAB_PICK(336, 336, 336);
-  else if (cap >= 288)
-    MI_SLAB_PICK(288, 288, 288);
-  else if (cap >= 200)
-    MI_SLAB_PICK(208, 208, 208);
+  else if (cap >= 292)
+    MI_SLAB_PICK(292, 292, 292);
+  else if (cap >= 260)
+    MI_SLAB_PICK(260, 260, 260);
+  else if (cap >= 256)
+    MI_SLAB_PICK(256, 256, 256);
   else
-    MI_SLAB_PICK(176, 176, 176);
+    MI_SLAB_PICK(196, 196, 196);
 #undef MI_SLAB_PICK
 #undef MI_LAUNCH_SLAB
   return check_launch("roi_align_fwd_slab");
