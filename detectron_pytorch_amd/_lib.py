@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_detectron_ops.so")
 
 MI_OK = 0
-ABI_VERSION = 7  # MI_ABI_VERSION of include/mi_detectron_ops.h this binding was written against
+ABI_VERSION = 8  # MI_ABI_VERSION of include/mi_detectron_ops.h this binding was written against
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 ROI_ALIGN_CAFFE2, ROI_ALIGN_LEGACY = 0, 1
 NMS_GE_ORIG_ASC, NMS_GT_SORTED_POS = 0, 1

@@ -46,8 +46,11 @@ extern "C" {
  * backward over a workspace is two launches (no trailing launch: its plan counters alternate between two sets), the
  * RoIPool / RoICrop kernels are LDS-staged (same entry points, same results).  7 (round 6): mi_roi_pool_backward OVERWRITES
  * (tile kernel, the reference's addition order, no atomics); mi_roi_crop_backward_ws + _workspace_bytes (tile kernel,
- * overwrites, no atomics). */
-#define MI_ABI_VERSION 7
+ * overwrites, no atomics).  8 (round 6): no new entry point -- a forward whose workspace has no room for a backward (smaller
+ * than mi_roi_align_backward_workspace_bytes), and the forward without a workspace, run the records-free NCHW kernel
+ * (roi_align_fwd_slab: ONE launch, nothing written to the workspace); mi_roi_align_forward_writes_records speaks of a
+ * backward-sized workspace. */
+#define MI_ABI_VERSION 8
 
 typedef void* mi_stream_t; /* hipStream_t */
 
@@ -132,8 +135,11 @@ int mi_roi_align_backward_ws(const float* top_grad, const float* rois, float* bo
                              int aligned_height, int aligned_width, float spatial_scale,
                              int sampling_ratio, int variant, int layout,
                              void* workspace, size_t workspace_bytes, int flags, mi_stream_t stream);
-/* 1 when mi_roi_align_forward_ws with these arguments leaves the records of its rois in the workspace (so that a
- * backward over the same rois may pass MI_ROI_ALIGN_RECORDS_READY); 0 when it takes a path without records. */
+/* 1 when mi_roi_align_forward_ws with these arguments AND a workspace of at least mi_roi_align_backward_workspace_bytes
+ * leaves the records of its rois in the workspace (so that a backward over the same rois may pass
+ * MI_ROI_ALIGN_RECORDS_READY); 0 when it takes a path without records.  With a smaller (forward-sized) workspace the
+ * NCHW forward writes no records (one launch, roi_align_fwd_slab); a backward over such a workspace ignores
+ * MI_ROI_ALIGN_RECORDS_READY and writes its own, as it always has. */
 int mi_roi_align_forward_writes_records(int channels, int height, int width, int num_rois, int aligned_height,
                                         int aligned_width, int variant, int layout);
 /* 1 when mi_roi_align_backward_ws would honour MI_ROI_ALIGN_OVERWRITE for these arguments (with a workspace). */

@@ -1969,3 +1969,113 @@ def test_polygon_rasteriser_contract():
     assert tuple(segms.polys_to_masks_wrt_boxes(packed, to_dev(np.zeros(0, np.int64)), to_dev(np.zeros((0, 4), np.float32)), 28).shape) == (0, 784)
     with pytest.raises(NotImplementedError):
         segms.polys_to_masks_wrt_boxes(packed, torch.zeros(3, dtype=torch.int64), torch.from_numpy(boxes), 28)
+
+
+# ---- the records-free forward (roi_align_fwd_slab): one launch, no workspace contents ----------------------------------
+def _forward_ws_raw(feat_t, rois_t, res, scale, sr, ws):
+    from detectron_pytorch_amd import _lib
+
+    n, c, h, w = feat_t.shape
+    r = rois_t.size(0)
+    out = torch.full((r, c, res, res), float("nan"), device=dev())
+    lib = _lib.lib()
+    rc = lib.mi_roi_align_forward_ws(feat_t.data_ptr(), rois_t.data_ptr(), out.data_ptr(), n, c, h, w, r, res, res, scale, sr,
+                                     0, 0, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                     _lib.current_stream_handle(dev()))
+    assert rc == 0, lib.mi_last_error()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,res,sr,nrois", [((1, 256, 200, 336), 7, 2, 300),   # config-2 geometry: 1 to 4 stages per RoI
+                                                ((2, 64, 100, 168), 14, 2, 96),    # mask resolution, two images
+                                                ((2, 8, 25, 42), 7, 2, 64),        # one channel tile: 7 of 8 XCD columns idle
+                                                ((1, 72, 50, 84), 7, 2, 80),       # 9 tiles: a second, partial phase
+                                                ((3, 40, 13, 21), 7, 0, 50),       # adaptive sampling grid, tiny map
+                                                ((1, 24, 30, 40), 6, 3, 40),       # generic instance, sampling ratio 3
+                                                ((1, 16, 9, 70), 3, 1, 33)])
+def test_roi_align_records_free_forward_equals_the_record_driven_one(oracle_mod, tuning_env, shape, res, sr, nrois):
+    """A forward whose workspace has no room for a backward runs roi_align_fwd_slab: one launch that computes every RoI's
+    geometry, tables and stages itself.  Same tables, same bins as the record-driven kernel -> the same bits wherever
+    that kernel serves the shape (32-channel tiles), the oracle within the fast paths' bar everywhere; adversarial RoIs
+    (outside the image, no image, degenerate, map-sized) take its in-kernel reference-order path."""
+    from detectron_pytorch_amd import _lib
+
+    n, c, h, w = shape
+    scale = 1.0 / 16 if h < 100 else 0.25
+    feat = syn.feature_map(n, c, h, w, seed=res + sr + c)
+    third = nrois // 3
+    rois = np.vstack([syn.rois_adversarial(third, n, h, w, scale, seed=nrois),
+                      syn.rois_canonical(third, n, seed=nrois + 1, side=(2.0 / scale, min(h, w) / scale * 0.9),
+                                         im_h=h / scale, im_w=w / scale),
+                      syn.rois_canonical(nrois - 2 * third, n, seed=nrois + 2, side=(1.5 / scale, 22.0 / scale),
+                                         im_h=h / scale, im_w=w / scale)])
+    f, rt = to_dev(feat), to_dev(rois)
+    lib = _lib.lib()
+    fws = torch.empty(lib.mi_roi_align_forward_workspace_bytes(nrois), dtype=torch.uint8, device=dev())
+    tuning_env(MI_ROI_ALIGN_SLAB="1")
+    got = _forward_ws_raw(f, rt, res, scale, sr, fws)
+    got_no_ws = _forward_ws_raw(f, rt, res, scale, sr, None)
+    assert torch.equal(got, got_no_ws), "the entry point without a workspace runs the same kernel"
+    ref = oracle_mod.roi_align_forward(feat, rois, res, res, scale, sr, threads=8)
+    assert_fwd(got, ref, "records-free forward", exact=False)
+    tuning_env(MI_ROI_ALIGN_SLAB="0")
+    base = _forward_ws_raw(f, rt, res, scale, sr, fws)
+    assert_fwd(base, ref, "record-driven / fallback", exact=False)
+    if c % 32 == 0:
+        # the two kernels cut their stages for different LDS capacities: a RoI whose single bin row overflows the smaller
+        # image takes the reference-order path there and the separable one here (last bits); everything smaller: same bits
+        side = np.maximum(rois[:, 3] - rois[:, 1], rois[:, 4] - rois[:, 2]) * scale
+        small = torch.from_numpy(np.nonzero(side <= 24.0)[0]).to(dev())
+        assert small.numel() >= nrois // 4
+        assert torch.equal(got[small], base[small]), "records-free and record-driven forwards differ"
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res", [7, 14])
+def test_roi_align_records_free_forward_over_a_pyramid(oracle_mod, tuning_env, res):
+    """mi_roi_align_forward_fpn with a forward-sized workspace (an inference call): the records-free kernel with the level
+    index of every RoI; equal to the record-driven pyramid call bit for bit and to the oracle level by level."""
+    import ctypes
+
+    from detectron_pytorch_amd import _lib
+    from detectron_pytorch_amd.roi_align import _fpn_table
+
+    frois, flvls = syn.rois_fpn_distributed(240, batch=2, seed=res)
+    maps = [syn.feature_map(2, 64, syn.FPN_LEVELS[l][0], syn.FPN_LEVELS[l][1], seed=l) for l in (5, 4, 3, 2)]
+    scales = [syn.FPN_LEVELS[l][2] for l in (5, 4, 3, 2)]
+    mt = [to_dev(m) for m in maps]
+    rt, idx = to_dev(frois), to_dev((5 - flvls).astype(np.int32))
+    lib = _lib.lib()
+    ftab = _fpn_table(mt, scales)
+    ws = torch.empty(lib.mi_roi_align_forward_workspace_bytes(240), dtype=torch.uint8, device=dev())
+    outs = {}
+    for slab in ("1", "0"):
+        tuning_env(MI_ROI_ALIGN_SLAB=slab)
+        o = torch.full((240, 64, res, res), float("nan"), device=dev())
+        rc = lib.mi_roi_align_forward_fpn(ctypes.byref(ftab), rt.data_ptr(), idx.data_ptr(), o.data_ptr(), 2, 64, 240, res, res, 2, 0,
+                                          ws.data_ptr(), ws.numel(), _lib.current_stream_handle(dev()))
+        assert rc == 0, lib.mi_last_error()
+        outs[slab] = o
+    assert torch.equal(outs["1"], outs["0"])
+    got = outs["1"].cpu().numpy()
+    for k, lvl in enumerate((5, 4, 3, 2)):
+        sel = np.nonzero(flvls == lvl)[0]
+        assert_fwd(got[sel], oracle_mod.roi_align_forward(maps[k], frois[sel], res, res, scales[k], 2, threads=8),
+                   "level %d" % lvl, exact=False)
+
+
+@pytest.mark.gpu
+def test_roi_align_records_free_forward_partial_wait(tuning_env):
+    """The records-free kernel's stage pipeline waits with vmcnt(#stores) like the record-driven one: against vmcnt(0)
+    (MI_ROI_ALIGN_FWD_FULL_WAIT=1) bit for bit on multi-stage shapes, release build."""
+    h, w, scale = 200, 336, 0.25
+    rois = to_dev(syn.rois_canonical(256, 1, seed=5, side=(64.0, 700.0)))
+    for c, res in ((64, 7), (32, 14)):
+        f = to_dev(syn.feature_map(1, c, h, w, seed=c))
+        tuning_env(MI_ROI_ALIGN_SLAB="1", MI_ROI_ALIGN_FWD_FULL_WAIT=None)
+        a = _forward_ws_raw(f, rois, res, scale, 2, None)
+        tuning_env(MI_ROI_ALIGN_SLAB="1", MI_ROI_ALIGN_FWD_FULL_WAIT="1")
+        b = _forward_ws_raw(f, rois, res, scale, 2, None)
+        assert torch.equal(a, b) and torch.isfinite(a).all()

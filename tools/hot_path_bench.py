@@ -136,7 +136,7 @@ def roofline_roi_align_forward(device, iters):
     ws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
 
-    def launch():  # one call of the C-ABI = both launches of the fast path (RoI records, then the gather)
+    def launch():  # one call of the C-ABI = ONE launch (roi_align_fwd_slab: a forward-sized workspace asks for no records)
         rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res,
                                          scale, sr, _lib.ROI_ALIGN_CAFFE2, layout, ws.data_ptr(), ws_bytes, stream)
         assert rc == 0
@@ -150,39 +150,58 @@ def roofline_roi_align_forward(device, iters):
     info = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             # "bound" names the roofline the fraction is quoted against (the contract's enum).  What LIMITS the kernel is
-            # not HBM: counters (profiles/r05_pmc_roi_align.json) have HBM at 1.2 x the algorithmic bytes, the L2 at ~42 %
-            # of its rate, the TA at ~50 %; the timeline (profiles/r04_records_timeline.txt) has a wave 2.2 us in the ISSUE
-            # of its window pieces -- 5.2 x the algorithmic bytes cross L2 -> L1 as cache lines, a 72-byte NCHW row segment
-            # dragging in 1.5 of them -- and 0.3 us waiting for their landing
-            "limited_by": "vector-memory issue of the per-RoI window gather (L2->L1 cache lines = 5.2 x algorithmic bytes); "
-                          "not HBM, L2 bandwidth or LDS landing capacity (profiles/r06_forward_pair_ab.txt)",
-            "kernel": "roi_align_prepare + roi_align_fwd_records (one mi_roi_align_forward_ws call)",
+            # not HBM (1.2 x the algorithmic bytes): the gather alone (bins and stores ablated) takes 16.6 us + the launch floor
+            # whatever the residency (14 or 18 waves per CU) -- 3.4 M cache lines = 5.2 x the algorithmic bytes cross
+            # L2 -> L1 at ~77 % of the 64 B / clk / CU fill rate, a 72-byte NCHW row segment dragging in 1.5 lines -- and the
+            # bins (LDS reads, 1.7 passes per tap read after the stride-4 layout) and stores overlap it only in part
+            "limited_by": "L2->L1 line fill of the per-RoI window gather (cache lines = 5.2 x algorithmic bytes; the gather alone "
+                          "runs at ~77 % of the L1 fill rate) + LDS tap reads and stores that overlap it only partly; not HBM "
+                          "(profiles/r06_slab_forward.txt)",
+            "kernel": "roi_align_fwd_slab (one launch per mi_roi_align_forward_ws call: records-free, one wave per (RoI, 8 channels), "
+                      "an XCD reads one 8-channel slab at a time)",
             "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
             "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
-    # the gather alone: the same call over records that are already in the workspace (the launch above has just written
-    # them) -- what a caller pays whose RoI producer writes the records (mi_rpn_collect_finish_records: rcnn's static
-    # inference path; the producer is measured as long as before, inference_path.producer_records_pair)
+    # The record-driven pair (what a training forward runs: its workspace has room for the backward, which reads the
+    # records): the full call, and its gather kernel alone over records already in the workspace -- what a caller pays whose
+    # RoI producer writes the records (mi_rpn_collect_finish_records; inference_path.producer_records_pair)
     if ready_fwd and not os.environ.get("MI_BENCH_NHWC"):
         import ctypes
 
+        from detectron_pytorch_amd.roi_align import _backward_workspace_bytes as _bwsb
+
+        rws_bytes = max(ws_bytes, _bwsb([(h, w)], 1, r))
+        rws = torch.empty(rws_bytes, dtype=torch.uint8, device=device)
+        first = out.clone()
+
+        def launch_records():
+            rc = lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), out.data_ptr(), 1, c, h, w, r, res, res,
+                                             scale, sr, _lib.ROI_ALIGN_CAFFE2, layout, rws.data_ptr(), rws_bytes, stream)
+            assert rc == 0
+
+        sec_records = time_kernel(launch_records, iters)
+        assert torch.equal(out, first), "the record-driven forward must reproduce the records-free call bit for bit"
         lvt = _lib.FpnLevels()
         lvt.num_levels = 1
         lvt.features[0], lvt.height[0], lvt.width[0], lvt.spatial_scale[0] = feat.data_ptr(), h, w, scale
         level0 = torch.zeros(r, dtype=torch.int32, device=device)
-        first = out.clone()
 
         def launch_ready():
             rc = lib.mi_roi_align_forward_fpn_records(ctypes.byref(lvt), rois.data_ptr(), level0.data_ptr(), out.data_ptr(), 1, c,
-                                                      r, res, res, sr, layout, ws.data_ptr(), ws_bytes, stream)
+                                                      r, res, res, sr, layout, rws.data_ptr(), rws_bytes, stream)
             assert rc == 0
 
         sec_ready = time_kernel(launch_ready, iters)
         assert torch.equal(out, first), "the records-ready forward must reproduce the full call bit for bit"
+        info["records_pair"] = {"avg_launch_us": round(sec_records * 1e6, 2), "achieved": round(alg_bytes / sec_records / 1e9, 1),
+                                "unit": "GB/s", "frac": round(alg_bytes / sec_records / 1e9 / HBM_PEAK_GBS, 4),
+                                "what": "roi_align_prepare (with the backward's tables) + roi_align_fwd_records: the same call with a "
+                                        "workspace that has room for a backward -- the training forward; rounds 1-5 and early round 6 "
+                                        "quoted this pair (with forward-only records) as the headline fraction"}
         info["records_ready"] = {"avg_launch_us": round(sec_ready * 1e6, 2), "achieved": round(alg_bytes / sec_ready / 1e9, 1),
                                  "unit": "GB/s", "frac": round(alg_bytes / sec_ready / 1e9 / HBM_PEAK_GBS, 4),
                                  "what": "roi_align_fwd_records alone (mi_roi_align_forward_fpn_records over the records the "
-                                         "full call has just written): the call of a consumer whose RoI producer writes the "
-                                         "records; NOT the headline fraction, which includes the records launch"}
+                                         "record-driven call has just written): the call of a consumer whose RoI producer writes "
+                                         "the records"}
     # backward at the same shape, reported beside it (bytes = 4*R*C*PH*PW read + 4*N*C*H*W written + 20*R)
     gtop = torch.randn(r, c, res, res, device=device)
     gin = torch.zeros(1, c, h, w, device=device)
@@ -230,7 +249,7 @@ def roofline_roi_align_forward(device, iters):
                                 "long lists of a training step's clustered RoIs into slices: roi_align_step_rois); unplanned = "
                                 "the same call under MI_ROI_ALIGN_BWD_SLICE=0 (one workgroup per tile scans the RoIs itself and "
                                 "walks the whole list: no atomics, bit-reproducible; + roi_align_bwd_untabled behind it)"}
-    info["l2_line_frac"] = pmc_l2_line_frac(info.get("records_ready", {}).get("avg_launch_us"))
+    info["l2_line_frac"] = pmc_l2_line_frac(info["avg_launch_us"])  # one launch per call: the call time is the kernel plus its launch floor
     info["other_shapes"] = other_shapes(device, lib, stream, max(iters // 4, 10))
     info["roi_pool_roi_crop"] = pool_and_crop(device, max(iters // 2, 20))
     if layout == _lib.LAYOUT_NCHW:

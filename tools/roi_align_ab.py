@@ -102,7 +102,9 @@ def shapes(dev, which):
         scales = [syn.FPN_LEVELS[l][2] for l in (5, 4, 3, 2)]
         r = int(rois.size(0))
         o = torch.empty((r, 256, res, res), device=dev)
-        ws = torch.empty(_backward_workspace_bytes([(m.size(2), m.size(3)) for m in maps], 2, r), dtype=torch.uint8, device=dev)
+        # WS=fwd: the forward-sized workspace of an inference call (no backward tables; the records-free kernel serves it)
+        ws = torch.empty(_lib.lib().mi_roi_align_forward_workspace_bytes(r) if os.environ.get("WS") == "fwd" else
+                         _backward_workspace_bytes([(m.size(2), m.size(3)) for m in maps], 2, r), dtype=torch.uint8, device=dev)
         ftab = _fpn_table(maps, scales)
         stream = _lib.current_stream_handle(dev)
 
