@@ -1935,8 +1935,11 @@ int launch_roi_align_fwd_slab(const LevelTable& lv, const float* rois, const int
       MI_LAUNCH_SLAB(0, CAPG, 0, true);                                                                               \
   } while (0)
   // default: the largest image that keeps a wave's LDS inside 8 granules; MI_ROI_ALIGN_SLAB >= 64 picks other capacities
+  // 7x7: 292 pixels (9 granules, 14 waves per CU) -- fewer two- and three-stage items pay for the lost residency on the large
+  // launches (1024 RoIs 56.0 -> 54.1 us, a step's box pyramid 57.1 -> 54.7, config 2 29.2 -> 28.6..29.1); the 14x14 heads keep
+  // 8 granules (128 x 14x14: 22.9 against 27.1 us)
   if (cap == 0)
-    MI_SLAB_PICK((SlabLds<2, 7>::kCapMax), (SlabLds<2, 14>::kCapMax), (SlabLds<0, 0>::kCapMax));
+    MI_SLAB_PICK(292, (SlabLds<2, 14>::kCapMax), (SlabLds<0, 0>::kCapMax));
   else if (cap >= 292)
     MI_SLAB_PICK(292, 292, 292);
   else if (cap >= 260)

@@ -29,14 +29,15 @@ rm -rf $O/pmc_mfma5
 fi
 if [ $STAGE = all ] || [ $STAGE = config2 ]; then
 echo "pass,kernel,calls,avg_ns,min_ns,max_ns" > $O/config2_kernel_durations.csv
-for pass in roi_align_fwd roi_align_bwd roi_align_bwd_unplanned nhwc_fwd; do
-  unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS MI_BENCH_BWD_UNPLANNED; k=roi_align_fwd
+for pass in roi_align_fwd roi_align_fwd_records roi_align_bwd roi_align_bwd_unplanned nhwc_fwd; do
+  unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS MI_BENCH_BWD_UNPLANNED MI_ROI_ALIGN_SLAB; k=roi_align_fwd
   case $pass in
+    roi_align_fwd_records) export MI_ROI_ALIGN_SLAB=0;;   # the record-driven pair the records-free kernel replaced
     roi_align_bwd) k=roi_align_bwd;;
     roi_align_bwd_unplanned) k=roi_align_bwd; export MI_BENCH_BWD_UNPLANNED=1;;
     nhwc_fwd) export MI_BENCH_NHWC=1;;
   esac
-  timeout 120 rocprofv3 --kernel-trace --stats -d $O/c2_$pass -o c -f csv -- python $R/tools/run_one_kernel.py $k 50 > $O/c2_$pass.log 2>&1
+  timeout 120 rocprofv3 --kernel-trace --stats -d $O/c2_$pass -o c -f csv -- python $R/tools/run_one_kernel.py $k 2000 > $O/c2_$pass.log 2>&1
   python - $O/c2_$pass $pass >> $O/config2_kernel_durations.csv <<'PY'
 import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
@@ -47,7 +48,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
 PY
   rm -rf $O/c2_$pass
 done
-unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS MI_BENCH_BWD_UNPLANNED
+unset MI_BENCH_NHWC MI_ROI_ALIGN_IMPL MI_BENCH_TILES_WS MI_BENCH_BWD_UNPLANNED MI_ROI_ALIGN_SLAB
 fi
 if [ $STAGE = all ] || [ $STAGE = pmc ]; then
 for variant in records bwd; do

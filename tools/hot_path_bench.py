@@ -96,19 +96,30 @@ def make_stepper(work, mode, device):
         return work.step, "eager"
 
 
-def time_kernel(fn, iters, warmup=10):
+def time_kernel(fn, iters, warmup=10, trace=None):
     """Average duration (s) of one call of `fn` over `iters` back-to-back launches, HIP events recorded
-    on the stream the kernels are launched on (torch's current stream)."""
+    on the stream the kernels are launched on (torch's current stream).  STEADY STATE: batches of `iters` calls are
+    repeated (at most 8) until two consecutive batches agree within 1 % -- after idle the chip needs ~30 ms of sustained work
+    before its clocks have ramped (a 29 us kernel measures 34.6, 31.9, 30.3, 29.6, 29.4 ... 28.9 us over the first batches of
+    200 calls: tools/_ramp.py, profiles/r06_slab_forward.txt); `trace` (a list) receives every batch's figure in us."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(iters):
-        fn()
-    stop.record()
-    stop.synchronize()
-    return start.elapsed_time(stop) * 1e-3 / iters
+    prev = None
+    for _ in range(8):
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(iters):
+            fn()
+        stop.record()
+        stop.synchronize()
+        t = start.elapsed_time(stop) * 1e-3 / iters
+        if trace is not None:
+            trace.append(round(t * 1e6, 2))
+        if prev is not None and abs(t - prev) <= 0.01 * t:
+            break
+        prev = t
+    return t
 
 
 def roofline_roi_align_forward(device, iters):
@@ -141,7 +152,8 @@ def roofline_roi_align_forward(device, iters):
                                          scale, sr, _lib.ROI_ALIGN_CAFFE2, layout, ws.data_ptr(), ws_bytes, stream)
         assert rc == 0
 
-    seconds = time_kernel(launch, iters)
+    batches = []
+    seconds = time_kernel(launch, iters, trace=batches)
     ready_fwd = bool(lib.mi_roi_align_forward_writes_records(c, h, w, r, res, res, _lib.ROI_ALIGN_CAFFE2, layout))
     touched = touched_pixels(rois_np, 1, h, w, res, res, scale, sr)
     alg_bytes = 4 * r * c * res * res + 4 * c * touched + 20 * r
@@ -160,7 +172,9 @@ def roofline_roi_align_forward(device, iters):
             "kernel": "roi_align_fwd_slab (one launch per mi_roi_align_forward_ws call: records-free, one wave per (RoI, 8 channels), "
                       "an XCD reads one 8-channel slab at a time)",
             "shape": "R=512 C=256 7x7 sr=2 on 200x336", "algorithmic_bytes": int(alg_bytes),
-            "avg_launch_us": round(seconds * 1e6, 2), "launches": iters}
+            "avg_launch_us": round(seconds * 1e6, 2), "launches": iters,
+            "timing": "steady state: batches of %d back-to-back calls until two consecutive batches agree within 1 %% (the "
+                      "chip's clocks ramp over the first ~30 ms after idle); us per call of every batch: %s" % (iters, batches)}
     # The record-driven pair (what a training forward runs: its workspace has room for the backward, which reads the
     # records): the full call, and its gather kernel alone over records already in the workspace -- what a caller pays whose
     # RoI producer writes the records (mi_rpn_collect_finish_records; inference_path.producer_records_pair)
@@ -377,13 +391,23 @@ def other_shapes(device, lib, stream, iters):
             assert lib.mi_roi_align_backward_ws(gtop.data_ptr(), rois.data_ptr(), gin.data_ptr(), n, c, h, w, r, res, res,
                                                 scale, sr, 0, 0, ws.data_ptr(), ws_bytes, flags, stream) == 0
 
+        fws_bytes = lib.mi_roi_align_forward_workspace_bytes(r)  # an inference call: no room for a backward -> records-free
+
+        def fwd_only():
+            assert lib.mi_roi_align_forward_ws(feat.data_ptr(), rois.data_ptr(), o.data_ptr(), n, c, h, w, r, res, res, scale,
+                                               sr, 0, 0, ws.data_ptr(), fws_bytes, stream) == 0
+
+        fwd_only_s = time_kernel(fwd_only, iters)
         fwd_s, bwd_s = time_kernel(fwd, iters), time_kernel(bwd, iters)
         # the same algorithmic-bytes formulas as the headline shape: forward 4 R C PH PW + 4 C U + 20 R
         # with U = distinct tapped pixels of THIS RoI set, backward 4 R C PH PW + 4 N C H W + 20 R
         u = touched_pixels(rois.cpu().numpy(), n, h, w, res, res, scale, sr)
         fwd_bytes = 4 * r * c * res * res + 4 * c * u + 20 * r
         bwd_bytes = 4 * r * c * res * res + 4 * n * c * h * w + 20 * r
-        out[name] = {"fwd_us": round(fwd_s * 1e6, 1), "bwd_us": round(bwd_s * 1e6, 1),
+        out[name] = {"fwd_only_us": round(fwd_only_s * 1e6, 1), "fwd_only_frac": round(fwd_bytes / fwd_only_s / 1e9 / HBM_PEAK_GBS, 4),
+                     "fwd_us": round(fwd_s * 1e6, 1), "bwd_us": round(bwd_s * 1e6, 1),
+                     "what": "fwd_only: forward-sized workspace (inference; roi_align_fwd_slab, one launch); fwd / bwd: the training pair "
+                             "over a workspace with room for the backward (records + gather, then plan + tiles)",
                      "touched_pixels": int(u), "fwd_algorithmic_bytes": int(fwd_bytes),
                      "fwd_achieved": round(fwd_bytes / fwd_s / 1e9, 1), "fwd_frac": round(fwd_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
                      "bwd_algorithmic_bytes": int(bwd_bytes), "bwd_achieved": round(bwd_bytes / bwd_s / 1e9, 1),
