@@ -21,7 +21,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libmi_detectron_ops.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["abi.hip", "roi_align.hip", "roi_align_fwd_tile.hip", "roi_align_records.hip", "roi_align_nhwc.hip", "roi_pool.hip", "roi_crop.hip", "nms.hip", "soft_nms.hip", "proposals.hip", "affine_channel.hip", "topk.hip", "results.hip", "box_voting.hip", "mask_targets.hip"]
+SOURCES = ["abi.hip", "roi_align.hip", "roi_align_records.hip", "roi_align_nhwc.hip", "roi_pool.hip", "roi_crop.hip", "nms.hip", "soft_nms.hip", "proposals.hip", "affine_channel.hip", "topk.hip", "results.hip", "box_voting.hip", "mask_targets.hip"]
 ARCH = "gfx950"
 # Per-unit flags.  roi_align_records.hip: the leading scalar / pointer kernel arguments arrive preloaded in SGPRs (gfx950
 # kernarg preload) -- the records-free RoIAlign forward starts with a chain of dependent fetches (arguments -> the RoI's five

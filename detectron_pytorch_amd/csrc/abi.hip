@@ -42,7 +42,6 @@ Tuning read_tuning() {
   t.fwd_split = env_int("MI_ROI_ALIGN_FWD_SPLIT", 0);
   t.fwd_full_wait = env_int("MI_ROI_ALIGN_FWD_FULL_WAIT", 0);
   t.slab = env_int("MI_ROI_ALIGN_SLAB", 1);
-  t.slab_map = env_int("MI_ROI_ALIGN_SLAB_MAP", 0);
   t.ablate = MI_ABLATE(env_int("MI_ROI_ALIGN_ABLATE", 0));
   t.copy_variant = env_int("MI_COPY_VARIANT", 411);
   return t;

@@ -57,7 +57,7 @@ inline int grid_for(long long total, int block) {
 //   MI_ROI_ALIGN_CAP=192|256|336|448|640   window pixels per channel of the NCHW forward LDS image
 //   MI_ROI_ALIGN_FWD_SPLIT=1|2|4           workgroups an NCHW forward item's stages are dealt to (0: by the launch's size)
 //   MI_ROI_ALIGN_FWD_FULL_WAIT=1           NCHW forward: vmcnt(0) in front of every stage (the check of the partial wait)
-//   MI_ROI_ALIGN_SLAB=0|1|240|288|336|448  records-free NCHW forward (roi_align_fwd_slab) off / on / on with that LDS capacity
+//   MI_ROI_ALIGN_SLAB=0|1|196|256|260|292  records-free NCHW forward (roi_align_fwd_slab) off / on / on with that LDS image capacity
 //   MI_ROI_ALIGN_BWD_TH=8|16|32            rows per backward tile
 //   MI_ROI_ALIGN_BWD_SLICE=n   RoIs per list slice of the planned backward (32; 0: no plan, no atomics)
 //   MI_ROI_ALIGN_NHWC_V / _PB / _ORDER_MUL / _ZIGZAG   channels-last forward variants
@@ -66,7 +66,7 @@ struct Tuning {
   bool force_direct, no_ws;
   int cap_px, bwd_tile_rows, bwd_slice;
   int nhwc_vec, nhwc_pb, nhwc_order_mul, nhwc_zigzag, fwd_split, fwd_full_wait;
-  int slab, slab_map;  // MI_ROI_ALIGN_SLAB: 0 = records-free forward off, 1 = on, >= 64: on with that LDS capacity; _SLAB_MAP: lane map
+  int slab;  // MI_ROI_ALIGN_SLAB: 0 = records-free forward off, 1 = on, >= 64: on with that LDS image capacity
   int ablate;
   int copy_variant;  // MI_COPY_VARIANT of mi_dbg_copy_float4 (tools/copy_sweep.py)
 };

@@ -11,8 +11,7 @@
 //       alignments the fast paths decline, MI_ROI_ALIGN_IMPL=direct.
 //   roi_align_legacy<fwd / bwd>   the legacy variant from a per-workgroup point table (see there).
 //   the dispatch of mi_roi_align_* to the fast paths, which live in files of their own: roi_align_records.hip (records,
-//       NCHW forward, tile backward), roi_align_nhwc.hip (channels-last forward), roi_align_fwd_tile.hip (NCHW forward
-//       without a workspace).
+//       the records-free and the record-driven NCHW forward, tile backward), roi_align_nhwc.hip (channels-last forward).
 #include "common.h"
 #include "roi_align_device.h"
 
@@ -246,7 +245,6 @@ int check_common(const void* a, const void* rois, const void* b, int batch, int 
 // Tuning aid, not part of include/mi_detectron_ops.h: device buffer of 8 int64 stamps per forward workgroup
 // (tools/timeline.py); nullptr switches the stamps off.
 extern "C" void mi_dbg_roi_align_timeline(long long* device_buffer) {
-  mi::roi_align_fwd_tile_set_timeline(device_buffer);
   mi::roi_align_fwd_nhwc_set_timeline(device_buffer);
   mi::roi_align_fwd_records_set_timeline(device_buffer);
 }
@@ -309,10 +307,6 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
     return mi::launch_roi_align_fwd_slab(mi::single_level(features, nullptr, batch, height, width, spatial_scale), rois,
                                          nullptr, output, batch, channels, num_rois, aligned_height, aligned_width,
                                          sampling_ratio, s);
-  if (layout == MI_LAYOUT_NCHW && !force_direct() &&
-      mi::roi_align_fwd_tile_supported(channels, height, width, aligned_height, aligned_width))
-    return mi::launch_roi_align_fwd_tile(features, rois, output, batch, channels, height, width, num_rois,
-                                         aligned_height, aligned_width, spatial_scale, sampling_ratio, cap, s);
   FeatStrides st = make_strides(layout, channels, height, width);
   roi_align_fwd_direct<<<(int)dir_grid, kDirThreads, 0, s>>>(features, rois, output, batch, channels, height, width,
                                                             aligned_height, aligned_width, spatial_scale, sampling_ratio, st);

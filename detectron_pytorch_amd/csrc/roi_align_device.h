@@ -105,12 +105,6 @@ inline LevelTable single_level(const float* feat, float* grad, int batch, int he
   return t;
 }
 
-// host-side launchers of the NCHW fast paths (roi_align_fwd_tile.hip)
-bool roi_align_fwd_tile_supported(int channels, int height, int width, int aligned_height, int aligned_width);
-int launch_roi_align_fwd_tile(const float* features, const float* rois, float* output, int batch, int channels,
-                              int height, int width, int num_rois, int aligned_height, int aligned_width,
-                              float spatial_scale, int sampling_ratio, int ring_words, hipStream_t stream);
-void roi_align_fwd_tile_set_timeline(long long* device_buffer);
 // two-launch forward fast path with caller scratch (roi_align_records.hip)
 size_t roi_align_records_workspace_bytes(int num_rois);
 void roi_align_fwd_records_set_timeline(long long* device_buffer);  // tuning builds only (no-op otherwise)

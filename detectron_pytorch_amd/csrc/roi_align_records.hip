@@ -18,14 +18,31 @@
 //       static pairs of ranks with the next window landing in VGPRs: a wave spends its time ISSUING the window pieces, not
 //       waiting for them, and register loads stall it at the same place: +28 %, profiles/r06_forward_pair_ab.txt -- see
 //       DESIGN.md section 5 and docs/history.md.)
+//   roi_align_fwd_slab   the forward WITHOUT records, one launch: one wave per (RoI, 8 channels), an XCD reads one 8-channel
+//       slab at a time (it fits its L2: no sweep order needed), geometry / tables / stages computed by the wave.  What every
+//       caller gets whose workspace has no room for a backward (see its comment below).
 //   roi_align_bwd_plan / roi_align_bwd_tiles   the backward over the same records (see below).
 //
-// Data movement and arithmetic are those of roi_align_fwd_tile.hip (see its header): LDS-DMA of the compact
-// [row][ww] window into one odd-stride plane per channel, lane & 31 = channel, conflict-free ds_read2_b32 tap pairs,
-// separable FMA evaluation (fp32 rounding differences only w.r.t. the reference's summation order, ~5e-7;
-// contract 1e-4), border samples as (size-1, size) with weights (1, 0) and the address of `size` clamped to size-1.
-// RoIs the LDS image cannot serve are flagged by roi_align_prepare and take the in-kernel direct path (reference
-// operation order, bit-exact).
+// Data movement and arithmetic of both forwards:
+//   * arithmetic contract: sample coordinates, tap rows / columns and interpolation weights are computed with exactly the
+//     reference's fp32 operations (roi_align_kernel.cu:74-110, :16-52), so every output reads the same feature pixels with the
+//     same weights; the weighted sum is evaluated separably with fused multiply-adds -- per bin
+//     0.25 * sum_iy (hy * R(y_lo) + ly * R(y_lo + 1)), R(row) = sum_ix (hx * F[row][x_lo] + lx * F[row][x_lo + 1]) -- instead of
+//     the reference's 16 products added left to right: fp32 rounding only (~5e-7 on unit-variance features; contract 1e-4);
+//   * window = the feature rows / columns any sample of the RoI touches, copied L2 -> LDS once by LDS-DMA
+//     (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write pass), lanes flattened over (row, 16-byte group), one plane per
+//     channel; tap pair (F[x], F[x + 1]) = one ds_read2_b32 (record-driven kernel: odd plane stride, lane & 31 = channel, no
+//     bank conflicts; records-free kernel: see slab_plane);
+//   * a clamped border sample is the pixel pair (size - 1, size) with weights (1, 0), the reference's (size - 1, size - 1) with
+//     (1, 0): the window ends one row / column past the map and the DMA reads that one from the clamped address, so
+//     "high = low + 1" holds for every sample (fixed +4 / +pitch tap addressing) and a non-finite border pixel propagates
+//     exactly as in the reference (1 * f + 0 * f);
+//   * results are staged in LDS as [channel][bin] and leave as contiguous 16-byte stores; windows larger than the LDS image
+//     are processed in stages of bin rows.
+// RoIs the LDS image cannot serve (a sample outside the [-1, size] band, one bin row larger than the image, > 32 samples per
+// axis, H or W < 2) take the in-kernel direct path (reference operation order, bit-exact).
+// (roi_align_fwd_tile.hip -- rounds 1-5's forward without a workspace: this structure per (RoI, 32 channels) in arrival
+// order -- is gone: the records-free kernel serves its callers.)
 #include "common.h"
 #include "roi_align_device.h"
 #include "lds_dma.h"
@@ -857,6 +874,8 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
                    int batch, int channels, int aligned_height_arg, int aligned_width_arg, int sampling_ratio, int full_wait,
                    const LevelTable lv MI_TL_PARAM) {
   MI_SLAB_STAMP(0);
+  // tuning builds only (MI_ROI_ALIGN_FWD_FULL_WAIT bits): 2 = no stores, 4 = no bins, 8 = plain stores, 16 = conflict-free taps
+  const int ablate = MI_ABLATE(full_wait);
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kPlane = slab_plane<kCap>();
@@ -915,7 +934,7 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
   const float xl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), 63));
   bool fast = h.flags == 0 && nsy <= kMaxS && nsx <= kMaxS && aligned_height <= kMaxStages && height >= 2 && width >= 2 &&
               !(yf < -1.0f || yl > (float)height || xf < -1.0f || xl > (float)width) && yl >= yf && xl >= xf;
-  const int wy0 = __builtin_amdgcn_readlane(ylo, 0), wx0 = __builtin_amdgcn_readlane(xlo, 0);
+  const int wx0 = __builtin_amdgcn_readlane(xlo, 0);
   const int wx1 = __builtin_amdgcn_readlane(xlo, 63) + 1;
   const int ww = wx1 - wx0 + 1;
   const int pitch_px = (ww + 3) & ~3;
@@ -961,7 +980,7 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
   }
   if (lane < nsx) {
     TabEntry e;
-    e.off = (full_wait & 16) ? (pw_of * 4 + (lane - pw_of * gw)) * 4 : (xlo - wx0) * 4;  // 16: conflict-free taps (wrong pixels)
+    e.off = (ablate & 16) ? (pw_of * 4 + (lane - pw_of * gw)) * 4 : (xlo - wx0) * 4;  // 16: conflict-free taps (wrong pixels)
     e.hw = xhw;
     e.lw = xlw;
     e.lo = xlo;
@@ -978,7 +997,7 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
     if (h.wx0 + h.ww > h.width) fwd_patch_edge<kSlabCT, 64, kPlane>(h, img, lane, nrows);
     const int nb = (ph1 - ph0) * aligned_width;
     const int ts = nb | 1;
-    if (!(full_wait & 4))
+    if (!(ablate & 4))
       fwd_bins<kSR, 8>(tab, tab + kNS, img + cl * kPlane, tile + cl * ts, slot, ph0, ph1, ph0, row0 * pitch, pitch,
                        aligned_width, gh, gw);
     const bool more = ph1 < aligned_height;
@@ -994,8 +1013,8 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
       fwd_issue_window<kSlabCT, kPlane>(h, c0, plane0, lane, n_row0, n_nrows);
     }
     stores_out = 0;
-    if (!(full_wait & 2)) {
-      fwd_store<kSlabCT, 64>(tile, dst, lane, ph0, nb, ts, bins, aligned_width, (full_wait & 8) != 0);
+    if (!(ablate & 2)) {
+      fwd_store<kSlabCT, 64>(tile, dst, lane, ph0, nb, ts, bins, aligned_width, (ablate & 8) != 0);
       stores_out = fwd_store_count<kSlabCT, 64>(dst, 0, nb, ts, bins);
     }
     if (!more) {

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 ATOL = 1e-4  # north_star tolerance for RoIAlign features / gradients
 RTOL = 1e-4
 # The NCHW fast path of RoIAlign forward reads the reference's taps with the reference's weights but sums them
-# separably with FMAs (roi_align_fwd_tile.hip): fp32 rounding differences only.  Bar used below: 1e-5 (10x inside
+# separably with FMAs (roi_align_records.hip): fp32 rounding differences only.  Bar used below: 1e-5 (10x inside
 # the contract); the generic direct kernel keeps the reference operation order and is checked bit-exactly.
 FAST_ATOL = 1e-5
 

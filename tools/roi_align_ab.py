@@ -19,7 +19,7 @@ import torch  # noqa: E402
 from detectron_pytorch_amd import _lib, synthetic as syn  # noqa: E402
 
 TUNING_VARS = ("MI_ROI_ALIGN_BWD_SLICE", "MI_ROI_ALIGN_BWD_TH", "MI_ROI_ALIGN_CAP", "MI_ROI_ALIGN_ABLATE", "MI_ROI_ALIGN_IMPL",
-               "MI_ROI_ALIGN_NO_WS", "MI_ROI_ALIGN_SLAB", "MI_ROI_ALIGN_SLAB_MAP", "MI_ROI_ALIGN_FWD_FULL_WAIT", "MI_ROI_ALIGN_NHWC_V", "MI_ROI_ALIGN_NHWC_PB", "MI_ROI_ALIGN_NHWC_ZIGZAG", "MI_ROI_ALIGN_FWD_SPLIT")
+               "MI_ROI_ALIGN_NO_WS", "MI_ROI_ALIGN_SLAB", "MI_ROI_ALIGN_FWD_FULL_WAIT", "MI_ROI_ALIGN_NHWC_V", "MI_ROI_ALIGN_NHWC_PB", "MI_ROI_ALIGN_NHWC_ZIGZAG", "MI_ROI_ALIGN_FWD_SPLIT")
 _LIBS = {}
 
 
