@@ -25,8 +25,11 @@ from .. import roi_align as roi_align_mod
 from . import fpn as fpn_mod
 from . import heads, targets
 
-# A/B switch of the measurement tools: 0 = the box head's pooling call writes its records itself
-PRODUCER_RECORDS = os.environ.get("MI_RCNN_PRODUCER_RECORDS", "1") != "0"
+# 1 = the proposal stage's last launch writes the RoIAlign records of the blob it emits (round 5: one launch fewer than a
+# pooling call that starts with its records launch).  Default 0 since the records-free forward (late round 6): the pooling call
+# of an inference pass is ONE launch that needs no records -- 58.6-63.2 us for collect + pooling against 65.2-65.7 with
+# producer-written records (bench.py inference_path.records_by_producer).  Kept as the A/B switch of the measurement tools.
+PRODUCER_RECORDS = os.environ.get("MI_RCNN_PRODUCER_RECORDS", "0") != "0"
 
 
 def _conv_body(cfg):
