@@ -40,12 +40,23 @@ __device__ __forceinline__ void dma_dword(srd_t srd, unsigned lds_base, unsigned
                : "memory");
 }
 
+// tools/build_defines.sh MI_DMA_AUX_ID=1|2|3: cache-policy bits of the 16-byte window pieces (nt / sc1 / sc0 sc1); measured
+// on the records-free forward, round 6: see profiles/r06_slab_forward.txt
+#if MI_DMA_AUX_ID == 1
+#define MI_DMA_AUX " nt"
+#elif MI_DMA_AUX_ID == 2
+#define MI_DMA_AUX " sc1"
+#elif MI_DMA_AUX_ID == 3
+#define MI_DMA_AUX " sc0 sc1"
+#else
+#define MI_DMA_AUX ""
+#endif
 // The 16-byte form: LDS[lds_base + lane * 16 .. + 15] = buffer[voff + soff .. + 15].  The LDS side needs no more than
 // dword alignment (LDS-DMA writes are not subject to the alignment replay of ds_write_b128).
 __device__ __forceinline__ void dma_dwordx4(srd_t srd, unsigned lds_base, unsigned voff, unsigned soff) {
   lds_base = (unsigned)uniform((int)lds_base);
   soff = (unsigned)uniform((int)soff);
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" MI_DMA_AUX " lds"
                :
                : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff)
                : "memory");
