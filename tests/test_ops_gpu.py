@@ -2079,3 +2079,15 @@ def test_roi_align_records_free_forward_partial_wait(tuning_env):
         tuning_env(MI_ROI_ALIGN_SLAB="1", MI_ROI_ALIGN_FWD_FULL_WAIT="1")
         b = _forward_ws_raw(f, rois, res, scale, 2, None)
         assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+@pytest.mark.gpu
+def test_roi_align_records_free_forward_many_rois(oracle_mod, tuning_env):
+    """The records keep one sweep key per RoI in LDS (8192 at most); the records-free forward has no such bound: 20 000 RoIs
+    in one call (grid x = 160 000 one-wave workgroups), checked against the oracle."""
+    n, c, h, w, scale, r = 2, 16, 50, 84, 1.0 / 16, 20000
+    feat = syn.feature_map(n, c, h, w, seed=21)
+    rois = syn.rois_canonical(r, n, seed=22, side=(2.0 / scale, 30.0 / scale), im_h=h / scale, im_w=w / scale)
+    tuning_env(MI_ROI_ALIGN_SLAB="1")
+    got = _forward_ws_raw(to_dev(feat), to_dev(rois), 7, scale, 2, None)
+    assert_fwd(got, oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2, threads=8), "20000 RoIs", exact=False)
