@@ -179,9 +179,9 @@ struct CollectedRois {
 
 template <class Src>
 __global__ void __launch_bounds__(256)
-roi_align_prepare(const Src src, int num_rois, int batch, const LevelTable lv, int aligned_height, int aligned_width,
-                  int sampling_ratio, int cap_px, int stage_px, int max_rows_tile, int bwd_tables, int channels,
-                  int* __restrict__ ws, int ablate_arg, int cost_in_band) {
+roi_align_prepare(int* __restrict__ ws, int num_rois, int batch, int aligned_height, int aligned_width, int sampling_ratio,
+                  int cap_px, int stage_px, int max_rows_tile, int bwd_tables, int channels, int ablate_arg, int cost_in_band,
+                  const Src src, const LevelTable lv) {  // scalars first: they arrive preloaded in SGPRs (build.py)
   const int ablate = MI_ABLATE(ablate_arg);  // tuning builds: 32 = no sweep keys / rank, 64 = no tables, 128 = no stage loop
   extern __shared__ unsigned keys[];  // [num_rois]
   const int lane = threadIdx.x & 63;
@@ -717,9 +717,9 @@ __device__ __forceinline__ void fwd_direct_item(const FwdRec& h, const LevelTabl
 // kA > 0: aligned_height == aligned_width == kA at compile time (7: box head, 14: mask / keypoint heads).
 template <int kSR, int kCap, int kA = 0>
 __global__ void __launch_bounds__(kCT * 8)
-roi_align_fwd_records(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
-                      const int* __restrict__ ws, int num_rois, int batch, int channels, int aligned_height_arg,
-                      int aligned_width_arg, int sampling_ratio, int split, int ablate_arg, int full_wait MI_TL_PARAM) {
+roi_align_fwd_records(const float* __restrict__ rois, float* __restrict__ out, const int* __restrict__ ws, int num_rois,
+                      int batch, int channels, int aligned_height_arg, int aligned_width_arg, int sampling_ratio, int split,
+                      int ablate_arg, int full_wait, const LevelTable lv MI_TL_PARAM) {
   MI_STAMP(0);
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   const int ablate = MI_ABLATE(ablate_arg);
@@ -1161,9 +1161,9 @@ __device__ __noinline__ void bwd_slow_in_tile(const float* __restrict__ top_grad
 // (Until round 5 a launch of its own behind the tile kernel -- roi_align_bwd_slow, 4.7 us + a launch boundary per call,
 // nearly always to find nothing -- did this and reset the counters.)
 __global__ void __launch_bounds__(kPlanThreads)
-roi_align_bwd_plan(const LevelTable lv, int* __restrict__ ws, int num_rois, int batch, int channels, int th, int plan_tiles,
-                   int plan_cap, int slice_len, int overwrite, const float* __restrict__ top_grad,
-                   const float* __restrict__ rois, int aligned_height, int aligned_width, int sampling_ratio) {
+roi_align_bwd_plan(int* __restrict__ ws, const float* __restrict__ top_grad, const float* __restrict__ rois, int num_rois,
+                   int batch, int channels, int th, int plan_tiles, int plan_cap, int slice_len, int overwrite,
+                   int aligned_height, int aligned_width, int sampling_ratio, const LevelTable lv) {
   __shared__ int wave_hits[2 * kPlanWaves];
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   // role 0 plans the tile, roles 1.. zero a share of a sliced tile; a tile's roles are neighbours in the grid (planners
@@ -1341,9 +1341,9 @@ roi_align_bwd_untabled(const float* __restrict__ top_grad, const float* __restri
 template <int kNHWC, int KC, int kTH, int kA = 0>
 __global__ void __launch_bounds__(kTH * 32)
     __attribute__((amdgpu_waves_per_eu(kTH == 16 && KC == 32 ? 6 : 1, kTH == 16 && KC == 32 ? 6 : 8)))
-roi_align_bwd_tiles(const float* __restrict__ top_grad, const LevelTable lv, int* __restrict__ ws,
-                    int num_rois, int batch, int channels, int aligned_height_arg, int aligned_width_arg, int overwrite,
-                    int ablate_arg, int plan_tiles, int plan_cap MI_TL_PARAM) {
+roi_align_bwd_tiles(const float* __restrict__ top_grad, int* __restrict__ ws, int num_rois, int batch, int channels,
+                    int aligned_height_arg, int aligned_width_arg, int overwrite, int ablate_arg, int plan_tiles, int plan_cap,
+                    const LevelTable lv MI_TL_PARAM) {
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   // the block of top gradients of one RoI and KC channels, as it lies in memory: [c][ph][pw], KC * bins floats
   const int g_words = (KC * aligned_height * aligned_width + 3) & ~3;
@@ -1664,8 +1664,8 @@ int launch_prepare_from(const Src& src, int* ws, int batch, const LevelTable& lv
                         bool cost_in_band = false) {
   const int max_rows_tile = kTileBins / aligned_width;
   roi_align_prepare<Src><<<(num_rois + 3) / 4, 256, (size_t)num_rois * sizeof(unsigned), stream>>>(
-      src, num_rois, batch, lv, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile,
-      bwd_tables ? 1 : 0, channels, ws, tuning().ablate, cost_in_band ? 1 : 0);
+      ws, num_rois, batch, aligned_height, aligned_width, sampling_ratio, cap_px, cap_px, max_rows_tile, bwd_tables ? 1 : 0,
+      channels, tuning().ablate, cost_in_band ? 1 : 0, src, lv);
   return check_launch("roi_align_prepare");
 }
 int launch_prepare(const float* rois, const int* levels, int* ws, int batch, const LevelTable& lv, int num_rois,
@@ -1705,8 +1705,8 @@ int launch_cap(const LevelTable& lv, const float* rois, const int* levels, float
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_records<SR, kCap, A>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
     roi_align_fwd_records<SR, kCap, A><<<items, kThreads, lds, stream>>>(                                             \
-        lv, rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, split,        \
-        tuning().ablate, tuning().fwd_full_wait MI_TL_ARG);                                                           \
+        rois, output, ws, num_rois, batch, channels, aligned_height, aligned_width, sampling_ratio, split,            \
+        tuning().ablate, tuning().fwd_full_wait, lv MI_TL_ARG);                                                       \
   } while (0)
   const int a = aligned_height == aligned_width ? aligned_height : 0;
   if (sampling_ratio == 2 && kCap == 336 && a == 7)
@@ -1783,8 +1783,8 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
     // files every tile's list AND adds the RoIs without backward tables (rare, but only the device knows whether there are
     // any): the trailing roi_align_bwd_slow launch of rounds 1-5 is gone from this, the default, path
     roi_align_bwd_plan<<<tiles * (overwrite ? 1 + kZeroParts : 1), kPlanThreads, 0, stream>>>(
-        lv, ws, num_rois, batch, channels, th, tiles, plan_cap, slice_min, (overwrite ? 1 : 0) | (nhwc ? 2 : 0), top_grad, rois,
-        aligned_height, aligned_width, sampling_ratio);
+        ws, top_grad, rois, num_rois, batch, channels, th, tiles, plan_cap, slice_min, (overwrite ? 1 : 0) | (nhwc ? 2 : 0),
+        aligned_height, aligned_width, sampling_ratio, lv);
     int rc = check_launch("roi_align_bwd_plan");
     if (rc != MI_OK) return rc;
     grid = (tiles + bwd_plan_extra(num_rois)) * (channels / kc);  // upper bound of the entries: every tile once + the budget of extra slices
@@ -1795,8 +1795,8 @@ int launch_roi_align_bwd_records_levels(const float* top_grad, const float* rois
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_bwd_tiles<SR, KC, TH, A>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
     roi_align_bwd_tiles<SR, KC, TH, A><<<grid, TH * 32, lds, stream>>>(                                              \
-        top_grad, lv, ws, num_rois, batch, channels, aligned_height, aligned_width,                                   \
-        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, planned ? tiles : 0, plan_cap MI_TL_ARG);              \
+        top_grad, ws, num_rois, batch, channels, aligned_height, aligned_width,                                       \
+        (overwrite ? 1 : 0) | (nhwc ? 2 : 0), g_ablate_p & 7, planned ? tiles : 0, plan_cap, lv MI_TL_ARG);          \
   } while (0)
 #define MI_LAUNCH_TILES_TH(SR, KC, TH)                                                                                \
   do {                                                                                                                \
