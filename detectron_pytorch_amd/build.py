@@ -26,7 +26,8 @@ ARCH = "gfx950"
 # Per-unit flags.  roi_align_records.hip: the leading scalar / pointer kernel arguments arrive preloaded in SGPRs (gfx950
 # kernarg preload) -- the records-free RoIAlign forward starts with a chain of dependent fetches (arguments -> the RoI's five
 # floats -> geometry -> window), and this takes the first link out of it.
-UNIT_FLAGS = {"roi_align_records.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
+UNIT_FLAGS = {"roi_align_records.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
+              "roi_align_nhwc.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
 
 
 def hipcc():

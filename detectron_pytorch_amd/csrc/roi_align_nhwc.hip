@@ -74,9 +74,9 @@ __device__ __forceinline__ void load_tap<1>(__amdgpu_buffer_rsrc_t img, unsigned
 template <int kSR, int PW, int V, int PB>
 __global__ void __launch_bounds__(PW <= 7 ? 448 : 1024)
     __attribute__((amdgpu_waves_per_eu(PW <= 7 && PB <= 4 ? 4 : 1, PW <= 7 && PB <= 4 ? 4 : 8)))
-roi_align_fwd_nhwc(const LevelTable lv, const float* __restrict__ rois, float* __restrict__ out,
-                   const int* __restrict__ ws, int batch, int channels, int aligned_height, int sampling_ratio,
-                   int chunks, int tile_stride, int order_mul, int zigzag,
+roi_align_fwd_nhwc(const float* __restrict__ rois, float* __restrict__ out, const int* __restrict__ ws, int batch,
+                   int channels, int aligned_height, int sampling_ratio, int chunks, int tile_stride, int order_mul,
+                   int zigzag, const LevelTable lv,  // scalars first: they arrive preloaded in SGPRs (build.py)
                    long long* __restrict__ timeline) {
   extern __shared__ float tile[];  // [V][64][tile_stride]
   // tuning builds only (tools/timeline_nhwc.py): clock stamps of wave 0 of every workgroup; the release kernel has none
@@ -356,8 +356,8 @@ int launch_roi_align_fwd_nhwc_levels(const LevelTable& lv, const float* rois, fl
   const bool split = tuning().nhwc_pb != 7;
 #define MI_LAUNCH_NHWC(SR, PW, V, PB)                                                                                 \
   roi_align_fwd_nhwc<SR, PW, V, PB><<<grid, 64 * nwaves, lds, stream>>>(                                              \
-      lv, rois, output, ws, batch, channels, aligned_height, sampling_ratio, chunks, stride, tuning().nhwc_order_mul,  \
-      tuning().nhwc_zigzag, g_nhwc_timeline)
+      rois, output, ws, batch, channels, aligned_height, sampling_ratio, chunks, stride, tuning().nhwc_order_mul,      \
+      tuning().nhwc_zigzag, lv, g_nhwc_timeline)
 #define MI_LAUNCH_NHWC_V(PW, V)                                                                                       \
   do {                                                                                                                \
     if (sr2 && split)                                                                                                 \
