@@ -168,13 +168,31 @@ __device__ __forceinline__ void legacy_build_table(LegacyTab* tab, const float* 
   tab->w_ratio[lane] = w - (float)wstart;
 }
 
+// The forward's workgroup = (RoI, 8 channels) on a grid (8 R, ceil(C / 64)): an XCD samples ONE 8-channel slab of the map at a
+// time (it fits its L2 whatever the order of the RoIs: roi_align_records.hip, roi_align_fwd_slab); the backward keeps
+// (RoI, 32 channels).  Config-2 shape: 29.6 -> 21.1 us (8 channels x 64 lanes; x 128: 22.4, x 256: 25.9;
+// tools/build_defines.sh MI_LEG_CT / MI_LEG_THREADS).
+#ifndef MI_LEG_CT
+#define MI_LEG_CT 8
+#endif
+#ifndef MI_LEG_THREADS
+#define MI_LEG_THREADS 64
+#endif
+constexpr int kLegFwdCT = MI_LEG_CT, kLegFwdThreads = MI_LEG_THREADS;
 template <bool kBackward>
-__global__ void __launch_bounds__(kDirThreads)
+__global__ void __launch_bounds__(kBackward ? kDirThreads : kLegFwdThreads)
 roi_align_legacy(const float* __restrict__ in, const float* __restrict__ rois, float* __restrict__ outp, int batch,
                  int channels, int height, int width, int aligned_height, int aligned_width, float spatial_scale) {
   __shared__ LegacyTab tab;
+  constexpr int kThreadsHere = kBackward ? kDirThreads : kLegFwdThreads;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const DirItem it = dir_item(channels, aligned_height, aligned_width);
+  DirItem it = dir_item(channels, aligned_height, aligned_width);
+  if (!kBackward && kLegFwdCT < 32) {
+    it.n = (int)(blockIdx.x >> 3);
+    it.c0 = (int)(blockIdx.y * 8 + (blockIdx.x & 7)) * kLegFwdCT;
+    if (it.c0 >= channels) return;
+    it.cvalid = min(kLegFwdCT, channels - it.c0);
+  }
   const float* __restrict__ roi = rois + (long long)it.n * 5;
   const long long limit = (long long)batch * channels * height * width;
   // :50 `int img_start = roi_batch_ind * channels * height * width` is a float product
@@ -188,7 +206,7 @@ roi_align_legacy(const float* __restrict__ in, const float* __restrict__ rois, f
     if (wave == 0) legacy_build_table(&tab, roi, p0, np, lane, spatial_scale, height, width, aligned_height, aligned_width);
     __syncthreads();
     const unsigned np_magic = (1u << 20) / (unsigned)np + 1u;
-    for (int i = tid; i < it.cvalid * np; i += kDirThreads) {
+    for (int i = tid; i < it.cvalid * np; i += kThreadsHere) {
       const int c = (int)(((unsigned)i * np_magic) >> 20), p = i - c * np;  // i / np, exact for i < 32 * 64
       const long long bin = tile_bins + (long long)c * it.bins + p0 + p;
       const int off = tab.off[p];
@@ -265,7 +283,9 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
   const long long dir_grid = (long long)num_rois * mi::ceil_div(channels, kDirCT);
   MI_REQUIRE(dir_grid < (1LL << 31) && (long long)kDirCT * aligned_height * aligned_width < (1LL << 31), "roi_align: too many (RoI, channel tile) items");
   if (variant == MI_ROI_ALIGN_LEGACY) {
-    roi_align_legacy<false><<<(int)dir_grid, kDirThreads, 0, s>>>(features, rois, output, batch, channels, height, width,
+    const dim3 lgrid = kLegFwdCT < 32 ? dim3((unsigned)num_rois * 8u, (unsigned)((mi::ceil_div(channels, kLegFwdCT) + 7) / 8))
+                                      : dim3((unsigned)dir_grid);
+    roi_align_legacy<false><<<lgrid, kLegFwdThreads, 0, s>>>(features, rois, output, batch, channels, height, width,
                                                                   aligned_height, aligned_width, spatial_scale);
     return mi::check_launch("roi_align_legacy<fwd>");
   }

@@ -32,6 +32,17 @@ using namespace mi;
 constexpr int kCropCT = 32;        // channels per workgroup
 constexpr int kCropThreads = 256;
 constexpr int kCropPts = 64;       // grid points per group: one per lane of the wave that builds the table
+// The forward's workgroup = (RoI, 8 channels) of 128 lanes on a grid (8 R, ceil(C / 64)): an XCD samples ONE 8-channel slab of
+// the map at a time (it fits its L2; roi_pool.hip, roi_align_records.hip: roi_align_fwd_slab).  Config-2 shape incl. the zero
+// fill: 37.3 -> 31.4 us (8 x 64 lanes 32.2, 8 x 256 35.8, 16 x 256 33.5; tools/build_defines.sh MI_CROP_CT / MI_CROP_THREADS).
+#ifndef MI_CROP_CT
+#define MI_CROP_CT 8
+#endif
+#ifndef MI_CROP_THREADS
+#define MI_CROP_THREADS 128
+#endif
+constexpr int kCropFwdCT = MI_CROP_CT, kCropFwdThreads = MI_CROP_THREADS;  // the forward's workgroup
+constexpr bool kCropSlab = MI_CROP_CT < 32;  // grid (8 R, phases): XCD x samples channel tile 8 * phase + x (see roi_pool.hip)
 
 // roi_crop_cuda_kernel.cu:17-23
 __device__ __forceinline__ void get_top_left(float x, int width, int& point, float& weight) {
@@ -88,17 +99,19 @@ __device__ __forceinline__ void crop_build_table(PointTab* tab, const float* __r
   }
 }
 
-__global__ void __launch_bounds__(kCropThreads)
+__global__ void __launch_bounds__(kCropFwdThreads)
 roi_crop_fwd(const float* __restrict__ input, const float* __restrict__ grids, float* __restrict__ output, int batch,
              int channels, int height, int width, int gh, int gw, int roiPerImage) {
   __shared__ PointTab tab;
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-  const int tiles = (channels + kCropCT - 1) / kCropCT;
-  const int r = blockIdx.x / tiles, c0 = (blockIdx.x - r * tiles) * kCropCT;
+  const int tiles = (channels + kCropFwdCT - 1) / kCropFwdCT;
+  const int r = kCropSlab ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x / tiles);
+  const int c0 = kCropSlab ? (int)(blockIdx.y * 8 + (blockIdx.x & 7)) * kCropFwdCT : (int)(blockIdx.x - r * tiles) * kCropFwdCT;
+  if (c0 >= channels) return;
   const int points = gh * gw;
   const int b_input = r / roiPerImage;  // :64
   const bool image_ok = b_input < batch;  // (the reference would read past its input)
-  const int cvalid = min(kCropCT, channels - c0);
+  const int cvalid = min(kCropFwdCT, channels - c0);
   const long long plane_px = (long long)height * width;
   const float* __restrict__ src = input + ((long long)(image_ok ? b_input : 0) * channels + c0) * plane_px;
   float* __restrict__ dst = output + ((long long)r * channels + c0) * points;
@@ -111,7 +124,7 @@ roi_crop_fwd(const float* __restrict__ input, const float* __restrict__ grids, f
     // lanes over (channel, point), the point fastest: neighbouring lanes tap neighbouring pixels of one plane and write
     // neighbouring outputs
     const unsigned np_magic = (1u << 20) / (unsigned)np + 1u;
-    for (int i = tid; i < cvalid * np; i += kCropThreads) {
+    for (int i = tid; i < cvalid * np; i += kCropFwdThreads) {
       const int c = (int)(((unsigned)i * np_magic) >> 20), p = i - c * np;  // i / np, exact for i < 32 * 64
       const int in = tab.in[p];
       if (in == 0) continue;  // :92-93: not written
@@ -456,8 +469,9 @@ extern "C" int mi_roi_crop_forward(const float* input, const float* grid_yx, flo
   if (rc != MI_OK) return rc;
   const long long total = (long long)num_rois * channels * grid_height * grid_width;
   if (total == 0) return MI_OK;
-  const int tiles = (channels + kCropCT - 1) / kCropCT;
-  roi_crop_fwd<<<num_rois * tiles, kCropThreads, 0, mi::as_stream(stream)>>>(
+  const int tiles = (channels + kCropFwdCT - 1) / kCropFwdCT;
+  const dim3 grid = kCropSlab ? dim3((unsigned)num_rois * 8u, (unsigned)((tiles + 7) / 8)) : dim3((unsigned)(num_rois * tiles));
+  roi_crop_fwd<<<grid, kCropFwdThreads, 0, mi::as_stream(stream)>>>(
       input, grid_yx, output, batch, channels, height, width, grid_height, grid_width, num_rois / batch);
   return mi::check_launch("roi_crop_fwd");
 }

@@ -48,8 +48,21 @@ __device__ __forceinline__ PoolRoi pool_roi(const float* __restrict__ roi, float
   return r;
 }
 
-constexpr int kPoolCT = 32;        // channels per workgroup
-constexpr int kPoolThreads = 256;
+// Workgroup = (RoI, 8 channels), grid (8 R, ceil(C / 64)): workgroups go round-robin over the XCDs, so XCD x pools channel tile
+// 8 * phase + x for every RoI in arrival order -- ONE 8-channel slab of the map at a time (2.15 MB at 200x336: it fits the 4 MB
+// L2, every line comes from the fabric once whatever the order of the RoIs; the records-free RoIAlign forward's mapping,
+// roi_align_records.hip).  With 32-channel tiles an XCD's slab was 8.6 MB and the RoIs' arrival order thrashed it: config-2 shape
+// 76.9 -> 66.9 us, stride-16 map with image-sized RoIs 91.2 -> 79.0 (tools/build_defines.sh MI_POOL_CT / MI_POOL_THREADS:
+// 8 x 64 lanes 73.4, 8 x 128 68.9, 8 x 448 76.7, 16 x 256 69.4, 4 x 256 70.9; profiles/r06_pool_crop.txt).
+#ifndef MI_POOL_CT
+#define MI_POOL_CT 8
+#endif
+#ifndef MI_POOL_THREADS
+#define MI_POOL_THREADS 256
+#endif
+constexpr int kPoolCT = MI_POOL_CT;        // channels per workgroup
+constexpr int kPoolThreads = MI_POOL_THREADS;
+constexpr bool kPoolSlab = MI_POOL_CT < 32;  // 32: rounds 1-6's mapping (RoI-major, tile = blockIdx % tiles)  // workgroups go round-robin over the XCDs: XCD x works on tile 8 * phase + x
 #ifndef MI_POOL_GATHER_ROWS
 #define MI_POOL_GATHER_ROWS 4
 #endif
@@ -72,7 +85,9 @@ roi_pool_fwd(const float* __restrict__ bottom_data, const float* __restrict__ ro
   int* wb = tabs + 2 * pooled_height;
   const int tid = threadIdx.x;
   const int tiles = (channels + kPoolCT - 1) / kPoolCT;
-  const int r = blockIdx.x / tiles, c0 = (blockIdx.x - r * tiles) * kPoolCT;
+  const int r = kPoolSlab ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x / tiles);
+  const int c0 = kPoolSlab ? (int)(blockIdx.y * 8 + (blockIdx.x & 7)) * kPoolCT : (int)(blockIdx.x - r * tiles) * kPoolCT;
+  if (c0 >= channels) return;
   const int bins = pooled_height * pooled_width;
   const const_float_ptr roi = (const_float_ptr)(uintptr_t)(rois + (long long)r * 5);
   const int batch_ind = (int)roi[0];
@@ -569,7 +584,8 @@ extern "C" int mi_roi_pool_forward(const float* features, const float* rois, flo
   if (total == 0) return MI_OK;
   MI_REQUIRE(pooled_height + pooled_width <= 4096, "roi_pool: pooled size %d x %d beyond the bin table", pooled_height, pooled_width);
   const int tiles = (channels + kPoolCT - 1) / kPoolCT;
-  roi_pool_fwd<<<num_rois * tiles, kPoolThreads, (size_t)2 * (pooled_height + pooled_width) * 4, mi::as_stream(stream)>>>(
+  const dim3 grid = kPoolSlab ? dim3((unsigned)num_rois * 8u, (unsigned)((tiles + 7) / 8)) : dim3((unsigned)(num_rois * tiles));
+  roi_pool_fwd<<<grid, kPoolThreads, (size_t)2 * (pooled_height + pooled_width) * 4, mi::as_stream(stream)>>>(
       features, rois, output, argmax, batch, channels, height, width, pooled_height, pooled_width, spatial_scale);
   return mi::check_launch("roi_pool_fwd");
 }
