@@ -55,11 +55,20 @@ __device__ __forceinline__ DirItem dir_item(int channels, int aligned_height, in
   return it;
 }
 
+// kSlabCT > 0 (planar storage): workgroup = (RoI, kSlabCT channels) on a grid (8 R, phases) -- an XCD reads one narrow channel slab
+// of the map at a time, which fits its L2 whatever the order of the RoIs (roi_align_fwd_slab's mapping); 0: (RoI, 32 channels)
+template <int kSlabCT>
 __global__ void __launch_bounds__(kDirThreads)
 roi_align_fwd_direct(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out, int batch,
                      int channels, int height, int width, int aligned_height, int aligned_width, float spatial_scale,
                      int sampling_ratio, FeatStrides st) {
-  const DirItem it = dir_item(channels, aligned_height, aligned_width);
+  DirItem it = dir_item(channels, aligned_height, aligned_width);
+  if (kSlabCT > 0) {
+    it.n = (int)(blockIdx.x >> 3);
+    it.c0 = (int)(blockIdx.y * 8 + (blockIdx.x & 7)) * kSlabCT;
+    if (it.c0 >= channels) return;
+    it.cvalid = min(kSlabCT, channels - it.c0);
+  }
   const RoiGeom g = roi_geometry(rois + (long long)it.n * 5, spatial_scale, aligned_height, aligned_width, sampling_ratio);
   float* __restrict__ dst = out + ((long long)it.n * channels + it.c0) * it.bins;
   const bool image_ok = g.batch_ind >= 0 && g.batch_ind < batch;  // the reference would read out of bounds
@@ -328,8 +337,15 @@ int roi_align_forward_impl(const float* features, const float* rois, float* outp
                                          nullptr, output, batch, channels, num_rois, aligned_height, aligned_width,
                                          sampling_ratio, s);
   FeatStrides st = make_strides(layout, channels, height, width);
-  roi_align_fwd_direct<<<(int)dir_grid, kDirThreads, 0, s>>>(features, rois, output, batch, channels, height, width,
+  if (layout == MI_LAYOUT_NCHW) {
+    constexpr int kCT = 8;
+    const dim3 sgrid((unsigned)num_rois * 8u, (unsigned)((mi::ceil_div(channels, kCT) + 7) / 8));
+    roi_align_fwd_direct<kCT><<<sgrid, kDirThreads, 0, s>>>(features, rois, output, batch, channels, height, width,
                                                             aligned_height, aligned_width, spatial_scale, sampling_ratio, st);
+  } else {
+    roi_align_fwd_direct<0><<<(int)dir_grid, kDirThreads, 0, s>>>(features, rois, output, batch, channels, height, width,
+                                                                  aligned_height, aligned_width, spatial_scale, sampling_ratio, st);
+  }
   return mi::check_launch("roi_align_fwd_direct");
 }
 }  // namespace
