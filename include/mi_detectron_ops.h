@@ -92,12 +92,16 @@ int mi_roi_align_forward(const float* features, const float* rois, float* output
                          int aligned_height, int aligned_width, float spatial_scale,
                          int sampling_ratio, int variant, int layout, mi_stream_t stream);
 
-/* Same operation with caller-provided device scratch (the fast paths: roi_align_fwd_records on NCHW features,
- * roi_align_fwd_nhwc on channels-last ones): a first launch condenses each RoI into a record in `workspace` (window,
- * tap tables, LDS stages) at its rank along a sweep of the image, a second launch consumes the records.
- * `workspace` must hold mi_roi_align_forward_workspace_bytes(num_rois) bytes, 16-byte aligned; its contents are
- * scratch (no initialisation needed, overwritten by every call; two calls that may run concurrently on different
- * streams need distinct workspaces).  workspace == NULL behaves exactly like mi_roi_align_forward. */
+/* Same operation with caller-provided device scratch.  What the call does with it depends on its SIZE:
+ *   >= mi_roi_align_backward_workspace_bytes(...)  "a backward over these RoIs follows": a first launch condenses each RoI
+ *        into a record in `workspace` (window, tap tables, LDS stages, the backward's merged weights) at its rank along a sweep
+ *        of the image, a second launch consumes the records (roi_align_fwd_records on NCHW features, roi_align_fwd_nhwc on
+ *        channels-last ones), and mi_roi_align_backward_ws may reuse them (MI_ROI_ALIGN_RECORDS_READY);
+ *   >= mi_roi_align_forward_workspace_bytes(num_rois) only  NCHW: ONE launch, nothing written (roi_align_fwd_slab: one wave
+ *        per (RoI, 8 channels), an XCD reads one 8-channel slab at a time; ABI 8); channels-last: records + roi_align_fwd_nhwc.
+ * 16-byte aligned; contents are scratch (no initialisation needed, overwritten by every call; two calls that may run
+ * concurrently on different streams need distinct workspaces).  workspace == NULL behaves exactly like mi_roi_align_forward
+ * (NCHW: the same one-launch kernel). */
 size_t mi_roi_align_forward_workspace_bytes(int num_rois);
 int mi_roi_align_forward_ws(const float* features, const float* rois, float* output,
                             int batch, int channels, int height, int width, int num_rois,
