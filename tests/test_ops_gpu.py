@@ -1993,7 +1993,10 @@ def _forward_ws_raw(feat_t, rois_t, res, scale, sr, ws):
                                                 ((1, 72, 50, 84), 7, 2, 80),       # 9 tiles: a second, partial phase
                                                 ((3, 40, 13, 21), 7, 0, 50),       # adaptive sampling grid, tiny map
                                                 ((1, 24, 30, 40), 6, 3, 40),       # generic instance, sampling ratio 3
-                                                ((1, 16, 9, 70), 3, 1, 33)])
+                                                ((1, 16, 9, 70), 3, 1, 33),
+                                                ((1, 32, 50, 84), 16, 2, 40),      # 32 samples per axis: the tables' limit
+                                                ((1, 16, 50, 84), 21, 2, 24),      # beyond it: every RoI on the in-kernel direct path
+                                                ((2, 32, 25, 42), 10, 0, 48)])
 def test_roi_align_records_free_forward_equals_the_record_driven_one(oracle_mod, tuning_env, shape, res, sr, nrois):
     """A forward whose workspace has no room for a backward runs roi_align_fwd_slab: one launch that computes every RoI's
     geometry, tables and stages itself.  Same tables, same bins as the record-driven kernel -> the same bits wherever
