@@ -2094,3 +2094,40 @@ def test_roi_align_records_free_forward_many_rois(oracle_mod, tuning_env):
     tuning_env(MI_ROI_ALIGN_SLAB="1")
     got = _forward_ws_raw(to_dev(feat), to_dev(rois), 7, scale, 2, None)
     assert_fwd(got, oracle_mod.roi_align_forward(feat, rois, 7, 7, scale, 2, threads=8), "20000 RoIs", exact=False)
+
+
+@pytest.mark.gpu
+def test_roi_align_records_free_forward_random_shapes(oracle_mod, tuning_env):
+    """Forty seeded random cases through the one-launch forward: maps from 2x2 to 60x90, 8 to 80 channels (any multiple of 8),
+    1 to 3 images, pooled sizes 1 to 12 (square and not), sampling ratio 0 to 3, RoIs from sub-pixel to beyond the image --
+    every one against the oracle at the fast paths' bar."""
+    tuning_env(MI_ROI_ALIGN_SLAB="1")
+    rng = np.random.RandomState(1234)
+    from detectron_pytorch_amd import _lib
+
+    lib = _lib.lib()
+    for case in range(40):
+        n, c = int(rng.randint(1, 4)), 8 * int(rng.randint(1, 11))
+        h, w = int(rng.randint(2, 61)), int(rng.randint(2, 91))
+        ph, pw = int(rng.randint(1, 13)), int(rng.randint(1, 13))
+        if rng.rand() < 0.5:
+            pw = ph
+        sr, r = int(rng.randint(0, 4)), int(rng.randint(1, 60))
+        scale = float(rng.choice([1.0, 0.5, 0.25, 1.0 / 16]))
+        feat = syn.feature_map(n, c, h, w, seed=case)
+        x1 = rng.uniform(-4, w + 2, r) / scale
+        y1 = rng.uniform(-4, h + 2, r) / scale
+        bw = rng.choice([0.3, 2.0, 9.0, 40.0], r) * rng.uniform(0.5, 1.5, r) / scale
+        bh = rng.choice([0.3, 2.0, 9.0, 40.0], r) * rng.uniform(0.5, 1.5, r) / scale
+        rois = np.stack([rng.randint(0, n, r).astype(np.float64), x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+        bad = rois[:2].copy()               # RoIs of no image pool zeros (the reference would read out of bounds)
+        bad[:, 0] = (-1, n)[: len(bad)]
+        f, rt = to_dev(feat), to_dev(np.vstack([rois, bad]))
+        r_all = r + len(bad)
+        out = torch.full((r_all, c, ph, pw), float("nan"), device=dev())
+        rc = lib.mi_roi_align_forward(f.data_ptr(), rt.data_ptr(), out.data_ptr(), n, c, h, w, r_all, ph, pw, scale, sr, 0, 0,
+                                      _lib.current_stream_handle(dev()))
+        assert rc == 0, lib.mi_last_error()
+        assert not out[r:].any(), "case %d: RoIs of no image must pool zeros" % case
+        ref = oracle_mod.roi_align_forward(feat, rois, ph, pw, scale, sr, threads=8)
+        assert_fwd(out[:r], ref, "case %d: n %d c %d %dx%d pooled %dx%d sr %d r %d" % (case, n, c, h, w, ph, pw, sr, r), exact=False)
