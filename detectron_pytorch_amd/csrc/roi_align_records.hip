@@ -846,16 +846,15 @@ constexpr int kSlabCT = 8;
   do {                                                                                                                \
   } while (0)
 #endif
-// LDS of a wave: axis tables | output tile | image.  The LDS is handed out in granules of 1280 bytes (tools/micro/
-// launch_rate.hip: residency of one-wave workgroups steps at 6400 / 7680 / 8960 / 10240 / 11520 bytes), and 8 granules is what
-// lets a CU hold 18 waves instead of 14 -- the tables and the tile are therefore sized for the instance (14 samples per axis and
-// 49 bins at 7x7, sampling ratio 2) and the image takes what is left of 10240 bytes.
+// LDS of a wave: axis tables | image (no output tile: a lane's bins go straight to memory, see the kernel).  The LDS is handed
+// out in granules of 1280 bytes (tools/micro/launch_rate.hip: residency of one-wave workgroups steps at 6400 / 7680 / 8960 /
+// 10240 / 11520 bytes), and 8 granules is what lets a CU hold 18 waves instead of 14 -- the tables are sized for the instance
+// (14 samples per axis at 7x7, sampling ratio 2) and the image takes what is left of 10240 bytes.
 template <int kSR, int kA>
 struct SlabLds {
   static constexpr int kNS = (kSR > 0 && kA > 0) ? kSR * kA : kMaxS;                          // table entries per axis
-  static constexpr int kTile = kSlabCT * ((kA > 0 ? (kTileBins / kA < kA ? kTileBins / kA : kA) * kA : kTileBins) | 1);  // words
   // the largest image capacity = 4 (mod 32) pixels that keeps the wave inside 8 granules
-  static constexpr int kCapMax = (((10240 - 2 * kNS * 16 - kTile * 4) / (kSlabCT * 4) - 4) & ~31) + 4;
+  static constexpr int kCapMax = (((10240 - 2 * kNS * 16) / (kSlabCT * 4) - 4) & ~31) + 4;
 };
 // Plane stride = 4 (mod 32) dwords with lanes of a 32-lane LDS group = 8 channels x 4 output columns: the eight planes start
 // on banks 0, 4, .., 28, and two lanes of a tap read meet in a bank only when two of the group's four columns are congruent
@@ -865,7 +864,7 @@ template <int kCap>
 constexpr int slab_plane() { return kCap % 32 == 4 ? kCap : (kCap | 1); }
 template <int kSR, int kCap, int kA>
 constexpr size_t slab_lds_bytes() {
-  return 2 * SlabLds<kSR, kA>::kNS * sizeof(TabEntry) + (size_t)(SlabLds<kSR, kA>::kTile + kSlabCT * slab_plane<kCap>()) * 4;
+  return 2 * SlabLds<kSR, kA>::kNS * sizeof(TabEntry) + (size_t)(kSlabCT * slab_plane<kCap>()) * 4;
 }
 // kLevels: the RoIs carry a level index (pyramid calls); otherwise level 0 and its kernel arguments, no indexed fetch
 template <int kSR, int kCap, int kA, bool kLevels>
@@ -874,15 +873,14 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
                    int batch, int channels, int aligned_height_arg, int aligned_width_arg, int sampling_ratio, int full_wait,
                    const LevelTable lv MI_TL_PARAM) {
   MI_SLAB_STAMP(0);
-  // tuning builds only (MI_ROI_ALIGN_FWD_FULL_WAIT bits): 2 = no stores, 4 = no bins, 8 = plain stores, 16 = conflict-free taps
+  // tuning builds only (MI_ROI_ALIGN_FWD_FULL_WAIT bits): 4 = no bins (and no stores), 16 = conflict-free taps
   const int ablate = MI_ABLATE(full_wait);
   const int aligned_height = kA > 0 ? kA : aligned_height_arg, aligned_width = kA > 0 ? kA : aligned_width_arg;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kPlane = slab_plane<kCap>();
   constexpr int kNS = SlabLds<kSR, kA>::kNS;
   TabEntry* tab = reinterpret_cast<TabEntry*>(smem);
-  float* tile = reinterpret_cast<float*>(tab + 2 * kNS);
-  float* img = tile + SlabLds<kSR, kA>::kTile;
+  float* img = reinterpret_cast<float*>(tab + 2 * kNS);
   const int lane = threadIdx.x;
   const int bins = aligned_height * aligned_width;
   const int c0 = (blockIdx.y * 8 + (blockIdx.x & 7)) * kSlabCT;
@@ -941,7 +939,7 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
   // The stages are cut from the lower taps of the LAST sample of every bin row (lanes `is_last`): "the bin rows from ph0 on
   // whose window still fits" is a prefix of them -- one ballot.
   const bool is_last = lane < nsy && lane - ph_of * gh == gh - 1;
-  const int max_rows_tile = kTileBins / aligned_width;
+  const int max_rows_tile = aligned_height;  // no output tile: a stage takes as many bin rows as its window fits the image
   auto cut = [&](int ph0, int& e, int& row0, int& nrows) {
     row0 = __builtin_amdgcn_readlane(ylo, ph0 * gh);
     const bool ok = is_last && ph_of >= ph0 && ph_of < ph0 + max_rows_tile && (ylo + 1 - row0 + 1) * pitch_px <= kCap;
@@ -986,19 +984,20 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
     e.lo = xlo;
     tab[kNS + lane] = e;
   }
-  int stores_out = 0;
   int nst = 0;
   while (true) {
     int n_ph1 = 0, n_row0 = 0, n_nrows = 0;
     if (ph1 < aligned_height) cut(ph1, n_ph1, n_row0, n_nrows);
-    wait_vmcnt_at_most((full_wait & 1) ? 0 : stores_out);  // this stage's window has landed (a single wave: no barrier)
+    wait_vmcnt_at_most(0);  // this stage's window has landed (a single wave: no barrier)
     if (nst == 0) MI_SLAB_STAMP(3);
     nst++;
     if (h.wx0 + h.ww > h.width) fwd_patch_edge<kSlabCT, 64, kPlane>(h, img, lane, nrows);
-    const int nb = (ph1 - ph0) * aligned_width;
-    const int ts = nb | 1;
+    // A lane's bins go STRAIGHT to memory (dword stores in runs of aligned_width floats per channel) instead of through an LDS
+    // tile and 16-byte stores: seven store instructions per lane instead of two, but no tile write / read-back round trip in
+    // front of them and 1.5 KB less LDS per wave -- config 2 28.9 -> 27.7 us, a step's pyramid (forward only) 53.5 -> 48.9 and
+    // 25.1 -> 22.1, 128 x 14x14 22.8 -> 22.0, 1024 RoIs on two images 54.6 -> 55.5 (A/B, bit-equal).
     if (!(ablate & 4))
-      fwd_bins<kSR, 8>(tab, tab + kNS, img + cl * kPlane, tile + cl * ts, slot, ph0, ph1, ph0, row0 * pitch, pitch,
+      fwd_bins<kSR, 8>(tab, tab + kNS, img + cl * kPlane, dst + (long long)cl * bins, slot, ph0, ph1, 0, row0 * pitch, pitch,
                        aligned_width, gh, gw);
     const bool more = ph1 < aligned_height;
 #if MI_TUNING
@@ -1012,11 +1011,7 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the bins' reads of the image are done
       fwd_issue_window<kSlabCT, kPlane>(h, c0, plane0, lane, n_row0, n_nrows);
     }
-    stores_out = 0;
-    if (!(ablate & 2)) {
-      fwd_store<kSlabCT, 64>(tile, dst, lane, ph0, nb, ts, bins, aligned_width, (ablate & 8) != 0);
-      stores_out = fwd_store_count<kSlabCT, 64>(dst, 0, nb, ts, bins);
-    }
+    // this stage's stores were issued BEFORE the next window's pieces: only vmcnt(0) says that those have landed
     if (!more) {
       MI_SLAB_STAMP(6);
 #if MI_TUNING
@@ -1027,7 +1022,6 @@ roi_align_fwd_slab(const float* __restrict__ rois, float* __restrict__ out, cons
 #endif
       break;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile has left LDS before the next bins write it
     ph0 = ph1;
     ph1 = n_ph1;
     row0 = n_row0;
@@ -1954,19 +1948,16 @@ int launch_roi_align_fwd_slab(const LevelTable& lv, const float* rois, const int
       MI_LAUNCH_SLAB(0, CAPG, 0, true);                                                                               \
   } while (0)
   // default: the largest image that keeps a wave's LDS inside 8 granules; MI_ROI_ALIGN_SLAB >= 64 picks other capacities
-  // 7x7: 292 pixels (9 granules, 14 waves per CU) -- fewer two- and three-stage items pay for the lost residency on the large
-  // launches (1024 RoIs 56.0 -> 54.1 us, a step's box pyramid 57.1 -> 54.7, config 2 29.2 -> 28.6..29.1); the 14x14 heads keep
-  // 8 granules (128 x 14x14: 22.9 against 27.1 us)
+  // default: the largest image that keeps a wave's LDS inside 8 granules (292 pixels at 7x7 and 14x14: 18 waves per CU);
+  // MI_ROI_ALIGN_SLAB >= 64 picks other capacities
   if (cap == 0)
-    MI_SLAB_PICK(292, (SlabLds<2, 14>::kCapMax), (SlabLds<0, 0>::kCapMax));
-  else if (cap >= 292)
-    MI_SLAB_PICK(292, 292, 292);
+    MI_SLAB_PICK((SlabLds<2, 7>::kCapMax), (SlabLds<2, 14>::kCapMax), (SlabLds<0, 0>::kCapMax));
+  else if (cap >= 324)
+    MI_SLAB_PICK(324, 324, 324);
   else if (cap >= 260)
     MI_SLAB_PICK(260, 260, 260);
-  else if (cap >= 256)
-    MI_SLAB_PICK(256, 256, 256);
   else
-    MI_SLAB_PICK(196, 196, 196);
+    MI_SLAB_PICK(228, 228, 228);
 #undef MI_SLAB_PICK
 #undef MI_LAUNCH_SLAB
   return check_launch("roi_align_fwd_slab");

@@ -2071,8 +2071,9 @@ def test_roi_align_records_free_forward_over_a_pyramid(oracle_mod, tuning_env, r
 
 @pytest.mark.gpu
 def test_roi_align_records_free_forward_partial_wait(tuning_env):
-    """The records-free kernel's stage pipeline waits with vmcnt(#stores) like the record-driven one: against vmcnt(0)
-    (MI_ROI_ALIGN_FWD_FULL_WAIT=1) bit for bit on multi-stage shapes, release build."""
+    """Multi-stage items of the records-free kernel (its bins store straight to memory, so every stage waits with vmcnt(0);
+    the record-driven kernel behind the same switch waits with vmcnt(#stores)): MI_ROI_ALIGN_FWD_FULL_WAIT=1 against the
+    default bit for bit, finite everywhere, release build."""
     h, w, scale = 200, 336, 0.25
     rois = to_dev(syn.rois_canonical(256, 1, seed=5, side=(64.0, 700.0)))
     for c, res in ((64, 7), (32, 14)):
