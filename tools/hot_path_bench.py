@@ -165,7 +165,7 @@ def roofline_roi_align_forward(device, iters):
             # not HBM (1.2 x the algorithmic bytes): the gather alone (bins and stores ablated) takes 16.6 us + the launch floor
             # whatever the residency (14 or 18 waves per CU) -- 3.4 M cache lines = 5.2 x the algorithmic bytes cross
             # L2 -> L1 at ~77 % of the 64 B / clk / CU fill rate, a 72-byte NCHW row segment dragging in 1.5 lines -- and the
-            # bins (LDS reads, 1.7 passes per tap read after the stride-4 layout) and stores overlap it only in part
+            # bins (LDS reads, 1.7 passes per tap read after the stride-4 layout) and stores (straight from the lanes) overlap it only in part
             "limited_by": "L2->L1 line fill of the per-RoI window gather (cache lines = 5.2 x algorithmic bytes; the gather alone "
                           "runs at ~77 % of the L1 fill rate) + LDS tap reads and stores that overlap it only partly; not HBM "
                           "(profiles/r06_slab_forward.txt)",
