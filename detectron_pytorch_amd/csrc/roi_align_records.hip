@@ -829,10 +829,11 @@ roi_align_fwd_records(const float* __restrict__ rois, float* __restrict__ out, c
 // channel tile 8 * phase + (x & 7), i.e. (workgroups go round-robin over the XCDs) at any time one XCD reads ONE
 // 8-channel slab (2.15 MB of its 4 MB L2) for all RoIs in arrival order: every line comes from the fabric once whatever
 // the order of the RoIs, and nobody has to rank them.  The wave computes the RoI's geometry and axis tables itself (the
-// arithmetic of roi_align_prepare, lane = sample), cuts the stages on the fly, and runs the same window DMA, bins and
-// tile store as the record-driven kernel on its own LDS image -- no barrier anywhere, 11-14 independent waves per CU.
+// arithmetic of roi_align_prepare, lane = sample), cuts the stages on the fly, and runs the same window DMA and bins as
+// the record-driven kernel on its own LDS image; its bins leave straight from the lanes (8 channels x 8 columns per wave: a
+// 28-byte run per channel and store instruction -- no LDS output tile) -- no barrier anywhere, 18 independent waves per CU.
 // Bit-equal to roi_align_fwd_records (same tables, same bins).  Callers whose workspace announces a backward keep the
-// records path: the backward reads the records.
+// records path: the backward reads the records (at their sweep rank: profiles/r06_slab_forward.txt section 8).
 // -------------------------------------------------------------------------------------------------------------------
 constexpr int kSlabCT = 8;
 #if MI_TUNING
